@@ -1,0 +1,149 @@
+"""ctypes binding of the C-ABI kernel library (include/dctn_amd.h).
+
+The library is the product path.  There is deliberately NO fallback: if the shared object is
+missing, or a tensor is not on an MI355X device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdctn_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, F64, BF16 = 0, 1, 2
+PREC_EXACT, PREC_BF16 = 0, 1
+ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_NULL = -1, -2, -3, -4, -5, -6
+
+_DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16}
+
+c_int, c_i64, c_void, c_size = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+_I64x5 = ctypes.POINTER(c_i64)
+_IntP = ctypes.POINTER(c_int)
+_PtrP = ctypes.POINTER(c_void)
+
+# name -> (restype, argtypes); mirrors include/dctn_amd.h one to one
+SIGNATURES = {
+    "dctn_version": (c_int, []),
+    "dctn_strerror": (ctypes.c_char_p, [c_int]),
+    "dctn_last_kernel": (ctypes.c_char_p, []),
+    "dctn_eps_fwd": (c_int, [c_void, _I64x5, c_void, c_void] + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_eps_bwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 4),
+    "dctn_eps_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_size]
+                     + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_convsbs_workspace_bytes": (c_size, [c_int, _IntP, _IntP] + [c_int] * 5 + [_IntP, _IntP, c_int, c_int]),
+    "dctn_convsbs_fwd": (c_int, [c_void, _I64x5, _PtrP, c_void, c_int, _IntP, _IntP, _IntP, _IntP]
+                         + [c_int] * 5 + [c_void, c_size, c_int, c_void]),
+    "dctn_convsbs_bwd": (c_int, [c_void, _I64x5, _PtrP, c_void, c_void, _PtrP, c_int, _IntP, _IntP, _IntP, _IntP]
+                         + [c_int] * 5 + [c_void, c_size, c_int, c_void]),
+    "dctn_logmatmulexp_fwd": (c_int, [c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void]),
+    "dctn_logmatmulexp_bwd": (c_int, [c_void] * 6 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void]),
+    "dctn_logmatmulexp_fold_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int]),
+    "dctn_logmatmulexp_fold_fwd": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_int, c_void]),
+    "dctn_logmatmulexp_fold_bwd": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_int, c_void]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile dctn_amd/csrc/*.hip for gfx950 into dctn_amd/libdctn_amd.so (hipcc cross-compiles
+    without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building libdctn_amd.so failed")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP kernel library is the only implementation of the "
+                "contraction path (no fallback).  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dctn_amd/csrc`."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def last_kernel() -> str:
+    return lib().dctn_last_kernel().decode()
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TypeError(f"dctn_amd supports float32, float64 and bfloat16 tensors, got {t.dtype}") from None
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "dctn_amd: the contraction path runs on an MI355X device only; got a tensor on "
+                f"'{t.device}'.  There is deliberately no CPU fallback."
+            )
+        if t.device != dev:
+            raise RuntimeError(f"dctn_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = lib().dctn_strerror(rc).decode()
+    if rc == ERR_BAD_SHAPE:
+        raise AssertionError(f"{what}: {msg}")  # the reference signals shape errors with `assert`
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def stream_ptr(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def strides5(t: torch.Tensor):
+    return (c_i64 * 5)(*t.stride())
+
+
+def int_array(values: Sequence[int]):
+    return (c_int * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    return (c_void * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+# precision policy for float32 tensors on the MFMA paths (bf16 tensors always use bf16 MFMA)
+_precision = PREC_EXACT
+
+
+def set_float32_matmul_precision(mode: str) -> None:
+    """'exact' (default): f32 in / f32 accumulate.  'bf16': operands rounded to bf16, f32 accumulate."""
+    global _precision
+    _precision = {"exact": PREC_EXACT, "highest": PREC_EXACT, "bf16": PREC_BF16}[mode]
+
+
+def precision() -> int:
+    return _precision

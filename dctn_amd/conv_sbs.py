@@ -1,0 +1,275 @@
+"""ConvSBS: a tensor-train / tensor-ring ("snake" string) of per-pixel cores laid over a window
+and slid over the image; ManyConvSBS: several strings over the same input.
+
+Mirror of the reference's dctn/conv_sbs.py:27-370 (same class names, constructor arguments,
+``cores`` ParameterList, methods).  ``ConvSBS.forward`` is the hot path: one HIP kernel sweeps the
+string per window (dctn_amd/csrc/convsbs_*.hip) instead of materialising one (B,H',W',o,l,r)
+tensor per core in HBM; backward is the adjoint sweep.  The parameter-only contractions
+(``sum``, ``squared_fro_norm``, ``as_explicit_tensor``, ``as_eps``) are tiny and go through the
+cached pairwise-einsum plans of ``contraction_path_cache``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from dataclasses import dataclass
+from itertools import chain
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib as L
+from .contraction_path_cache import contract
+from .conv_sbs_spec import SBSSpecCore, SBSSpecString
+
+
+# --- initialisation tags (dctn/conv_sbs.py:27-43)
+@dataclass(frozen=True)
+class DumbNormalInitialization:
+    std_of_elements_of_cores: float
+
+
+@dataclass(frozen=True)
+class KhrulkovNormalInitialization:
+    std_of_elements_of_matrix: Optional[float]
+
+
+class NormalPreservingOutputStdInitialization:
+    pass
+
+
+@dataclass(frozen=True)
+class MinRandomEyeInitialization:
+    base_std: float
+
+
+Initialization = Union[
+    DumbNormalInitialization, KhrulkovNormalInitialization, NormalPreservingOutputStdInitialization,
+    MinRandomEyeInitialization,
+]
+
+
+class _ConvSBSFunction(torch.autograd.Function):
+    """x: (C, B, H, W, q) any strides; cores in string order."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, spec: SBSSpecString, *cores: Tensor) -> Tensor:
+        dev = L.require_device(x, *cores)
+        C, B, H, W, q = x.shape
+        n = len(spec)
+        shapes = spec.shapes
+        for core, shape in zip(cores, shapes):
+            assert tuple(core.shape) == shape.as_tuple()
+            if core.dtype != x.dtype:
+                raise TypeError(f"ConvSBS: core is {core.dtype} but input is {x.dtype}")
+        assert C == spec.in_num_channels and q == spec.in_quantum_dim_size
+        cores_c = [c.contiguous() for c in cores]
+        outs = L.int_array([s.out_quantum_dim_size for s in shapes])
+        bonds = L.int_array(spec.bond_sizes)
+        ph = L.int_array([p.h for p in spec.positions])
+        pw = L.int_array([p.w for p in spec.positions])
+        Ho, Wo = H - spec.max_height_pos, W - spec.max_width_pos
+        out = torch.empty((B, Ho, Wo, spec.out_total_quantum_dim_size), dtype=x.dtype, device=dev)
+        code = L.dtype_code(x)
+        ws = L.workspace(L.lib().dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 0), dev)
+        L.check(
+            L.lib().dctn_convsbs_fwd(x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), out.data_ptr(), n,
+                                     outs, bonds, ph, pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
+                                     L.stream_ptr(dev)),
+            "ConvSBS forward",
+        )
+        ctx.save_for_backward(x, *cores_c)
+        ctx.meta = (n, outs, bonds, ph, pw, C, B, H, W, q, code)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        x, *cores_c = ctx.saved_tensors
+        n, outs, bonds, ph, pw, C, B, H, W, q, code = ctx.meta
+        dev = x.device
+        need_dx = ctx.needs_input_grad[0]
+        need_dcores = any(ctx.needs_input_grad[2:])
+        g = d_out.contiguous()
+        d_x = torch.empty((C, B, H, W, q), dtype=x.dtype, device=dev) if need_dx else None
+        d_cores = [torch.empty_like(c) for c in cores_c] if need_dcores else None
+        ws = L.workspace(L.lib().dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 1), dev)
+        L.check(
+            L.lib().dctn_convsbs_bwd(
+                x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), g.data_ptr(),
+                None if d_x is None else d_x.data_ptr(), None if d_cores is None else L.ptr_array(d_cores),
+                n, outs, bonds, ph, pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code, L.stream_ptr(dev)),
+            "ConvSBS backward",
+        )
+        grads = [None] * n if d_cores is None else [
+            dc if need else None for dc, need in zip(d_cores, ctx.needs_input_grad[2:])
+        ]
+        return (d_x, None, *grads)
+
+
+class ConvSBS(nn.Module):
+    def __init__(self, spec: SBSSpecString, initialization: Initialization = DumbNormalInitialization(0.9)):
+        super().__init__()
+        logger = logging.getLogger(f"{__name__}.ConvSBS.__init__")
+        self.spec = spec
+        scale = (
+            initialization.std_of_elements_of_cores
+            if isinstance(initialization, DumbNormalInitialization)
+            else float("nan")
+        )
+        self.cores = nn.ParameterList(
+            nn.Parameter(scale * torch.randn(*shape.as_tuple())) for shape in spec.shapes
+        )
+        if isinstance(initialization, KhrulkovNormalInitialization):
+            self.init_khrulkov_normal(initialization.std_of_elements_of_matrix)
+        elif isinstance(initialization, NormalPreservingOutputStdInitialization):
+            logger.info("Using normal preserving output std initialization")
+            self.init_normal_preserving_output_std()
+        elif isinstance(initialization, MinRandomEyeInitialization):
+            self.init_min_random_eye(initialization.base_std)
+        logger.info(f"self.var()**0.5={self.var()**0.5}")
+
+    # ------------------------------------------------------------------ initialisers
+    @property
+    def tt_matrix_num_columns(self) -> int:
+        return self.spec.in_quantum_dim_size ** (self.spec.in_num_channels * len(self.spec.cores))
+
+    def init_khrulkov_normal(self, std_of_elements_of_matrix: Optional[float] = None) -> None:
+        """i.i.d. normal cores whose variance makes the elements of the represented matrix have
+        the requested std (default: Glorot-like 2/(cols+rows), Khrulkov et al., TT embeddings)."""
+        logger = logging.getLogger(f"{__name__}.ConvSBS.init_khrulkov_normal")
+        if std_of_elements_of_matrix is not None:
+            var_matrix = std_of_elements_of_matrix**2
+        else:
+            var_matrix = 2 / (self.tt_matrix_num_columns + self.spec.out_total_quantum_dim_size)
+        n = len(self.cores)
+        prod_of_ranks = math.prod(self.spec.bond_sizes)
+        var_cores = var_matrix ** (1 / n) / prod_of_ranks ** (1 / n)
+        logger.info(f"bond_sizes={self.spec.bond_sizes}, prod_of_ranks={prod_of_ranks}, var_of_cores_elements={var_cores}")
+        for core in self.cores:
+            nn.init.normal_(core, std=math.sqrt(var_cores))
+
+    def init_normal_preserving_output_std(self) -> None:
+        """If a window's coordinates are i.i.d. with mean mu and std sigma, every output
+        coordinate gets std sqrt(sigma^2 + mu^2)."""
+        self.init_khrulkov_normal(self.tt_matrix_num_columns**-0.5)
+
+    def init_min_random_eye(self, base_std: float) -> None:
+        """Truncated scaled identities plus gaussian noise, so that the layer initially
+        averages its window.  Needs an open chain with equal bonds and a single output core."""
+        spec = self.spec
+        assert spec.bond_sizes[0] == 1
+        assert all(b == spec.bond_sizes[1] for b in spec.bond_sizes[1:])
+        bond = spec.bond_sizes[1]
+        assert spec.out_total_quantum_dim_size == max(s.out_quantum_dim_size for s in spec.shapes)
+        out_dim = spec.out_total_quantum_dim_size
+        total_in = spec.in_quantum_dim_size**spec.in_num_channels
+        k = min(bond, out_dim)
+        eye = torch.zeros(bond, bond)
+        eye[:k, :k] = torch.eye(k) / total_in
+        eye = eye.reshape((1, bond, bond) + (1,) * spec.in_num_channels)
+        for core in list(self.cores)[1:-1]:
+            core.data.zero_()
+            core.data += eye.expand_as(core)
+            core.data += torch.randn_like(core) * base_std / total_in
+        for core in (self.cores[0], self.cores[-1]):
+            core.data.zero_()
+            core.data[0, 0, 0] = 1 / total_in
+            assert torch.allclose(core.data.sum(), torch.tensor(1.0))
+            core.data += torch.randn_like(core) * base_std / total_in
+
+    # ------------------------------------------------------------------ parameter-only contractions
+    def _cores_with(self, names):
+        return chain.from_iterable((core, dims) for core, dims in zip(self.cores, names))
+
+    def sum(self) -> Tensor:
+        """Sum of all elements of the represented tensor."""
+        return contract(*self._cores_with(self.spec.all_dim_names), ())
+
+    def mean(self) -> Tensor:
+        return self.sum() / float(self.spec.nelement)
+
+    def squared_fro_norm(self) -> Tensor:
+        return contract(
+            *self._cores_with(self.spec.get_all_dim_names_add_suffix_to_bonds("_a")),
+            *self._cores_with(self.spec.get_all_dim_names_add_suffix_to_bonds("_b")),
+            (),
+        )
+
+    def fro_norm(self) -> Tensor:
+        return self.squared_fro_norm() ** 0.5
+
+    def var(self, unbiased: bool = True) -> Tensor:
+        """Empirical variance of the elements (Bessel-corrected iff ``unbiased``)."""
+        total = self.sum()
+        n = self.spec.nelement
+        mean = total / n
+        divisor = n - 1 if unbiased else n
+        return self.squared_fro_norm() / divisor - 2 * total / divisor * mean + n / divisor * mean**2
+
+    def as_explicit_tensor(self) -> Tensor:
+        """The represented tensor as one array, dims ordered like ``spec.all_dangling_dim_names``."""
+        return contract(*self._cores_with(self.spec.all_dim_names), self.spec.all_dangling_dim_names)
+
+    def as_eps(self) -> Tensor:
+        """For a string that fills a square: the equivalent dense EPS core (out dims merged,
+        input dims moved to the row-major position order EPS uses)."""
+        spec = self.spec
+        assert spec.max_height_pos == spec.max_width_pos
+        C, n, q = spec.in_num_channels, len(spec), spec.in_quantum_dim_size
+        t = self.as_explicit_tensor().reshape((q,) * (C * n) + (-1,))
+        std_index = spec.get_indices_wrt_standard_order()
+        perm = [0] * (C * n)
+        for s, target in enumerate(std_index):
+            for c in range(C):
+                perm[target * C + c] = s * C + c
+        return t.permute(*perm, C * n)
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, input: Union[Tensor, Tuple[Tensor, ...]], /) -> Tensor:
+        """``input``: a tensor whose first dim is channels, or a tuple of per-channel tensors
+        (batch, height, width, q).  Returns (batch, height', width', prod of out sizes)."""
+        x = input if isinstance(input, Tensor) else torch.stack(tuple(input))
+        return _ConvSBSFunction.apply(x, self.spec, *self.cores)
+
+    def multiply_by_scalar(self, scalar: float, /):
+        """Multiplies the represented tensor by ``scalar`` in place (spread over the cores)."""
+        for core in self.cores:
+            core.data *= scalar ** (1 / len(self.cores))
+        return self
+
+
+class ManyConvSBS(nn.Module):
+    def __init__(
+        self,
+        in_num_channels: int,
+        in_quantum_dim_size: int,
+        bond_dim_size: int,
+        trace_edge: bool,
+        cores_specs: Tuple[Tuple[SBSSpecCore, ...], ...],
+        initializations: Optional[Tuple[Initialization, ...]] = None,
+    ):
+        """``initializations is None`` -> ConvSBS's default initialisation."""
+        super().__init__()
+        if initializations is not None:
+            assert len(initializations) == len(cores_specs)
+        specs = tuple(
+            SBSSpecString(
+                cores_spec,
+                (bond_dim_size if trace_edge else 1,) + (bond_dim_size,) * (len(cores_spec) - 1),
+                in_num_channels,
+                in_quantum_dim_size,
+            )
+            for cores_spec in cores_specs
+        )
+        out_sizes = [s.out_total_quantum_dim_size for s in specs]
+        assert all(o == out_sizes[0] for o in out_sizes[1:])
+        if initializations is None:
+            self.strings = nn.ModuleList([ConvSBS(s) for s in specs])
+        else:
+            self.strings = nn.ModuleList([ConvSBS(s, i) for s, i in zip(specs, initializations)])
+
+    def forward(self, channels: Union[Tensor, Tuple[Tensor, ...]], /) -> Tuple[Tensor, ...]:
+        x = channels if isinstance(channels, Tensor) else torch.stack(tuple(channels))
+        return tuple(string(x) for string in self.strings)

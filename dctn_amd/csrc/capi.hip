@@ -1,0 +1,66 @@
+// C-ABI entry points (include/dctn_amd.h): argument validation + dispatch to kernel families.
+#include "common.h"
+
+static thread_local const char* g_last_kernel = "none";
+void dctn_set_last_kernel(const char* name) { g_last_kernel = name; }
+
+extern "C" {
+
+int dctn_version(void) { return 100; }
+
+const char* dctn_last_kernel(void) { return g_last_kernel; }
+
+const char* dctn_strerror(int code) {
+  switch (code) {
+    case DCTN_OK: return "ok";
+    case DCTN_ERR_BAD_SHAPE: return "inconsistent shape";
+    case DCTN_ERR_BAD_DTYPE: return "unknown dtype code";
+    case DCTN_ERR_UNSUPPORTED: return "shape/dtype not covered by any kernel of this build";
+    case DCTN_ERR_WORKSPACE: return "workspace missing or too small";
+    case DCTN_ERR_LAUNCH: return "HIP launch error";
+    case DCTN_ERR_NULL: return "required pointer is NULL";
+  }
+  return "unknown error";
+}
+
+static bool dtype_ok(int dtype) { return dtype == DCTN_F32 || dtype == DCTN_F64 || dtype == DCTN_BF16; }
+
+int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out, int C,
+                 int B, int H, int W, int Q, int K, int O, int dtype, int precision, void* stream) {
+  if (!x || !core || !out || !x_strides) return DCTN_ERR_NULL;
+  if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
+  EpsP p;
+  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
+  if (rc != DCTN_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  return eps_fwd_generic(x, core, out, p, dtype, st);
+}
+
+size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
+                                    int precision, int need_dx, int need_dcore) {
+  EpsP p;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  const size_t a = eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore);
+  const size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
+  return (a > b ? a : b) + 256;
+}
+
+int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
+                 void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
+                 int H, int W, int Q, int K, int O, int dtype, int precision, void* stream) {
+  if (!x || !core || !dY || !x_strides) return DCTN_ERR_NULL;
+  if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
+  if (!dX && !dCore) return DCTN_OK;
+  EpsP p;
+  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
+  if (rc != DCTN_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = eps_bwd_mfma(x, core, dY, dX, dCore, workspace, workspace_bytes, p, dtype, precision, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  return eps_bwd_generic(x, core, dY, dX, dCore, workspace, workspace_bytes, p, dtype, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Shared helpers for the dctn_amd HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dctn_amd.h"
+
+typedef __bf16 bf16_t;
+
+template <typename S> struct AccOf { typedef float type; };
+template <> struct AccOf<double> { typedef double type; };
+
+#define DCTN_WAVE 64
+#define DCTN_LDS_BUDGET (150 * 1024)  // bytes of the 160 KiB LDS a single workgroup may claim here
+
+#define DCTN_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    if (hipGetLastError() != hipSuccess) return DCTN_ERR_LAUNCH; \
+  } while (0)
+
+// thread-local name of the kernel family the last call dispatched to
+void dctn_set_last_kernel(const char* name);
+
+static inline long long ipow_ll(long long b, int e) {
+  long long r = 1;
+  for (int i = 0; i < e; ++i) r *= b;
+  return r;
+}
+
+static inline size_t dtype_size(int dtype) {
+  return dtype == DCTN_F64 ? 8 : (dtype == DCTN_F32 ? 4 : 2);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// -------------------------------------------------------------------------------- EPS shapes
+struct EpsP {
+  int C, B, H, W, Q, K, O, N, Ho, Wo;
+  long long Wn;    // B*Ho*Wo windows
+  long long R;     // Q^N core rows
+  long long s[5];  // element strides of x
+  int m, LO, NH;   // low split: last m factors, LO = Q^m, NH = N-m high factors
+  long long HI;    // Q^NH
+  int bits;        // bits per packed digit in the dCore kernel
+};
+
+int eps_fill_params(EpsP& p, const int64_t x_strides[5], int C, int B, int H, int W, int Q, int K,
+                    int O);
+
+// generic (any shape, f32/f64/bf16-storage) kernels — eps_generic.hip
+int eps_fwd_generic(const void* x, const void* core, void* out, EpsP p, int dtype, hipStream_t st);
+size_t eps_bwd_generic_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore);
+int eps_bwd_generic(const void* x, const void* core, const void* dY, void* dX, void* dCore,
+                    void* ws, size_t ws_bytes, EpsP p, int dtype, hipStream_t st);
+
+// MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
+// is outside the family so that the dispatcher can take the generic kernels.
+int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int dtype,
+                 int precision, hipStream_t st);
+size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx, int need_dcore);
+int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
+                 size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);

@@ -1,0 +1,431 @@
+// Generic ConvSBS kernels: any string (arbitrary core order, ring or open chain, per-bond sizes,
+// outputs on several cores, C channels), float32 / float64 / bf16 storage.
+//
+// Replaces dctn/conv_sbs.py:258-304 (ConvSBS.forward) and torch autograd through it.
+// The reference materialises, per core, a (B,H',W',o,l,r) tensor in HBM and then multiplies the
+// chain.  Here one lane owns one window and sweeps the string left to right carrying only the
+// state v[o_acc][bond] in its LDS column; the per-window matrices T_c are never written out.
+// A ring (bond_sizes[0] > 1) is closed by running the sweep once per value of the traced bond.
+//
+// Backward: the forward states are kept in a caller-supplied workspace ([element][window],
+// coalesced), then an adjoint sweep right to left produces dT_c, from which
+//   dCore_c += dT_c (x) f_c   (wave reduction, one float atomic per element per wave)
+//   df_c -> d/d(pixel features), written per window and summed per pixel by a gather kernel.
+#include "common.h"
+
+#define SBS_MAXC 32
+
+struct SbsP {
+  int n, C, B, H, W, q, qc, Ho, Wo, l0, Otot, vmax;
+  long long Wn;
+  long long s[5];
+  int o[SBS_MAXC], bl[SBS_MAXC], br[SBS_MAXC], ph[SBS_MAXC], pw[SBS_MAXC];
+  int oacc[SBS_MAXC + 1];        // product of out sizes of cores < c
+  long long st_off[SBS_MAXC + 1];  // element offsets of the stored forward states
+  const void* core[SBS_MAXC];
+  void* dcore[SBS_MAXC];  // A-typed accumulators (== dCores for f32/f64)
+};
+
+namespace {
+
+struct WinCoord {
+  long long b;
+  int ho, wo;
+};
+__device__ __forceinline__ WinCoord win_coord(const SbsP& p, long long w) {
+  WinCoord c;
+  const int hw = p.Ho * p.Wo;
+  c.b = w / hw;
+  const int rem = (int)(w - c.b * hw);
+  c.ho = rem / p.Wo;
+  c.wo = rem - c.ho * p.Wo;
+  return c;
+}
+
+// f[qq] = prod_ch x[ch][pixel of core c][digit_ch(qq)], channel 0 most significant
+template <typename S, typename A>
+__device__ __forceinline__ void pixel_features(const S* __restrict__ x, const SbsP& p, int c,
+                                               bool valid, const WinCoord& wc, A* f, int tid) {
+  for (int qq = 0; qq < p.qc; ++qq) {
+    A pr = A(1);
+    int t = qq;
+    for (int ch = p.C - 1; ch >= 0; --ch) {
+      const int dg = t % p.q;
+      t /= p.q;
+      const S* px = x + ch * p.s[0] + wc.b * p.s[1] + (long long)(wc.ho + p.ph[c]) * p.s[2] +
+                    (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4];
+      pr *= valid ? (A)(*px) : A(0);
+    }
+    f[qq * DCTN_WAVE + tid] = pr;
+  }
+}
+
+// one sweep step: vb[(a*oc+o)*R + r] = sum_l va[a*L + l] * sum_qq core[o,l,r,qq] f[qq]
+template <typename S, typename A>
+__device__ __forceinline__ void sweep_step(const SbsP& p, int c, const A* va, A* vb, const A* f,
+                                           int tid) {
+  const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
+  const S* core = (const S*)p.core[c];
+  for (int e = 0; e < Oacc * oc * R; ++e) vb[e * DCTN_WAVE + tid] = A(0);
+  for (int o = 0; o < oc; ++o)
+    for (int l = 0; l < L; ++l)
+      for (int r = 0; r < R; ++r) {
+        const S* cp = core + (long long)((o * L + l) * R + r) * p.qc;
+        A t = A(0);
+        for (int qq = 0; qq < p.qc; ++qq) t += (A)cp[qq] * f[qq * DCTN_WAVE + tid];
+        for (int a = 0; a < Oacc; ++a)
+          vb[((a * oc + o) * R + r) * DCTN_WAVE + tid] += va[(a * L + l) * DCTN_WAVE + tid] * t;
+      }
+}
+
+template <typename S, typename A>
+__global__ __launch_bounds__(DCTN_WAVE) void convsbs_fwd_generic_k(const S* __restrict__ x,
+                                                                   S* __restrict__ out, SbsP p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  A* va = reinterpret_cast<A*>(smem);
+  A* vb = va + (size_t)p.vmax * DCTN_WAVE;
+  A* f = vb + (size_t)p.vmax * DCTN_WAVE;
+  A* oa = f + (size_t)p.qc * DCTN_WAVE;
+  const int tid = threadIdx.x;
+  const long long w = (long long)blockIdx.x * DCTN_WAVE + tid;
+  const bool valid = w < p.Wn;
+  WinCoord wc = {0, 0, 0};
+  if (valid) wc = win_coord(p, w);
+  for (int a = 0; a < p.Otot; ++a) oa[a * DCTN_WAVE + tid] = A(0);
+  for (int s = 0; s < p.l0; ++s) {
+    for (int l = 0; l < p.l0; ++l) va[l * DCTN_WAVE + tid] = (l == s) ? A(1) : A(0);
+    A* cur = va;
+    A* nxt = vb;
+    for (int c = 0; c < p.n; ++c) {
+      pixel_features<S, A>(x, p, c, valid, wc, f, tid);
+      sweep_step<S, A>(p, c, cur, nxt, f, tid);
+      A* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (int a = 0; a < p.Otot; ++a)
+      oa[a * DCTN_WAVE + tid] += cur[(a * p.l0 + s) * DCTN_WAVE + tid];
+  }
+  if (valid)
+    for (int a = 0; a < p.Otot; ++a) out[w * p.Otot + a] = (S)oa[a * DCTN_WAVE + tid];
+}
+
+template <typename S, typename A>
+__global__ __launch_bounds__(DCTN_WAVE) void convsbs_bwd_generic_k(
+    const S* __restrict__ x, const S* __restrict__ dY, A* __restrict__ states,
+    A* __restrict__ gxw, SbsP p, int need_dx, int need_dcore) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  A* va = reinterpret_cast<A*>(smem);
+  A* vb = va + (size_t)p.vmax * DCTN_WAVE;
+  A* vc = vb + (size_t)p.vmax * DCTN_WAVE;
+  A* f = vc + (size_t)p.vmax * DCTN_WAVE;
+  A* df = f + (size_t)p.qc * DCTN_WAVE;
+  A* dys = df + (size_t)p.qc * DCTN_WAVE;
+  const int tid = threadIdx.x;
+  const long long w = (long long)blockIdx.x * DCTN_WAVE + tid;
+  const bool valid = w < p.Wn;
+  const long long wcol = valid ? w : 0;
+  WinCoord wc = {0, 0, 0};
+  if (valid) wc = win_coord(p, w);
+  for (int a = 0; a < p.Otot; ++a) dys[a * DCTN_WAVE + tid] = valid ? (A)dY[w * p.Otot + a] : A(0);
+
+  for (int s = 0; s < p.l0; ++s) {
+    // ---- forward sweep, storing the input state of every core
+    for (int l = 0; l < p.l0; ++l) va[l * DCTN_WAVE + tid] = (l == s) ? A(1) : A(0);
+    A* cur = va;
+    A* nxt = vb;
+    for (int c = 0; c < p.n; ++c) {
+      const int ne = p.oacc[c] * p.bl[c];
+      if (valid)
+        for (int e = 0; e < ne; ++e)
+          states[(p.st_off[c] + e) * p.Wn + wcol] = cur[e * DCTN_WAVE + tid];
+      if (c + 1 < p.n) {
+        pixel_features<S, A>(x, p, c, valid, wc, f, tid);
+        sweep_step<S, A>(p, c, cur, nxt, f, tid);
+        A* tmp = cur; cur = nxt; nxt = tmp;
+      }
+    }
+    // ---- adjoint sweep.  dv: gradient wrt the OUTPUT state of core c, shape [Oacc*oc][R]
+    A* dv = vb;
+    A* dvn = vc;
+    for (int a = 0; a < p.Otot; ++a)
+      for (int r = 0; r < p.l0; ++r)
+        dv[(a * p.l0 + r) * DCTN_WAVE + tid] = (r == s) ? dys[a * DCTN_WAVE + tid] : A(0);
+    for (int c = p.n - 1; c >= 0; --c) {
+      const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
+      const S* core = (const S*)p.core[c];
+      A* dcore = (A*)p.dcore[c];
+      for (int e = 0; e < Oacc * L; ++e)
+        va[e * DCTN_WAVE + tid] = valid ? states[(p.st_off[c] + e) * p.Wn + wcol] : A(0);
+      pixel_features<S, A>(x, p, c, valid, wc, f, tid);
+      for (int e = 0; e < Oacc * L; ++e) dvn[e * DCTN_WAVE + tid] = A(0);
+      for (int qq = 0; qq < p.qc; ++qq) df[qq * DCTN_WAVE + tid] = A(0);
+      for (int o = 0; o < oc; ++o)
+        for (int l = 0; l < L; ++l)
+          for (int r = 0; r < R; ++r) {
+            const long long cbase = (long long)((o * L + l) * R + r) * p.qc;
+            A t = A(0);
+            for (int qq = 0; qq < p.qc; ++qq) t += (A)core[cbase + qq] * f[qq * DCTN_WAVE + tid];
+            A dT = A(0);
+            for (int a = 0; a < Oacc; ++a) {
+              const A g = dv[((a * oc + o) * R + r) * DCTN_WAVE + tid];
+              dT += va[(a * L + l) * DCTN_WAVE + tid] * g;
+              dvn[(a * L + l) * DCTN_WAVE + tid] += t * g;
+            }
+            for (int qq = 0; qq < p.qc; ++qq) {
+              df[qq * DCTN_WAVE + tid] += dT * (A)core[cbase + qq];
+              if (need_dcore) {
+                const A red = wave_reduce_sum<A>(dT * f[qq * DCTN_WAVE + tid]);
+                if (tid == 0) atomicAdd(&dcore[cbase + qq], red);
+              }
+            }
+          }
+      if (need_dx && valid) {
+        // d/d x[ch][pixel_c][qv] = sum_{qq: digit_ch(qq) = qv} df[qq] * prod_{ch' != ch} x[ch'][digit]
+        for (int ch = 0; ch < p.C; ++ch)
+          for (int qv = 0; qv < p.q; ++qv) {
+            A g = A(0);
+            for (int qq = 0; qq < p.qc; ++qq) {
+              int t = qq;
+              A pr = A(1);
+              bool hit = false;
+              for (int c2 = p.C - 1; c2 >= 0; --c2) {
+                const int dg = t % p.q;
+                t /= p.q;
+                if (c2 == ch) {
+                  hit = (dg == qv);
+                } else {
+                  pr *= (A)x[c2 * p.s[0] + wc.b * p.s[1] + (long long)(wc.ho + p.ph[c]) * p.s[2] +
+                             (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4]];
+                }
+              }
+              if (hit) g += df[qq * DCTN_WAVE + tid] * pr;
+            }
+            A* dst = &gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + w];
+            if (s == 0) *dst = g; else *dst += g;
+          }
+      }
+      A* tmp = dv; dv = dvn; dvn = tmp;
+    }
+  }
+}
+
+// dX[ch,b,h,w,qv] = sum_c gxw[((c*C+ch)*q+qv)][window (h-ph_c, w-pw_c)]
+template <typename S, typename A>
+__global__ void convsbs_gather_dx_k(const A* __restrict__ gxw, S* __restrict__ dX, SbsP p) {
+  const long long total = (long long)p.C * p.B * p.H * p.W * p.q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    long long t = idx;
+    const int qv = (int)(t % p.q); t /= p.q;
+    const int wi = (int)(t % p.W); t /= p.W;
+    const int hi = (int)(t % p.H); t /= p.H;
+    const int b = (int)(t % p.B);
+    const int ch = (int)(t / p.B);
+    A acc = A(0);
+    for (int c = 0; c < p.n; ++c) {
+      const int ho = hi - p.ph[c], wo = wi - p.pw[c];
+      if (ho < 0 || ho >= p.Ho || wo < 0 || wo >= p.Wo) continue;
+      const long long win = ((long long)b * p.Ho + ho) * p.Wo + wo;
+      acc += gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + win];
+    }
+    dX[idx] = (S)acc;
+  }
+}
+
+template <typename S, typename A>
+__global__ void convert_sbs_k(const A* __restrict__ src, S* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = (S)src[i];
+}
+
+int fill(SbsP& p, const int64_t xs[5], int n, const int* out_sizes, const int* bond_sizes,
+         const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q) {
+  if (n < 1 || n > SBS_MAXC) return n < 1 ? DCTN_ERR_BAD_SHAPE : DCTN_ERR_UNSUPPORTED;
+  if (C < 1 || B < 1 || q < 1) return DCTN_ERR_BAD_SHAPE;
+  int max_h = 0, max_w = 0, min_h = 1 << 30, min_w = 1 << 30;
+  for (int c = 0; c < n; ++c) {
+    if (out_sizes[c] < 1 || bond_sizes[c] < 1 || pos_h[c] < 0 || pos_w[c] < 0)
+      return DCTN_ERR_BAD_SHAPE;
+    max_h = pos_h[c] > max_h ? pos_h[c] : max_h;
+    max_w = pos_w[c] > max_w ? pos_w[c] : max_w;
+    min_h = pos_h[c] < min_h ? pos_h[c] : min_h;
+    min_w = pos_w[c] < min_w ? pos_w[c] : min_w;
+  }
+  if (min_h != 0 || min_w != 0) return DCTN_ERR_BAD_SHAPE;  // dctn/align.py:18-19
+  if (H <= max_h || W <= max_w) return DCTN_ERR_BAD_SHAPE;
+  p.n = n; p.C = C; p.B = B; p.H = H; p.W = W; p.q = q;
+  long long qc = 1;
+  for (int c = 0; c < C; ++c) { qc *= q; if (qc > 4096) return DCTN_ERR_UNSUPPORTED; }
+  p.qc = (int)qc;
+  p.Ho = H - max_h; p.Wo = W - max_w;
+  p.Wn = (long long)B * p.Ho * p.Wo;
+  for (int i = 0; i < 5; ++i) p.s[i] = xs ? xs[i] : 0;
+  p.l0 = bond_sizes[0];
+  long long oacc = 1, off = 0;
+  int vmax = p.l0;
+  for (int c = 0; c < n; ++c) {
+    p.o[c] = out_sizes[c];
+    p.bl[c] = bond_sizes[c];
+    p.br[c] = bond_sizes[(c + 1) % n];
+    p.ph[c] = pos_h[c];
+    p.pw[c] = pos_w[c];
+    p.oacc[c] = (int)oacc;
+    p.st_off[c] = off;
+    off += oacc * p.bl[c];
+    oacc *= out_sizes[c];
+    if (oacc * p.br[c] > (1 << 20)) return DCTN_ERR_UNSUPPORTED;
+    if ((int)(oacc * p.br[c]) > vmax) vmax = (int)(oacc * p.br[c]);
+  }
+  p.oacc[n] = (int)oacc;
+  p.st_off[n] = off;
+  p.Otot = (int)oacc;
+  p.vmax = vmax;
+  return DCTN_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+long long core_elems(const SbsP& p, int c) {
+  return (long long)p.o[c] * p.bl[c] * p.br[c] * p.qc;
+}
+
+template <typename S, typename A>
+int fwd_launch(const void* x, void* out, SbsP& p, hipStream_t st) {
+  const size_t lds = ((size_t)2 * p.vmax + p.qc + p.Otot) * DCTN_WAVE * sizeof(A);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+  (void)hipFuncSetAttribute((const void*)convsbs_fwd_generic_k<S, A>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((convsbs_fwd_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,
+                     (const S*)x, (S*)out, p);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("convsbs_fwd_generic");
+  return DCTN_OK;
+}
+
+size_t bwd_ws(const SbsP& p, int dtype) {
+  const size_t asz = dtype == DCTN_F64 ? 8 : 4;
+  size_t total = align256((size_t)p.st_off[p.n] * p.Wn * asz);      // forward states
+  total += align256((size_t)p.n * p.C * p.q * p.Wn * asz);           // per-window d/d(pixel features)
+  if (dtype == DCTN_BF16)
+    for (int c = 0; c < p.n; ++c) total += align256((size_t)core_elems(p, c) * asz);
+  return total;
+}
+
+template <typename S, typename A>
+int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, void* ws,
+               size_t ws_bytes, SbsP& p, int dtype, hipStream_t st) {
+  if (!ws || bwd_ws(p, dtype) > ws_bytes) return DCTN_ERR_WORKSPACE;
+  const size_t lds = ((size_t)3 * p.vmax + 2 * p.qc + p.Otot) * DCTN_WAVE * sizeof(A);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  unsigned char* wsp = (unsigned char*)ws;
+  A* states = (A*)wsp;
+  wsp += align256((size_t)p.st_off[p.n] * p.Wn * sizeof(A));
+  A* gxw = (A*)wsp;
+  wsp += align256((size_t)p.n * p.C * p.q * p.Wn * sizeof(A));
+  const int need_dcore = dCores != nullptr;
+  if (need_dcore) {
+    for (int c = 0; c < p.n; ++c) {
+      if (!dCores[c]) return DCTN_ERR_NULL;
+      if constexpr (sizeof(S) == sizeof(A)) {
+        p.dcore[c] = dCores[c];
+      } else {
+        p.dcore[c] = wsp;
+        wsp += align256((size_t)core_elems(p, c) * sizeof(A));
+      }
+      if (hipMemsetAsync(p.dcore[c], 0, (size_t)core_elems(p, c) * sizeof(A), st) != hipSuccess)
+        return DCTN_ERR_LAUNCH;
+    }
+  }
+  const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+  (void)hipFuncSetAttribute((const void*)convsbs_bwd_generic_k<S, A>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((convsbs_bwd_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,
+                     (const S*)x, (const S*)dY, states, gxw, p, dX != nullptr, need_dcore);
+  DCTN_CHECK_LAUNCH();
+  if (dX) {
+    const long long total = (long long)p.C * p.B * p.H * p.W * p.q;
+    const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((convsbs_gather_dx_k<S, A>), dim3(g2), dim3(256), 0, st, gxw, (S*)dX, p);
+    DCTN_CHECK_LAUNCH();
+  }
+  if constexpr (sizeof(S) != sizeof(A)) {
+    if (need_dcore)
+      for (int c = 0; c < p.n; ++c) {
+        const long long ne = core_elems(p, c);
+        hipLaunchKernelGGL((convert_sbs_k<S, A>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0,
+                           st, (const A*)p.dcore[c], (S*)dCores[c], ne);
+        DCTN_CHECK_LAUNCH();
+      }
+  }
+  dctn_set_last_kernel("convsbs_bwd_generic");
+  return DCTN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int* bond_sizes,
+                                    int C, int B, int H, int W, int q, const int* pos_h,
+                                    const int* pos_w, int dtype, int backward) {
+  SbsP p;
+  if (!out_sizes || !bond_sizes || !pos_h || !pos_w) return 0;
+  if (fill(p, nullptr, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q) != DCTN_OK)
+    return 0;
+  return backward ? bwd_ws(p, dtype) + 256 : 256;
+}
+
+int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* const* cores,
+                     void* out, int n_cores, const int* out_sizes, const int* bond_sizes,
+                     const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q,
+                     void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (!x || !x_strides || !cores || !out || !out_sizes || !bond_sizes || !pos_h || !pos_w)
+    return DCTN_ERR_NULL;
+  SbsP p;
+  int rc = fill(p, x_strides, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q);
+  if (rc != DCTN_OK) return rc;
+  for (int c = 0; c < n_cores; ++c) {
+    if (!cores[c]) return DCTN_ERR_NULL;
+    p.core[c] = cores[c];
+    p.dcore[c] = nullptr;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case DCTN_F32: return fwd_launch<float, float>(x, out, p, st);
+    case DCTN_F64: return fwd_launch<double, double>(x, out, p, st);
+    case DCTN_BF16: return fwd_launch<bf16_t, float>(x, out, p, st);
+  }
+  return DCTN_ERR_BAD_DTYPE;
+}
+
+int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* const* cores,
+                     const void* dY, void* dX, void* const* dCores, int n_cores,
+                     const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                     const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
+                     size_t workspace_bytes, int dtype, void* stream) {
+  if (!x || !x_strides || !cores || !dY || !out_sizes || !bond_sizes || !pos_h || !pos_w)
+    return DCTN_ERR_NULL;
+  if (!dX && !dCores) return DCTN_OK;
+  SbsP p;
+  int rc = fill(p, x_strides, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q);
+  if (rc != DCTN_OK) return rc;
+  for (int c = 0; c < n_cores; ++c) {
+    if (!cores[c]) return DCTN_ERR_NULL;
+    p.core[c] = cores[c];
+    p.dcore[c] = nullptr;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case DCTN_F32:
+      return bwd_launch<float, float>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st);
+    case DCTN_F64:
+      return bwd_launch<double, double>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st);
+    case DCTN_BF16:
+      return bwd_launch<bf16_t, float>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st);
+  }
+  return DCTN_ERR_BAD_DTYPE;
+}
+
+}  // extern "C"

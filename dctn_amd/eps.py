@@ -1,0 +1,177 @@
+"""EPS ("entangled plaquette state") layer: one dense core of order K*K*C + 1 contracted with
+every K x K window of the input.
+
+Mirror of the reference's dctn/eps.py:19-187 (same function / class names, argument order and
+error behaviour).  ``eps`` and ``eps_one_by_one`` are the hot path: they run as hand-written HIP
+kernels (dctn_amd/csrc/eps_*.hip) through the C-ABI of include/dctn_amd.h — forward and backward,
+with no Khatri-Rao half, GEMM result or aligned view ever materialised in HBM.
+"""
+from __future__ import annotations
+
+import math
+from logging import getLogger
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib as L
+
+
+class _EpsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, core: Tensor, input: Tensor) -> Tensor:
+        C, B, H, W, Q = input.shape
+        K = math.isqrt((core.ndim - 1) // C)
+        O = core.shape[-1]
+        dev = L.require_device(core, input)
+        if core.dtype != input.dtype:
+            raise TypeError(f"eps: core is {core.dtype} but input is {input.dtype}")
+        core_c = core.contiguous()
+        out = torch.empty((B, H - K + 1, W - K + 1, O), dtype=input.dtype, device=dev)
+        prec = L.precision()
+        L.check(
+            L.lib().dctn_eps_fwd(input.data_ptr(), L.strides5(input), core_c.data_ptr(), out.data_ptr(),
+                                 C, B, H, W, Q, K, O, L.dtype_code(input), prec, L.stream_ptr(dev)),
+            "eps forward",
+        )
+        ctx.save_for_backward(core_c, input)
+        ctx.dims = (C, B, H, W, Q, K, O, prec)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        core_c, input = ctx.saved_tensors
+        C, B, H, W, Q, K, O, prec = ctx.dims
+        need_dcore, need_dx = ctx.needs_input_grad
+        dev = input.device
+        g = d_out.contiguous()
+        d_core = torch.empty_like(core_c) if need_dcore else None
+        d_x = torch.empty((C, B, H, W, Q), dtype=input.dtype, device=dev) if need_dx else None
+        code = L.dtype_code(input)
+        nbytes = L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, int(need_dx), int(need_dcore))
+        ws = L.workspace(nbytes, dev)
+        L.check(
+            L.lib().dctn_eps_bwd(
+                input.data_ptr(), L.strides5(input), core_c.data_ptr(), g.data_ptr(),
+                None if d_x is None else d_x.data_ptr(), None if d_core is None else d_core.data_ptr(),
+                ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
+            "eps backward",
+        )
+        return d_core, d_x
+
+
+def _check_core(core: Tensor, input: Tensor) -> None:
+    num_channels, batch_size, height, width, in_size = input.shape
+    kernel_size = math.isqrt((core.ndim - 1) // num_channels)
+    assert core.shape[:-1] == tuple(in_size for _ in range(kernel_size**2 * num_channels))
+
+
+def eps(core: Tensor, input: Tensor) -> Tensor:
+    """``input``: (channels, batch, height, width, in_size); ``core``: (in_size,)*(K*K*channels) +
+    (out_size,) with factor index = window position (row-major) * channels + channel.
+    Returns (batch, height-K+1, width-K+1, out_size)."""
+    _check_core(core, input)
+    return _EpsFunction.apply(core, input)
+
+
+def eps_one_by_one(core: Tensor, input: Tensor) -> Tensor:
+    """Same contraction.  In the reference this is a second, factor-by-factor evaluation order
+    (dctn/eps.py:43-63) used by its tests; on the device both names run the same fused kernel."""
+    _check_core(core, input)
+    out = _EpsFunction.apply(core, input)
+    num_channels, batch_size, height, width, _ = input.shape
+    kernel_size = math.isqrt((core.ndim - 1) // num_channels)
+    assert out.shape == (batch_size, height - kernel_size + 1, width - kernel_size + 1, core.shape[-1])
+    return out
+
+
+def calc_eps_shape(kernel_size: int, in_num_channels: int, in_size: int, out_size: int) -> Tuple[int, ...]:
+    return (in_size,) * (kernel_size**2 * in_num_channels) + (out_size,)
+
+
+spec_to_shape = calc_eps_shape
+
+
+def total_in_dim_size(kernel_size: int, in_num_channels: int, in_size: int) -> int:
+    return in_size ** (in_num_channels * kernel_size**2)
+
+
+def is_eps(a: Tensor) -> bool:
+    """Whether ``a`` can be an EPS core judging by its shape: all dims but the last are equal."""
+    return a.ndim >= 2 and all(d == a.shape[0] for d in a.shape[:-1])
+
+
+def matrix_shape(eps_core: Tensor) -> Tuple[int, int]:
+    assert is_eps(eps_core)
+    return eps_core.shape[-1], math.prod(eps_core.shape[:-1])
+
+
+def contract_on_input_dims(a: Tensor, b: Tensor) -> Tensor:
+    """(out dim of a, out dim of b): both cores contracted over all their input dims."""
+    assert is_eps(a)
+    assert is_eps(b)
+    return a.reshape(-1, a.shape[-1]).T @ b.reshape(-1, b.shape[-1])
+
+
+def inner_product(a: Tensor, b: Tensor) -> Tensor:
+    assert a.shape == b.shape
+    assert is_eps(a)
+    return torch.dot(a.reshape(-1), b.reshape(-1))
+
+
+@torch.no_grad()
+def transform_in_slices(eps_core: Tensor, x: Tensor, batch_size: int) -> Tensor:
+    """Applies ``eps`` to ``x`` (channels, dataset_size, H, W, in_size) slice by slice along the
+    dataset dim, without autograd; returns (1, dataset_size, H', W', out_size)."""
+    assert is_eps(eps_core)
+    return torch.cat([eps(eps_core, part) for part in x.split(batch_size, dim=1)]).unsqueeze(0)
+
+
+def make_eps_unit_theoretical_output_std(
+    kernel_size: int, in_num_channels: int, in_size: int, out_size: int, device: torch.device, dtype: torch.dtype
+) -> Tensor:
+    """randn scaled by (in_size^(K*K*C))^-1/2, which keeps the std of a unit-variance window."""
+    std = total_in_dim_size(kernel_size, in_num_channels, in_size) ** -0.5
+    getLogger(f"{__name__}.make_eps_unit_theoretical_output_std").info(
+        f"Multiplying the output of randn by {std:.30e}"
+    )
+    shape = calc_eps_shape(kernel_size, in_num_channels, in_size, out_size)
+    return std * torch.randn(*shape, dtype=dtype).to(device)
+
+
+def make_eps_unit_empirical_output_std(
+    kernel_size: int, out_size: int, input: Tensor, device: torch.device, dtype: torch.dtype, batch_size: int
+) -> Tensor:
+    """randn core rescaled so that its output over ``input`` has unit (biased) std."""
+    num_channels, dataset_size, height, width, in_size = input.shape
+    core = torch.randn(*(in_size,) * (kernel_size**2 * num_channels), out_size, dtype=dtype).to(device)
+    output = transform_in_slices(core, input.to(device, dtype), batch_size)
+    inverse_output_std = output.std(unbiased=False) ** -1
+    logger = getLogger(f"{__name__}.make_eps_unit_empirical_output_std")
+    logger.info(f"Multiplying the output of randn by {inverse_output_std:.30e}")
+    core *= inverse_output_std
+    logger.info(f"Initialized an EPS with empirical std = {core.std(unbiased=False):.30e}")
+    return core
+
+
+class EPS(nn.Module):
+    def __init__(self, kernel_size: int, in_num_channels: int, in_size: int, out_size: int):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.in_num_channels = in_num_channels
+        self.in_size = in_size
+        self.out_size = out_size
+        self.core = nn.Parameter(
+            make_eps_unit_theoretical_output_std(
+                kernel_size, in_num_channels, in_size, out_size, torch.device("cpu"), torch.float32
+            )
+        )
+
+    @property
+    def matrix_shape(self) -> Tuple[int, int]:
+        return matrix_shape(self.core)
+
+    def forward(self, input: Tensor) -> Tensor:
+        return eps(self.core, input)

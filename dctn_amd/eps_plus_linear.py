@@ -1,0 +1,133 @@
+"""EPSesPlusLinear: a stack of EPS layers followed by a linear classifier head.
+
+Mirror of the reference's dctn/eps_plus_linear.py:30-196: constructor arguments
+(``epses_specs, initialization, p, device, dtype, image_size=28, Q_0=2``), parameters
+``epses`` (ParameterList) / ``linear`` / buffer ``p`` (state_dict keys ``p``, ``epses.i``,
+``linear.weight``, ``linear.bias``), forward, the two L2 regularisers.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from logging import getLogger
+from typing import Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import eps, epses_composition
+from .utils import OneTensorInitialization, ZeroCenteredNormalInitialization, ZeroCenteredUniformInitialization
+
+
+@dataclass(frozen=True)
+class UnitEmpiricalOutputStd:
+    input: Tensor
+    batch_size: int = 128
+
+
+class UnitTheoreticalOutputStd:
+    pass
+
+
+@dataclass(frozen=True)
+class ManuallyChosenInitialization:
+    epses: Tuple[OneTensorInitialization, ...]
+    linear_weight: OneTensorInitialization
+    linear_bias: OneTensorInitialization
+
+
+Initialization = Union[UnitEmpiricalOutputStd, UnitTheoreticalOutputStd, ManuallyChosenInitialization]
+
+
+class EPSesPlusLinear(nn.Module):
+    def __init__(
+        self,
+        epses_specs: Tuple[Tuple[int, int], ...],
+        initialization: Initialization,
+        p: float,
+        device: torch.device,
+        dtype: torch.dtype,
+        image_size: int = 28,
+        Q_0: int = 2,
+    ):
+        """``epses_specs``: (kernel_size, out_size) per layer; ``p``: probability of KEEPING a
+        component of a core during training (1 = no dropout)."""
+        assert 0.0 < p <= 1
+        super().__init__()
+        if isinstance(initialization, UnitEmpiricalOutputStd):
+            assert initialization.input.shape[2] == image_size
+            assert initialization.input.shape[3] == image_size
+            cores = epses_composition.make_epses_composition_unit_empirical_output_std(
+                epses_specs, initialization.input, device, dtype, initialization.batch_size
+            )
+        elif isinstance(initialization, UnitTheoreticalOutputStd):
+            cores = epses_composition.make_epses_composition_unit_theoretical_output_std(
+                epses_specs, Q_0, device, dtype
+            )
+        elif isinstance(initialization, ManuallyChosenInitialization):
+            cores = epses_composition.make_epses_composition_manually_chosen_inializations(
+                epses_specs, initialization.epses, Q_0, device, dtype
+            )
+        else:
+            raise ValueError(f"initialization={initialization} is not {Initialization}")
+        self.epses = nn.ParameterList(nn.Parameter(core) for core in cores)
+
+        side = image_size - sum(k for k, _ in epses_specs) + len(epses_specs)
+        self.linear = nn.Linear(side * side * eps.matrix_shape(self.epses[-1])[0], 10, bias=True).to(dtype)
+        if isinstance(initialization, ManuallyChosenInitialization):
+            for param, init in (
+                (self.linear.weight, initialization.linear_weight),
+                (self.linear.bias, initialization.linear_bias),
+            ):
+                if isinstance(init, ZeroCenteredNormalInitialization):
+                    param.data.copy_(torch.randn_like(param) * init.std)
+                elif isinstance(init, ZeroCenteredUniformInitialization):
+                    param.data.copy_(torch.rand_like(param) * (2 * init.maximum) - init.maximum)
+                else:
+                    raise ValueError(f"initialization={initialization} must be {ManuallyChosenInitialization}")
+        else:
+            logger = getLogger(f"{__name__}.EPSesPlusLinear.__init__")
+            weight_std = self.linear.in_features**-0.5 / 4.0
+            self.linear.weight.data.copy_(torch.randn_like(self.linear.weight) * weight_std)
+            logger.info(f"Initialized linear.weight as randn * {weight_std:.30e}")
+            bias_max = self.linear.in_features**-0.5
+            self.linear.bias.data.copy_(torch.rand_like(self.linear.bias) * (2 * bias_max) - bias_max)
+            logger.info(f"Initialized linear.bias from Uniform[{-bias_max:.30e}, {bias_max:.30e}]")
+        self.linear.to(device)
+        self.register_buffer("p", torch.tensor(p, device=device, dtype=dtype))
+        self._p_float = float(p)
+
+    def forward(self, input: Tensor) -> Tensor:
+        """``input``: (channels, batch, height, width, Q_0) -> logits (batch, 10)."""
+        if self._p_float < 1.0 and self.training:
+            cores = tuple(self.p.expand_as(core).bernoulli() * core / self.p for core in self.epses)
+        else:
+            cores = tuple(self.epses)
+        features = epses_composition.contract_with_input(cores, input)
+        return self.linear(features.reshape(features.shape[0], -1))
+
+    def epswise_l2_regularizer(self) -> Tensor:
+        """||linear.weight||^2 + sum of squared Frobenius norms of the cores (bias excluded)."""
+        return self.linear.weight.norm(p="fro") ** 2 + epses_composition.epswise_squared_fro_norm(self.epses)
+
+    def epses_composition_l2_regularizer(self) -> Tensor:
+        return self.linear.weight.norm(p="fro") ** 2 + epses_composition.inner_product(self.epses, self.epses)
+
+    @torch.no_grad()
+    def log_intermediate_reps_stats(self, x: Tensor, batch_size: int = 128) -> None:
+        """Logs mean / std of every intermediate representation (as in eval mode)."""
+        logger = getLogger(f"{__name__}.EPSesPlusLinear.log_intermediate_reps_stats")
+
+        def log_one(t: Tensor, name: str) -> None:
+            mu, sigma = t.mean(), t.std(unbiased=False)
+            logger.info(f"{name}: mu={mu:.7e}, sigma={sigma:.7e}, mu^2+sigma^2={mu**2+sigma**2:.7e}, shape={tuple(t.shape)}")
+
+        for n, core in enumerate(self.epses):
+            log_one(x, f"x_{n}")
+            x = eps.transform_in_slices(core, x, batch_size)
+        flat = x.reshape(x.shape[1], -1)
+        log_one(flat, f"x_{len(self.epses)}")
+        log_one(F.linear(flat, self.linear.weight), "output_of_linear_without_bias")
+        log_one(self.linear(flat), "output_of_linear_with_bias")

@@ -1,0 +1,136 @@
+/*
+ * dctn_amd — C-ABI of the MI355X (gfx950) kernel library for dctn's hot path.
+ *
+ * Drop-in boundary.  The reference (philip-bl/dctn) is pure Python: it has no FFI for this path;
+ * its arithmetic is delegated to opt_einsum -> torch.einsum.  The entry points below are what a
+ * binding for this path binds (ctypes stub: INTEGRATION.md); each one names the reference
+ * function whose arithmetic it replaces (file:line relative to the reference repository).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes and element strides; no torch / C++ types.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream).  No allocation, no synchronisation, no host<->device copies inside: calls can be
+ *     captured into a hipGraph.  Scratch memory is supplied by the caller (`*_workspace_bytes`).
+ *   - return value: 0 on success, negative DCTN_ERR_* otherwise (dctn_strerror()).  The Python
+ *     host layer turns shape errors into AssertionError like the reference's `assert`s.
+ *   - dtype codes: DCTN_F32 / DCTN_F64 / DCTN_BF16 (bf16 storage, fp32 accumulation).
+ *   - re-entrant; no global mutable state.
+ */
+#ifndef DCTN_AMD_H
+#define DCTN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DCTN_F32 = 0, DCTN_F64 = 1, DCTN_BF16 = 2 };
+
+enum {
+  DCTN_OK = 0,
+  DCTN_ERR_BAD_SHAPE = -1,    /* sizes inconsistent (reference: AssertionError) */
+  DCTN_ERR_BAD_DTYPE = -2,    /* unknown dtype code */
+  DCTN_ERR_UNSUPPORTED = -3,  /* valid request no kernel of this build covers */
+  DCTN_ERR_WORKSPACE = -4,    /* workspace missing or too small */
+  DCTN_ERR_LAUNCH = -5,       /* HIP reported a launch error */
+  DCTN_ERR_NULL = -6          /* required pointer is NULL */
+};
+
+/* precision policy for float32 tensors on the MFMA paths */
+enum {
+  DCTN_PREC_EXACT = 0, /* f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32 or VALU fma) */
+  DCTN_PREC_BF16 = 1   /* operands rounded to bf16, f32 accumulate (v_mfma_f32_32x32x16_bf16) */
+};
+
+int dctn_version(void);
+const char* dctn_strerror(int code);
+/* name of the kernel family the last successful call on this thread dispatched to
+ * (diagnostics / tests: proves which HIP path ran) */
+const char* dctn_last_kernel(void);
+
+/* ------------------------------------------------------------------------------------------
+ * EPS — replaces dctn/eps.py:19-40 `eps(core, input)` (and :43-63 `eps_one_by_one`, same result)
+ *   x    : (C, B, H, W, Q) with element strides x_strides[5]
+ *   core : (Q,)*(K*K*C) + (O,) contiguous == row-major matrix (Q^(K*K*C), O); factor index
+ *          n = pos*C + ch, pos row-major over (dh, dw)  (dctn/align.py:31-32,41-45)
+ *   out  : (B, H-K+1, W-K+1, O) contiguous
+ * ------------------------------------------------------------------------------------------ */
+int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
+                 int C, int B, int H, int W, int Q, int K, int O,
+                 int dtype, int precision, void* stream);
+
+/* Autograd of the above (reference: torch autograd through the 4 path steps, dctn/training.py:81).
+ *   dY    : (B, H', W', O) contiguous
+ *   dX    : (C, B, H, W, Q) contiguous, or NULL when the input needs no gradient
+ *   dCore : same layout as core, or NULL
+ *   Both are OVERWRITTEN (not accumulated).  `workspace` must hold dctn_eps_bwd_workspace_bytes().
+ */
+size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
+                                    int dtype, int precision, int need_dx, int need_dcore);
+int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
+                 void* dX, void* dCore, void* workspace, size_t workspace_bytes,
+                 int C, int B, int H, int W, int Q, int K, int O,
+                 int dtype, int precision, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ConvSBS — replaces dctn/conv_sbs.py:258-304 `ConvSBS.forward`
+ *   x         : (C, B, H, W, q) with element strides x_strides[5] (channel c = x[c])
+ *   n_cores   : number of cores in the string (string order)
+ *   cores[c]  : device pointer to core c, shape (out_sizes[c], bond_sizes[c],
+ *               bond_sizes[(c+1)%n], q, ..., q [C times]) contiguous (dctn/conv_sbs_spec.py:24-27,65-80)
+ *   pos_h/pos_w : position of core c inside the window (min must be 0, dctn/align.py:18-19)
+ *   out       : (B, H-max_h, W-max_w, prod(out_sizes)) contiguous, out dims in string order
+ * ------------------------------------------------------------------------------------------ */
+size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int* bond_sizes,
+                                    int C, int B, int H, int W, int q,
+                                    const int* pos_h, const int* pos_w, int dtype, int backward);
+int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* const* cores,
+                     void* out, int n_cores, const int* out_sizes, const int* bond_sizes,
+                     const int* pos_h, const int* pos_w,
+                     int C, int B, int H, int W, int q,
+                     void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* dX (C,B,H,W,q contiguous) and dCores[c] (same layout as cores[c]) are OVERWRITTEN; either
+ * dX or the whole dCores array may be NULL. */
+int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* const* cores,
+                     const void* dY, void* dX, void* const* dCores,
+                     int n_cores, const int* out_sizes, const int* bond_sizes,
+                     const int* pos_h, const int* pos_w,
+                     int C, int B, int H, int W, int q,
+                     void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * logmatmulexp — replaces dctn/logmatmulexp.py:5-14 (and the checkpointed :17-22; nothing of
+ * size Theta*R*I is ever materialised here, forward or backward).
+ *   batched: logA (batch, Theta, R), logB (batch, R, I), out (batch, Theta, I), all contiguous;
+ *   the reference's strictly 2-D call is batch == 1.  stride_*_batch in elements (0 = broadcast).
+ * ------------------------------------------------------------------------------------------ */
+int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out,
+                          int64_t batch, int Theta, int R, int I,
+                          int64_t strideA_batch, int64_t strideB_batch,
+                          int dtype, void* stream);
+/* dA / dB are OVERWRITTEN; either may be NULL.  With a broadcast operand (stride 0) its
+ * gradient is summed over the batch. */
+int dctn_logmatmulexp_bwd(const void* logA, const void* logB, const void* out, const void* dOut,
+                          void* dA, void* dB,
+                          int64_t batch, int Theta, int R, int I,
+                          int64_t strideA_batch, int64_t strideB_batch,
+                          int dtype, void* stream);
+
+/* Left fold over L square log-matrices per window — the loop
+ * `reduce(logmatmulexp, matrices)` of small_experiments/logmatmulexp_benchmark/benchmark.py:30,
+ * batched over windows (BASELINE config 5).
+ *   mats : (Wn, L, D, D) contiguous;  out : (Wn, D, D)
+ * Backward recomputes the prefix folds; `workspace` holds dctn_logmatmulexp_fold_workspace_bytes(). */
+size_t dctn_logmatmulexp_fold_workspace_bytes(int64_t Wn, int L, int D, int dtype, int backward);
+int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, int D,
+                               int dtype, void* stream);
+int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats,
+                               void* workspace, size_t workspace_bytes,
+                               int64_t Wn, int L, int D, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTN_AMD_H */

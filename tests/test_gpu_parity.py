@@ -1,0 +1,296 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the Python
+host layer and the C-ABI, against (a) the golden vectors produced by the reference itself and
+(b) the CPU oracle on seeded inputs.  Tolerances are stated per dtype below.
+
+Nothing here reads /root/reference.
+"""
+import functools
+import glob
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dctn_amd
+from dctn_amd import _lib
+from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization, ManyConvSBS
+from dctn_amd.conv_sbs_spec import SBSSpecCore, SBSSpecString
+from dctn_amd.eps import eps, eps_one_by_one, transform_in_slices
+from dctn_amd.epses_composition import contract_with_input
+from dctn_amd.logmatmulexp import logmatmulexp, logmatmulexp_batched, logmatmulexp_fold, logmatmulexp_lowmem
+from dctn_amd.pos2d import Pos2D
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = torch.device("cuda:0")
+
+# float64: different summation order only.  float32: fp32 accumulation of up to 2^16 products.
+TOL = {torch.float64: dict(rtol=1e-9, atol=1e-11), torch.float32: dict(rtol=2e-4, atol=2e-5)}
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def dev(a, dtype=None, grad=False):
+    t = torch.from_numpy(np.asarray(a)).to(DEV)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.requires_grad_(grad)
+
+
+def close(got, want, dtype, scale=None):
+    want = torch.as_tensor(want).to(torch.float64)
+    got = got.detach().cpu().to(torch.float64)
+    tol = dict(TOL[dtype])
+    if scale is None:
+        scale = float(want.abs().max()) or 1.0
+    tol["atol"] = tol["atol"] * max(scale, 1e-30)
+    ok = torch.allclose(got, want, **tol)
+    if not ok:
+        print("max abs err", float((got - want).abs().max()), "scale", scale)
+    return ok
+
+
+EPS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "eps_c*.npz")))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("name", EPS_CASES)
+def test_eps_golden(name, dtype):
+    g = load(name)
+    x, core = dev(g["x"], dtype, True), dev(g["core"], dtype, True)
+    y = eps(core, x)
+    assert "eps_fwd" in dctn_amd.last_kernel()
+    assert y.shape == g["y"].shape and y.dtype == dtype
+    assert close(y, g["y"], dtype)
+    assert close(eps_one_by_one(core, x), g["y_one_by_one"], dtype)
+    y.backward(dev(g["dy"], dtype))
+    assert "eps_bwd" in dctn_amd.last_kernel()
+    assert close(x.grad, g["dx"], dtype)
+    assert close(core.grad, g["dcore"], dtype)
+
+
+def test_eps_single_pixel_output():  # reference test: tests/test_eps.py:9-26
+    x = torch.randn((2, 3, 2, 2, 2), dtype=torch.float64)
+    core = torch.rand((*(2 for _ in range(8)), 4), dtype=torch.float64)
+    got = eps_one_by_one(core.to(DEV), x.to(DEV)).reshape(3, 4)
+    want = torch.einsum("abcdefgho,ia,ib,ic,id,ie,if,ig,ih->io", core, x[0, :, 0, 0], x[1, :, 0, 0], x[0, :, 0, 1],
+                        x[1, :, 0, 1], x[0, :, 1, 0], x[1, :, 1, 0], x[0, :, 1, 1], x[1, :, 1, 1])
+    assert torch.allclose(got.cpu(), want)
+
+
+def test_eps_two_pixels_output():  # reference test: tests/test_eps.py:29-61
+    x = torch.randn((1, 1, 4, 3, 2), dtype=torch.float64)
+    core = torch.rand((*(2 for _ in range(9)), 4), dtype=torch.float64)
+    got = eps_one_by_one(core.to(DEV), x.to(DEV)).cpu()
+    assert got.shape == (1, 2, 1, 4)
+    for row in (0, 1):
+        pix = [x[0, 0, row + dh, dw] for dh in range(3) for dw in range(3)]
+        want = torch.einsum("abcdefghio,a,b,c,d,e,f,g,h,i->o", core, *pix)
+        assert torch.allclose(got[0, row, 0], want)
+
+
+@pytest.mark.parametrize(
+    "C,B,H,W,Q,K,O,dtype",
+    [
+        (1, 5, 28, 28, 2, 3, 4, torch.float32),   # BASELINE cfg2 geometry, reduced batch
+        (1, 2, 28, 28, 2, 4, 2, torch.float64),   # cfg1 geometry (eps2d benchmark), reduced batch
+        (1, 2, 12, 11, 2, 4, 4, torch.float32),   # cfg3a layer 1 core
+        (1, 2, 6, 7, 4, 3, 6, torch.float32),     # cfg3a layer 2 core (6 MiB), reduced image
+        (1, 3, 9, 9, 8, 2, 8, torch.float32),     # cfg3b layer 2
+        (2, 2, 7, 6, 2, 2, 3, torch.float64),     # two channels
+        (1, 2, 7, 7, 3, 2, 20, torch.float32),    # out_size > 8 (several o-tiles)
+        (3, 2, 4, 4, 3, 1, 5, torch.float64),     # K = 1
+        (1, 70, 5, 5, 2, 3, 4, torch.float32),    # several workgroups, ragged tail
+    ],
+)
+def test_eps_vs_oracle_seeded(C, B, H, W, Q, K, O, dtype):
+    torch.manual_seed(C * 1000 + B * 100 + K * 10 + Q)
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q, dtype=dtype)
+    core = torch.randn(*(Q,) * N, O, dtype=dtype) * Q ** (-N / 4)
+    xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    want = R.eps_4step(core.double(), x.double())
+    assert close(y, want, dtype)
+    dy = torch.randn(*want.shape, dtype=dtype)
+    y.backward(dy.to(DEV))
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    assert close(xd.grad, dx, dtype)
+    assert close(cd.grad, dcore, dtype)
+
+
+def test_eps_noncontiguous_input_and_needs_input_grad():
+    torch.manual_seed(3)
+    big = torch.randn(1, 9, 8, 8, 2, dtype=torch.float64, device=DEV)
+    core = (torch.randn(*(2,) * 9, 4, dtype=torch.float64, device=DEV) / 4).requires_grad_(True)
+    part = big.split(4, dim=1)[1]                      # dctn/eps.py:136 passes such slices
+    assert not part.is_contiguous() or part.storage_offset() != 0
+    perm = big.permute(0, 1, 3, 2, 4)                  # genuinely strided
+    for v in (part, perm):
+        want = R.eps_4step(core.detach().cpu(), v.cpu())
+        assert close(eps(core, v), want, torch.float64)
+    y = eps(core, perm)                                # input without grad: only dCore is produced
+    y.backward(torch.ones_like(y))
+    assert core.grad is not None
+    frozen = core.detach()                             # new_runner.py:443-444 freezes cores
+    xg = perm.clone().requires_grad_(True)
+    eps(frozen, xg).sum().backward()
+    dcore, dx = R.grads(R.eps_4step, [frozen.cpu(), perm.cpu()], torch.ones(y.shape, dtype=torch.float64))
+    assert close(xg.grad, dx, torch.float64)
+    assert close(core.grad, dcore, torch.float64)
+    out = transform_in_slices(frozen, big, 4)
+    assert out.shape == (1, 9, 6, 6, 4) and not out.requires_grad
+
+
+def test_epses_composition_golden_and_eps_plus_linear():
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    g = load("epses_composition_33_25")
+    for dtype in (torch.float64, torch.float32):
+        x, e1, e2 = dev(g["x"], dtype, True), dev(g["e1"], dtype, True), dev(g["e2"], dtype, True)
+        y = contract_with_input((e1, e2), x)
+        assert close(y, g["y"], dtype)
+        y.backward(dev(g["dy"], dtype))
+        assert close(x.grad, g["dx"], dtype) and close(e1.grad, g["de1"], dtype) and close(e2.grad, g["de2"], dtype)
+    torch.manual_seed(5)
+    m = EPSesPlusLinear(((3, 4), (2, 3)), UnitTheoreticalOutputStd(), 1.0, DEV, torch.float32, image_size=10)
+    x = torch.rand(1, 6, 10, 10, 2, device=DEV)
+    out = m(x)
+    assert out.shape == (6, 10)
+    want = R.eps_plus_linear_forward([c.detach().cpu().double() for c in m.epses], m.linear.weight.detach().cpu().double(),
+                                     m.linear.bias.detach().cpu().double(), x.cpu().double())
+    assert close(out, want, torch.float32)
+    out.logsumexp(1).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    m.train()
+    m.p.fill_(0.5); m._p_float = 0.5                    # component dropout path (eps_plus_linear.py:139-143)
+    assert m(x).shape == (6, 10)
+
+
+# ------------------------------------------------------------------ ConvSBS
+SBS_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "sbs_*.npz")))
+
+
+def sbs_from_golden(g, dtype):
+    spec = SBSSpecString(
+        tuple(SBSSpecCore(Pos2D(int(h), int(w)), int(o)) for (h, w), o in zip(g["positions"], g["out_sizes"])),
+        tuple(int(b) for b in g["bond_sizes"]), int(g["C"]), int(g["q"]),
+    )
+    m = ConvSBS(spec).to(dtype)
+    with torch.no_grad():
+        for i, c in enumerate(m.cores):
+            c.copy_(torch.from_numpy(g[f"core{i}"]))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("name", SBS_CASES)
+def test_convsbs_golden(name, dtype):
+    g = load(name)
+    m = sbs_from_golden(g, dtype)
+    x = dev(g["x"], dtype, True)
+    y = m(x)
+    assert "convsbs_fwd" in dctn_amd.last_kernel()
+    assert close(y, g["y"], dtype)
+    y.backward(dev(g["dy"], dtype))
+    assert close(x.grad, g["dx"], dtype)
+    for i, c in enumerate(m.cores):
+        assert close(c.grad, g[f"dcore{i}"], dtype), f"dcore{i}"
+    # tuple-of-channels input (conv_sbs.py:258-262) gives the same result
+    y2 = m(tuple(ch for ch in x.detach()))
+    assert torch.equal(y2, y.detach())
+
+
+def test_conversion_all_24_permutations():  # reference test: tests/test_conversion_of_convsbs_to_eps.py:13-56
+    cores = (SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 3), SBSSpecCore(Pos2D(1, 0), 2), SBSSpecCore(Pos2D(1, 1), 4))
+    torch.manual_seed(24)
+    for perm in itertools.permutations(cores):
+        spec = SBSSpecString(perm, (3, 4, 5, 6), 2, 2)
+        m = ConvSBS(spec).double().to(DEV)
+        with torch.no_grad():
+            eps_tensor = m.as_eps()
+        assert eps_tensor.shape == (2,) * 8 + (24,)
+        x = torch.randn(2, 3, 4, 5, 2, dtype=torch.float64, device=DEV, requires_grad=True)
+        ys = m(x)
+        dy = torch.randn_like(ys)
+        ys.backward(dy)
+        g_sbs = x.grad.clone()
+        x.grad.zero_()
+        ye = eps(eps_tensor, x)
+        assert torch.allclose(ye, ys)
+        ye.backward(dy)
+        assert torch.allclose(x.grad, g_sbs)
+
+
+@pytest.mark.parametrize("r,q,C,B,HW", [(4, 3, 1, 3, 12), (8, 3, 1, 2, 10), (16, 3, 1, 2, 8), (16, 2, 2, 2, 7)])
+def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
+    """BASELINE cfg4: the 9-core snake of mnist.py:190-199 on the CIFAR colour layout (q=3) and its
+    second-layer variant (C=2, q=2), float32."""
+    snake = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]
+    torch.manual_seed(r * 10 + q)
+    many = ManyConvSBS(C, q, r, False, (tuple(SBSSpecCore(Pos2D(*p), 2 if i == 4 else 1) for i, p in enumerate(snake)),),
+                       (DumbNormalInitialization((q**C * r) ** -0.5),))
+    m = many.strings[0].to(DEV)
+    x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
+    (y,) = many(x)
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, snake, x.detach().cpu().double())
+    assert close(y, want, torch.float32)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, snake, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
+    assert close(x.grad, gr[0], torch.float32)
+    for c, gc in zip(m.cores, gr[1:]):
+        assert close(c.grad, gc, torch.float32)
+
+
+# ------------------------------------------------------------------ logmatmulexp
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_logmatmulexp_golden(dtype):
+    g = load("logmatmulexp")
+    for i in (0, 1):
+        A, B = dev(g[f"A{i}"], dtype, True), dev(g[f"B{i}"], dtype, True)
+        y = logmatmulexp(A, B)
+        assert close(y, g[f"y{i}"], dtype)
+        y.backward(dev(g[f"dy{i}"], dtype))
+        assert close(A.grad, g[f"dA{i}"], dtype) and close(B.grad, g[f"dB{i}"], dtype)
+        assert torch.equal(logmatmulexp_lowmem(A.detach(), B.detach()), y.detach())
+    y2 = logmatmulexp(dev(g["A2"], dtype), dev(g["B2"], dtype)).cpu()
+    want = torch.from_numpy(g["y2"])
+    assert torch.equal(torch.isinf(y2), torch.isinf(want)) and torch.all(y2[2] == -float("inf"))
+    fin = torch.isfinite(want)
+    assert close(y2[fin], want[fin], dtype)
+    with pytest.raises(AssertionError):  # dctn/logmatmulexp.py:10
+        logmatmulexp(dev(g["A0"], dtype), dev(g["A0"], dtype))
+
+
+def test_logmatmulexp_fold_and_batched():
+    g = load("logmatmulexp")
+    mats = dev(g["fold_mats"], torch.float32)
+    y = functools.reduce(logmatmulexp, list(mats))       # logmatmulexp_benchmark/benchmark.py:30
+    assert torch.allclose(y.cpu(), torch.from_numpy(g["fold_y"]), rtol=1e-5, atol=1e-4)
+    torch.manual_seed(9)
+    m = torch.randn(37, 9, 16, 16, dtype=torch.float64)  # BASELINE cfg5 geometry: 9 16x16 matrices / window
+    md = m.to(DEV).requires_grad_(True)
+    yf = logmatmulexp_fold(md)
+    want = R.logmatmulexp_fold_batched(m)
+    assert close(yf, want, torch.float64)
+    dy = torch.randn_like(want)
+    yf.backward(dy.to(DEV))
+    (gm,) = R.grads(R.logmatmulexp_fold_batched, [m], dy)
+    assert close(md.grad, gm, torch.float64)
+    a, b = torch.randn(5, 4, 6, dtype=torch.float64), torch.randn(1, 6, 3, dtype=torch.float64)
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yb = logmatmulexp_batched(ad, bd)
+    ref = lambda aa, bb: torch.logsumexp(aa.unsqueeze(3) + bb.unsqueeze(1), dim=2)
+    assert close(yb, ref(a, b), torch.float64)
+    dyb = torch.randn(5, 4, 3, dtype=torch.float64)
+    yb.backward(dyb.to(DEV))
+    ga, gb = R.grads(ref, [a, b], dyb)
+    assert close(ad.grad, ga, torch.float64) and close(bd.grad, gb, torch.float64)

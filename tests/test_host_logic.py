@@ -1,0 +1,250 @@
+"""CPU tests (no GPU): host-side mirror of the reference interface, C-ABI exports, and the
+loud failure of the product path without a device.  The assertions marked "reference test"
+restate /root/reference/tests/*.py against this package."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dctn_amd
+from dctn_amd import _lib
+from dctn_amd.align import align, align_with_positions
+from dctn_amd.contraction_path_cache import ContractionPathCache, contract
+from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization, KhrulkovNormalInitialization, ManyConvSBS
+from dctn_amd.conv_sbs_spec import SBSCoreShape, SBSSpecCore, SBSSpecString
+from dctn_amd.eps import EPS, contract_on_input_dims, eps, is_eps, matrix_shape
+from dctn_amd.epses_composition import inner_product, specs_to_full_specs
+from dctn_amd.pos2d import Pos2D, index_to_pos, pos_to_index
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+# ------------------------------------------------------------------ C-ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "dctn_amd.h")).read()
+    declared = set(re.findall(r"\b(dctn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} not exported by {_lib.LIB_PATH}"
+    assert _lib.lib().dctn_version() >= 100
+    assert _lib.lib().dctn_strerror(-1) == b"inconsistent shape"
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens on the host before any launch, so it is checkable here."""
+    lib = _lib.lib()
+    s = (ctypes.c_int64 * 5)(1, 1, 1, 1, 1)
+    assert lib.dctn_eps_fwd(None, s, None, None, 1, 1, 4, 4, 2, 3, 4, 0, 0, None) == _lib.ERR_NULL
+    assert lib.dctn_eps_fwd(8, s, 8, 8, 1, 1, 2, 2, 2, 3, 4, 0, 0, None) == _lib.ERR_BAD_SHAPE  # H < K
+    assert lib.dctn_eps_fwd(8, s, 8, 8, 1, 1, 4, 4, 2, 3, 4, 7, 0, None) == _lib.ERR_BAD_DTYPE
+    assert lib.dctn_eps_bwd_workspace_bytes(1, 2, 8, 8, 2, 3, 4, 0, 0, 1, 1) > 0
+    assert lib.dctn_logmatmulexp_fwd(8, 8, 8, 1, 0, 3, 3, 0, 0, 0, None) == _lib.ERR_BAD_SHAPE
+
+
+def test_product_path_has_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eps(torch.randn(2, 2, 2, 2, 3), torch.randn(1, 2, 4, 4, 2))
+    from dctn_amd.logmatmulexp import logmatmulexp
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        logmatmulexp(torch.randn(3, 4), torch.randn(4, 5))
+    spec = SBSSpecString((SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 2)), (1, 3), 1, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ConvSBS(spec)(torch.randn(1, 2, 3, 3, 2))
+
+
+def test_product_code_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dctn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+    for f in os.listdir(os.path.join(ROOT, "dctn")):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "dctn", f)).read()
+
+
+def test_shape_errors_are_assertion_errors():
+    # reference: dctn/eps.py:22 asserts the core's input dims equal in_size
+    with pytest.raises(AssertionError):
+        eps(torch.randn(3, 3, 3, 3, 4), torch.randn(1, 2, 4, 4, 2))
+
+
+# ------------------------------------------------------------------ pos2d / align (bit-exact)
+def test_pos_index_conversion():  # reference test: tests/test_pos2d.py:4-31
+    for max_w, cases in ((3, ((Pos2D(0, 0), 0), (Pos2D(1, 0), 4), (Pos2D(1, 1), 5), (Pos2D(2, 3), 11))),
+                         (0, ((Pos2D(0, 0), 0), (Pos2D(1, 0), 1), (Pos2D(2, 0), 2), (Pos2D(3, 0), 3)))):
+        for pos, index in cases:
+            assert pos_to_index(max_w, pos) == index
+            assert index_to_pos(max_w, index) == pos
+
+
+def test_pos2d_golden_table():
+    for max_w, idx, h, w, back in load("pos2d")["table"]:
+        assert index_to_pos(int(max_w), int(idx)) == Pos2D(int(h), int(w))
+        assert pos_to_index(int(max_w), Pos2D(int(h), int(w))) == int(back)
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_align_golden_index_map(K):
+    g = load(f"align_k{K}")
+    H, W = int(g["H"]), int(g["W"])
+    ramp = torch.arange(H * W, dtype=torch.float64).reshape(1, 1, H, W, 1)
+    views = torch.stack(list(align(ramp, K)))[:, 0, :, :, 0].to(torch.int64).numpy()
+    assert np.array_equal(views, g["src"])
+
+
+def test_align_with_positions_golden_and_asserts():
+    g = load("align_snake")
+    H, W = int(g["H"]), int(g["W"])
+    ramp = torch.arange(H * W, dtype=torch.float64).reshape(1, 1, H, W, 1)
+    pos = tuple(Pos2D(int(h), int(w)) for h, w in g["positions"])
+    views = torch.stack(list(align_with_positions(ramp, pos)))[:, 0, :, :, 0].to(torch.int64).numpy()
+    assert np.array_equal(views, g["src"])
+    with pytest.raises(AssertionError):  # dctn/align.py:18-19
+        list(align_with_positions(ramp, (Pos2D(1, 0), Pos2D(1, 1))))
+
+
+# ------------------------------------------------------------------ spec
+def test_all_dangling_dim_names():  # reference test: tests/test_conv_sbs_spec.py:5-35
+    spec = SBSSpecString(
+        (SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 1), SBSSpecCore(Pos2D(1, 1), 2), SBSSpecCore(Pos2D(1, 0), 1)),
+        bond_sizes=(5, 5, 5, 5), in_num_channels=3, in_quantum_dim_size=100,
+    )
+    expect = tuple(f"in_quantum_{c}_{k}" for k in range(4) for c in range(3)) + tuple(f"out_quantum_{k}" for k in range(4))
+    assert spec.all_dangling_dim_names == expect
+
+
+def test_spec_shapes_and_validators():
+    cores = (SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 3), SBSSpecCore(Pos2D(1, 0), 2), SBSSpecCore(Pos2D(1, 1), 4))
+    spec = SBSSpecString(cores, (3, 4, 5, 6), 2, 2)
+    assert [s.as_tuple() for s in spec.shapes] == [(1, 3, 4, 2, 2), (3, 4, 5, 2, 2), (2, 5, 6, 2, 2), (4, 6, 3, 2, 2)]
+    assert spec.out_total_quantum_dim_size == 24 and len(spec) == 4
+    assert spec.nelement == (1 * 4) * (3 * 4) * (2 * 4) * (4 * 4)
+    assert spec.get_indices_wrt_standard_order() == (0, 1, 2, 3)
+    assert spec.get_dim_names(3) == ("out_quantum_3", "bond_3", "bond_0", "in_quantum_0_3", "in_quantum_1_3")
+    assert SBSCoreShape(2, 3, 4, 2, 5).dimensions_names == ("out_quantum", "bond_left", "bond_right", "in_quantum_0", "in_quantum_1")
+    with pytest.raises(ValueError):
+        SBSSpecString((SBSSpecCore(Pos2D(1, 0), 1), SBSSpecCore(Pos2D(1, 1), 1)), (1, 2), 1)
+    with pytest.raises(ValueError):
+        SBSSpecString(cores, (1, 2, 3), 1)
+    g = load("sbs_2x2_ring_perm0")
+    assert np.array_equal(np.array([s.as_tuple()[:3] for s in spec.shapes]), g["shapes"])
+
+
+# ------------------------------------------------------------------ path cache
+def test_contraction_path_cache_formats_bit_identical():  # reference test: tests/test_contraction_path_cache.py:6-26
+    cache = ContractionPathCache()
+    a, b = torch.randn(3, 4), torch.randn(4, 5)
+    ab0 = cache.contract("ij,jk->ijk", a, b)
+    for ab in (cache.contract("ij,jk->ijk", a, b), cache.contract(a, "ij", b, "jk", "ijk"),
+               cache.contract(a, (0, 1), b, (1, 2), (0, 1, 2))):
+        assert torch.all(ab == ab0)
+    assert ContractionPathCache() is cache
+    n = len(cache.paths)
+    contract("ij,jk->ijk", a, b)
+    assert len(cache.paths) == n  # memoised on shapes + subscripts
+    assert torch.allclose(contract("ij,jk->ik", a, b), a @ b, atol=1e-6)
+    assert torch.allclose(contract(a, ("x", "y"), ()), a.sum(), atol=1e-5)
+
+
+# ------------------------------------------------------------------ parameter-only contractions
+def test_contract_on_inner_dims():  # reference test: tests/test_eps.py:64-73
+    a = torch.einsum("oi,j->ijo", torch.eye(3), 2.0 * torch.ones(3))
+    assert torch.allclose(contract_on_input_dims(a, a), 12.0 * torch.eye(3))
+    a = torch.einsum("oi,j->ijo", 2.0 * torch.eye(4), torch.tensor([1.0, 2.0, 3.0, 4.0]))
+    b = torch.einsum("pj,i->ijp", 3.0 * torch.eye(4), torch.ones(4))
+    assert torch.allclose(contract_on_input_dims(a, b),
+                          torch.einsum("o,p->op", 2.0 * torch.ones(4), torch.tensor([3.0, 6.0, 9.0, 12.0])))
+
+
+def test_epses_inner_product_closed_forms():  # reference test: tests/test_epses_composition.py:7-41
+    a = torch.einsum("oi,j->ijo", torch.eye(3), torch.ones(3))
+    assert torch.allclose(inner_product((a,), (a,)), torch.tensor(9.0))
+    assert torch.allclose(inner_product((a, a), (a, a)), torch.tensor(3.0**4))
+    assert torch.allclose(inner_product((a, a, a), (a, a, a)), torch.tensor(3.0**8))
+    green = torch.einsum("oj,i->ijo", torch.eye(6)[:4], torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))
+    black = torch.einsum("oi,j->ijo", torch.eye(4)[:3], torch.tensor([1.5, 0.0, 0.0, 0.0]))
+    orange = torch.einsum("oi,j->ijo", torch.eye(6)[:4], torch.ones(6))
+    red = torch.einsum("oi,j->ijo", torch.eye(4)[1:], torch.tensor([1.0, 0.0, 0.0, 1.0]))
+    assert torch.allclose(inner_product((green, black), (orange, red)), torch.tensor((2 + 3 + 4) * 5 * 1.5))
+
+
+@pytest.mark.parametrize("name", ["sbs_2x2_ring_perm0", "sbs_2x2_ring_perm1"])
+def test_convsbs_parameter_contractions_match_reference(name):
+    g = load(name)
+    spec = SBSSpecString(
+        tuple(SBSSpecCore(Pos2D(int(h), int(w)), int(o)) for (h, w), o in zip(g["positions"], g["out_sizes"])),
+        tuple(int(b) for b in g["bond_sizes"]), int(g["C"]), int(g["q"]),
+    )
+    m = ConvSBS(spec).double()
+    with torch.no_grad():
+        for i, c in enumerate(m.cores):
+            c.copy_(torch.from_numpy(g[f"core{i}"]))
+        assert m.as_eps().shape == (2,) * 8 + (24,)
+        assert torch.all(m.as_eps() == m.as_eps())  # deterministic (tests/test_conversion...:33)
+        assert torch.allclose(m.as_eps(), torch.from_numpy(g["as_eps"]), rtol=1e-10, atol=1e-12)
+        assert torch.allclose(m.as_explicit_tensor(), torch.from_numpy(g["explicit"]), rtol=1e-10, atol=1e-12)
+        assert torch.allclose(m.sum(), torch.from_numpy(g["tt_sum"]), rtol=1e-10)
+        assert torch.allclose(m.squared_fro_norm(), torch.from_numpy(g["tt_sqnorm"]), rtol=1e-10)
+        assert torch.allclose(m.var(), torch.from_numpy(g["tt_var"]), rtol=1e-9)
+        explicit = m.as_explicit_tensor()  # reference test: tests/test_conv_sbs.py:52-57
+        assert torch.allclose(m.var(), explicit.var(), rtol=1e-9)
+        assert torch.allclose(m.mean(), explicit.mean(), rtol=1e-9)
+        assert torch.allclose(m.fro_norm(), explicit.norm(), rtol=1e-9)
+
+
+def test_khrulkov_init_reaches_requested_std():  # reference test: tests/test_conv_sbs.py:10-50 (reduced draws)
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(0, i), 2 if i == 1 else 1) for i in range(4)), (1, 3, 3, 3), 1, 2)
+    stds = [float(ConvSBS(spec, KhrulkovNormalInitialization(0.5)).as_explicit_tensor().std()) for _ in range(300)]
+    assert abs(np.sqrt(np.mean(np.square(stds))) - 0.5) / 0.5 < 0.3
+
+
+def test_module_surfaces():
+    e = EPS(3, 1, 2, 4)
+    assert e.core.shape == (2,) * 9 + (4,) and e.core.dtype == torch.float32 and e.core.device.type == "cpu"
+    assert e.matrix_shape == (4, 512) and is_eps(e.core) and matrix_shape(e.core) == (4, 512)
+    assert specs_to_full_specs(((4, 4), (3, 6)), 2) == (
+        dict(kernel_size=4, in_num_channels=1, in_size=2, out_size=4),
+        dict(kernel_size=3, in_num_channels=1, in_size=4, out_size=6),
+    )
+    many = ManyConvSBS(1, 2, 3, False, ((SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 2)),) * 2)
+    assert [tuple(c.shape) for c in many.strings[0].cores] == [(1, 1, 3, 2), (2, 3, 1, 2)]
+    ring = ManyConvSBS(2, 2, 3, True, ((SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 2)),),
+                       (DumbNormalInitialization(0.5),))
+    assert [tuple(c.shape) for c in ring.strings[0].cores] == [(1, 3, 3, 2, 2), (2, 3, 3, 2, 2)]
+    import dctn.eps as alias  # drop-in module path
+
+    assert alias.eps is eps
+
+
+def test_eps_plus_linear_ctor_state_dict_and_manual_init():  # cf. reference tests/test_eps_plus_linear.py:13-36
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, ManuallyChosenInitialization, UnitTheoreticalOutputStd
+    from dctn_amd.utils import ZeroCenteredNormalInitialization, ZeroCenteredUniformInitialization
+
+    for dtype in (torch.float32, torch.float64):
+        m = EPSesPlusLinear(((3, 4), (2, 3)), UnitTheoreticalOutputStd(), 1.0, torch.device("cpu"), dtype, image_size=10)
+        sd = m.state_dict()
+        assert list(sd) == ["p", "epses.0", "epses.1", "linear.weight", "linear.bias"]
+        assert sd["epses.0"].shape == (2,) * 9 + (4,) and sd["epses.1"].shape == (4,) * 4 + (3,)
+        assert sd["linear.weight"].shape == (10, 7 * 7 * 3) and sd["linear.weight"].dtype == dtype
+    for p in (1e-3, 0.4, 1.0):
+        m = EPSesPlusLinear(
+            ((2, 3),),
+            ManuallyChosenInitialization((ZeroCenteredUniformInitialization(0.25),), ZeroCenteredNormalInitialization(0.1),
+                                         ZeroCenteredUniformInitialization(0.5)),
+            p, torch.device("cpu"), torch.float32, image_size=6)
+        assert m.epses[0].abs().max() <= 0.25 and m.linear.bias.abs().max() <= 0.5
+        assert float(m.p) == pytest.approx(p)
+    with pytest.raises(ValueError):
+        EPSesPlusLinear(((2, 3),), object(), 1.0, torch.device("cpu"), torch.float32)
