@@ -1,7 +1,7 @@
 // C-ABI entry points (include/dctn_amd.h): argument validation + dispatch to kernel families.
 #include "common.h"
 
-static thread_local const char* g_last_kernel = "none";
+static const char* volatile g_last_kernel = "none";  // process-wide: autograd runs backward on its own thread
 void dctn_set_last_kernel(const char* name) { g_last_kernel = name; }
 
 extern "C" {

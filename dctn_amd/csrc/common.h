@@ -18,7 +18,7 @@ template <> struct AccOf<double> { typedef double type; };
     if (hipGetLastError() != hipSuccess) return DCTN_ERR_LAUNCH; \
   } while (0)
 
-// thread-local name of the kernel family the last call dispatched to
+// name of the kernel family the last call dispatched to
 void dctn_set_last_kernel(const char* name);
 
 static inline long long ipow_ll(long long b, int e) {

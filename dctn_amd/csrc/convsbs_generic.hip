@@ -17,6 +17,7 @@
 
 struct SbsP {
   int n, C, B, H, W, q, qc, Ho, Wo, l0, Otot, vmax;
+  int cs;  // window columns per workgroup (power of two <= 64); lanes t and t+cs mirror one window
   long long Wn;
   long long s[5];
   int o[SBS_MAXC], bl[SBS_MAXC], br[SBS_MAXC], ph[SBS_MAXC], pw[SBS_MAXC];
@@ -45,7 +46,7 @@ __device__ __forceinline__ WinCoord win_coord(const SbsP& p, long long w) {
 // f[qq] = prod_ch x[ch][pixel of core c][digit_ch(qq)], channel 0 most significant
 template <typename S, typename A>
 __device__ __forceinline__ void pixel_features(const S* __restrict__ x, const SbsP& p, int c,
-                                               bool valid, const WinCoord& wc, A* f, int tid) {
+                                               bool valid, const WinCoord& wc, A* f, int col) {
   for (int qq = 0; qq < p.qc; ++qq) {
     A pr = A(1);
     int t = qq;
@@ -56,25 +57,25 @@ __device__ __forceinline__ void pixel_features(const S* __restrict__ x, const Sb
                     (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4];
       pr *= valid ? (A)(*px) : A(0);
     }
-    f[qq * DCTN_WAVE + tid] = pr;
+    f[qq * p.cs + col] = pr;
   }
 }
 
 // one sweep step: vb[(a*oc+o)*R + r] = sum_l va[a*L + l] * sum_qq core[o,l,r,qq] f[qq]
 template <typename S, typename A>
 __device__ __forceinline__ void sweep_step(const SbsP& p, int c, const A* va, A* vb, const A* f,
-                                           int tid) {
+                                           int col) {
   const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
   const S* core = (const S*)p.core[c];
-  for (int e = 0; e < Oacc * oc * R; ++e) vb[e * DCTN_WAVE + tid] = A(0);
+  for (int e = 0; e < Oacc * oc * R; ++e) vb[e * p.cs + col] = A(0);
   for (int o = 0; o < oc; ++o)
     for (int l = 0; l < L; ++l)
       for (int r = 0; r < R; ++r) {
         const S* cp = core + (long long)((o * L + l) * R + r) * p.qc;
         A t = A(0);
-        for (int qq = 0; qq < p.qc; ++qq) t += (A)cp[qq] * f[qq * DCTN_WAVE + tid];
+        for (int qq = 0; qq < p.qc; ++qq) t += (A)cp[qq] * f[qq * p.cs + col];
         for (int a = 0; a < Oacc; ++a)
-          vb[((a * oc + o) * R + r) * DCTN_WAVE + tid] += va[(a * L + l) * DCTN_WAVE + tid] * t;
+          vb[((a * oc + o) * R + r) * p.cs + col] += va[(a * L + l) * p.cs + col] * t;
       }
 }
 
@@ -83,29 +84,31 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_fwd_generic_k(const S* __re
                                                                    S* __restrict__ out, SbsP p) {
   extern __shared__ __align__(16) unsigned char smem[];
   A* va = reinterpret_cast<A*>(smem);
-  A* vb = va + (size_t)p.vmax * DCTN_WAVE;
-  A* f = vb + (size_t)p.vmax * DCTN_WAVE;
-  A* oa = f + (size_t)p.qc * DCTN_WAVE;
+  A* vb = va + (size_t)p.vmax * p.cs;
+  A* f = vb + (size_t)p.vmax * p.cs;
+  A* oa = f + (size_t)p.qc * p.cs;
   const int tid = threadIdx.x;
-  const long long w = (long long)blockIdx.x * DCTN_WAVE + tid;
+  const int col = tid & (p.cs - 1);
+  const bool primary = tid < p.cs;  // lanes tid >= cs mirror the window of lane tid % cs
+  const long long w = (long long)blockIdx.x * p.cs + col;
   const bool valid = w < p.Wn;
   WinCoord wc = {0, 0, 0};
   if (valid) wc = win_coord(p, w);
-  for (int a = 0; a < p.Otot; ++a) oa[a * DCTN_WAVE + tid] = A(0);
+  for (int a = 0; a < p.Otot; ++a) oa[a * p.cs + col] = A(0);
   for (int s = 0; s < p.l0; ++s) {
-    for (int l = 0; l < p.l0; ++l) va[l * DCTN_WAVE + tid] = (l == s) ? A(1) : A(0);
+    for (int l = 0; l < p.l0; ++l) va[l * p.cs + col] = (l == s) ? A(1) : A(0);
     A* cur = va;
     A* nxt = vb;
     for (int c = 0; c < p.n; ++c) {
-      pixel_features<S, A>(x, p, c, valid, wc, f, tid);
-      sweep_step<S, A>(p, c, cur, nxt, f, tid);
+      pixel_features<S, A>(x, p, c, valid, wc, f, col);
+      sweep_step<S, A>(p, c, cur, nxt, f, col);
       A* tmp = cur; cur = nxt; nxt = tmp;
     }
     for (int a = 0; a < p.Otot; ++a)
-      oa[a * DCTN_WAVE + tid] += cur[(a * p.l0 + s) * DCTN_WAVE + tid];
+      oa[a * p.cs + col] += cur[(a * p.l0 + s) * p.cs + col];
   }
-  if (valid)
-    for (int a = 0; a < p.Otot; ++a) out[w * p.Otot + a] = (S)oa[a * DCTN_WAVE + tid];
+  if (valid && primary)
+    for (int a = 0; a < p.Otot; ++a) out[w * p.Otot + a] = (S)oa[a * p.cs + col];
 }
 
 template <typename S, typename A>
@@ -114,32 +117,34 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_bwd_generic_k(
     A* __restrict__ gxw, SbsP p, int need_dx, int need_dcore) {
   extern __shared__ __align__(16) unsigned char smem[];
   A* va = reinterpret_cast<A*>(smem);
-  A* vb = va + (size_t)p.vmax * DCTN_WAVE;
-  A* vc = vb + (size_t)p.vmax * DCTN_WAVE;
-  A* f = vc + (size_t)p.vmax * DCTN_WAVE;
-  A* df = f + (size_t)p.qc * DCTN_WAVE;
-  A* dys = df + (size_t)p.qc * DCTN_WAVE;
+  A* vb = va + (size_t)p.vmax * p.cs;
+  A* vc = vb + (size_t)p.vmax * p.cs;
+  A* f = vc + (size_t)p.vmax * p.cs;
+  A* df = f + (size_t)p.qc * p.cs;
+  A* dys = df + (size_t)p.qc * p.cs;
   const int tid = threadIdx.x;
-  const long long w = (long long)blockIdx.x * DCTN_WAVE + tid;
+  const int col = tid & (p.cs - 1);
+  const bool primary = tid < p.cs;  // lanes tid >= cs mirror the window of lane tid % cs
+  const long long w = (long long)blockIdx.x * p.cs + col;
   const bool valid = w < p.Wn;
   const long long wcol = valid ? w : 0;
   WinCoord wc = {0, 0, 0};
   if (valid) wc = win_coord(p, w);
-  for (int a = 0; a < p.Otot; ++a) dys[a * DCTN_WAVE + tid] = valid ? (A)dY[w * p.Otot + a] : A(0);
+  for (int a = 0; a < p.Otot; ++a) dys[a * p.cs + col] = valid ? (A)dY[w * p.Otot + a] : A(0);
 
   for (int s = 0; s < p.l0; ++s) {
     // ---- forward sweep, storing the input state of every core
-    for (int l = 0; l < p.l0; ++l) va[l * DCTN_WAVE + tid] = (l == s) ? A(1) : A(0);
+    for (int l = 0; l < p.l0; ++l) va[l * p.cs + col] = (l == s) ? A(1) : A(0);
     A* cur = va;
     A* nxt = vb;
     for (int c = 0; c < p.n; ++c) {
       const int ne = p.oacc[c] * p.bl[c];
-      if (valid)
+      if (valid)  // mirror lanes store the same values: every lane later reads what it wrote itself
         for (int e = 0; e < ne; ++e)
-          states[(p.st_off[c] + e) * p.Wn + wcol] = cur[e * DCTN_WAVE + tid];
+          states[(p.st_off[c] + e) * p.Wn + wcol] = cur[e * p.cs + col];
       if (c + 1 < p.n) {
-        pixel_features<S, A>(x, p, c, valid, wc, f, tid);
-        sweep_step<S, A>(p, c, cur, nxt, f, tid);
+        pixel_features<S, A>(x, p, c, valid, wc, f, col);
+        sweep_step<S, A>(p, c, cur, nxt, f, col);
         A* tmp = cur; cur = nxt; nxt = tmp;
       }
     }
@@ -148,37 +153,37 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_bwd_generic_k(
     A* dvn = vc;
     for (int a = 0; a < p.Otot; ++a)
       for (int r = 0; r < p.l0; ++r)
-        dv[(a * p.l0 + r) * DCTN_WAVE + tid] = (r == s) ? dys[a * DCTN_WAVE + tid] : A(0);
+        dv[(a * p.l0 + r) * p.cs + col] = (r == s) ? dys[a * p.cs + col] : A(0);
     for (int c = p.n - 1; c >= 0; --c) {
       const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
       const S* core = (const S*)p.core[c];
       A* dcore = (A*)p.dcore[c];
       for (int e = 0; e < Oacc * L; ++e)
-        va[e * DCTN_WAVE + tid] = valid ? states[(p.st_off[c] + e) * p.Wn + wcol] : A(0);
-      pixel_features<S, A>(x, p, c, valid, wc, f, tid);
-      for (int e = 0; e < Oacc * L; ++e) dvn[e * DCTN_WAVE + tid] = A(0);
-      for (int qq = 0; qq < p.qc; ++qq) df[qq * DCTN_WAVE + tid] = A(0);
+        va[e * p.cs + col] = valid ? states[(p.st_off[c] + e) * p.Wn + wcol] : A(0);
+      pixel_features<S, A>(x, p, c, valid, wc, f, col);
+      for (int e = 0; e < Oacc * L; ++e) dvn[e * p.cs + col] = A(0);
+      for (int qq = 0; qq < p.qc; ++qq) df[qq * p.cs + col] = A(0);
       for (int o = 0; o < oc; ++o)
         for (int l = 0; l < L; ++l)
           for (int r = 0; r < R; ++r) {
             const long long cbase = (long long)((o * L + l) * R + r) * p.qc;
             A t = A(0);
-            for (int qq = 0; qq < p.qc; ++qq) t += (A)core[cbase + qq] * f[qq * DCTN_WAVE + tid];
+            for (int qq = 0; qq < p.qc; ++qq) t += (A)core[cbase + qq] * f[qq * p.cs + col];
             A dT = A(0);
             for (int a = 0; a < Oacc; ++a) {
-              const A g = dv[((a * oc + o) * R + r) * DCTN_WAVE + tid];
-              dT += va[(a * L + l) * DCTN_WAVE + tid] * g;
-              dvn[(a * L + l) * DCTN_WAVE + tid] += t * g;
+              const A g = dv[((a * oc + o) * R + r) * p.cs + col];
+              dT += va[(a * L + l) * p.cs + col] * g;
+              dvn[(a * L + l) * p.cs + col] += t * g;
             }
             for (int qq = 0; qq < p.qc; ++qq) {
-              df[qq * DCTN_WAVE + tid] += dT * (A)core[cbase + qq];
+              df[qq * p.cs + col] += dT * (A)core[cbase + qq];
               if (need_dcore) {
-                const A red = wave_reduce_sum<A>(dT * f[qq * DCTN_WAVE + tid]);
+                const A red = wave_reduce_sum<A>(primary ? dT * f[qq * p.cs + col] : A(0));
                 if (tid == 0) atomicAdd(&dcore[cbase + qq], red);
               }
             }
           }
-      if (need_dx && valid) {
+      if (need_dx && valid && primary) {
         // d/d x[ch][pixel_c][qv] = sum_{qq: digit_ch(qq) = qv} df[qq] * prod_{ch' != ch} x[ch'][digit]
         for (int ch = 0; ch < p.C; ++ch)
           for (int qv = 0; qv < p.q; ++qv) {
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_bwd_generic_k(
                              (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4]];
                 }
               }
-              if (hit) g += df[qq * DCTN_WAVE + tid] * pr;
+              if (hit) g += df[qq * p.cs + col] * pr;
             }
             A* dst = &gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + w];
             if (s == 0) *dst = g; else *dst += g;
@@ -291,9 +296,12 @@ long long core_elems(const SbsP& p, int c) {
 
 template <typename S, typename A>
 int fwd_launch(const void* x, void* out, SbsP& p, hipStream_t st) {
-  const size_t lds = ((size_t)2 * p.vmax + p.qc + p.Otot) * DCTN_WAVE * sizeof(A);
+  const size_t per_col = ((size_t)2 * p.vmax + p.qc + p.Otot) * sizeof(A);
+  p.cs = DCTN_WAVE;
+  while (p.cs > 1 && per_col * p.cs > DCTN_LDS_BUDGET) p.cs >>= 1;
+  const size_t lds = per_col * p.cs;
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
-  const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+  const unsigned grid = (unsigned)((p.Wn + p.cs - 1) / p.cs);
   (void)hipFuncSetAttribute((const void*)convsbs_fwd_generic_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((convsbs_fwd_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,
@@ -316,7 +324,10 @@ template <typename S, typename A>
 int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, void* ws,
                size_t ws_bytes, SbsP& p, int dtype, hipStream_t st) {
   if (!ws || bwd_ws(p, dtype) > ws_bytes) return DCTN_ERR_WORKSPACE;
-  const size_t lds = ((size_t)3 * p.vmax + 2 * p.qc + p.Otot) * DCTN_WAVE * sizeof(A);
+  const size_t per_col = ((size_t)3 * p.vmax + 2 * p.qc + p.Otot) * sizeof(A);
+  p.cs = DCTN_WAVE;
+  while (p.cs > 1 && per_col * p.cs > DCTN_LDS_BUDGET) p.cs >>= 1;
+  const size_t lds = per_col * p.cs;
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   unsigned char* wsp = (unsigned char*)ws;
   A* states = (A*)wsp;
@@ -337,7 +348,7 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
         return DCTN_ERR_LAUNCH;
     }
   }
-  const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+  const unsigned grid = (unsigned)((p.Wn + p.cs - 1) / p.cs);
   (void)hipFuncSetAttribute((const void*)convsbs_bwd_generic_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((convsbs_bwd_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,

@@ -46,8 +46,8 @@ enum {
 
 int dctn_version(void);
 const char* dctn_strerror(int code);
-/* name of the kernel family the last successful call on this thread dispatched to
- * (diagnostics / tests: proves which HIP path ran) */
+/* name of the kernel family the last successful call dispatched to
+ * (diagnostics / tests: proves which HIP path ran; process-wide, last writer wins) */
 const char* dctn_last_kernel(void);
 
 /* ------------------------------------------------------------------------------------------
