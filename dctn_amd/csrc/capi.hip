@@ -38,14 +38,16 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   return eps_fwd_generic(x, core, out, p, dtype, st);
 }
 
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
                                     int precision, int need_dx, int need_dcore) {
   EpsP p;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
-  const size_t a = eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore);
+  const size_t a = align256(eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore));
   const size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
-  return (a > b ? a : b) + 256;
+  return a + b + 256;
 }
 
 int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
@@ -58,9 +60,22 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
   if (rc != DCTN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  rc = eps_bwd_mfma(x, core, dY, dX, dCore, workspace, workspace_bytes, p, dtype, precision, st);
-  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
-  return eps_bwd_generic(x, core, dY, dX, dCore, workspace, workspace_bytes, p, dtype, st);
+  // dCore on the MFMA family when it covers the shape; whatever is left goes to the generic kernels
+  unsigned char* ws = (unsigned char*)workspace;
+  const size_t wa = align256(eps_bwd_mfma_workspace(p, dtype, precision, 0, dCore != nullptr));
+  if (dCore && wa > 0) {
+    if (!ws || workspace_bytes < wa) return DCTN_ERR_WORKSPACE;
+    rc = eps_bwd_mfma(x, core, dY, nullptr, dCore, ws, wa, p, dtype, precision, st);
+    if (rc == DCTN_OK) {
+      dCore = nullptr;
+    } else if (rc != DCTN_ERR_UNSUPPORTED) {
+      return rc;
+    }
+  }
+  if (!dX && !dCore) return DCTN_OK;
+  const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
+  return eps_bwd_generic(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p,
+                         dtype, st);
 }
 
 }  // extern "C"

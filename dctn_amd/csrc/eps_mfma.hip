@@ -1,12 +1,433 @@
-// MFMA EPS kernels (placeholder until the first MFMA family lands): everything is routed to the
-// generic kernels.
+// MFMA EPS kernels, family "q2-reg": Q == 2 and a core small enough to live in registers
+// (N = K*K*C in {8, 9}: the 3x3 single-channel MNIST layer of BASELINE config 2 and the 2x2
+// two-channel layer).  Operands are bf16, accumulation f32 (v_mfma_f32_32x32x16_bf16).
+//
+// Forward (replaces dctn/eps.py:19-40).  The reference's path is K-R half 0, K-R half 1, one GEMM
+// core x half0, a per-window dot with half 1.  Here, with a = index over the first n0 factors
+// (A = 2^n0), b over the last n1 (Bn = 2^n1):
+//     T[(b,o), w] = sum_a core[a,b,o] * P0[w,a]      <- MFMA, M = (b,o) rows, N = 32 windows, K = a
+//     out[w,o]    = sum_b P1[w,b] * T[(b,o), w]      <- lane-local epilogue
+// A lane owns ONE window (column of the MFMA tile): it builds its P0 fragment in registers from
+// the window's 2N features, gets 16 rows (b,o) of T back in its accumulator registers, weights
+// them with its own P1 values and reduces over b; one permlane32_swap joins the two lane halves.
+// Nothing but x and out touches HBM; no LDS in the main loop, no barriers.
+//
+// Backward dCore[a,b,o] = sum_w P0[w,a] P1[w,b] dY[w,o]  reduces over windows, so windows must
+// become the MFMA K index while lanes own windows.  The transpose is done ON the matrix core:
+// multiplying the lane-owns-window fragment (as A operand) by an identity B operand returns the
+// tile with the feature index on the lane and 16 windows in the accumulator registers — exactly
+// the layout the next MFMA consumes as an operand summing over windows (no LDS round trip).
+//     Z[w,(b,o)] = P1[w,b] dY[w,o];   dCoreT[(b,o), a] += Zt (A operand) x P0t (B operand)
+// Per-wave partial sums stay in registers over all of the wave's windows, are reduced over the
+// workgroup's waves in LDS, written to a workspace and summed by a second small kernel
+// (deterministic: no float atomics).
 #include "common.h"
 
-int eps_fwd_mfma(const void*, const void*, void*, const EpsP&, int, int, hipStream_t) {
-  return DCTN_ERR_UNSUPPORTED;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) int int2v;
+
+namespace {
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+template <typename S> __device__ __forceinline__ float to_f32(S v) { return (float)v; }
+
+// sum over the two lane halves (lane l and l^32), result in every lane
+__device__ __forceinline__ float half_sum(float v) {
+  const int iv = __float_as_int(v);
+  const int2v r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
-size_t eps_bwd_mfma_workspace(const EpsP&, int, int, int, int) { return 0; }
-int eps_bwd_mfma(const void*, const void*, const void*, void*, void*, void*, size_t, const EpsP&,
-                 int, int, hipStream_t) {
+
+struct MfmaP {
+  int C, B, H, W, K, O, Ho, Wo;
+  long long Wn, ngroups;  // groups of 32 windows
+  long long s[5];
+  int vec_ok;             // x: last stride 1, even strides, 4-byte aligned base (bf16 pair loads)
+};
+
+// Features of one window: xv[n][q], n = pos*C + ch.  Lanes l and l+32 load the same window.
+template <typename S, int N>
+__device__ __forceinline__ void load_window(const S* __restrict__ x, const MfmaP& p, long long w,
+                                            bool valid, float (&xv)[N][2]) {
+  const int hw = p.Ho * p.Wo;
+  const long long b = w / hw;
+  const int rem = (int)(w - b * hw);
+  const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const int pos = n / p.C, ch = n - pos * p.C;
+    const int dh = pos / p.K, dw = pos - dh * p.K;
+    const S* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] +
+                  (long long)(wo + dw) * p.s[3];
+    if (!valid) {
+      xv[n][0] = 0.f;
+      xv[n][1] = 0.f;
+    } else if (sizeof(S) == 2 && p.vec_ok) {
+      const unsigned u = *reinterpret_cast<const unsigned*>(px);
+      xv[n][0] = __uint_as_float(u << 16);
+      xv[n][1] = __uint_as_float(u & 0xffff0000u);
+    } else if (sizeof(S) == 4 && p.vec_ok) {
+      const float2 u = *reinterpret_cast<const float2*>(px);
+      xv[n][0] = u.x;
+      xv[n][1] = u.y;
+    } else {
+      xv[n][0] = to_f32(px[0]);
+      xv[n][1] = to_f32(px[p.s[4]]);
+    }
+  }
+}
+
+// P0 fragments of this lane's window: frag[s][j] = P0[w][a = 16 s + 8 h + j], a's MSB = factor 0.
+template <int N0>
+__device__ __forceinline__ void build_p0(const float (*xv)[2], int h, bf16x8 (&frag)[(1 << N0) / 16]) {
+  constexpr int KS = (1 << N0) / 16;
+  float lo8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    lo8[j] = xv[N0 - 3][(j >> 2) & 1] * xv[N0 - 2][(j >> 1) & 1] * xv[N0 - 1][j & 1];
+  const float xh = h ? xv[N0 - 4][1] : xv[N0 - 4][0];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    float hi = xh;
+#pragma unroll
+    for (int t = 0; t < N0 - 4; ++t) hi *= xv[N0 - 5 - t][(s >> t) & 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) frag[s][j] = (bf16_t)(hi * lo8[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ forward
+// Row code of accumulator register v of M-tile t (lane-half bit h excluded):
+//   code = (t << 4) | ((v >> 2) << 2) | (v & 3);   o = code & (OP-1);   b = ((code >> LOGO) << 1) | h
+template <typename S, int N0, int N1, int OP>
+__global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
+                                                       const S* __restrict__ core,
+                                                       S* __restrict__ out, MfmaP p) {
+  constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
+  constexpr int LOGO = ilog2(OP);
+  static_assert(MT >= 1 && KS >= 1, "tile too small");
+  __shared__ bf16_t cs[A * BN * OP];  // core[a][b][o], o padded to OP
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+
+  for (int e = tid; e < A * BN * OP; e += 256) {
+    const int o = e % OP, ab = e / OP;
+    cs[e] = o < p.O ? (bf16_t)to_f32(core[(long long)ab * p.O + o]) : (bf16_t)0.f;
+  }
+  __syncthreads();
+  // A-operand fragments: row r of tile t = accumulator row (i = r&3, h' = (r>>2)&1, g = r>>3)
+  bf16x8 cf[MT][KS];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int code = (t << 4) | ((r >> 3) << 2) | (r & 3);
+    const int o = code & (OP - 1);
+    const int b = ((code >> LOGO) << 1) | ((r >> 2) & 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cf[t][s][j] = cs[((16 * s + 8 * h + j) * BN + b) * OP + o];
+  }
+
+  const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long g = wave; g < p.ngroups; g += nwaves) {
+    const long long w = g * 32 + r;
+    const bool valid = w < p.Wn;
+    float xv[N][2];
+    load_window<S, N>(x, p, w, valid, xv);
+    bf16x8 pf[KS];
+    build_p0<N0>(xv, h, pf);
+    // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 is the lane half
+    float p1hi[BN / 2];
+#pragma unroll
+    for (int bh = 0; bh < BN / 2; ++bh) {
+      float v = 1.f;
+#pragma unroll
+      for (int u = 1; u < N1; ++u) v *= xv[N - 1 - u][(bh >> (u - 1)) & 1];
+      p1hi[bh] = v;
+    }
+    const float xl = h ? xv[N - 1][1] : xv[N - 1][0];
+    float res[OP];
+#pragma unroll
+    for (int o = 0; o < OP; ++o) res[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], pf[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
+        res[code & (OP - 1)] += acc[v] * p1hi[code >> LOGO];
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < OP; ++o) res[o] = half_sum(res[o] * xl);
+    if (valid && h == 0) {
+#pragma unroll
+      for (int o = 0; o < OP; ++o)
+        if (o < p.O) out[w * p.O + o] = (S)res[o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ backward: dCore
+// feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
+template <typename S, int N0, int N1, int OP>
+__global__ __launch_bounds__(256) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
+                                                             const S* __restrict__ dY,
+                                                             float* __restrict__ partial, MfmaP p) {
+  constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
+  constexpr int AT = A >= 32 ? A / 32 : 1;
+  constexpr int LOGO = ilog2(OP);
+  __shared__ float red[4][32 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wv = tid >> 6;
+
+  // identity B operands of the transposing MFMA: element j of k-step parity sp is
+  // [16*sp + 8*h + j == r]
+  bf16x8 ident[2];
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ident[sp][j] = (bf16_t)((16 * sp + 8 * h + j == r) ? 1.f : 0.f);
+
+  f32x16 acc[MT][AT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int a = 0; a < AT; ++a)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][a][v] = 0.f;
+
+  const long long wave = (long long)blockIdx.x * 4 + wv;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long g = wave; g < p.ngroups; g += nwaves) {
+    const long long w = g * 32 + r;
+    const bool valid = w < p.Wn;
+    float xv[N][2];
+    load_window<S, N>(x, p, w, valid, xv);
+    float dy[OP];
+#pragma unroll
+    for (int o = 0; o < OP; ++o) dy[o] = (valid && o < p.O) ? to_f32(dY[w * p.O + o]) : 0.f;
+
+    // P0 transposed: features on lanes, windows in registers -> B operand fragments
+    bf16x8 pf[KS];
+    build_p0<N0>(xv, h, pf);
+    bf16x8 p0t[AT][2];
+#pragma unroll
+    for (int a = 0; a < AT; ++a) {
+      f32x16 d;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+        if (2 * a + sp < KS)
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[2 * a + sp], ident[sp], d, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) p0t[a][v >> 3][v & 7] = (bf16_t)d[v];
+    }
+    // full P1 table of this window (b bit u <-> factor N-1-u)
+    float p1[BN];
+#pragma unroll
+    for (int b = 0; b < BN; ++b) {
+      float v = 1.f;
+#pragma unroll
+      for (int u = 0; u < N1; ++u) v *= xv[N - 1 - u][(b >> u) & 1];
+      p1[b] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      f32x16 d;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        bf16x8 zf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m0 = (t << 5) | (sp << 4) | j;        // h == 0
+          const int m1 = m0 | 8;                           // h == 1
+          const float z0 = p1[m0 >> LOGO] * dy[m0 & (OP - 1)];
+          const float z1 = p1[m1 >> LOGO] * dy[m1 & (OP - 1)];
+          zf[j] = (bf16_t)(h ? z1 : z0);
+        }
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, ident[sp], d, 0, 0, 0);
+      }
+      bf16x8 zt[2];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) zt[v >> 3][v & 7] = (bf16_t)d[v];
+#pragma unroll
+      for (int a = 0; a < AT; ++a)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          acc[t][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt[s2], p0t[a][s2], acc[t][a], 0, 0, 0);
+    }
+  }
+
+  // workgroup reduction of the per-wave partial dCoreT tiles, then one coalesced store per block
+  float* dst = partial + (long long)blockIdx.x * (MT * 32) * (AT * 32);
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int a = 0; a < AT; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
+        red[wv][row * 32 + r] = acc[t][a][v];
+      }
+      __syncthreads();
+      for (int e = tid; e < 1024; e += 256) {
+        const float sum = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        const int row = e >> 5, col = e & 31;
+        dst[(long long)(t * 32 + row) * (AT * 32) + a * 32 + col] = sum;
+      }
+    }
+}
+
+// dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a]
+template <typename S>
+__global__ void eps_bwd_dcore_reduce_k(const float* __restrict__ partial, S* __restrict__ dCore,
+                                       int nblk, int A, int BN, int O, int OP, int ACOLS) {
+  const int total = A * BN * O;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int o = e % O, ab = e / O, b = ab % BN, a = ab / BN;
+  const long long stride = (long long)BN * OP * ACOLS;
+  const float* src = partial + (long long)(b * OP + o) * ACOLS + a;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nblk; k += 4) {
+    s0 += src[(k + 0) * stride];
+    s1 += src[(k + 1) * stride];
+    s2 += src[(k + 2) * stride];
+    s3 += src[(k + 3) * stride];
+  }
+  for (; k < nblk; ++k) s0 += src[k * stride];
+  dCore[e] = (S)((s0 + s1) + (s2 + s3));
+}
+
+int next_pow2(int v) {
+  int r = 1;
+  while (r < v) r <<= 1;
+  return r;
+}
+
+bool family_ok(const EpsP& p, int dtype, int precision) {
+  if (p.Q != 2) return false;
+  if (dtype == DCTN_F64) return false;
+  if (dtype == DCTN_F32 && precision != DCTN_PREC_BF16) return false;
+  if (p.N != 8 && p.N != 9) return false;
+  const int op = next_pow2(p.O);
+  return op >= 2 ? op <= 16 : true;
+}
+
+void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
+  m.C = p.C; m.B = p.B; m.H = p.H; m.W = p.W; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
+  m.Wn = p.Wn;
+  m.ngroups = (p.Wn + 31) / 32;
+  for (int i = 0; i < 5; ++i) m.s[i] = p.s[i];
+  const size_t esz = dtype == DCTN_BF16 ? 2 : 4;
+  m.vec_ok = p.s[4] == 1 && p.s[0] % 2 == 0 && p.s[1] % 2 == 0 && p.s[2] % 2 == 0 &&
+             p.s[3] % 2 == 0 && ((uintptr_t)x % (2 * esz)) == 0;
+}
+
+constexpr int FWD_BLOCKS_PER_CU = 4;
+constexpr int NUM_CU = 256;
+
+int bwd_grid(const MfmaP& m) {
+  long long blocks = (m.ngroups + 3) / 4;
+  if (blocks > 2 * NUM_CU) blocks = 2 * NUM_CU;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename S, int N0, int N1, int OP>
+int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m, hipStream_t st) {
+  long long blocks = (m.ngroups + 3) / 4;
+  if (blocks > FWD_BLOCKS_PER_CU * NUM_CU) blocks = FWD_BLOCKS_PER_CU * NUM_CU;
+  hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP>), dim3((unsigned)blocks), dim3(256), 0, st,
+                     (const S*)x, (const S*)core, (S*)out, m);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_fwd_mfma_q2reg");
+  return DCTN_OK;
+}
+
+template <typename S, int N0, int N1, int OP>
+int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const MfmaP& m,
+                 hipStream_t st) {
+  constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
+  const int grid = bwd_grid(m);
+  hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP>), dim3(grid), dim3(256), 0, st,
+                     (const S*)x, (const S*)dY, (float*)ws, m);
+  DCTN_CHECK_LAUNCH();
+  const int total = A * BN * m.O;
+  hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3((total + 255) / 256), dim3(256), 0, st,
+                     (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_bwd_mfma_q2reg");
+  return DCTN_OK;
+}
+
+#define DISPATCH_OP(FN, S, N0, N1, OPV, ...)                         \
+  switch (OPV) {                                                     \
+    case 2: return FN<S, N0, N1, 2>(__VA_ARGS__);                    \
+    case 4: return FN<S, N0, N1, 4>(__VA_ARGS__);                    \
+    case 8: return FN<S, N0, N1, 8>(__VA_ARGS__);                    \
+    case 16: return FN<S, N0, N1, 16>(__VA_ARGS__);                  \
+  }                                                                  \
   return DCTN_ERR_UNSUPPORTED;
+
+template <typename S>
+int fwd_dispatch(const void* x, const void* core, void* out, const MfmaP& m, int N, int op,
+                 hipStream_t st) {
+  if (N == 9) { DISPATCH_OP(fwd_launch_t, S, 5, 4, op, x, core, out, m, st) }
+  DISPATCH_OP(fwd_launch_t, S, 4, 4, op, x, core, out, m, st)
+}
+
+template <typename S>
+int bwd_dispatch(const void* x, const void* dY, void* dCore, void* ws, const MfmaP& m, int N,
+                 int op, hipStream_t st) {
+  if (N == 9) { DISPATCH_OP(bwd_launch_t, S, 5, 4, op, x, dY, dCore, ws, m, st) }
+  DISPATCH_OP(bwd_launch_t, S, 4, 4, op, x, dY, dCore, ws, m, st)
+}
+
+}  // namespace
+
+int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int dtype,
+                 int precision, hipStream_t st) {
+  if (!family_ok(p, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  MfmaP m;
+  fill_mp(m, p, x, dtype);
+  const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
+  if (dtype == DCTN_BF16) return fwd_dispatch<bf16_t>(x, core, out, m, p.N, op, st);
+  return fwd_dispatch<float>(x, core, out, m, p.N, op, st);
+}
+
+size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx,
+                              int need_dcore) {
+  (void)need_dx;
+  if (!need_dcore || !family_ok(p, dtype, precision)) return 0;
+  const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
+  const int n0 = (p.N + 1) / 2, n1 = p.N - n0;
+  const long long A = 1LL << n0, BN = 1LL << n1, acols = A >= 32 ? A : 32;
+  return (size_t)(2 * NUM_CU) * (size_t)(BN * op) * (size_t)acols * sizeof(float);
+}
+
+// dCore only; the caller (capi) sends dX to the generic kernels.
+int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
+                 size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st) {
+  (void)core;
+  if (dX || !dCore) return DCTN_ERR_UNSUPPORTED;
+  if (!family_ok(p, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < eps_bwd_mfma_workspace(p, dtype, precision, 0, 1)) return DCTN_ERR_WORKSPACE;
+  MfmaP m;
+  fill_mp(m, p, x, dtype);
+  const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
+  if (dtype == DCTN_BF16) return bwd_dispatch<bf16_t>(x, dY, dCore, ws, m, p.N, op, st);
+  return bwd_dispatch<float>(x, dY, dCore, ws, m, p.N, op, st);
 }

@@ -294,3 +294,73 @@ def test_logmatmulexp_fold_and_batched():
     yb.backward(dyb.to(DEV))
     ga, gb = R.grads(ref, [a, b], dyb)
     assert close(ad.grad, ga, torch.float64) and close(bd.grad, gb, torch.float64)
+
+
+# ------------------------------------------------------------------ bf16 MFMA family (q2-reg)
+# bf16 operands (8-bit mantissa), f32 accumulation: every Khatri-Rao product and core entry is
+# rounded to bf16 once -> relative error ~2^-8 per term; tolerance 2e-2 of the output scale.
+BF16_TOL = 2e-2
+
+
+def bf16_close(got, want):
+    want = want.double()
+    got = got.detach().cpu().double()
+    scale = float(want.abs().max()) or 1.0
+    err = float((got - want).abs().max()) / scale
+    if err >= BF16_TOL:
+        print("bf16 rel err", err)
+    return err < BF16_TOL
+
+
+@pytest.mark.parametrize(
+    "C,B,H,W,K,O",
+    [(1, 7, 28, 28, 3, 4), (1, 70, 8, 8, 3, 4), (2, 5, 9, 7, 2, 4), (1, 3, 10, 10, 3, 1), (1, 3, 10, 10, 3, 2),
+     (1, 3, 10, 10, 3, 3), (1, 3, 10, 10, 3, 6), (1, 3, 10, 10, 3, 8), (1, 2, 9, 9, 3, 10), (2, 3, 6, 6, 2, 16)],
+)
+def test_eps_bf16_mfma_vs_oracle(C, B, H, W, K, O):
+    torch.manual_seed(100 * K + O)
+    N = K * K * C
+    u = torch.rand(C, B, H, W)
+    x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1).bfloat16()
+    core = (torch.randn(*(2,) * N, O) * 2 ** (-N / 4)).bfloat16()
+    xd, cd = x.to(DEV), core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_q2reg"
+    assert y.dtype == torch.bfloat16
+    want = R.eps_4step(core.double(), x.double())
+    assert bf16_close(y, want)
+    dy = torch.randn(*want.shape).bfloat16()
+    y.backward(dy.to(DEV))
+    assert dctn_amd.last_kernel() == "eps_bwd_mfma_q2reg"
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    assert bf16_close(cd.grad, dcore)
+    # with an input gradient too: dCore on the MFMA family, dX on the generic kernels
+    xg = xd.clone().requires_grad_(True)
+    cd.grad = None
+    eps(cd, xg).backward(dy.to(DEV))
+    assert bf16_close(cd.grad, dcore) and bf16_close(xg.grad, dx)
+
+
+def test_eps_bf16_mfma_strided_input_and_f32_policy():
+    torch.manual_seed(8)
+    x = torch.rand(1, 6, 12, 12, 2).bfloat16().to(DEV)
+    core = (torch.randn(*(2,) * 9, 4) / 4).bfloat16().to(DEV)
+    xt = x.permute(0, 1, 3, 2, 4)  # strided: scalar-load path of the same kernel
+    assert bf16_close(eps(core, xt), R.eps_4step(core.cpu().double(), xt.cpu().double()))
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_q2reg"
+    # float32 tensors keep exact f32 arithmetic unless the caller opts in to bf16 operands
+    xf, cf = x.float(), core.float().requires_grad_(True)
+    y = eps(cf, xf)
+    assert dctn_amd.last_kernel() == "eps_fwd_generic"
+    assert close(y, R.eps_4step(cf.detach().cpu().double(), xf.cpu().double()), torch.float32)
+    dctn_amd.set_float32_matmul_precision("bf16")
+    try:
+        y2 = eps(cf, xf)
+        assert dctn_amd.last_kernel() == "eps_fwd_mfma_q2reg" and y2.dtype == torch.float32
+        assert bf16_close(y2, y.detach().cpu())
+        y2.sum().backward()
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_q2reg"
+        dcore, _ = R.grads(R.eps_4step, [cf.detach().cpu().double(), xf.cpu().double()], torch.ones(y.shape).double())
+        assert bf16_close(cf.grad, dcore)
+    finally:
+        dctn_amd.set_float32_matmul_precision("exact")
