@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EPS-contraction windows/s, forward + backward, on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): `EPSesPlusLinear(((3,4),), p=1)` on
+MNIST-shaped synthetic input x (1, B, 28, 28, 2) = (sin^2, cos^2)(pi u / 2), bf16 tensors with f32
+accumulation, B = 1024 per GPU.  A step follows dctn/benchmark.py:40-43: `model(x).backward(out_grad)`
+with a fixed `out_grad = randn_like(out)`; with N > 1 every rank runs its own batch (weak scaling)
+and the step ends with the flat-bucket RCCL all-reduce of the parameter gradients.
+A window = one output site of one sample: 26*26 = 676 windows per sample.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6 for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (epses_specs, image_size, Q0, dtype)
+    "cfg2": (((3, 4),), 28, 2, torch.bfloat16),
+    "cfg2_f32": (((3, 4),), 28, 2, torch.float32),
+    "cfg3a": (((4, 4), (3, 6)), 28, 2, torch.float32),
+    "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
+}
+
+
+def synthetic_input(batch, image_size, q0, dtype, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = torch.rand(1, batch, image_size, image_size, generator=g)
+    if q0 == 2:  # dataset_loading.py:33-36,63 feature map with nu = 1
+        x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1)
+    else:
+        x = torch.randn(1, batch, image_size, image_size, q0, generator=g)
+    return x.to(dtype).to(device)
+
+
+def windows_per_sample(specs, image_size):
+    total, side = 0, image_size
+    for k, _ in specs:
+        side = side - k + 1
+        total += side * side
+    return total
+
+
+def usable_cores():
+    """Host cores this process may really use: cgroup quota if there is one (a 1-GPU box gets a
+    16-core share of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cap = int(os.environ.get("DCTN_BENCH_CPU_THREADS", "0"))
+    return cap if cap > 0 else min(n, 64)
+
+
+def cpu_baseline(specs, image_size, q0, target_seconds=12.0):
+    """The oracle's restatement of the reference's 4-step path (oracle/ref_cpu.py), float32, all
+    host cores, same fwd+bwd protocol, on a bounded sample of the workload."""
+    from oracle import ref_cpu as R
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    batch = 128
+    x = synthetic_input(batch, image_size, q0, torch.float32, "cpu", 0)
+    epses, in_size = [], q0
+    for k, o in specs:
+        epses.append((torch.randn(*(in_size,) * (k * k), o) * in_size ** (-k * k / 2)).requires_grad_(True))
+        in_size = o
+    side = image_size - sum(k for k, _ in specs) + len(specs)
+    weight = (torch.randn(10, side * side * in_size) * 0.01).requires_grad_(True)
+    bias = torch.zeros(10, requires_grad=True)
+
+    def step():
+        out = R.eps_plus_linear_forward(epses, weight, bias, x)
+        out.backward(out_grad)
+
+    out_grad = torch.randn(batch, 10)
+    step()  # warm-up
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    iters = max(1, min(200, int(target_seconds / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    wps = windows_per_sample(specs, image_size) * batch / dt
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": wps, "unit": "windows/s", "cores": cores, "kind": "port",
+        "sample": f"oracle 4-step path (torch CPU f32, {cores} threads, {model}), batch {batch}, "
+                  f"{iters} fwd+bwd iterations, {dt*1e3:.1f} ms/iteration",
+    }
+
+
+def kernel_roofline(model, x, specs, image_size, steps):
+    """Times the EPS kernels of the first layer alone with HIP events on the stream they are
+    launched on (torch's current stream) and prices the dominant one against the HBM roofline."""
+    from dctn_amd import _lib as L
+
+    dev = x.device
+    core = model.epses[0].detach().contiguous()
+    C, B, H, W, Q = x.shape
+    K, O = specs[0]
+    Ho = H - K + 1
+    out = torch.empty((B, Ho, Ho, O), dtype=x.dtype, device=dev)
+    dy = torch.randn((B, Ho, Ho, O), device=dev).to(x.dtype)
+    dcore = torch.empty_like(core)
+    code, prec = L.dtype_code(x), L.precision()
+    ws = L.workspace(L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1), dev)
+    lib, st = L.lib(), L.stream_ptr(dev)
+    esz = x.element_size()
+
+    def fwd():
+        L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), C, B, H, W, Q, K, O,
+                                 code, prec, st), "fwd")
+
+    def bwd():
+        L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, st), "bwd")
+
+    res = {}
+    for name, fn in (("eps_fwd", fwd), ("eps_bwd_dcore", bwd)):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        n = max(steps, 50)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        res[name] = (e0.elapsed_time(e1) / n * 1e-3, L.last_kernel())
+    wn = B * Ho * Ho
+    # algorithmic bytes per launch: read x once, write out (fwd) / read dY (bwd) once, core / dCore once
+    bytes_x = C * B * H * W * Q * esz
+    bytes_y = wn * O * esz
+    bytes_core = core.numel() * esz
+    alg = {"eps_fwd": bytes_x + bytes_y + bytes_core, "eps_bwd_dcore": bytes_x + bytes_y + bytes_core}
+    dom = max(res, key=lambda k: res[k][0])
+    sec, kname = res[dom]
+    achieved = alg[dom] / sec / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{kname}:B{B}")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "kernel": kname, "launch_us": sec * 1e6, "algorithmic_bytes": alg[dom],
+        "bytes_per_window": alg[dom] / wn,
+        "all_kernels_us": {k: v[0] * 1e6 for k, v in res.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default 1024 for cfg2, 128 for cfg3)")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from dctn_amd import ddp
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    import dctn_amd
+
+    rank, local_rank, world = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    specs, image_size, q0, dtype = WORKLOADS[args.workload]
+    batch = args.batch or (1024 if args.workload.startswith("cfg2") else 128)
+
+    torch.manual_seed(0)
+    model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
+    ddp.broadcast_parameters(model.parameters())
+    x = synthetic_input(batch, image_size, q0, dtype, dev, seed=1 + rank)  # resident in HBM before timing
+    out_grad = torch.randn(batch, 10, device=dev).to(dtype)
+    reducer = ddp.FlatGradAllReducer(model.parameters()) if world > 1 else None
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        model(x).backward(out_grad)
+
+    graph = None
+    if args.graph:
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+        except Exception as e:  # keep measuring eagerly, and say so in the JSON line
+            print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(dev)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        if reducer is not None:
+            reducer()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_used = dctn_amd.last_kernel()
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    windows_step = windows_per_sample(specs, image_size) * batch * world
+    line = {
+        "metric": "EPS-contraction windows/sec (fwd+bwd)",
+        "value": windows_step * args.steps / elapsed,
+        "unit": "windows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: EPSesPlusLinear({specs}) on MNIST-shaped {image_size}x{image_size} Q0={q0}, "
+                        f"fwd + bwd(out_grad), batch {batch}/GPU",
+            "windows_per_step": windows_step,
+            "per_gpu_batch": batch,
+            "parallelism": f"dp{world}",
+            "hip_graph": graph is not None,
+            "last_kernel": kernel_used,
+        },
+    }
+    if rank == 0:
+        line["roofline"] = kernel_roofline(model, x, specs, image_size, args.steps)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(specs, image_size, q0)
+        print(json.dumps(line), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,8 @@
 // (deterministic: no float atomics).
 #include "common.h"
 
+#include <type_traits>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) int int2v;
@@ -40,42 +42,109 @@ __device__ __forceinline__ float half_sum(float v) {
   return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 
+// unsigned 32-bit division by an invariant (Granlund-Montgomery, round-up variant):
+//   q = (t + ((n - t) >> s1)) >> s2,  t = umulhi(M, n)
+struct FastDiv {
+  unsigned M, s1, s2;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& d) {
+  const unsigned t = __umulhi(d.M, n);
+  return (t + ((n - t) >> d.s1)) >> d.s2;
+}
+
+#define MFMA_MAXN 16
 struct MfmaP {
   int C, B, H, W, K, O, Ho, Wo;
-  long long Wn, ngroups;  // groups of 32 windows
+  long long Wn, ngroups;  // groups of 32 windows (Wn < 2^31 in this family)
   long long s[5];
+  unsigned foffb[MFMA_MAXN];  // BYTE offset of factor n relative to the window's top-left pixel
+  unsigned s1b, s2b, s3b, s4b;  // byte strides of x (batch, row, column, feature); x spans < 4 GiB
+  FastDiv div_hw, div_wo;
   int vec_ok;             // x: last stride 1, even strides, 4-byte aligned base (bf16 pair loads)
 };
 
-// Features of one window: xv[n][q], n = pos*C + ch.  Lanes l and l+32 load the same window.
-template <typename S, int N>
-__device__ __forceinline__ void load_window(const S* __restrict__ x, const MfmaP& p, long long w,
-                                            bool valid, float (&xv)[N][2]) {
-  const int hw = p.Ho * p.Wo;
-  const long long b = w / hw;
-  const int rem = (int)(w - b * hw);
-  const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+// Raw features of one window, as loaded (2 values of type S per factor): the loads are issued
+// back to back with no control flow between them and no use of the data, so a whole group's
+// loads are in flight together and the next group's can be issued before this one is consumed.
+// Addresses are uniform base + 32-bit lane offset (+ uniform per-factor offset).
+// Lanes l and l+32 load the same window; lanes without a window read window 0 (masked later).
+template <typename S, int N, bool VEC>
+struct RawWindow {
+  typedef typename std::conditional<sizeof(S) == 2, unsigned, float2>::type vec_t;
+  vec_t v[VEC ? N : 1];
+  S e[VEC ? 1 : N][2];
+};
+
+template <typename S, int N, bool VEC>
+__device__ __forceinline__ void issue_window(const S* __restrict__ x, const MfmaP& p, long long w,
+                                             bool valid, RawWindow<S, N, VEC>& raw) {
+  const unsigned wu = valid ? (unsigned)w : 0u;
+  const unsigned b = fdiv(wu, p.div_hw);
+  const unsigned rem = wu - b * (unsigned)(p.Ho * p.Wo);
+  const unsigned ho = fdiv(rem, p.div_wo), wo = rem - ho * (unsigned)p.Wo;
+  const unsigned off0 = b * p.s1b + ho * p.s2b + wo * p.s3b;
+  const char* xb = reinterpret_cast<const char*>(x);
+  if constexpr (VEC) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      raw.v[n] = *reinterpret_cast<const typename RawWindow<S, N, VEC>::vec_t*>(xb + (size_t)(off0 + p.foffb[n]));
+  } else {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      raw.e[n][0] = *reinterpret_cast<const S*>(xb + (size_t)(off0 + p.foffb[n]));
+      raw.e[n][1] = *reinterpret_cast<const S*>(xb + (size_t)(off0 + p.foffb[n] + p.s4b));
+    }
+  }
+}
+
+template <typename S, int N, bool VEC>
+__device__ __forceinline__ void unpack_window(const RawWindow<S, N, VEC>& raw, float (&xv)[N][2]) {
 #pragma unroll
   for (int n = 0; n < N; ++n) {
-    const int pos = n / p.C, ch = n - pos * p.C;
-    const int dh = pos / p.K, dw = pos - dh * p.K;
-    const S* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] +
-                  (long long)(wo + dw) * p.s[3];
-    if (!valid) {
-      xv[n][0] = 0.f;
-      xv[n][1] = 0.f;
-    } else if (sizeof(S) == 2 && p.vec_ok) {
-      const unsigned u = *reinterpret_cast<const unsigned*>(px);
-      xv[n][0] = __uint_as_float(u << 16);
-      xv[n][1] = __uint_as_float(u & 0xffff0000u);
-    } else if (sizeof(S) == 4 && p.vec_ok) {
-      const float2 u = *reinterpret_cast<const float2*>(px);
-      xv[n][0] = u.x;
-      xv[n][1] = u.y;
+    if constexpr (VEC && sizeof(S) == 2) {
+      xv[n][0] = __uint_as_float(raw.v[n] << 16);
+      xv[n][1] = __uint_as_float(raw.v[n] & 0xffff0000u);
+    } else if constexpr (VEC) {
+      xv[n][0] = raw.v[n].x;
+      xv[n][1] = raw.v[n].y;
     } else {
-      xv[n][0] = to_f32(px[0]);
-      xv[n][1] = to_f32(px[p.s[4]]);
+      xv[n][0] = to_f32(raw.e[n][0]);
+      xv[n][1] = to_f32(raw.e[n][1]);
     }
+  }
+}
+
+// OP consecutive values of one window (dY row / out row), as one vector access when VEC
+template <typename S, int OP>
+struct alignas(sizeof(S) * OP) RowPack {
+  S e[OP];
+};
+template <typename S, int OP, bool VEC>
+__device__ __forceinline__ void issue_row(const S* __restrict__ src, int O, RowPack<S, OP>& pk) {
+  if constexpr (VEC) {
+    pk = *reinterpret_cast<const RowPack<S, OP>*>(src);
+  } else {
+#pragma unroll
+    for (int o = 0; o < OP; ++o) pk.e[o] = src[o < O ? o : 0];
+  }
+}
+template <typename S, int OP>
+__device__ __forceinline__ void unpack_row(const RowPack<S, OP>& pk, int O, float (&v)[OP]) {
+#pragma unroll
+  for (int o = 0; o < OP; ++o) v[o] = o < O ? to_f32(pk.e[o]) : 0.f;
+}
+template <typename S, int OP, bool VEC>
+__device__ __forceinline__ void store_row(S* __restrict__ dst, int O, const float (&v)[OP]) {
+  if constexpr (VEC) {
+    struct alignas(sizeof(S) * OP) Pack { S e[OP]; };
+    Pack pk;
+#pragma unroll
+    for (int o = 0; o < OP; ++o) pk.e[o] = (S)v[o];
+    *reinterpret_cast<Pack*>(dst) = pk;
+  } else {
+#pragma unroll
+    for (int o = 0; o < OP; ++o)
+      if (o < O) dst[o] = (S)v[o];
   }
 }
 
@@ -101,41 +170,58 @@ __device__ __forceinline__ void build_p0(const float (*xv)[2], int h, bf16x8 (&f
 // ------------------------------------------------------------------------------------ forward
 // Row code of accumulator register v of M-tile t (lane-half bit h excluded):
 //   code = (t << 4) | ((v >> 2) << 2) | (v & 3);   o = code & (OP-1);   b = ((code >> LOGO) << 1) | h
-template <typename S, int N0, int N1, int OP>
+template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC>
 __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
                                                        const S* __restrict__ core,
                                                        S* __restrict__ out, MfmaP p) {
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int LOGO = ilog2(OP);
   static_assert(MT >= 1 && KS >= 1, "tile too small");
-  __shared__ bf16_t cs[A * BN * OP];  // core[a][b][o], o padded to OP
+  // A-operand fragments of the core, staged through LDS in fragment order
+  // cs[((t*KS + s)*64 + lane)*8 + j] = core[a = 16s + 8h + j][b][o], where lane = 32h + row and
+  // row = (g << 3) | (h' << 2) | i, code = (t << 4) | (g << 2) | i = (b >> 1 << LOGO) | o, h' = b & 1
+  constexpr int TOT = A * BN * OP, PER = TOT / 256;
+  static_assert(TOT % 256 == 0, "core staging assumes a multiple of 256 elements");
+  __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-
-  for (int e = tid; e < A * BN * OP; e += 256) {
-    const int o = e % OP, ab = e / OP;
-    cs[e] = o < p.O ? (bf16_t)to_f32(core[(long long)ab * p.O + o]) : (bf16_t)0.f;
+  {
+    S tmp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {  // all loads in flight together: one memory round trip
+      const int e = tid + 256 * i, o = e % OP, ab = e / OP;
+      tmp[i] = core[(long long)ab * p.O + (o < p.O ? o : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i, o = e % OP, ab = e / OP, bb = ab % BN, aa = ab / BN;
+      const int code = ((bb >> 1) << LOGO) | o;
+      const int row = (((code >> 2) & 3) << 3) | ((bb & 1) << 2) | (code & 3);
+      const int dst = ((((code >> 4) * KS + (aa >> 4)) * 64 + ((aa >> 3) & 1) * 32 + row) << 3) | (aa & 7);
+      cs[dst] = o < p.O ? (bf16_t)to_f32(tmp[i]) : (bf16_t)0.f;
+    }
   }
   __syncthreads();
-  // A-operand fragments: row r of tile t = accumulator row (i = r&3, h' = (r>>2)&1, g = r>>3)
   bf16x8 cf[MT][KS];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    const int code = (t << 4) | ((r >> 3) << 2) | (r & 3);
-    const int o = code & (OP - 1);
-    const int b = ((code >> LOGO) << 1) | ((r >> 2) & 1);
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cf[t][s][j] = cs[((16 * s + 8 * h + j) * BN + b) * OP + o];
-  }
+      cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
   const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
+  RawWindow<S, N, XVEC> raw;
+  if (wave < p.ngroups) issue_window<S, N, XVEC>(x, p, wave * 32 + r, wave * 32 + r < p.Wn, raw);
   for (long long g = wave; g < p.ngroups; g += nwaves) {
     const long long w = g * 32 + r;
     const bool valid = w < p.Wn;
     float xv[N][2];
-    load_window<S, N>(x, p, w, valid, xv);
+    unpack_window<S, N, XVEC>(raw, xv);
+    {  // prefetch the next group of this wave (the last iteration re-reads its own group)
+      const long long gn = g + nwaves < p.ngroups ? g + nwaves : g;
+      issue_window<S, N, XVEC>(x, p, gn * 32 + r, gn * 32 + r < p.Wn, raw);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
+    }
     bf16x8 pf[KS];
     build_p0<N0>(xv, h, pf);
     // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 is the lane half
@@ -167,24 +253,22 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
     }
 #pragma unroll
     for (int o = 0; o < OP; ++o) res[o] = half_sum(res[o] * xl);
-    if (valid && h == 0) {
-#pragma unroll
-      for (int o = 0; o < OP; ++o)
-        if (o < p.O) out[w * p.O + o] = (S)res[o];
-    }
+    if (valid && h == 0) store_row<S, OP, OVEC>(out + w * p.O, p.O, res);
   }
 }
 
 // ------------------------------------------------------------------------------ backward: dCore
 // feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
-template <typename S, int N0, int N1, int OP>
-__global__ __launch_bounds__(256) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
+constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LDS reduction per block)
+
+template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC>
+__global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
                                                              const S* __restrict__ dY,
                                                              float* __restrict__ partial, MfmaP p) {
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int AT = A >= 32 ? A / 32 : 1;
   constexpr int LOGO = ilog2(OP);
-  __shared__ float red[4][32 * 32];
+  __shared__ float red[BWD_WAVES][32 * 32];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wv = tid >> 6;
 
   // identity B operands of the transposing MFMA: element j of k-step parity sp is
@@ -203,16 +287,33 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_q2reg_k(const S* __restrict
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[t][a][v] = 0.f;
 
-  const long long wave = (long long)blockIdx.x * 4 + wv;
-  const long long nwaves = (long long)gridDim.x * 4;
+  const long long wave = (long long)blockIdx.x * BWD_WAVES + wv;
+  const long long nwaves = (long long)gridDim.x * BWD_WAVES;
+  RawWindow<S, N, XVEC> raw;
+  RowPack<S, OP> rawdy;
+  if (wave < p.ngroups) {
+    const long long w0 = wave * 32 + r;
+    issue_window<S, N, XVEC>(x, p, w0, w0 < p.Wn, raw);
+    issue_row<S, OP, OVEC>(dY + (w0 < p.Wn ? w0 : 0) * p.O, p.O, rawdy);
+  }
   for (long long g = wave; g < p.ngroups; g += nwaves) {
     const long long w = g * 32 + r;
     const bool valid = w < p.Wn;
     float xv[N][2];
-    load_window<S, N>(x, p, w, valid, xv);
+    unpack_window<S, N, XVEC>(raw, xv);
     float dy[OP];
-#pragma unroll
-    for (int o = 0; o < OP; ++o) dy[o] = (valid && o < p.O) ? to_f32(dY[w * p.O + o]) : 0.f;
+    unpack_row<S, OP>(rawdy, p.O, dy);
+    {  // prefetch the next group of this wave
+      const long long gn = g + nwaves < p.ngroups ? g + nwaves : g;
+      const long long wn = gn * 32 + r;
+      issue_window<S, N, XVEC>(x, p, wn, wn < p.Wn, raw);
+      issue_row<S, OP, OVEC>(dY + (wn < p.Wn ? wn : 0) * p.O, p.O, rawdy);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
+    }
+    if (!valid) {  // lanes past the last window contribute nothing: P0 carries factor 0
+      xv[0][0] = 0.f;
+      xv[0][1] = 0.f;
+    }
 
     // P0 transposed: features on lanes, windows in registers -> B operand fragments
     bf16x8 pf[KS];
@@ -281,34 +382,46 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_q2reg_k(const S* __restrict
         red[wv][row * 32 + r] = acc[t][a][v];
       }
       __syncthreads();
-      for (int e = tid; e < 1024; e += 256) {
-        const float sum = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      for (int e = tid; e < 1024; e += 64 * BWD_WAVES) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < BWD_WAVES; ++k) sum += red[k][e];
         const int row = e >> 5, col = e & 31;
         dst[(long long)(t * 32 + row) * (AT * 32) + a * 32 + col] = sum;
       }
     }
 }
 
-// dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a]
+// dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a].  One workgroup per 32 consecutive
+// (m, a) entries: lane (k8 = tid / 32, c = tid % 32) streams every 8th block's 128-byte segment
+// (coalesced), the 8 partial sums meet in LDS.
 template <typename S>
-__global__ void eps_bwd_dcore_reduce_k(const float* __restrict__ partial, S* __restrict__ dCore,
-                                       int nblk, int A, int BN, int O, int OP, int ACOLS) {
-  const int total = A * BN * O;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int o = e % O, ab = e / O, b = ab % BN, a = ab / BN;
+__global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __restrict__ partial,
+                                                              S* __restrict__ dCore, int nblk, int A,
+                                                              int BN, int O, int OP, int ACOLS) {
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, c = tid & 31, k8 = tid >> 5;
   const long long stride = (long long)BN * OP * ACOLS;
-  const float* src = partial + (long long)(b * OP + o) * ACOLS + a;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    s0 += src[(k + 0) * stride];
-    s1 += src[(k + 1) * stride];
-    s2 += src[(k + 2) * stride];
-    s3 += src[(k + 3) * stride];
+  const long long e = (long long)blockIdx.x * 32 + c;  // flat (m, a) index
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  int k = k8;
+  for (; k + 56 < nblk; k += 64) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += partial[(k + 8 * i) * stride + e];
   }
-  for (; k < nblk; ++k) s0 += src[k * stride];
-  dCore[e] = (S)((s0 + s1) + (s2 + s3));
+  for (; k < nblk; k += 8) acc[0] += partial[k * stride + e];
+  red[k8][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (k8 == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    const int m = (int)(e / ACOLS), a = (int)(e % ACOLS);
+    const int b = m / OP, o = m % OP;
+    if (a < A && o < O) dCore[((long long)a * BN + b) * O + o] = (S)t;
+  }
 }
 
 int next_pow2(int v) {
@@ -322,11 +435,45 @@ bool family_ok(const EpsP& p, int dtype, int precision) {
   if (dtype == DCTN_F64) return false;
   if (dtype == DCTN_F32 && precision != DCTN_PREC_BF16) return false;
   if (p.N != 8 && p.N != 9) return false;
+  if (p.Wn >= (1LL << 31) - 64) return false;
+  {  // 32-bit byte offsets: non-negative strides and an extent below 4 GiB
+    long long ext = 0;
+    const long long dims[5] = {p.C, p.B, p.H, p.W, p.Q};
+    for (int i = 0; i < 5; ++i) {
+      if (p.s[i] < 0) return false;
+      ext += (dims[i] - 1) * p.s[i];
+    }
+    if ((ext + 1) * 4 >= (1LL << 32)) return false;
+  }
   const int op = next_pow2(p.O);
   return op >= 2 ? op <= 16 : true;
 }
 
+FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  if (d <= 1) {
+    f.M = 0; f.s1 = 0; f.s2 = 0;
+    return f;
+  }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.M = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = 1;
+  f.s2 = l - 1;
+  return f;
+}
+
 void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
+  const long long esz_ = dtype == DCTN_BF16 ? 2 : 4;
+  for (int n = 0; n < p.N && n < MFMA_MAXN; ++n) {
+    const int pos = n / p.C, ch = n - pos * p.C;
+    const int dh = pos / p.K, dw = pos - dh * p.K;
+    m.foffb[n] = (unsigned)((ch * p.s[0] + dh * p.s[2] + dw * p.s[3]) * esz_);
+  }
+  m.s1b = (unsigned)(p.s[1] * esz_); m.s2b = (unsigned)(p.s[2] * esz_);
+  m.s3b = (unsigned)(p.s[3] * esz_); m.s4b = (unsigned)(p.s[4] * esz_);
+  m.div_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  m.div_wo = make_fastdiv((unsigned)p.Wo);
   m.C = p.C; m.B = p.B; m.H = p.H; m.W = p.W; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
   m.Wn = p.Wn;
   m.ngroups = (p.Wn + 31) / 32;
@@ -340,8 +487,8 @@ constexpr int FWD_BLOCKS_PER_CU = 4;
 constexpr int NUM_CU = 256;
 
 int bwd_grid(const MfmaP& m) {
-  long long blocks = (m.ngroups + 3) / 4;
-  if (blocks > 2 * NUM_CU) blocks = 2 * NUM_CU;
+  long long blocks = (m.ngroups + BWD_WAVES - 1) / BWD_WAVES;
+  if (blocks > NUM_CU) blocks = NUM_CU;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -350,8 +497,17 @@ template <typename S, int N0, int N1, int OP>
 int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m, hipStream_t st) {
   long long blocks = (m.ngroups + 3) / 4;
   if (blocks > FWD_BLOCKS_PER_CU * NUM_CU) blocks = FWD_BLOCKS_PER_CU * NUM_CU;
-  hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP>), dim3((unsigned)blocks), dim3(256), 0, st,
-                     (const S*)x, (const S*)core, (S*)out, m);
+  const bool ovec = m.O == OP && ((uintptr_t)out % (sizeof(S) * OP)) == 0;
+  const dim3 g((unsigned)blocks), b(256);
+  if (m.vec_ok && ovec)
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true>), g, b, 0, st, (const S*)x,
+                       (const S*)core, (S*)out, m);
+  else if (m.vec_ok)
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, false>), g, b, 0, st, (const S*)x,
+                       (const S*)core, (S*)out, m);
+  else
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, false, false>), g, b, 0, st, (const S*)x,
+                       (const S*)core, (S*)out, m);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_fwd_mfma_q2reg");
   return DCTN_OK;
@@ -362,11 +518,19 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
                  hipStream_t st) {
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
   const int grid = bwd_grid(m);
-  hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP>), dim3(grid), dim3(256), 0, st,
-                     (const S*)x, (const S*)dY, (float*)ws, m);
+  const bool ovec = m.O == OP && ((uintptr_t)dY % (sizeof(S) * OP)) == 0;
+  const dim3 g(grid), b(64 * BWD_WAVES);
+  if (m.vec_ok && ovec)
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (float*)ws, m);
+  else if (m.vec_ok)
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (float*)ws, m);
+  else
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (float*)ws, m);
   DCTN_CHECK_LAUNCH();
-  const int total = A * BN * m.O;
-  hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3((total + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
                      (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_q2reg");
@@ -415,7 +579,7 @@ size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_
   const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
   const int n0 = (p.N + 1) / 2, n1 = p.N - n0;
   const long long A = 1LL << n0, BN = 1LL << n1, acols = A >= 32 ? A : 32;
-  return (size_t)(2 * NUM_CU) * (size_t)(BN * op) * (size_t)acols * sizeof(float);
+  return (size_t)NUM_CU * (size_t)(BN * op) * (size_t)acols * sizeof(float);
 }
 
 // dCore only; the caller (capi) sends dX to the generic kernels.

@@ -1,0 +1,98 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, `torch.distributed`
+backend "nccl" (= RCCL over xGMI on ROCm), batch sharded per rank, ONE flat-bucket sum
+all-reduce of all parameter gradients per step.
+
+The reference has no distributed code at all; windows — hence samples — are
+independent, so the only exchange the path needs is the gradient sum.  All parameters of the
+models here total < 8 MB (BASELINE cfg2: 58 KB), so the all-reduce is latency-bound: a single
+bucket, no per-layer overlap machinery.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and creates the
+    process group.  Returns (rank, local_rank, world_size)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def shard_batch(x: Tensor, rank: int, world: int, dim: int = 1) -> Tensor:
+    """Even split of the batch dim (dim 1 of the (C,B,H,W,Q) layout); a remainder is dropped
+    like the reference's DataLoader(drop_last=True) (dataset_loading.py:325)."""
+    per = x.shape[dim] // world
+    return x.narrow(dim, rank * per, per)
+
+
+@torch.no_grad()
+def broadcast_parameters(params: Iterable[Tensor], src: int = 0) -> None:
+    """Identical initial parameters on every rank (the reference seeds one process)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for p in params:
+        dist.broadcast(p.data, src=src)
+
+
+class FlatGradAllReducer:
+    """Sums (or averages) the gradients of `params` over all ranks through one flat buffer."""
+
+    def __init__(self, params: Iterable[Tensor], average: bool = True):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        self.average = average
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        numel = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        # fp32 bucket even for bf16 parameters: the sum over ranks must not lose bits
+        self.bucket = torch.zeros(numel, dtype=torch.float32 if ref.dtype != torch.float64 else torch.float64,
+                                  device=ref.device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.bucket[off : off + p.numel()].view_as(p))
+            off += p.numel()
+
+    @torch.no_grad()
+    def __call__(self) -> None:
+        if self.world == 1:
+            return
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+        if self.average:
+            self.bucket.div_(self.world)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.to(p.dtype).clone()
+            else:
+                p.grad.copy_(v)
+
+
+@torch.no_grad()
+def all_reduce_scalar_sums(*values: Tensor) -> List[Tensor]:
+    """Sum of evaluation statistics (summed CE, correct counts: evaluation.py:18-19) over ranks."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(values)
+    packed = torch.stack([v.double().reshape(()) for v in values])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    return list(packed.unbind(0))

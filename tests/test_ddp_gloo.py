@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing: batch sharding, parameter
+broadcast, the flat-bucket gradient all-reduce, and metric reduction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dctn_amd import ddp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, lr, w = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(1234 + rank)                       # deliberately different init per rank
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ddp.broadcast_parameters(model.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    torch.manual_seed(7)
+    x = torch.randn(1, 8, 2, 3)                          # (C, B, ...) layout: batch is dim 1
+    y = torch.randn(8, 3)
+    xs = ddp.shard_batch(x, rank, world)
+    assert xs.shape[1] == 4 and torch.equal(xs, x[:, rank * 4 : rank * 4 + 4])
+    loss = ((model(xs[0].reshape(4, 6)) - y[rank * 4 : rank * 4 + 4]) ** 2).sum()
+    loss.backward()
+    reducer = ddp.FlatGradAllReducer(model.parameters(), average=False)
+    reducer()
+    # single-process reference on the full batch
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref.load_state_dict(model.state_dict())
+    ((ref(x[0].reshape(8, 6)) - y) ** 2).sum().backward()
+    for p, pr in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, pr.grad, atol=1e-5)
+    tot, cnt = ddp.all_reduce_scalar_sums(torch.tensor(float(rank + 1)), torch.tensor(4.0))
+    assert float(tot) == 3.0 and float(cnt) == 8.0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_flat_bucket_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_single_process_is_a_noop():
+    m = torch.nn.Linear(3, 2)
+    m(torch.randn(4, 3)).sum().backward()
+    g = m.weight.grad.clone()
+    ddp.FlatGradAllReducer(m.parameters())()
+    assert torch.equal(m.weight.grad, g)
+    assert ddp.shard_batch(torch.zeros(1, 9, 2), 1, 2).shape == (1, 4, 2)
