@@ -35,6 +35,8 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   hipStream_t st = (hipStream_t)stream;
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  rc = eps_fwd_bigcore(x, core, out, p, dtype, precision, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   return eps_fwd_generic(x, core, out, p, dtype, st);
 }
 
@@ -74,6 +76,30 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   }
   if (!dX && !dCore) return DCTN_OK;
   const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
+  if (dCore) {
+    rc = eps_bwd_dcore_bigcore(x, dY, dCore, p, dtype, precision, st);
+    if (rc == DCTN_OK) {
+      dCore = nullptr;
+    } else if (rc != DCTN_ERR_UNSUPPORTED) {
+      return rc;
+    }
+  }
+  if (dX && dtype == DCTN_F32) {
+    // dX on the bigcore MFMA family: per-window factor gradients into the region the generic
+    // kernels would use (the head of their workspace), then the shared deterministic gather
+    const size_t need = (size_t)p.Wn * p.N * p.Q * sizeof(float);
+    if (ws && workspace_bytes >= off + need) {
+      rc = eps_bwd_dfactor_bigcore(x, core, dY, (float*)(ws + off), p, dtype, precision, st);
+      if (rc == DCTN_OK) {
+        rc = eps_gather_dx_launch(ws + off, dX, p, dtype, st);
+        if (rc != DCTN_OK) return rc;
+        dX = nullptr;
+      } else if (rc != DCTN_ERR_UNSUPPORTED) {
+        return rc;
+      }
+    }
+  }
+  if (!dX && !dCore) return DCTN_OK;
   return eps_bwd_generic(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p,
                          dtype, st);
 }

@@ -1,0 +1,623 @@
+// MFMA EPS kernels, family "bigcore": power-of-two Q, cores that do not fit in registers
+// (BASELINE cfg3: K=4/Q=2 cores of 1-2 MiB, K=3/Q=4 of 6 MiB, K=2/Q=8).  Exact float32:
+// v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, so this path keeps the reference's
+// float32 numerics (no bf16 rounding) while running on the matrix cores.
+//
+// One template covers the three GEMMs of the path (reference: dctn/eps.py:25-30 and its autograd):
+//     FWD  T[(b,o), w] = sum_a     core[a,b,o] * P0[w,a]            rows (b,o), k = a
+//     G0   G0[a, w]    = sum_(b,o) core[a,b,o] * P1[w,b] dY[w,o]    rows a,     k = (b,o)
+//     G1   G1[b, w]    = sum_(a,o) core[a,b,o] * P0[w,a] dY[w,o]    rows b,     k = (a,o)
+// In every mode the matrix operand is a 32-row tile of the core streamed through LDS (double
+// buffered, gathered from the core's natural layout - no packed copy in HBM), and the other
+// operand is GENERATED: a lane owns one window (column of the MFMA tile) and produces
+// P[w][k] = hi(k) * table[k_lo] from a small per-lane register table and the window's features in
+// LDS.  Epilogues are lane-local: FWD weights the 16 accumulator rows with P1[w,b] and reduces
+// over b; G0/G1 turn dL/dP0 (dL/dP1) into per-factor gradients by leave-one-out products.
+// A wave carries NT column tiles (NT*32 windows) per streamed core tile.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) int int2v;
+
+namespace {
+
+constexpr int BC_WAVES = 4;     // waves per workgroup
+constexpr int BC_NT_FWD = 4;    // column tiles (of 32 windows) per wave, forward
+constexpr int BC_NT_G = 2;      // ... transposed GEMMs (their LDS also holds the factor gradients)
+constexpr int BC_SROW = 33;     // padded row length of a staged k-row (32 rows + 1: conflict-free both ways)
+constexpr int BC_TBL = 8;       // generated-operand table entries per lane (k-steps per hi block)
+constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
+
+enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
+
+struct BigP {
+  int C, B, H, W, K, O, Q, LQ, N, n0, n1, Ho, Wo;
+  int OP, LOGO;       // O padded to a power of two
+  long long Wn;
+  long long s[5];
+  int mode;
+  int rows;           // GEMM rows (multiple of 32 after padding is handled by guards)
+  int kdim;           // GEMM k extent (even)
+  int mk, ID;         // inner block: ID = 2*tbl k-values = Q^mk * (mode==FWD ? 1 : OP); tbl <= BC_TBL
+  int tbl;
+  int nhb;            // hi blocks: kdim / ID
+  int khalf_first, khalf_n;   // factors of the half generating the k operand: first factor, count
+  int rhalf_first, rhalf_n;   // factors of the half indexing the rows
+};
+
+__device__ __forceinline__ float half_sum(float v) {
+  const int iv = __float_as_int(v);
+  const int2v r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// source offset of core[a][b][o]
+__device__ __forceinline__ long long core_off(const BigP& p, int a, int b, int o) {
+  return ((long long)a * (1 << (p.n1 * p.LQ)) + b) * p.O + o;
+}
+
+// element (row R, k) of the mode's matrix operand, 0 outside the real extents
+__device__ __forceinline__ float amat(const float* __restrict__ core, const BigP& p, int R, int k) {
+  int a, b, o;
+  if (p.mode == MODE_FWD) {
+    a = k; b = R >> p.LOGO; o = R & (p.OP - 1);
+  } else if (p.mode == MODE_G0) {
+    a = R; b = k >> p.LOGO; o = k & (p.OP - 1);
+  } else {
+    b = R; a = k >> p.LOGO; o = k & (p.OP - 1);
+  }
+  if (R >= p.rows || o >= p.O) return 0.f;
+  return core[core_off(p, a, b, o)];
+}
+
+// Khatri-Rao product over `nf` factors starting at factor `first`, digits of `idx` most significant
+// first, features from the block's LDS image xs[(n*Q+q)][BC_WPB]
+template <int WPB>
+__device__ __forceinline__ float kr(const float* xs, const BigP& p, int first, int nf, int idx, int wl) {
+  float v = 1.f;
+  for (int d = 0; d < nf; ++d) {
+    const int dg = (idx >> ((nf - 1 - d) * p.LQ)) & (p.Q - 1);
+    v *= xs[((first + d) * p.Q + dg) * WPB + wl];
+  }
+  return v;
+}
+
+// LOGO_T: log2 of the padded out size (compile time for FWD, whose epilogue selects output slots
+// statically); ignored (0) by the G modes.
+template <int MODE, int BC_NT, int LOGO_T>
+__global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __restrict__ x,
+                                                                const float* __restrict__ core,
+                                                                const float* __restrict__ dY,
+                                                                float* __restrict__ out, BigP p) {
+  constexpr int BC_WPB = BC_WAVES * BC_NT * 32;  // windows per workgroup
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NQ = p.N * p.Q;
+  float* xs = smem;                                   // [NQ][BC_WPB]
+  float* dys = xs + (size_t)NQ * BC_WPB;              // [OP][BC_WPB]  (G modes)
+  float* stage = dys + (MODE == MODE_FWD ? 0 : (size_t)p.OP * BC_WPB);  // [2][BC_KSTG][64]
+  float* gxs = stage + 2 * BC_KSTG * 2 * BC_SROW;     // G modes: [rhalf_n*Q][64*BC_WAVES*BC_NT]
+  const int tid = threadIdx.x, lane = tid & 63, wl32 = lane & 31, h = lane >> 5, wv = tid >> 6;
+  const long long w_block = (long long)blockIdx.x * BC_WPB;
+
+  // ---- window features (and dY rows) of the block's windows -> LDS
+  for (int e = tid; e < BC_WPB * p.N; e += 64 * BC_WAVES) {
+    const int wl = e % BC_WPB, n = e / BC_WPB;
+    const long long w = w_block + wl;
+    const bool valid = w < p.Wn;
+    const long long ww = valid ? w : 0;
+    const int hw = p.Ho * p.Wo;
+    const long long bb = ww / hw;
+    const int rem = (int)(ww - bb * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int pos = n / p.C, ch = n - pos * p.C;
+    const int dh = pos / p.K, dw = pos - dh * p.K;
+    const float* px = x + ch * p.s[0] + bb * p.s[1] + (long long)(ho + dh) * p.s[2] +
+                      (long long)(wo + dw) * p.s[3];
+    for (int q = 0; q < p.Q; ++q) xs[(n * p.Q + q) * BC_WPB + wl] = valid ? px[q * p.s[4]] : 0.f;
+  }
+  if (MODE != MODE_FWD) {
+    for (int e = tid; e < BC_WPB * p.OP; e += 64 * BC_WAVES) {
+      const int wl = e % BC_WPB, o = e / BC_WPB;
+      const long long w = w_block + wl;
+      dys[o * BC_WPB + wl] = (w < p.Wn && o < p.O) ? dY[w * p.O + o] : 0.f;
+    }
+    for (int e = tid; e < p.rhalf_n * p.Q * 64 * BC_WAVES * BC_NT; e += 64 * BC_WAVES) gxs[e] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- per-lane table of the low part of the generated operand: entry t <-> inner k = 2t + h
+  float tab[BC_NT][BC_TBL];
+#pragma unroll
+  for (int nt = 0; nt < BC_NT; ++nt) {
+    const int wl = (wv * BC_NT + nt) * 32 + wl32;
+#pragma unroll
+    for (int t = 0; t < BC_TBL; ++t) {
+      float v = 0.f;
+      if (t < p.tbl) {
+        const int kin = 2 * t + h;
+        if (MODE == MODE_FWD) {
+          v = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
+        } else {
+          v = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
+              dys[(kin & (p.OP - 1)) * BC_WPB + wl];
+        }
+      }
+      tab[nt][t] = v;
+    }
+  }
+
+  float oacc[BC_NT][16];  // FWD: output slots per lane (OP <= 4: OP slots; else OP/2 <= 16)
+#pragma unroll
+  for (int nt = 0; nt < BC_NT; ++nt)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) oacc[nt][s] = 0.f;
+
+  const int mtiles = (p.rows + 31) / 32;
+  const int ksteps = p.kdim / 2;                      // MFMA k-steps in total
+  const int nstage = (ksteps + BC_KSTG - 1) / BC_KSTG;
+  const int hb_per_stage = BC_KSTG / p.tbl;           // hi blocks per stage (tbl divides BC_KSTG)
+  constexpr int PER = BC_KSTG * 64 / (64 * BC_WAVES); // staged elements per thread
+  float pre[PER];
+
+  // element e of a stage: FWD/G1 walk rows fastest (the core is contiguous along the rows there),
+  // G0 walks k fastest (rows = a are Bn*O apart, k = (b,o) is contiguous)
+  auto stage_fetch = [&](int mt, int st) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 64 * BC_WAVES * i;
+      const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
+      const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
+      const int k = st * BC_KSTG * 2 + kl;
+      pre[i] = k < p.kdim ? amat(core, p, mt * 32 + row, k) : 0.f;
+    }
+  };
+  auto stage_commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 64 * BC_WAVES * i;
+      const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
+      const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
+      stage[buf * BC_KSTG * 2 * BC_SROW + kl * BC_SROW + row] = pre[i];
+    }
+  };
+
+  for (int mt = 0; mt < mtiles; ++mt) {
+    f32x16 acc[BC_NT];
+#pragma unroll
+    for (int nt = 0; nt < BC_NT; ++nt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[nt][v] = 0.f;
+
+    stage_fetch(mt, 0);
+    __syncthreads();  // previous tile's readers are done with both buffers
+    stage_commit(0);
+    for (int st = 0; st < nstage; ++st) {
+      __syncthreads();  // stage st visible; buffer (st+1)&1 free
+      if (st + 1 < nstage) stage_fetch(mt, st + 1);
+      const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW;
+      for (int hb = 0; hb < hb_per_stage; ++hb) {
+        const int hbi = st * hb_per_stage + hb;       // global hi-block index
+        if (hbi >= p.nhb) break;
+        float hi[BC_NT];
+#pragma unroll
+        for (int nt = 0; nt < BC_NT; ++nt)
+          hi[nt] = kr<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hbi, (wv * BC_NT + nt) * 32 + wl32);
+#pragma unroll
+        for (int t = 0; t < BC_TBL; ++t) {
+          if (t < p.tbl) {
+            const float av = sb[(2 * (hb * p.tbl + t) + h) * BC_SROW + wl32];
+#pragma unroll
+            for (int nt = 0; nt < BC_NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      if (st + 1 < nstage) stage_commit((st + 1) & 1);
+    }
+
+    // ---- epilogue of this row tile
+    if (MODE == MODE_FWD) {
+      constexpr int OPT = 1 << LOGO_T;
+      constexpr int STEPV = OPT <= 4 ? OPT : OPT / 2;
+#pragma unroll
+      for (int nt = 0; nt < BC_NT; ++nt) {
+        const int wl = (wv * BC_NT + nt) * 32 + wl32;
+        float p1 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          if (v % STEPV == 0) {
+            const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
+            p1 = R < p.rows ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, R >> LOGO_T, wl) : 0.f;
+          }
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int slot = OPT <= 4 ? (v & (OPT - 1)) : ((v & 3) | (((v >> 2) & (OPT / 8 - 1)) << 2));
+          oacc[nt][slot] += acc[nt][v] * p1;
+        }
+      }
+    } else {
+      // dL/dP[w][R] -> per-factor gradients of the row half by leave-one-out products
+      const int nf = p.rhalf_n;
+#pragma unroll
+      for (int nt = 0; nt < BC_NT; ++nt) {
+        const int wl = (wv * BC_NT + nt) * 32 + wl32;
+        float* gcol = gxs + ((wv * BC_NT + nt) * 64 + lane);
+        const int gstride = 64 * BC_WAVES * BC_NT;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
+          if (R < p.rows) {
+            const float g = acc[nt][v];
+            // prefix products on the fly, suffix by recomputation (nf <= 8)
+            float pre_p = 1.f;
+            for (int d = 0; d < nf; ++d) {
+              const int dg = (R >> ((nf - 1 - d) * p.LQ)) & (p.Q - 1);
+              float suf = 1.f;
+              for (int d2 = d + 1; d2 < nf; ++d2) {
+                const int dg2 = (R >> ((nf - 1 - d2) * p.LQ)) & (p.Q - 1);
+                suf *= xs[((p.rhalf_first + d2) * p.Q + dg2) * BC_WPB + wl];
+              }
+              gcol[(d * p.Q + dg) * gstride] += g * pre_p * suf;
+              pre_p *= xs[((p.rhalf_first + d) * p.Q + dg) * BC_WPB + wl];
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- results
+  if (MODE == MODE_FWD) {
+#pragma unroll
+    for (int nt = 0; nt < BC_NT; ++nt) {
+      const long long w = w_block + (wv * BC_NT + nt) * 32 + wl32;
+      constexpr int OPT = 1 << LOGO_T;
+      if constexpr (OPT <= 4) {
+#pragma unroll
+        for (int s = 0; s < OPT; ++s) {
+          const float r = half_sum(oacc[nt][s]);
+          if (s < p.O && h == 0 && w < p.Wn) out[w * p.O + s] = r;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < OPT / 2; ++s) {
+          const int o = (s & 3) + 4 * h + 8 * (s >> 2);
+          if (o < p.O && w < p.Wn) out[w * p.O + o] = oacc[nt][s];
+        }
+      }
+    }
+  } else {
+    // out = gxw[(factor*Q + q)][Wn] for the factors of the row half (sum of the two lane halves)
+    __syncthreads();
+    const int nfq = p.rhalf_n * p.Q;
+    for (int e = tid; e < nfq * BC_WPB; e += 64 * BC_WAVES) {
+      const int wl = e % BC_WPB, f = e / BC_WPB;
+      const int grp = wl >> 5, l32 = wl & 31;
+      const long long w = w_block + wl;
+      if (w < p.Wn) {
+        const float* g = gxs + (size_t)f * 64 * BC_WAVES * BC_NT + grp * 64 + l32;
+        out[(long long)(p.rhalf_first * p.Q + f) * p.Wn + w] = g[0] + g[32];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dCore
+// dCore[a][(b,o)] += sum_w P0[w][a] * (P1[w][b] dY[w][o]):  rows a, columns (b,o), k = windows.
+// Both MFMA operands are generated: per window the Khatri-Rao halves are kept FACTORED in LDS
+// (lo table x hi table, built once per window chunk from the window's features), a lane multiplies
+// the two table entries of its row / column for the 2 windows of the k-step.  A wave owns
+// DC_AT x DC_BT output tiles; window chunks are spread over grid.y and combined with float atomics.
+constexpr int DC_AT = 2, DC_BT = 4;   // tiles per wave (rows, columns); workgroup = 2 x 2 waves
+constexpr int DC_WC = 128;            // windows per LDS chunk
+
+struct DcoreP {
+  int C, B, H, W, K, O, Q, LQ, N, n0, n1, Ho, Wo, OP, LOGO;
+  long long Wn;
+  long long s[5];
+  int A, BN, cols;                 // cols = BN * OP
+  int lb0, lb1;                    // bits of the lo tables of half 0 / half 1 (multiples of LQ)
+  int nlo0, nhi0, nlo1, nhi1;      // table sizes
+  int tstride;                     // floats per window in the table image (odd: conflict-free)
+  long long win_per_block;
+};
+
+__global__ __launch_bounds__(256) void eps_bigcore_dcore_k(const float* __restrict__ x,
+                                                           const float* __restrict__ dY,
+                                                           float* __restrict__ dCore, DcoreP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NQ = p.N * p.Q;
+  float* xs = smem;                         // [DC_WC][NQ + 1]
+  float* tb = xs + DC_WC * (NQ + 1);        // [DC_WC][tstride]: T0lo | T0hi | T1lo | T1hi | dy
+  const int o_t0lo = 0, o_t0hi = p.nlo0, o_t1lo = o_t0hi + p.nhi0, o_t1hi = o_t1lo + p.nlo1,
+            o_dy = o_t1hi + p.nhi1;
+  const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, kk = lane >> 5, wv = tid >> 6;
+  const int ntile_c = (p.cols + 2 * DC_BT * 32 - 1) / (2 * DC_BT * 32);
+  const int bt_a = blockIdx.x / ntile_c, bt_c = blockIdx.x % ntile_c;
+  const int a_tile0 = (bt_a * 2 + (wv >> 1)) * DC_AT;      // first row tile of this wave
+  const int c_tile0 = (bt_c * 2 + (wv & 1)) * DC_BT;       // first column tile of this wave
+
+  // per-lane table offsets of its rows / columns (constant over the whole kernel)
+  int offa_lo[DC_AT], offa_hi[DC_AT];
+  bool a_ok[DC_AT];
+#pragma unroll
+  for (int at = 0; at < DC_AT; ++at) {
+    const int a = (a_tile0 + at) * 32 + il;
+    a_ok[at] = a < p.A;
+    const int ac = a_ok[at] ? a : 0;
+    offa_lo[at] = o_t0lo + (ac & ((1 << p.lb0) - 1));
+    offa_hi[at] = o_t0hi + (ac >> p.lb0);
+  }
+  int offb_lo[DC_BT], offb_hi[DC_BT], offb_dy[DC_BT];
+  bool c_ok[DC_BT];
+#pragma unroll
+  for (int bt = 0; bt < DC_BT; ++bt) {
+    const int col = (c_tile0 + bt) * 32 + il;
+    const int o = col & (p.OP - 1), b = col >> p.LOGO;
+    c_ok[bt] = col < p.cols && o < p.O;
+    const int bc = col < p.cols ? b : 0;
+    offb_lo[bt] = o_t1lo + (bc & ((1 << p.lb1) - 1));
+    offb_hi[bt] = o_t1hi + (bc >> p.lb1);
+    offb_dy[bt] = o_dy + o;
+  }
+
+  f32x16 acc[DC_AT][DC_BT];
+#pragma unroll
+  for (int at = 0; at < DC_AT; ++at)
+#pragma unroll
+    for (int bt = 0; bt < DC_BT; ++bt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[at][bt][v] = 0.f;
+
+  const long long w_begin = (long long)blockIdx.y * p.win_per_block;
+  long long w_end = w_begin + p.win_per_block;
+  if (w_end > p.Wn) w_end = p.Wn;
+
+  for (long long w0 = w_begin; w0 < w_end; w0 += DC_WC) {
+    __syncthreads();
+    // window features of the chunk
+    for (int e = tid; e < DC_WC * p.N; e += 256) {
+      const int wl = e % DC_WC, n = e / DC_WC;
+      const long long w = w0 + wl;
+      const bool valid = w < w_end;
+      const long long ww = valid ? w : 0;
+      const int hw = p.Ho * p.Wo;
+      const long long bb = ww / hw;
+      const int rem = (int)(ww - bb * hw);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const int pos = n / p.C, ch = n - pos * p.C;
+      const int dh = pos / p.K, dw = pos - dh * p.K;
+      const float* px = x + ch * p.s[0] + bb * p.s[1] + (long long)(ho + dh) * p.s[2] +
+                        (long long)(wo + dw) * p.s[3];
+      for (int q = 0; q < p.Q; ++q) xs[wl * (NQ + 1) + n * p.Q + q] = valid ? px[q * p.s[4]] : 0.f;
+    }
+    __syncthreads();
+    // factored Khatri-Rao tables (and dY) of the chunk
+    const int nent = o_dy + p.OP;
+    for (int e = tid; e < DC_WC * nent; e += 256) {
+      const int wl = e % DC_WC, ent = e / DC_WC;
+      const float* xw = xs + wl * (NQ + 1);
+      float v;
+      if (ent >= o_dy) {
+        const int o = ent - o_dy;
+        const long long w = w0 + wl;
+        v = (w < w_end && o < p.O) ? dY[w * p.O + o] : 0.f;
+      } else {
+        int first, nf, idx;
+        if (ent < o_t0hi) { nf = p.lb0 / p.LQ; first = p.n0 - nf; idx = ent - o_t0lo; }
+        else if (ent < o_t1lo) { nf = p.n0 - p.lb0 / p.LQ; first = 0; idx = ent - o_t0hi; }
+        else if (ent < o_t1hi) { nf = p.lb1 / p.LQ; first = p.N - nf; idx = ent - o_t1lo; }
+        else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; idx = ent - o_t1hi; }
+        v = 1.f;
+        for (int d = 0; d < nf; ++d) {
+          const int dg = (idx >> ((nf - 1 - d) * p.LQ)) & (p.Q - 1);
+          v *= xw[(first + d) * p.Q + dg];
+        }
+      }
+      tb[wl * p.tstride + ent] = v;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < DC_WC / 2; ++ks) {
+      const float* tw = tb + (2 * ks + kk) * p.tstride;
+      float pa[DC_AT], pz[DC_BT];
+#pragma unroll
+      for (int at = 0; at < DC_AT; ++at) pa[at] = a_ok[at] ? tw[offa_lo[at]] * tw[offa_hi[at]] : 0.f;
+#pragma unroll
+      for (int bt = 0; bt < DC_BT; ++bt)
+        pz[bt] = c_ok[bt] ? tw[offb_lo[bt]] * tw[offb_hi[bt]] * tw[offb_dy[bt]] : 0.f;
+#pragma unroll
+      for (int at = 0; at < DC_AT; ++at)
+#pragma unroll
+        for (int bt = 0; bt < DC_BT; ++bt)
+          acc[at][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[at], pz[bt], acc[at][bt], 0, 0, 0);
+    }
+  }
+
+  // accumulate into dCore (zero-initialised by the launcher): one register = two 128-byte row segments
+#pragma unroll
+  for (int at = 0; at < DC_AT; ++at)
+#pragma unroll
+    for (int bt = 0; bt < DC_BT; ++bt) {
+      const int col = (c_tile0 + bt) * 32 + il;
+      const int o = col & (p.OP - 1), b = col >> p.LOGO;
+      if (col < p.cols && o < p.O) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int a = (a_tile0 + at) * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
+          if (a < p.A) atomicAdd(&dCore[((long long)a * p.BN + b) * p.O + o], acc[at][bt][v]);
+        }
+      }
+    }
+}
+
+int ilog2i(int v) {
+  int r = 0;
+  while ((1 << r) < v) ++r;
+  return r;
+}
+
+bool fill_big(BigP& b, const EpsP& p, int mode) {
+  if (p.Q < 2 || (p.Q & (p.Q - 1))) return false;
+  b.C = p.C; b.B = p.B; b.H = p.H; b.W = p.W; b.K = p.K; b.O = p.O; b.Q = p.Q; b.N = p.N;
+  b.LQ = ilog2i(p.Q);
+  b.n0 = (p.N + 1) / 2; b.n1 = p.N - b.n0;
+  if (b.n1 < 1) return false;
+  if (b.n0 * b.LQ > 20 || b.n1 * b.LQ > 20) return false;
+  b.Ho = p.Ho; b.Wo = p.Wo; b.Wn = p.Wn;
+  for (int i = 0; i < 5; ++i) b.s[i] = p.s[i];
+  b.OP = 1;
+  while (b.OP < p.O) b.OP <<= 1;
+  if (b.OP < 2) b.OP = 2;
+  if (b.OP > 32) return false;
+  b.LOGO = ilog2i(b.OP);
+  b.mode = mode;
+  const int A = 1 << (b.n0 * b.LQ), BN = 1 << (b.n1 * b.LQ);
+  int khalf_bits;
+  if (mode == MODE_FWD) {
+    b.rows = BN * b.OP; b.kdim = A;
+    b.khalf_first = 0; b.khalf_n = b.n0; b.rhalf_first = b.n0; b.rhalf_n = b.n1;
+  } else if (mode == MODE_G0) {
+    b.rows = A; b.kdim = BN * b.OP;
+    b.khalf_first = b.n0; b.khalf_n = b.n1; b.rhalf_first = 0; b.rhalf_n = b.n0;
+  } else {
+    b.rows = BN; b.kdim = A * b.OP;
+    b.khalf_first = 0; b.khalf_n = b.n0; b.rhalf_first = b.n0; b.rhalf_n = b.n1;
+  }
+  khalf_bits = b.khalf_n * b.LQ;
+  (void)khalf_bits;
+  // inner block: ID = Q^mk * (FWD ? 1 : OP) k-values, ID/2 <= BC_TBL table entries, mk >= 0 digits
+  const int opk = mode == MODE_FWD ? 1 : b.OP;
+  int mk = 0;
+  while (mk + 1 <= b.khalf_n && ((1 << ((mk + 1) * b.LQ)) * opk) / 2 <= BC_TBL) ++mk;
+  b.mk = mk;
+  b.ID = (1 << (mk * b.LQ)) * opk;
+  if (b.ID < 2 || b.ID / 2 > BC_TBL) return false;
+  b.tbl = b.ID / 2;
+  if (BC_KSTG % b.tbl) return false;
+  b.nhb = b.kdim / b.ID;
+  return true;
+}
+
+size_t big_lds(const BigP& b) {
+  const int nt = b.mode == MODE_FWD ? BC_NT_FWD : BC_NT_G;
+  const size_t wpb = (size_t)BC_WAVES * nt * 32;
+  size_t f = (size_t)b.N * b.Q * wpb + 2 * BC_KSTG * 2 * BC_SROW;
+  if (b.mode != MODE_FWD) f += (size_t)b.OP * wpb + (size_t)b.rhalf_n * b.Q * 64 * BC_WAVES * nt;
+  return f * sizeof(float);
+}
+
+template <int LOGO_T>
+int launch_fwd(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st) {
+  constexpr int WPB = BC_WAVES * BC_NT_FWD * 32;
+  const unsigned grid = (unsigned)((b.Wn + WPB - 1) / WPB);
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_FWD, BC_NT_FWD, LOGO_T>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((eps_bigcore_k<MODE_FWD, BC_NT_FWD, LOGO_T>), dim3(grid), dim3(64 * BC_WAVES), lds,
+                     st, (const float*)x, (const float*)core, (const float*)nullptr, (float*)out, b);
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+}  // namespace
+
+// worthwhile only when the core is large: small cores stay on the register family / generic path
+static bool bigcore_wanted(const EpsP& p) {
+  return p.R * p.O >= 1024;
+}
+
+int eps_fwd_bigcore(const void* x, const void* core, void* out, const EpsP& p, int dtype,
+                    int precision, hipStream_t st) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
+  BigP b;
+  if (!fill_big(b, p, MODE_FWD)) return DCTN_ERR_UNSUPPORTED;
+  const size_t lds = big_lds(b);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  int rc = DCTN_ERR_UNSUPPORTED;
+  switch (b.LOGO) {
+    case 1: rc = launch_fwd<1>(x, core, out, b, lds, st); break;
+    case 2: rc = launch_fwd<2>(x, core, out, b, lds, st); break;
+    case 3: rc = launch_fwd<3>(x, core, out, b, lds, st); break;
+    case 4: rc = launch_fwd<4>(x, core, out, b, lds, st); break;
+    case 5: rc = launch_fwd<5>(x, core, out, b, lds, st); break;
+  }
+  if (rc != DCTN_OK) return rc;
+  dctn_set_last_kernel("eps_fwd_mfma_bigcore_f32");
+  return DCTN_OK;
+}
+
+// dX through the two transposed GEMMs G0, G1: per-window factor gradients into gxw[N*Q][Wn]
+// (same layout as the generic kernel's, so the generic deterministic gather finishes the job)
+int eps_bwd_dfactor_bigcore(const void* x, const void* core, const void* dY, float* gxw,
+                            const EpsP& p, int dtype, int precision, hipStream_t st) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
+  BigP b0, b1;
+  if (!fill_big(b0, p, MODE_G0) || !fill_big(b1, p, MODE_G1)) return DCTN_ERR_UNSUPPORTED;
+  const size_t l0 = big_lds(b0), l1 = big_lds(b1);
+  if (l0 > DCTN_LDS_BUDGET || l1 > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  constexpr int WPB = BC_WAVES * BC_NT_G * 32;
+  const unsigned grid = (unsigned)((p.Wn + WPB - 1) / WPB);
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_G0, BC_NT_G, 0>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
+  hipLaunchKernelGGL((eps_bigcore_k<MODE_G0, BC_NT_G, 0>), dim3(grid), dim3(64 * BC_WAVES), l0, st,
+                     (const float*)x, (const float*)core, (const float*)dY, gxw, b0);
+  DCTN_CHECK_LAUNCH();
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_G1, BC_NT_G, 0>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+  hipLaunchKernelGGL((eps_bigcore_k<MODE_G1, BC_NT_G, 0>), dim3(grid), dim3(64 * BC_WAVES), l1, st,
+                     (const float*)x, (const float*)core, (const float*)dY, gxw, b1);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
+  return DCTN_OK;
+}
+
+int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
+                          int precision, hipStream_t st) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
+  if (p.Q < 2 || (p.Q & (p.Q - 1))) return DCTN_ERR_UNSUPPORTED;
+  DcoreP d;
+  d.C = p.C; d.B = p.B; d.H = p.H; d.W = p.W; d.K = p.K; d.O = p.O; d.Q = p.Q; d.N = p.N;
+  d.LQ = ilog2i(p.Q);
+  d.n0 = (p.N + 1) / 2; d.n1 = p.N - d.n0;
+  if (d.n1 < 1 || d.n0 * d.LQ > 20 || d.n1 * d.LQ > 20) return DCTN_ERR_UNSUPPORTED;
+  d.Ho = p.Ho; d.Wo = p.Wo; d.Wn = p.Wn;
+  for (int i = 0; i < 5; ++i) d.s[i] = p.s[i];
+  d.OP = 2;
+  while (d.OP < p.O) d.OP <<= 1;
+  if (d.OP > 32) return DCTN_ERR_UNSUPPORTED;
+  d.LOGO = ilog2i(d.OP);
+  d.A = 1 << (d.n0 * d.LQ); d.BN = 1 << (d.n1 * d.LQ); d.cols = d.BN * d.OP;
+  // lo tables: as many whole digits as fit in 5 bits (32 entries), at least one digit
+  auto lo_bits = [&](int nfac) {
+    int m = 5 / d.LQ;
+    if (m < 1) m = 1;
+    if (m > nfac) m = nfac;
+    return m * d.LQ;
+  };
+  d.lb0 = lo_bits(d.n0); d.lb1 = lo_bits(d.n1);
+  d.nlo0 = 1 << d.lb0; d.nhi0 = d.A >> d.lb0; d.nlo1 = 1 << d.lb1; d.nhi1 = d.BN >> d.lb1;
+  int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP;
+  if (tstride % 2 == 0) ++tstride;
+  d.tstride = tstride;
+  const size_t lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  const int ntile_a = (d.A + 2 * DC_AT * 32 - 1) / (2 * DC_AT * 32);
+  const int ntile_c = (d.cols + 2 * DC_BT * 32 - 1) / (2 * DC_BT * 32);
+  const long long tiles = (long long)ntile_a * ntile_c;
+  long long chunks = 1024 / tiles;
+  if (chunks < 1) chunks = 1;
+  const long long max_chunks = (p.Wn + DC_WC - 1) / DC_WC;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks > 65535) chunks = 65535;
+  long long wpb = (p.Wn + chunks - 1) / chunks;
+  wpb = (wpb + DC_WC - 1) / DC_WC * DC_WC;
+  chunks = (p.Wn + wpb - 1) / wpb;
+  d.win_per_block = wpb;
+  if (hipMemsetAsync(dCore, 0, (size_t)p.R * p.O * sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(eps_bigcore_dcore_k, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, st,
+                     (const float*)x, (const float*)dY, (float*)dCore, d);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
+  return DCTN_OK;
+}

@@ -451,6 +451,27 @@ static int bwd_launch(const void* x, const void* core, const void* dY, void* dX,
   return DCTN_OK;
 }
 
+// deterministic per-pixel sum of the per-window factor gradients gxw[N*Q][Wn] (float32 or float64
+// accumulator type of `dtype`) into dX; shared by the generic and the MFMA backward kernels
+int eps_gather_dx_launch(const void* gxw, void* dX, const EpsP& p, int dtype, hipStream_t st) {
+  const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
+  const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  switch (dtype) {
+    case DCTN_F32:
+      hipLaunchKernelGGL((eps_gather_dx_k<float, float>), dim3(g2), dim3(256), 0, st, (const float*)gxw, (float*)dX, p);
+      break;
+    case DCTN_F64:
+      hipLaunchKernelGGL((eps_gather_dx_k<double, double>), dim3(g2), dim3(256), 0, st, (const double*)gxw, (double*)dX, p);
+      break;
+    case DCTN_BF16:
+      hipLaunchKernelGGL((eps_gather_dx_k<bf16_t, float>), dim3(g2), dim3(256), 0, st, (const float*)gxw, (bf16_t*)dX, p);
+      break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
 int eps_bwd_generic(const void* x, const void* core, const void* dY, void* dX, void* dCore,
                     void* ws, size_t ws_bytes, EpsP p, int dtype, hipStream_t st) {
   switch (dtype) {

@@ -23,6 +23,7 @@
 // (deterministic: no float atomics).
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -488,7 +489,8 @@ constexpr int NUM_CU = 256;
 
 int bwd_grid(const MfmaP& m) {
   long long blocks = (m.ngroups + BWD_WAVES - 1) / BWD_WAVES;
-  if (blocks > NUM_CU) blocks = NUM_CU;
+  static const int bdiv = getenv("DCTN_BWD_DIV") ? atoi(getenv("DCTN_BWD_DIV")) : 1;
+  if (blocks > NUM_CU / bdiv) blocks = NUM_CU / bdiv;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -496,7 +498,8 @@ int bwd_grid(const MfmaP& m) {
 template <typename S, int N0, int N1, int OP>
 int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m, hipStream_t st) {
   long long blocks = (m.ngroups + 3) / 4;
-  if (blocks > FWD_BLOCKS_PER_CU * NUM_CU) blocks = FWD_BLOCKS_PER_CU * NUM_CU;
+  static const int bpc = getenv("DCTN_FWD_BPC") ? atoi(getenv("DCTN_FWD_BPC")) : FWD_BLOCKS_PER_CU;
+  if (blocks > (long long)bpc * NUM_CU) blocks = (long long)bpc * NUM_CU;
   const bool ovec = m.O == OP && ((uintptr_t)out % (sizeof(S) * OP)) == 0;
   const dim3 g((unsigned)blocks), b(256);
   if (m.vec_ok && ovec)

@@ -364,3 +364,38 @@ def test_eps_bf16_mfma_strided_input_and_f32_policy():
         assert bf16_close(cf.grad, dcore)
     finally:
         dctn_amd.set_float32_matmul_precision("exact")
+
+
+# ------------------------------------------------------------------ f32 MFMA family "bigcore"
+@pytest.mark.parametrize(
+    "C,B,H,W,Q,K,O",
+    [
+        (1, 3, 9, 10, 2, 4, 4),    # cfg3a layer 1 core (1 MiB), small image
+        (1, 2, 8, 8, 2, 4, 8),     # cfg3b layer 1 (O = 8: outputs split over the lane halves)
+        (1, 2, 7, 7, 2, 4, 2),     # cfg1 core in f32
+        (1, 2, 6, 7, 4, 3, 6),     # cfg3a layer 2 core (6 MiB), O padded 6 -> 8
+        (1, 3, 9, 9, 8, 2, 8),     # cfg3b layer 2
+        (1, 40, 6, 6, 4, 2, 5),    # Q=4 K=2, O padded 5 -> 8, several workgroups
+        (2, 3, 6, 5, 4, 2, 3),     # two channels, N=8 factors of size 4
+        (1, 2, 6, 6, 2, 3, 16),    # O = 16
+        (1, 2, 7, 7, 16, 2, 4),    # Q = 16
+    ],
+)
+def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
+    torch.manual_seed(7 * Q + K + O)
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q)
+    core = torch.randn(*(Q,) * N, O) * Q ** (-N / 4)
+    xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    if Q < 16:  # Q = 16 exceeds the family's LDS budget and falls back to the generic kernels
+        assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+    want = R.eps_4step(core.double(), x.double())
+    assert close(y, want, torch.float32)
+    dy = torch.randn(*want.shape)
+    y.backward(dy.to(DEV))
+    if Q < 16:
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bigcore_f32"
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    assert close(xd.grad, dx, torch.float32)
+    assert close(cd.grad, dcore, torch.float32)
