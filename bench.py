@@ -136,9 +136,11 @@ def kernel_roofline(model, x, specs, image_size, steps):
     lib, st = L.lib(), L.stream_ptr(dev)
     esz = x.element_size()
 
+    wsf = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
+
     def fwd():
-        L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), C, B, H, W, Q, K, O,
-                                 code, prec, st), "fwd")
+        L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), wsf.data_ptr(),
+                                 wsf.numel(), C, B, H, W, Q, K, O, code, prec, st), "fwd")
 
     def bwd():
         L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),

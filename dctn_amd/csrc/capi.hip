@@ -25,8 +25,17 @@ const char* dctn_strerror(int code) {
 
 static bool dtype_ok(int dtype) { return dtype == DCTN_F32 || dtype == DCTN_F64 || dtype == DCTN_BF16; }
 
-int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out, int C,
-                 int B, int H, int W, int Q, int K, int O, int dtype, int precision, void* stream) {
+size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
+                                    int precision) {
+  EpsP p;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  return eps_fwd_bigcore_workspace(p, dtype, precision) + 256;
+}
+
+int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
+                 void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q, int K,
+                 int O, int dtype, int precision, void* stream) {
   if (!x || !core || !out || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   EpsP p;
@@ -35,7 +44,7 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   hipStream_t st = (hipStream_t)stream;
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
-  rc = eps_fwd_bigcore(x, core, out, p, dtype, precision, st);
+  rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   return eps_fwd_generic(x, core, out, p, dtype, st);
 }
@@ -48,7 +57,9 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
   const size_t a = align256(eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore));
-  const size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
+  size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
+  const size_t c = need_dx ? eps_bwd_dfactor_bigcore_workspace(p, dtype, precision) : 0;
+  if (c > b) b = c;
   return a + b + 256;
 }
 
@@ -84,19 +95,14 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
       return rc;
     }
   }
-  if (dX && dtype == DCTN_F32) {
-    // dX on the bigcore MFMA family: per-window factor gradients into the region the generic
-    // kernels would use (the head of their workspace), then the shared deterministic gather
-    const size_t need = (size_t)p.Wn * p.N * p.Q * sizeof(float);
-    if (ws && workspace_bytes >= off + need) {
-      rc = eps_bwd_dfactor_bigcore(x, core, dY, (float*)(ws + off), p, dtype, precision, st);
-      if (rc == DCTN_OK) {
-        rc = eps_gather_dx_launch(ws + off, dX, p, dtype, st);
-        if (rc != DCTN_OK) return rc;
-        dX = nullptr;
-      } else if (rc != DCTN_ERR_UNSUPPORTED) {
-        return rc;
-      }
+  if (dX) {
+    // dX on the bigcore MFMA family (it shares the tail of the workspace with the generic kernels)
+    rc = eps_bwd_dx_bigcore(x, core, dY, dX, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype,
+                            precision, st);
+    if (rc == DCTN_OK) {
+      dX = nullptr;
+    } else if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) {
+      return rc;
     }
   }
   if (!dX && !dCore) return DCTN_OK;

@@ -61,12 +61,14 @@ int eps_bwd_generic(const void* x, const void* core, const void* dY, void* dX, v
 int eps_gather_dx_launch(const void* gxw, void* dX, const EpsP& p, int dtype, hipStream_t st);
 
 // MFMA family "bigcore" (exact f32, LDS-streamed core) — eps_bigcore.hip
-int eps_fwd_bigcore(const void* x, const void* core, void* out, const EpsP& p, int dtype,
-                    int precision, hipStream_t st);
+size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision);
+int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t ws_bytes,
+                    const EpsP& p, int dtype, int precision, hipStream_t st);
 int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
                           int precision, hipStream_t st);
-int eps_bwd_dfactor_bigcore(const void* x, const void* core, const void* dY, float* gxw,
-                            const EpsP& p, int dtype, int precision, hipStream_t st);
+size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision);
+int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
+                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
 
 // MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
 // is outside the family so that the dispatcher can take the generic kernels.

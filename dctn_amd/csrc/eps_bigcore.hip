@@ -25,7 +25,7 @@ constexpr int BC_WAVES = 4;     // waves per workgroup
 constexpr int BC_NT_FWD = 4;    // column tiles (of 32 windows) per wave, forward
 constexpr int BC_NT_G = 2;      // ... transposed GEMMs (their LDS also holds the factor gradients)
 constexpr int BC_SROW = 33;     // padded row length of a staged k-row (32 rows + 1: conflict-free both ways)
-constexpr int BC_TBL = 8;       // generated-operand table entries per lane (k-steps per hi block)
+constexpr int BC_TBL_MAX = 16;  // generated-operand table entries per lane (k-steps per hi block): 4, 8 or 16
 constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
 
 enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
@@ -43,6 +43,8 @@ struct BigP {
   int nhb;            // hi blocks: kdim / ID
   int khalf_first, khalf_n;   // factors of the half generating the k operand: first factor, count
   int rhalf_first, rhalf_n;   // factors of the half indexing the rows
+  int rg_count, mt_per_rg;    // row tiles are split over grid.y (deterministic partial slices)
+  int BnO;                    // Bn * O: stride of `a` in the core
 };
 
 __device__ __forceinline__ float half_sum(float v) {
@@ -82,9 +84,27 @@ __device__ __forceinline__ float kr(const float* xs, const BigP& p, int first, i
   return v;
 }
 
+// Same product with a compile-time bound on the number of factors: every LDS read is issued
+// before the first multiply (digits past `nf` read a row of ones), so the latency of all of them
+// overlaps - and overlaps with MFMAs in flight.
+constexpr int BC_MAXD = 8;
+template <int WPB>
+__device__ __forceinline__ float kr_flat(const float* xs, const BigP& p, int first, int nf, int idx,
+                                         int wl, int one_row) {
+  float f[BC_MAXD];
+#pragma unroll
+  for (int d = 0; d < BC_MAXD; ++d) {
+    const int sh = d < nf ? (nf - 1 - d) * p.LQ : 0;
+    const int dg = (idx >> sh) & (p.Q - 1);
+    const int rowi = d < nf ? (first + d) * p.Q + dg : one_row;
+    f[d] = xs[rowi * WPB + wl];
+  }
+  return ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
+}
+
 // LOGO_T: log2 of the padded out size (compile time for FWD, whose epilogue selects output slots
 // statically); ignored (0) by the G modes.
-template <int MODE, int BC_NT, int LOGO_T>
+template <int MODE, int BC_NT, int LOGO_T, int BC_TBL>
 __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __restrict__ x,
                                                                 const float* __restrict__ core,
                                                                 const float* __restrict__ dY,
@@ -92,8 +112,8 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   constexpr int BC_WPB = BC_WAVES * BC_NT * 32;  // windows per workgroup
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NQ = p.N * p.Q;
-  float* xs = smem;                                   // [NQ][BC_WPB]
-  float* dys = xs + (size_t)NQ * BC_WPB;              // [OP][BC_WPB]  (G modes)
+  float* xs = smem;                                   // [NQ + 1][BC_WPB]; row NQ holds ones
+  float* dys = xs + (size_t)(NQ + 1) * BC_WPB;        // [OP][BC_WPB]  (G modes)
   float* stage = dys + (MODE == MODE_FWD ? 0 : (size_t)p.OP * BC_WPB);  // [2][BC_KSTG][64]
   float* gxs = stage + 2 * BC_KSTG * 2 * BC_SROW;     // G modes: [rhalf_n*Q][64*BC_WAVES*BC_NT]
   const int tid = threadIdx.x, lane = tid & 63, wl32 = lane & 31, h = lane >> 5, wv = tid >> 6;
@@ -115,6 +135,7 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
                       (long long)(wo + dw) * p.s[3];
     for (int q = 0; q < p.Q; ++q) xs[(n * p.Q + q) * BC_WPB + wl] = valid ? px[q * p.s[4]] : 0.f;
   }
+  for (int e = tid; e < BC_WPB; e += 64 * BC_WAVES) xs[NQ * BC_WPB + e] = 1.f;
   if (MODE != MODE_FWD) {
     for (int e = tid; e < BC_WPB * p.OP; e += 64 * BC_WAVES) {
       const int wl = e % BC_WPB, o = e / BC_WPB;
@@ -132,17 +153,13 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     const int wl = (wv * BC_NT + nt) * 32 + wl32;
 #pragma unroll
     for (int t = 0; t < BC_TBL; ++t) {
-      float v = 0.f;
-      if (t < p.tbl) {
-        const int kin = 2 * t + h;
-        if (MODE == MODE_FWD) {
-          v = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
-        } else {
-          v = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
-              dys[(kin & (p.OP - 1)) * BC_WPB + wl];
-        }
+      const int kin = 2 * t + h;
+      if (MODE == MODE_FWD) {
+        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
+      } else {
+        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
+                     dys[(kin & (p.OP - 1)) * BC_WPB + wl];
       }
-      tab[nt][t] = v;
     }
   }
 
@@ -155,20 +172,45 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   const int mtiles = (p.rows + 31) / 32;
   const int ksteps = p.kdim / 2;                      // MFMA k-steps in total
   const int nstage = (ksteps + BC_KSTG - 1) / BC_KSTG;
-  const int hb_per_stage = BC_KSTG / p.tbl;           // hi blocks per stage (tbl divides BC_KSTG)
+  constexpr int hb_per_stage = BC_KSTG / BC_TBL;      // hi blocks per stage
   constexpr int PER = BC_KSTG * 64 / (64 * BC_WAVES); // staged elements per thread
   float pre[PER];
 
   // element e of a stage: FWD/G1 walk rows fastest (the core is contiguous along the rows there),
-  // G0 walks k fastest (rows = a are Bn*O apart, k = (b,o) is contiguous)
+  // G0 walks k fastest (rows = a are Bn*O apart, k = (b,o) is contiguous).  The source offset is
+  // a per-thread constant plus a uniform term per (row tile, stage): 32 and 128 are multiples of OP.
+  unsigned coff[PER];
+  unsigned okmask = 0;  // bit i: element i has o < O
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + 64 * BC_WAVES * i;
+    const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
+    const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
+    int o;
+    if (MODE == MODE_FWD) {
+      o = row & (p.OP - 1);
+      coff[i] = (unsigned)kl * p.BnO + (row >> p.LOGO) * p.O + o;
+    } else if (MODE == MODE_G0) {
+      o = kl & (p.OP - 1);
+      coff[i] = (unsigned)row * p.BnO + (kl >> p.LOGO) * p.O + o;
+    } else {
+      o = kl & (p.OP - 1);
+      coff[i] = (unsigned)(kl >> p.LOGO) * p.BnO + row * p.O + o;
+    }
+    if (o < p.O) okmask |= 1u << i;
+  }
   auto stage_fetch = [&](int mt, int st) {
+    unsigned u;
+    if (MODE == MODE_FWD) u = (unsigned)st * 128u * p.BnO + (unsigned)mt * (32 >> p.LOGO) * p.O;
+    else if (MODE == MODE_G0) u = (unsigned)mt * 32u * p.BnO + (unsigned)st * (128 >> p.LOGO) * p.O;
+    else u = (unsigned)st * (128 >> p.LOGO) * p.BnO + (unsigned)mt * 32u * p.O;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid + 64 * BC_WAVES * i;
       const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
       const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
-      const int k = st * BC_KSTG * 2 + kl;
-      pre[i] = k < p.kdim ? amat(core, p, mt * 32 + row, k) : 0.f;
+      const bool ok = ((okmask >> i) & 1u) && (st * BC_KSTG * 2 + kl < p.kdim) && (mt * 32 + row < p.rows);
+      pre[i] = ok ? core[u + coff[i]] : 0.f;
     }
   };
   auto stage_commit = [&](int buf) {
@@ -181,7 +223,9 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     }
   };
 
-  for (int mt = 0; mt < mtiles; ++mt) {
+  const int mt_begin = blockIdx.y * p.mt_per_rg;
+  const int mt_end = mt_begin + p.mt_per_rg < mtiles ? mt_begin + p.mt_per_rg : mtiles;
+  for (int mt = mt_begin; mt < mt_end; ++mt) {
     f32x16 acc[BC_NT];
 #pragma unroll
     for (int nt = 0; nt < BC_NT; ++nt)
@@ -191,26 +235,48 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     stage_fetch(mt, 0);
     __syncthreads();  // previous tile's readers are done with both buffers
     stage_commit(0);
+    float hi[BC_NT];
+#pragma unroll
+    for (int nt = 0; nt < BC_NT; ++nt)
+      hi[nt] = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, 0, (wv * BC_NT + nt) * 32 + wl32, NQ);
     for (int st = 0; st < nstage; ++st) {
       __syncthreads();  // stage st visible; buffer (st+1)&1 free
       if (st + 1 < nstage) stage_fetch(mt, st + 1);
-      const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW;
-      for (int hb = 0; hb < hb_per_stage; ++hb) {
+      const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW + h * BC_SROW + wl32;
+      int nhb_here = p.nhb - st * hb_per_stage;
+      if (nhb_here > hb_per_stage) nhb_here = hb_per_stage;
+      float av[BC_TBL];  // matrix-operand values of the current hi block
+#pragma unroll
+      for (int t = 0; t < BC_TBL; ++t) av[t] = sb[2 * t * BC_SROW];
+      for (int hb = 0; hb < nhb_here; ++hb) {
         const int hbi = st * hb_per_stage + hb;       // global hi-block index
-        if (hbi >= p.nhb) break;
-        float hi[BC_NT];
+        // software pipeline: the NEXT block's hi products and operand values are fetched while
+        // this block's MFMAs execute (LDS latency hidden behind the matrix pipe)
+        float hin[BC_NT], avn[BC_TBL];
+        const int hbn = hbi + 1 < p.nhb ? hbi + 1 : hbi;
+        const int hbl = hb + 1 < nhb_here ? hb + 1 : hb;
+#pragma unroll
+        for (int t = 0; t < BC_TBL / 2; ++t) {
+#pragma unroll
+          for (int nt = 0; nt < BC_NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
+        }
 #pragma unroll
         for (int nt = 0; nt < BC_NT; ++nt)
-          hi[nt] = kr<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hbi, (wv * BC_NT + nt) * 32 + wl32);
+          hin[nt] = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hbn,
+                                    (wv * BC_NT + nt) * 32 + wl32, NQ);
 #pragma unroll
-        for (int t = 0; t < BC_TBL; ++t) {
-          if (t < p.tbl) {
-            const float av = sb[(2 * (hb * p.tbl + t) + h) * BC_SROW + wl32];
+        for (int t = 0; t < BC_TBL; ++t) avn[t] = sb[2 * (hbl * BC_TBL + t) * BC_SROW];
 #pragma unroll
-            for (int nt = 0; nt < BC_NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
-          }
+        for (int t = BC_TBL / 2; t < BC_TBL; ++t) {
+#pragma unroll
+          for (int nt = 0; nt < BC_NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
         }
+#pragma unroll
+        for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hin[nt];
+#pragma unroll
+        for (int t = 0; t < BC_TBL; ++t) av[t] = avn[t];
       }
       if (st + 1 < nstage) stage_commit((st + 1) & 1);
     }
@@ -266,8 +332,9 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     }
   }
 
-  // ---- results
+  // ---- results (slice blockIdx.y of the output: row groups are summed by a fixed-order reduce)
   if (MODE == MODE_FWD) {
+    out += (long long)blockIdx.y * p.Wn * p.O;
 #pragma unroll
     for (int nt = 0; nt < BC_NT; ++nt) {
       const long long w = w_block + (wv * BC_NT + nt) * 32 + wl32;
@@ -296,7 +363,7 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
       const long long w = w_block + wl;
       if (w < p.Wn) {
         const float* g = gxs + (size_t)f * 64 * BC_WAVES * BC_NT + grp * 64 + l32;
-        out[(long long)(p.rhalf_first * p.Q + f) * p.Wn + w] = g[0] + g[32];
+        out[((long long)blockIdx.y * p.N * p.Q + p.rhalf_first * p.Q + f) * p.Wn + w] = g[0] + g[32];
       }
     }
   }
@@ -463,6 +530,7 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   b.n0 = (p.N + 1) / 2; b.n1 = p.N - b.n0;
   if (b.n1 < 1) return false;
   if (b.n0 * b.LQ > 20 || b.n1 * b.LQ > 20) return false;
+  if (b.n0 > BC_MAXD || b.n1 > BC_MAXD) return false;
   b.Ho = p.Ho; b.Wo = p.Wo; b.Wn = p.Wn;
   for (int i = 0; i < 5; ++i) b.s[i] = p.s[i];
   b.OP = 1;
@@ -488,34 +556,110 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   // inner block: ID = Q^mk * (FWD ? 1 : OP) k-values, ID/2 <= BC_TBL table entries, mk >= 0 digits
   const int opk = mode == MODE_FWD ? 1 : b.OP;
   int mk = 0;
-  while (mk + 1 <= b.khalf_n && ((1 << ((mk + 1) * b.LQ)) * opk) / 2 <= BC_TBL) ++mk;
+  while (mk + 1 <= b.khalf_n && ((1 << ((mk + 1) * b.LQ)) * opk) / 2 <= BC_TBL_MAX) ++mk;
   b.mk = mk;
   b.ID = (1 << (mk * b.LQ)) * opk;
-  if (b.ID < 2 || b.ID / 2 > BC_TBL) return false;
+  if (b.ID < 2 || b.ID / 2 > BC_TBL_MAX) return false;
   b.tbl = b.ID / 2;
-  if (BC_KSTG % b.tbl) return false;
+  if (b.tbl != 4 && b.tbl != 8 && b.tbl != 16) return false;
   b.nhb = b.kdim / b.ID;
+  b.BnO = BN * p.O;
+  if (p.R * p.O >= (1LL << 31)) return false;  // 32-bit core offsets
+  b.rg_count = 1;
+  b.mt_per_rg = (b.rows + 31) / 32;
   return true;
+}
+
+// split the row tiles over grid.y so that the grid has ~8 workgroups per CU (tail balance)
+void choose_row_groups(BigP& b, int nt, int max_rg) {
+  const long long wpb = (long long)BC_WAVES * nt * 32;
+  const long long wblocks = (b.Wn + wpb - 1) / wpb;
+  const int mtiles = (b.rows + 31) / 32;
+  long long rg = (8 * 256 + wblocks - 1) / wblocks;
+  if (rg > mtiles) rg = mtiles;
+  if (rg > max_rg) rg = max_rg;
+  if (rg < 1) rg = 1;
+  b.mt_per_rg = (int)((mtiles + rg - 1) / rg);
+  b.rg_count = (mtiles + b.mt_per_rg - 1) / b.mt_per_rg;
+}
+
+constexpr int BC_MAX_RG = 16;
+
+// out[i] = sum_g part[g][i], fixed order
+__global__ void bigcore_sum_slices_k(const float* __restrict__ part, float* __restrict__ out,
+                                     long long n, int groups) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[g * n + i];
+    out[i] = s;
+  }
+}
+
+// dX from per-window factor gradients stored as `parts` slices gxw[part][N*Q][Wn]
+__global__ void bigcore_gather_dx_k(const float* __restrict__ gxw, float* __restrict__ dX, EpsP p,
+                                    int parts) {
+  const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
+  const long long slice = (long long)p.N * p.Q * p.Wn;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    long long t = idx;
+    const int q = (int)(t % p.Q); t /= p.Q;
+    const int wi = (int)(t % p.W); t /= p.W;
+    const int hi = (int)(t % p.H); t /= p.H;
+    const int b = (int)(t % p.B);
+    const int ch = (int)(t / p.B);
+    float acc = 0.f;
+    for (int dh = 0; dh < p.K; ++dh) {
+      const int ho = hi - dh;
+      if (ho < 0 || ho >= p.Ho) continue;
+      for (int dw = 0; dw < p.K; ++dw) {
+        const int wo = wi - dw;
+        if (wo < 0 || wo >= p.Wo) continue;
+        const long long win = ((long long)b * p.Ho + ho) * p.Wo + wo;
+        const long long e = (long long)(((dh * p.K + dw) * p.C + ch) * p.Q + q) * p.Wn + win;
+        for (int g = 0; g < parts; ++g) acc += gxw[g * slice + e];
+      }
+    }
+    dX[idx] = acc;
+  }
 }
 
 size_t big_lds(const BigP& b) {
   const int nt = b.mode == MODE_FWD ? BC_NT_FWD : BC_NT_G;
   const size_t wpb = (size_t)BC_WAVES * nt * 32;
-  size_t f = (size_t)b.N * b.Q * wpb + 2 * BC_KSTG * 2 * BC_SROW;
+  size_t f = ((size_t)b.N * b.Q + 1) * wpb + 2 * BC_KSTG * 2 * BC_SROW;
   if (b.mode != MODE_FWD) f += (size_t)b.OP * wpb + (size_t)b.rhalf_n * b.Q * 64 * BC_WAVES * nt;
   return f * sizeof(float);
 }
 
-template <int LOGO_T>
-int launch_fwd(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st) {
-  constexpr int WPB = BC_WAVES * BC_NT_FWD * 32;
+template <int MODE, int NT, int LOGO_T, int TBL>
+int launch_one(const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
+               hipStream_t st) {
+  constexpr int WPB = BC_WAVES * NT * 32;
   const unsigned grid = (unsigned)((b.Wn + WPB - 1) / WPB);
-  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_FWD, BC_NT_FWD, LOGO_T>,
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE, NT, LOGO_T, TBL>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((eps_bigcore_k<MODE_FWD, BC_NT_FWD, LOGO_T>), dim3(grid), dim3(64 * BC_WAVES), lds,
-                     st, (const float*)x, (const float*)core, (const float*)nullptr, (float*)out, b);
+  hipLaunchKernelGGL((eps_bigcore_k<MODE, NT, LOGO_T, TBL>), dim3(grid, b.rg_count), dim3(64 * BC_WAVES), lds, st,
+                     (const float*)x, (const float*)core, (const float*)dY, (float*)out, b);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
+}
+
+template <int MODE, int NT, int LOGO_T>
+int launch_tbl(const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
+               hipStream_t st) {
+  switch (b.tbl) {
+    case 4: return launch_one<MODE, NT, LOGO_T, 4>(x, core, dY, out, b, lds, st);
+    case 8: return launch_one<MODE, NT, LOGO_T, 8>(x, core, dY, out, b, lds, st);
+    case 16: return launch_one<MODE, NT, LOGO_T, 16>(x, core, dY, out, b, lds, st);
+  }
+  return DCTN_ERR_UNSUPPORTED;
+}
+
+template <int LOGO_T>
+int launch_fwd(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st) {
+  return launch_tbl<MODE_FWD, BC_NT_FWD, LOGO_T>(x, core, nullptr, out, b, lds, st);
 }
 
 }  // namespace
@@ -525,46 +669,89 @@ static bool bigcore_wanted(const EpsP& p) {
   return p.R * p.O >= 1024;
 }
 
-int eps_fwd_bigcore(const void* x, const void* core, void* out, const EpsP& p, int dtype,
-                    int precision, hipStream_t st) {
+size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
+  BigP b;
+  if (!fill_big(b, p, MODE_FWD)) return 0;
+  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG);
+  return b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
+}
+
+int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t ws_bytes,
+                    const EpsP& p, int dtype, int precision, hipStream_t st) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
   BigP b;
   if (!fill_big(b, p, MODE_FWD)) return DCTN_ERR_UNSUPPORTED;
   const size_t lds = big_lds(b);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG);
+  const size_t need = b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
+  if (need > 0 && (!ws || ws_bytes < need)) {  // no scratch: keep every row tile in one workgroup
+    b.rg_count = 1;
+    b.mt_per_rg = (b.rows + 31) / 32;
+  }
+  void* dst = b.rg_count > 1 ? ws : out;
   int rc = DCTN_ERR_UNSUPPORTED;
   switch (b.LOGO) {
-    case 1: rc = launch_fwd<1>(x, core, out, b, lds, st); break;
-    case 2: rc = launch_fwd<2>(x, core, out, b, lds, st); break;
-    case 3: rc = launch_fwd<3>(x, core, out, b, lds, st); break;
-    case 4: rc = launch_fwd<4>(x, core, out, b, lds, st); break;
-    case 5: rc = launch_fwd<5>(x, core, out, b, lds, st); break;
+    case 1: rc = launch_fwd<1>(x, core, dst, b, lds, st); break;
+    case 2: rc = launch_fwd<2>(x, core, dst, b, lds, st); break;
+    case 3: rc = launch_fwd<3>(x, core, dst, b, lds, st); break;
+    case 4: rc = launch_fwd<4>(x, core, dst, b, lds, st); break;
+    case 5: rc = launch_fwd<5>(x, core, dst, b, lds, st); break;
   }
   if (rc != DCTN_OK) return rc;
+  if (b.rg_count > 1) {
+    const long long n = p.Wn * p.O;
+    const unsigned g = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(bigcore_sum_slices_k, dim3(g), dim3(256), 0, st, (const float*)ws, (float*)out, n,
+                       b.rg_count);
+    DCTN_CHECK_LAUNCH();
+  }
   dctn_set_last_kernel("eps_fwd_mfma_bigcore_f32");
   return DCTN_OK;
 }
 
-// dX through the two transposed GEMMs G0, G1: per-window factor gradients into gxw[N*Q][Wn]
-// (same layout as the generic kernel's, so the generic deterministic gather finishes the job)
-int eps_bwd_dfactor_bigcore(const void* x, const void* core, const void* dY, float* gxw,
-                            const EpsP& p, int dtype, int precision, hipStream_t st) {
+// dX through the two transposed GEMMs G0, G1: per-window factor gradients into
+// gxw[row group][N*Q][Wn], then a deterministic gather (sum over row groups and over the K*K
+// windows covering each pixel).
+static bool dfactor_plan(const EpsP& p, BigP& b0, BigP& b1) {
+  if (!fill_big(b0, p, MODE_G0) || !fill_big(b1, p, MODE_G1)) return false;
+  if (big_lds(b0) > DCTN_LDS_BUDGET || big_lds(b1) > DCTN_LDS_BUDGET) return false;
+  const int mt0 = (b0.rows + 31) / 32, mt1 = (b1.rows + 31) / 32;
+  int cap = mt0 < mt1 ? mt0 : mt1;
+  if (cap > BC_MAX_RG) cap = BC_MAX_RG;
+  choose_row_groups(b0, BC_NT_G, cap);
+  choose_row_groups(b1, BC_NT_G, cap);
+  // both halves must fill the same number of slices: take the smaller count for both
+  const int rg = b0.rg_count < b1.rg_count ? b0.rg_count : b1.rg_count;
+  b0.mt_per_rg = (mt0 + rg - 1) / rg; b0.rg_count = (mt0 + b0.mt_per_rg - 1) / b0.mt_per_rg;
+  b1.mt_per_rg = (mt1 + rg - 1) / rg; b1.rg_count = (mt1 + b1.mt_per_rg - 1) / b1.mt_per_rg;
+  return b0.rg_count == b1.rg_count;
+}
+
+size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
+  BigP b0, b1;
+  if (!dfactor_plan(p, b0, b1)) return 0;
+  return (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
+}
+
+int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
+                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
   BigP b0, b1;
-  if (!fill_big(b0, p, MODE_G0) || !fill_big(b1, p, MODE_G1)) return DCTN_ERR_UNSUPPORTED;
-  const size_t l0 = big_lds(b0), l1 = big_lds(b1);
-  if (l0 > DCTN_LDS_BUDGET || l1 > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
-  constexpr int WPB = BC_WAVES * BC_NT_G * 32;
-  const unsigned grid = (unsigned)((p.Wn + WPB - 1) / WPB);
-  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_G0, BC_NT_G, 0>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0);
-  hipLaunchKernelGGL((eps_bigcore_k<MODE_G0, BC_NT_G, 0>), dim3(grid), dim3(64 * BC_WAVES), l0, st,
-                     (const float*)x, (const float*)core, (const float*)dY, gxw, b0);
-  DCTN_CHECK_LAUNCH();
-  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE_G1, BC_NT_G, 0>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
-  hipLaunchKernelGGL((eps_bigcore_k<MODE_G1, BC_NT_G, 0>), dim3(grid), dim3(64 * BC_WAVES), l1, st,
-                     (const float*)x, (const float*)core, (const float*)dY, gxw, b1);
+  if (!dfactor_plan(p, b0, b1)) return DCTN_ERR_UNSUPPORTED;
+  const size_t need = (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
+  if (!ws || ws_bytes < need) return DCTN_ERR_WORKSPACE;
+  float* gxw = (float*)ws;
+  int rc = launch_tbl<MODE_G0, BC_NT_G, 0>(x, core, dY, gxw, b0, big_lds(b0), st);
+  if (rc != DCTN_OK) return rc;
+  rc = launch_tbl<MODE_G1, BC_NT_G, 0>(x, core, dY, gxw, b1, big_lds(b1), st);
+  if (rc != DCTN_OK) return rc;
+  const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
+  const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(bigcore_gather_dx_k, dim3(g2), dim3(256), 0, st, (const float*)gxw, (float*)dX, p,
+                     b0.rg_count);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
   return DCTN_OK;

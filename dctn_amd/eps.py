@@ -31,9 +31,11 @@ class _EpsFunction(torch.autograd.Function):
         core_c = core.contiguous()
         out = torch.empty((B, H - K + 1, W - K + 1, O), dtype=input.dtype, device=dev)
         prec = L.precision()
+        code = L.dtype_code(input)
+        ws = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
         L.check(
             L.lib().dctn_eps_fwd(input.data_ptr(), L.strides5(input), core_c.data_ptr(), out.data_ptr(),
-                                 C, B, H, W, Q, K, O, L.dtype_code(input), prec, L.stream_ptr(dev)),
+                                 ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
             "eps forward",
         )
         ctx.save_for_backward(core_c, input)

@@ -56,8 +56,13 @@ const char* dctn_last_kernel(void);
  *   core : (Q,)*(K*K*C) + (O,) contiguous == row-major matrix (Q^(K*K*C), O); factor index
  *          n = pos*C + ch, pos row-major over (dh, dw)  (dctn/align.py:31-32,41-45)
  *   out  : (B, H-K+1, W-K+1, O) contiguous
+ *   workspace : scratch of dctn_eps_fwd_workspace_bytes() bytes (0 for most shapes; the large-core
+ *          family splits its row tiles over the grid and sums the slices in a fixed order)
  * ------------------------------------------------------------------------------------------ */
+size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
+                                    int dtype, int precision);
 int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
+                 void* workspace, size_t workspace_bytes,
                  int C, int B, int H, int W, int Q, int K, int O,
                  int dtype, int precision, void* stream);
 

@@ -351,7 +351,7 @@ def test_eps_bf16_mfma_strided_input_and_f32_policy():
     # float32 tensors keep exact f32 arithmetic unless the caller opts in to bf16 operands
     xf, cf = x.float(), core.float().requires_grad_(True)
     y = eps(cf, xf)
-    assert dctn_amd.last_kernel() == "eps_fwd_generic"
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"  # exact f32 on v_mfma_f32_32x32x2_f32
     assert close(y, R.eps_4step(cf.detach().cpu().double(), xf.cpu().double()), torch.float32)
     dctn_amd.set_float32_matmul_precision("bf16")
     try:

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Per-op measurements for the SURVEY 8(d) configs that are not the headline bench line:
+ConvSBS (cfg4), logmatmulexp fold (cfg5), single EPS layers (cfg1/cfg3).  HIP events around
+forward and forward+backward (dctn/benchmark.py protocol), optional CPU oracle timing.
+
+    python tools/bench_ops.py [--cpu] [--only convsbs|lme|eps]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def time_gpu(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def time_cpu(fn, budget=6.0):
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    one = time.perf_counter() - t0
+    n = max(1, min(50, int(budget / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    return (time.perf_counter() - t0) / n
+
+
+def report(name, windows, fwd_s, fb_s, extra=None):
+    row = {"op": name, "windows": windows, "fwd_us": round(fwd_s * 1e6, 1), "fwd_bwd_us": round(fb_s * 1e6, 1),
+           "fwd_Mwin_s": round(windows / fwd_s / 1e6, 1), "fwd_bwd_Mwin_s": round(windows / fb_s / 1e6, 1)}
+    if extra:
+        row.update(extra)
+    print(json.dumps(row), flush=True)
+
+
+def bench_convsbs(cpu):
+    from dctn_amd.conv_sbs import DumbNormalInitialization, ManyConvSBS
+    from dctn_amd.conv_sbs_spec import SBSSpecCore
+    from dctn_amd.pos2d import Pos2D
+    from oracle import ref_cpu as R
+
+    snake = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]
+    spec = (tuple(SBSSpecCore(Pos2D(*p), 2 if i == 4 else 1) for i, p in enumerate(snake)),)
+    for (C, q, HW, tag) in ((1, 3, 32, "cfg4 CIFAR colour q=3"), (2, 2, 30, "cfg4 second layer C=2 q=2")):
+        for r in (4, 8, 16):
+            B = 128
+            torch.manual_seed(r)
+            many = ManyConvSBS(C, q, r, False, spec, (DumbNormalInitialization((q**C * r) ** -0.5),)).to(DEV)
+            x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
+            (y,) = many(x)
+            dy = torch.randn_like(y)
+            windows = y.shape[0] * y.shape[1] * y.shape[2]
+
+            def fwd():
+                with torch.no_grad():
+                    many(x)
+
+            def fb():
+                many(x)[0].backward(dy)
+
+            extra = {}
+            if cpu:
+                Bc = 16
+                cores = [c.detach().cpu() for c in many.strings[0].cores]
+                xc = x.detach().cpu()[:, :Bc].clone().requires_grad_(True)
+                cc = [c.clone().requires_grad_(True) for c in cores]
+                dyc = dy.cpu()[:Bc]
+                torch.set_num_threads(min(16, os.cpu_count() or 1))
+                t = time_cpu(lambda: R.convsbs_forward(cc, snake, xc).backward(dyc))
+                extra["cpu_fwd_bwd_Mwin_s"] = round(windows * Bc / B / t / 1e6, 3)
+            report(f"ConvSBS snake r={r} {tag} B={B} f32", windows, time_gpu(fwd, 20), time_gpu(fb, 10), extra)
+
+
+def bench_lme(cpu):
+    from dctn_amd.logmatmulexp import logmatmulexp, logmatmulexp_fold
+    from oracle import ref_cpu as R
+    import functools
+
+    for Wn in (86528, 692224):  # 128 and 1024 samples of 26x26 windows (cfg5)
+        m = torch.randn(Wn, 9, 16, 16, device=DEV, requires_grad=True)
+        y = logmatmulexp_fold(m)
+        dy = torch.randn_like(y)
+
+        def fwd():
+            with torch.no_grad():
+                logmatmulexp_fold(m)
+
+        def fb():
+            logmatmulexp_fold(m).backward(dy)
+
+        extra = {"fwd_GBs": None}
+        f = time_gpu(fwd, 10)
+        extra["fwd_GBs"] = round(Wn * 10240 / f / 1e9, 1)
+        if cpu and Wn < 100000:
+            mc = m.detach().cpu()[:4096].clone().requires_grad_(True)
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            t = time_cpu(lambda: R.logmatmulexp_fold_batched(mc).backward(dy.cpu()[:4096]))
+            extra["cpu_fwd_bwd_Mwin_s"] = round(4096 / t / 1e6, 3)
+        report(f"logmatmulexp fold 9x(16x16) f32 windows={Wn}", Wn, f, time_gpu(fb, 5), extra)
+    # the reference's own benchmark: reduce(logmatmulexp, 6 x (256x256)) f32 (results.json row 1)
+    mats = [torch.randn(256, 256, device=DEV, requires_grad=True) for _ in range(6)]
+    y = functools.reduce(logmatmulexp, mats)
+    dy = torch.randn_like(y)
+    f = time_gpu(lambda: functools.reduce(logmatmulexp, [t.detach() for t in mats]), 20)
+    fb = time_gpu(lambda: functools.reduce(logmatmulexp, mats).backward(dy), 10)
+    print(json.dumps({"op": "reduce(logmatmulexp, 6x(256x256)) f32", "fwd_ms": round(f * 1e3, 3),
+                      "fwd_bwd_ms": round(fb * 1e3, 3),
+                      "reference_published_ms": {"fwd": 5.51, "fwd_bwd": 11.08, "hardware": "unnamed CUDA GPU"}}),
+          flush=True)
+
+
+def bench_eps(cpu):
+    from dctn_amd.eps import eps
+    from oracle import ref_cpu as R
+
+    cases = [("cfg1 K=4 Q=2 O=2 f64 B=64", 1, 64, 28, 2, 4, 2, torch.float64),
+             ("cfg3a-L1 K=4 Q=2 O=4 f32 B=128", 1, 128, 28, 2, 4, 4, torch.float32),
+             ("cfg3a-L2 K=3 Q=4 O=6 f32 B=128", 1, 128, 25, 4, 3, 6, torch.float32),
+             ("cfg3b-L1 K=4 Q=2 O=8 f32 B=128", 1, 128, 28, 2, 4, 8, torch.float32),
+             ("cfg3b-L2 K=2 Q=8 O=8 f32 B=128", 1, 128, 25, 8, 2, 8, torch.float32)]
+    for name, C, B, HW, Q, K, O, dt in cases:
+        N = K * K * C
+        x = torch.randn(C, B, HW, HW, Q, device=DEV, dtype=dt, requires_grad=True)
+        core = (torch.randn(*(Q,) * N, O, device=DEV, dtype=dt) * Q ** (-N / 2)).requires_grad_(True)
+        y = eps(core, x)
+        dy = torch.randn_like(y)
+        windows = y.shape[0] * y.shape[1] * y.shape[2]
+        flops = 2 * Q**N * O * windows
+
+        def fwd():
+            with torch.no_grad():
+                eps(core, x)
+
+        def fb():
+            eps(core, x).backward(dy)
+
+        f, b = time_gpu(fwd, 5), time_gpu(fb, 3)
+        report("eps " + name, windows, f, b, {"fwd_TFLOPs": round(flops / f / 1e12, 2),
+                                                "fwd_bwd_TFLOPs": round(3 * flops / b / 1e12, 2)})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    if a.only in ("", "eps"):
+        bench_eps(a.cpu)
+    if a.only in ("", "convsbs"):
+        bench_convsbs(a.cpu)
+    if a.only in ("", "lme"):
+        bench_lme(a.cpu)
