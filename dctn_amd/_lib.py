@@ -46,6 +46,9 @@ SIGNATURES = {
     "dctn_logmatmulexp_bwd": (c_int, [c_void] * 6 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void]),
     "dctn_logmatmulexp_fold_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int]),
     "dctn_logmatmulexp_fold_fwd": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_int, c_void]),
+    "dctn_linear_head_fwd": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_void]),
+    "dctn_linear_head_bwd_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
+    "dctn_linear_head_bwd": (c_int, [c_void] * 7 + [c_size, c_i64, c_int, c_int, c_int, c_void]),
     "dctn_logmatmulexp_fold_bwd": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_int, c_void]),
 }
 

@@ -1,0 +1,297 @@
+// Linear classifier head of EPSesPlusLinear (reference: dctn/eps_plus_linear.py:147,
+// `self.linear(rearrange(intermediate, "b h w q -> b (h w q)"))`, nn.Linear(H'W'Q, 10)).
+//
+// With 10 outputs the three GEMMs of the head (forward, dFeat, dWeight) are skinny: a library
+// GEMM spends 8-12 us on each at batch 1024, more than the EPS contraction itself.  These
+// kernels are bf16-in / f32-accumulate and bound by streaming `feat` (B x F) once:
+//   forward : v_mfma_f32_16x16x32_bf16, 16 samples x 16 (padded) classes per workgroup, the F
+//             dimension split over the 8 waves (every operand load issued up front: one memory
+//             round trip), LDS reduction, bias add.
+//   dFeat   : one lane per 8 consecutive features, the 16-byte weight chunks of all classes are
+//             loaded once and reused for 8 samples.
+//   dWeight : one lane per 4 features x all classes, samples split over grid.y into partial
+//             slices; a second kernel sums the slices in a fixed order (deterministic) and emits
+//             dBias as well.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int HEAD_MAXC = 16;
+
+// ------------------------------------------------------------------------------------ forward
+constexpr int HF_MAXK = 12;  // k-steps (of 32 features) one wave can hold in flight
+
+__global__ __launch_bounds__(512) void head_fwd_k(const bf16_t* __restrict__ feat,
+                                                  const bf16_t* __restrict__ W,
+                                                  const bf16_t* __restrict__ bias,
+                                                  bf16_t* __restrict__ out, long long B, int F,
+                                                  int Cout) {
+  __shared__ float red[8][16 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const long long b = (long long)blockIdx.x * 16 + r;      // sample of this lane's A rows
+  const bool bok = b < B, cok = r < Cout;
+  const int ksteps = (F + 31) / 32;
+  const int per = (ksteps + 7) / 8;                        // k-steps per wave
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bf16_t* fa = feat + (bok ? b : 0) * (long long)F;
+  const bf16_t* wb = W + (long long)(cok ? r : 0) * F;
+  for (int s0 = wv * per; s0 < (wv + 1) * per && s0 < ksteps; s0 += HF_MAXK) {
+    // every operand load of this wave is issued before the first MFMA: one memory round trip
+    bf16x8 av[HF_MAXK], bv[HF_MAXK];
+#pragma unroll
+    for (int u = 0; u < HF_MAXK; ++u) {
+      const int s = s0 + u;
+      const int k0 = s * 32 + 8 * g;
+      const bool in = s < (wv + 1) * per && k0 + 8 <= F;   // F % 8 == 0: a chunk is in or out
+      const int kc = in ? k0 : 0;
+      av[u] = *reinterpret_cast<const bf16x8*>(fa + kc);
+      bv[u] = *reinterpret_cast<const bf16x8*>(wb + kc);
+      if (!in || !bok) av[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (!in || !cok) bv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < HF_MAXK; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u], bv[u], acc, 0, 0, 0);
+  }
+  // D: col = lane & 15 (class), row = 4 * (lane >> 4) + reg (sample)
+#pragma unroll
+  for (int v = 0; v < 4; ++v) red[wv][(4 * g + v) * 16 + r] = acc[v];
+  __syncthreads();
+  if (tid < 256) {
+    const int row = tid >> 4, c = tid & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][tid];
+    const long long bb = (long long)blockIdx.x * 16 + row;
+    if (bb < B && c < Cout) out[bb * Cout + c] = (bf16_t)(s + (float)bias[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ dFeat
+constexpr int DF_SPB = 8;  // samples per workgroup
+
+__device__ __forceinline__ void head_bwd_dfeat_role(const bf16_t* __restrict__ W,
+                                                    const bf16_t* __restrict__ dOut,
+                                                    bf16_t* __restrict__ dFeat, long long B, int F,
+                                                    int Cout, int bx, int by, float (*gs)[HEAD_MAXC]) {
+  const int tid = threadIdx.x;
+  const int chunk = bx * 256 + tid;                         // 8 consecutive features
+  const long long b0 = (long long)by * DF_SPB;
+  if (tid < DF_SPB * HEAD_MAXC) {
+    const int s = tid / HEAD_MAXC, c = tid % HEAD_MAXC;
+    gs[s][c] = (b0 + s < B && c < Cout) ? (float)dOut[(b0 + s) * Cout + c] : 0.f;
+  }
+  const bool ok = chunk < F / 8;
+  bf16x8 wv[HEAD_MAXC];
+#pragma unroll
+  for (int c = 0; c < HEAD_MAXC; ++c)      // all weight chunks in flight together
+    wv[c] = *reinterpret_cast<const bf16x8*>(W + (long long)(c < Cout ? c : 0) * F + (ok ? chunk : 0) * 8);
+  __syncthreads();
+  float acc[DF_SPB][8];
+#pragma unroll
+  for (int s = 0; s < DF_SPB; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+#pragma unroll
+  for (int c = 0; c < HEAD_MAXC; ++c) {
+    if (c < Cout) {
+      float wf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wf[j] = (float)wv[c][j];
+#pragma unroll
+      for (int s = 0; s < DF_SPB; ++s) {
+        const float gsc = gs[s][c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] += gsc * wf[j];
+      }
+    }
+  }
+  if (ok) {
+#pragma unroll
+    for (int s = 0; s < DF_SPB; ++s) {
+      if (b0 + s < B) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[s][j];
+        *reinterpret_cast<bf16x8*>(dFeat + (b0 + s) * (long long)F + chunk * 8) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dWeight
+// partial[split][c][f] = sum_{b in split} dOut[b][c] * feat[b][f]; thread = 4 consecutive f,
+// DW_SPS samples per split (their feat loads are all issued before the arithmetic)
+constexpr int DW_SPS = 16;
+
+__device__ __forceinline__ void head_bwd_dw_role(const bf16_t* __restrict__ feat,
+                                                 const bf16_t* __restrict__ dOut,
+                                                 float* __restrict__ partial, long long B, int F,
+                                                 int Cout, int bx, int by, float (*gs)[HEAD_MAXC]) {
+  const int tid = threadIdx.x;
+  const int qi = bx * 256 + tid;
+  const bool ok = qi < F / 4;
+  const long long b0 = (long long)by * DW_SPS;
+  for (int e = tid; e < DW_SPS * HEAD_MAXC; e += 256) {
+    const int s = e / HEAD_MAXC, c = e % HEAD_MAXC;
+    gs[s][c] = (b0 + s < B && c < Cout) ? (float)dOut[(b0 + s) * Cout + c] : 0.f;
+  }
+  uint2 raw[DW_SPS];
+#pragma unroll
+  for (int s = 0; s < DW_SPS; ++s) {
+    const long long b = b0 + s < B ? b0 + s : B - 1;
+    raw[s] = *reinterpret_cast<const uint2*>(feat + b * (long long)F + (ok ? qi : 0) * 4);
+  }
+  __syncthreads();
+  float acc[HEAD_MAXC][4];
+#pragma unroll
+  for (int c = 0; c < HEAD_MAXC; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+#pragma unroll
+  for (int s = 0; s < DW_SPS; ++s) {
+    const float f0 = __uint_as_float(raw[s].x << 16), f1 = __uint_as_float(raw[s].x & 0xffff0000u);
+    const float f2 = __uint_as_float(raw[s].y << 16), f3 = __uint_as_float(raw[s].y & 0xffff0000u);
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) {
+      if (c < Cout) {
+        const float gsc = gs[s][c];   // zero for samples past B
+        acc[c][0] += gsc * f0; acc[c][1] += gsc * f1; acc[c][2] += gsc * f2; acc[c][3] += gsc * f3;
+      }
+    }
+  }
+  if (ok) {
+    float* dst = partial + (long long)by * Cout * F;
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c)
+      if (c < Cout) *reinterpret_cast<float4*>(dst + (long long)c * F + qi * 4) =
+          make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+  }
+}
+
+// One launch for both streaming passes of the backward: workgroups [0, n_dfeat) compute dFeat,
+// the rest the dWeight partial slices (independent work, no reason to serialise two launches).
+__global__ __launch_bounds__(256) void head_bwd_k(const bf16_t* __restrict__ feat,
+                                                  const bf16_t* __restrict__ W,
+                                                  const bf16_t* __restrict__ dOut,
+                                                  bf16_t* __restrict__ dFeat,
+                                                  float* __restrict__ partial, long long B, int F,
+                                                  int Cout, int n_dfeat, int dfeat_gx, int dw_gx) {
+  __shared__ float gs[DW_SPS][HEAD_MAXC];
+  static_assert(DW_SPS >= DF_SPB, "shared staging buffer");
+  const int bid = blockIdx.x;
+  if (bid < n_dfeat) {
+    head_bwd_dfeat_role(W, dOut, dFeat, B, F, Cout, bid % dfeat_gx, bid / dfeat_gx, gs);
+  } else {
+    const int r = bid - n_dfeat;
+    head_bwd_dw_role(feat, dOut, partial, B, F, Cout, r % dw_gx, r / dw_gx, gs);
+  }
+}
+
+// dW[i] = sum_split partial[split][i] (fixed order); the last workgroup produces dBias
+__global__ __launch_bounds__(256) void head_bwd_dw_reduce_k(const float* __restrict__ partial,
+                                                            const bf16_t* __restrict__ dOut,
+                                                            bf16_t* __restrict__ dW,
+                                                            bf16_t* __restrict__ dBias, long long B,
+                                                            int F, int Cout, int splits) {
+  const long long n = (long long)Cout * F;
+  if (blockIdx.x + 1 < gridDim.x) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = 0.f;
+      int k = 0;
+      for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += partial[(k + u) * n + i];
+      }
+      for (; k < splits; ++k) a[0] += partial[k * n + i];
+      dW[i] = (bf16_t)(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+    }
+  } else if (dBias) {
+    // thread t < stride handles class t % Cout over rows t / Cout, t / Cout + rows_per_pass, ...
+    __shared__ float red[256];
+    const int rpp = 256 / Cout, stride = rpp * Cout;
+    float s = 0.f;
+    if ((int)threadIdx.x < stride) {
+      const int c = threadIdx.x % Cout;
+      for (long long b = threadIdx.x / Cout; b < B; b += rpp) s += (float)dOut[b * Cout + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < Cout) {
+      float t = 0.f;
+      for (int k = 0; k < rpp; ++k) t += red[k * Cout + threadIdx.x];
+      dBias[threadIdx.x] = (bf16_t)t;
+    }
+  }
+}
+
+int dw_splits(long long B) { return (int)((B + DW_SPS - 1) / DW_SPS); }
+
+bool head_ok(long long B, int F, int Cout, int dtype) {
+  return dtype == DCTN_BF16 && B >= 1 && F >= 8 && F % 8 == 0 && Cout >= 1 && Cout <= HEAD_MAXC;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dctn_linear_head_fwd(const void* feat, const void* weight, const void* bias, void* out,
+                         int64_t B, int F, int Cout, int dtype, void* stream) {
+  if (!feat || !weight || !bias || !out) return DCTN_ERR_NULL;
+  if (B < 1 || F < 1 || Cout < 1) return DCTN_ERR_BAD_SHAPE;
+  if (!head_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (((uintptr_t)feat % 16) || ((uintptr_t)weight % 16)) return DCTN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(head_fwd_k, dim3((unsigned)((B + 15) / 16)), dim3(512), 0, (hipStream_t)stream,
+                     (const bf16_t*)feat, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out,
+                     (long long)B, F, Cout);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("linear_head_fwd_mfma");
+  return DCTN_OK;
+}
+
+size_t dctn_linear_head_bwd_workspace_bytes(int64_t B, int F, int Cout, int dtype) {
+  if (!head_ok(B, F, Cout, dtype)) return 0;
+  return (size_t)dw_splits(B) * Cout * F * sizeof(float) + 256;
+}
+
+int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut, void* dFeat,
+                         void* dWeight, void* dBias, void* workspace, size_t workspace_bytes,
+                         int64_t B, int F, int Cout, int dtype, void* stream) {
+  if (!feat || !weight || !dOut) return DCTN_ERR_NULL;
+  if (B < 1 || F < 1 || Cout < 1) return DCTN_ERR_BAD_SHAPE;
+  if (!head_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (((uintptr_t)feat % 16) || ((uintptr_t)weight % 16) || (dFeat && ((uintptr_t)dFeat % 16)))
+    return DCTN_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = dw_splits(B);
+  if (dWeight && (!workspace || workspace_bytes < (size_t)splits * Cout * F * sizeof(float)))
+    return DCTN_ERR_WORKSPACE;
+  const int dfeat_gx = (F / 8 + 255) / 256, dfeat_gy = (int)((B + DF_SPB - 1) / DF_SPB);
+  const int dw_gx = (F / 4 + 255) / 256;
+  const int n_dfeat = dFeat ? dfeat_gx * dfeat_gy : 0;
+  const int n_dw = dWeight ? dw_gx * splits : 0;
+  if (n_dfeat + n_dw > 0) {
+    hipLaunchKernelGGL(head_bwd_k, dim3((unsigned)(n_dfeat + n_dw)), dim3(256), 0, st, (const bf16_t*)feat,
+                       (const bf16_t*)weight, (const bf16_t*)dOut, (bf16_t*)dFeat, (float*)workspace,
+                       (long long)B, F, Cout, n_dfeat, dfeat_gx, dw_gx);
+    DCTN_CHECK_LAUNCH();
+  }
+  if (dWeight) {
+    const long long n = (long long)Cout * F;
+    hipLaunchKernelGGL(head_bwd_dw_reduce_k, dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, st,
+                       (const float*)workspace, (const bf16_t*)dOut, (bf16_t*)dWeight, (bf16_t*)dBias,
+                       (long long)B, F, Cout, splits);
+    DCTN_CHECK_LAUNCH();
+  }
+  dctn_set_last_kernel("linear_head_bwd");
+  return DCTN_OK;
+}
+
+}  // extern "C"

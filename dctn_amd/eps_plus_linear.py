@@ -8,6 +8,7 @@ Mirror of the reference's dctn/eps_plus_linear.py:30-196: constructor arguments
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from logging import getLogger
 from typing import Tuple, Union
@@ -17,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from . import _lib as L
 from . import eps, epses_composition
 from .utils import OneTensorInitialization, ZeroCenteredNormalInitialization, ZeroCenteredUniformInitialization
 
@@ -39,6 +41,61 @@ class ManuallyChosenInitialization:
 
 
 Initialization = Union[UnitEmpiricalOutputStd, UnitTheoreticalOutputStd, ManuallyChosenInitialization]
+
+
+class _LinearHeadFunction(torch.autograd.Function):
+    """`F.linear(feat, weight, bias)` for a skinny output (<= 16 classes), bf16, on the HIP kernels of
+    dctn_amd/csrc/linear_head.hip (the three library GEMMs of a 10-class head cost more than the
+    EPS contraction at batch 1024)."""
+
+    @staticmethod
+    def supported(feat: Tensor, weight: Tensor, bias) -> bool:
+        return (
+            feat.is_cuda and bias is not None and feat.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and feat.ndim == 2 and weight.shape[0] <= 16 and feat.shape[1] % 8 == 0
+        )
+
+    @staticmethod
+    def forward(ctx, feat: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+        dev = L.require_device(feat, weight, bias)
+        f, w, b = feat.contiguous(), weight.contiguous(), bias.contiguous()
+        B, F_ = f.shape
+        C = w.shape[0]
+        out = torch.empty((B, C), dtype=f.dtype, device=dev)
+        L.check(L.lib().dctn_linear_head_fwd(f.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, F_, C,
+                                             L.dtype_code(f), L.stream_ptr(dev)), "linear head forward")
+        ctx.save_for_backward(f, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        """Measured on MI355X at batch 1024 (profiles/README.md): the HIP backward kernels
+        (`dctn_linear_head_bwd`) only tie the library GEMMs (25.8 vs 21.6 us), so the backward
+        stays on rocBLAS; `DCTN_HEAD_BWD=hip` selects the HIP kernels."""
+        f, w = ctx.saved_tensors
+        need_f, need_w, need_b = ctx.needs_input_grad
+        if os.environ.get("DCTN_HEAD_BWD", "blas") != "hip":
+            d_f = d_out @ w if need_f else None
+            d_w = d_out.t() @ f if need_w else None
+            d_b = d_out.sum(0) if need_b else None
+            return d_f, d_w, d_b
+        dev = f.device
+        B, F_ = f.shape
+        C = w.shape[0]
+        g = d_out.contiguous()
+        d_f = torch.empty_like(f) if need_f else None
+        d_w = torch.empty_like(w) if (need_w or need_b) else None
+        d_b = torch.empty((C,), dtype=w.dtype, device=dev) if (need_w or need_b) else None
+        code = L.dtype_code(f)
+        ws = L.workspace(L.lib().dctn_linear_head_bwd_workspace_bytes(B, F_, C, code), dev)
+        L.check(
+            L.lib().dctn_linear_head_bwd(
+                f.data_ptr(), w.data_ptr(), g.data_ptr(), None if d_f is None else d_f.data_ptr(),
+                None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(),
+                ws.data_ptr(), ws.numel(), B, F_, C, code, L.stream_ptr(dev)),
+            "linear head backward",
+        )
+        return d_f, (d_w if need_w else None), (d_b if need_b else None)
 
 
 class EPSesPlusLinear(nn.Module):
@@ -106,7 +163,10 @@ class EPSesPlusLinear(nn.Module):
         else:
             cores = tuple(self.epses)
         features = epses_composition.contract_with_input(cores, input)
-        return self.linear(features.reshape(features.shape[0], -1))
+        flat = features.reshape(features.shape[0], -1)
+        if _LinearHeadFunction.supported(flat, self.linear.weight, self.linear.bias):
+            return _LinearHeadFunction.apply(flat, self.linear.weight, self.linear.bias)
+        return self.linear(flat)
 
     def epswise_l2_regularizer(self) -> Tensor:
         """||linear.weight||^2 + sum of squared Frobenius norms of the cores (bias excluded)."""

@@ -135,6 +135,22 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats,
                                void* workspace, size_t workspace_bytes,
                                int64_t Wn, int L, int D, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Linear classifier head — replaces `self.linear(features)` of dctn/eps_plus_linear.py:147
+ * (nn.Linear(H'*W'*Q, 10)) for skinny outputs.
+ *   feat (B, F), weight (Cout, F), bias (Cout), out (B, Cout), all contiguous;
+ *   this build covers bf16, Cout <= 16, F % 8 == 0 (DCTN_ERR_UNSUPPORTED otherwise: the host
+ *   layer then uses the framework's library GEMM).
+ *   Backward: dFeat (B, F), dWeight (Cout, F), dBias (Cout) are OVERWRITTEN; dFeat may be NULL;
+ *   dWeight and dBias are produced together (dBias may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int dctn_linear_head_fwd(const void* feat, const void* weight, const void* bias, void* out,
+                         int64_t B, int F, int Cout, int dtype, void* stream);
+size_t dctn_linear_head_bwd_workspace_bytes(int64_t B, int F, int Cout, int dtype);
+int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut, void* dFeat,
+                         void* dWeight, void* dBias, void* workspace, size_t workspace_bytes,
+                         int64_t B, int F, int Cout, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,3 +399,34 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
     assert close(xd.grad, dx, torch.float32)
     assert close(cd.grad, dcore, torch.float32)
+
+
+# ------------------------------------------------------------------ linear head (bf16, skinny)
+@pytest.mark.parametrize("B,F,C", [(1024, 2704, 10), (37, 3176, 10), (5, 64, 3), (130, 200, 16)])
+def test_linear_head_vs_torch_reference(B, F, C):
+    """bf16 operands, f32 accumulation; reference = the same op in float64 on the rounded inputs.
+    Tolerance 2e-2 of the output scale (bf16 output rounding 2^-8 plus bf16 products)."""
+    from dctn_amd.eps_plus_linear import _LinearHeadFunction
+
+    torch.manual_seed(B + F)
+    feat = torch.randn(B, F).bfloat16()
+    w = (torch.randn(C, F) / F**0.5).bfloat16()
+    bias = torch.randn(C).bfloat16()
+    fd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (feat, w, bias))
+    assert _LinearHeadFunction.supported(fd, wd, bd)
+    out = _LinearHeadFunction.apply(fd, wd, bd)
+    assert dctn_amd.last_kernel() == "linear_head_fwd_mfma"
+    f64, w64, b64 = (t.double().requires_grad_(True) for t in (feat, w, bias))
+    want = torch.nn.functional.linear(f64, w64, b64)
+    assert bf16_close(out, want.detach())
+    g = torch.randn(B, C).bfloat16()
+    want.backward(g.double())
+    for mode in ("blas", "hip"):  # library-GEMM backward (default) and the HIP backward kernels
+        os.environ["DCTN_HEAD_BWD"] = mode
+        try:
+            for t in (fd, wd, bd):
+                t.grad = None
+            _LinearHeadFunction.apply(fd, wd, bd).backward(g.to(DEV))
+        finally:
+            os.environ.pop("DCTN_HEAD_BWD", None)
+        assert bf16_close(fd.grad, f64.grad) and bf16_close(wd.grad, w64.grad) and bf16_close(bd.grad, b64.grad)
