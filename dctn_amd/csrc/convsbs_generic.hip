@@ -17,7 +17,10 @@
 
 struct SbsP {
   int n, C, B, H, W, q, qc, Ho, Wo, l0, Otot, vmax;
-  int cs;  // window columns per workgroup (power of two <= 64); lanes t and t+cs mirror one window
+  int cs;   // window columns per workgroup (power of two <= 64); lanes t and t+cs mirror one window
+  int cst;  // LDS column stride (cs forward; cs + 1 backward: conflict-free for both lane roles)
+  int cmax;                          // largest core (elements): size of the LDS core tile
+  long long core_off[SBS_MAXC + 1];  // offsets of the cores in the workgroup's LDS dCore accumulator
   long long Wn;
   long long s[5];
   int o[SBS_MAXC], bl[SBS_MAXC], br[SBS_MAXC], ph[SBS_MAXC], pw[SBS_MAXC];
@@ -57,7 +60,7 @@ __device__ __forceinline__ void pixel_features(const S* __restrict__ x, const Sb
                     (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4];
       pr *= valid ? (A)(*px) : A(0);
     }
-    f[qq * p.cs + col] = pr;
+    f[qq * p.cst + col] = pr;
   }
 }
 
@@ -67,15 +70,15 @@ __device__ __forceinline__ void sweep_step(const SbsP& p, int c, const A* va, A*
                                            int col) {
   const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
   const S* core = (const S*)p.core[c];
-  for (int e = 0; e < Oacc * oc * R; ++e) vb[e * p.cs + col] = A(0);
+  for (int e = 0; e < Oacc * oc * R; ++e) vb[e * p.cst + col] = A(0);
   for (int o = 0; o < oc; ++o)
     for (int l = 0; l < L; ++l)
       for (int r = 0; r < R; ++r) {
         const S* cp = core + (long long)((o * L + l) * R + r) * p.qc;
         A t = A(0);
-        for (int qq = 0; qq < p.qc; ++qq) t += (A)cp[qq] * f[qq * p.cs + col];
+        for (int qq = 0; qq < p.qc; ++qq) t += (A)cp[qq] * f[qq * p.cst + col];
         for (int a = 0; a < Oacc; ++a)
-          vb[((a * oc + o) * R + r) * p.cs + col] += va[(a * L + l) * p.cs + col] * t;
+          vb[((a * oc + o) * R + r) * p.cst + col] += va[(a * L + l) * p.cst + col] * t;
       }
 }
 
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_fwd_generic_k(const S* __re
   const int tid = threadIdx.x;
   const int col = tid & (p.cs - 1);
   const bool primary = tid < p.cs;  // lanes tid >= cs mirror the window of lane tid % cs
-  const long long w = (long long)blockIdx.x * p.cs + col;
+  const long long w = (long long)blockIdx.x * p.cst + col;
   const bool valid = w < p.Wn;
   WinCoord wc = {0, 0, 0};
   if (valid) wc = win_coord(p, w);
-  for (int a = 0; a < p.Otot; ++a) oa[a * p.cs + col] = A(0);
+  for (int a = 0; a < p.Otot; ++a) oa[a * p.cst + col] = A(0);
   for (int s = 0; s < p.l0; ++s) {
-    for (int l = 0; l < p.l0; ++l) va[l * p.cs + col] = (l == s) ? A(1) : A(0);
+    for (int l = 0; l < p.l0; ++l) va[l * p.cst + col] = (l == s) ? A(1) : A(0);
     A* cur = va;
     A* nxt = vb;
     for (int c = 0; c < p.n; ++c) {
@@ -105,110 +108,151 @@ __global__ __launch_bounds__(DCTN_WAVE) void convsbs_fwd_generic_k(const S* __re
       A* tmp = cur; cur = nxt; nxt = tmp;
     }
     for (int a = 0; a < p.Otot; ++a)
-      oa[a * p.cs + col] += cur[(a * p.l0 + s) * p.cs + col];
+      oa[a * p.cst + col] += cur[(a * p.l0 + s) * p.cst + col];
   }
   if (valid && primary)
-    for (int a = 0; a < p.Otot; ++a) out[w * p.Otot + a] = (S)oa[a * p.cs + col];
+    for (int a = 0; a < p.Otot; ++a) out[w * p.Otot + a] = (S)oa[a * p.cst + col];
 }
 
+// Backward.  Lanes play two roles per core:
+//   role "window"  (lane = window column): forward sweep (states to the workspace), adjoint sweep:
+//       dT, d(state), d(pixel features); v_c, dv_{c+1} and f_c stay in the lane's LDS column;
+//   role "element" (lane = core element (o,l,r,qq)): dCore_c[e] += sum over the block's windows of
+//       f[qq] * sum_a v[a,l] * dv[(a,o),r], read from the same LDS image (column stride cs + 1 keeps
+//       both access patterns conflict-free).  No shuffles, no atomics inside the loop.
+// Workgroups are persistent: dCore is accumulated in LDS over all their window groups and
+// flushed with one atomic per element per workgroup at the end.
 template <typename S, typename A>
-__global__ __launch_bounds__(DCTN_WAVE) void convsbs_bwd_generic_k(
+__global__ __launch_bounds__(256) void convsbs_bwd_generic_k(
     const S* __restrict__ x, const S* __restrict__ dY, A* __restrict__ states,
-    A* __restrict__ gxw, SbsP p, int need_dx, int need_dcore) {
+    A* __restrict__ gxw, SbsP p, int need_dx, int need_dcore, long long ngroups) {
   extern __shared__ __align__(16) unsigned char smem[];
   A* va = reinterpret_cast<A*>(smem);
-  A* vb = va + (size_t)p.vmax * p.cs;
-  A* vc = vb + (size_t)p.vmax * p.cs;
-  A* f = vc + (size_t)p.vmax * p.cs;
-  A* df = f + (size_t)p.qc * p.cs;
-  A* dys = df + (size_t)p.qc * p.cs;
-  const int tid = threadIdx.x;
-  const int col = tid & (p.cs - 1);
-  const bool primary = tid < p.cs;  // lanes tid >= cs mirror the window of lane tid % cs
-  const long long w = (long long)blockIdx.x * p.cs + col;
-  const bool valid = w < p.Wn;
-  const long long wcol = valid ? w : 0;
-  WinCoord wc = {0, 0, 0};
-  if (valid) wc = win_coord(p, w);
-  for (int a = 0; a < p.Otot; ++a) dys[a * p.cs + col] = valid ? (A)dY[w * p.Otot + a] : A(0);
+  A* vb = va + (size_t)p.vmax * p.cst;
+  A* vc = vb + (size_t)p.vmax * p.cst;
+  A* f = vc + (size_t)p.vmax * p.cst;
+  A* df = f + (size_t)p.qc * p.cst;
+  A* dys = df + (size_t)p.qc * p.cst;
+  A* dacc = dys + (size_t)p.Otot * p.cst;   // [core_off[n]] dCore accumulator of this workgroup
+  // a workgroup has blockDim.x / 64 waves; with several waves every wave carries 64 columns
+  // (cs == 64), with one wave the mirror-lane scheme applies (cs <= 64)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int csb = p.cst - 1;                       // window columns of the workgroup
+  const int col = nthr > DCTN_WAVE ? tid : (tid & (p.cs - 1));
+  const bool primary = nthr > DCTN_WAVE ? true : tid < p.cs;
+  if (need_dcore)
+    for (long long e = tid; e < p.core_off[p.n]; e += nthr) dacc[e] = A(0);
 
-  for (int s = 0; s < p.l0; ++s) {
-    // ---- forward sweep, storing the input state of every core
-    for (int l = 0; l < p.l0; ++l) va[l * p.cs + col] = (l == s) ? A(1) : A(0);
-    A* cur = va;
-    A* nxt = vb;
-    for (int c = 0; c < p.n; ++c) {
-      const int ne = p.oacc[c] * p.bl[c];
-      if (valid)  // mirror lanes store the same values: every lane later reads what it wrote itself
-        for (int e = 0; e < ne; ++e)
-          states[(p.st_off[c] + e) * p.Wn + wcol] = cur[e * p.cs + col];
-      if (c + 1 < p.n) {
+  for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long long w = grp * csb + col;
+    const bool valid = w < p.Wn;
+    const long long wcol = valid ? w : 0;
+    WinCoord wc = {0, 0, 0};
+    if (valid) wc = win_coord(p, w);
+    __syncthreads();
+    for (int a = 0; a < p.Otot; ++a) dys[a * p.cst + col] = valid ? (A)dY[w * p.Otot + a] : A(0);
+
+    for (int s = 0; s < p.l0; ++s) {
+      // ---- forward sweep, storing the input state of every core
+      for (int l = 0; l < p.l0; ++l) va[l * p.cst + col] = (l == s) ? A(1) : A(0);
+      A* cur = va;
+      A* nxt = vb;
+      for (int c = 0; c < p.n; ++c) {
+        const int ne = p.oacc[c] * p.bl[c];
+        if (valid)  // mirror lanes store the same values: every lane later reads what it wrote itself
+          for (int e = 0; e < ne; ++e)
+            states[(p.st_off[c] + e) * p.Wn + wcol] = cur[e * p.cst + col];
+        if (c + 1 < p.n) {
+          pixel_features<S, A>(x, p, c, valid, wc, f, col);
+          sweep_step<S, A>(p, c, cur, nxt, f, col);
+          A* tmp = cur; cur = nxt; nxt = tmp;
+        }
+      }
+      // ---- adjoint sweep.  dv: gradient wrt the OUTPUT state of core c, shape [Oacc*oc][R]
+      A* dv = vb;
+      A* dvn = vc;
+      for (int a = 0; a < p.Otot; ++a)
+        for (int r = 0; r < p.l0; ++r)
+          dv[(a * p.l0 + r) * p.cst + col] = (r == s) ? dys[a * p.cst + col] : A(0);
+      for (int c = p.n - 1; c >= 0; --c) {
+        const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
+        const S* core = (const S*)p.core[c];
+        for (int e = 0; e < Oacc * L; ++e)
+          va[e * p.cst + col] = valid ? states[(p.st_off[c] + e) * p.Wn + wcol] : A(0);
         pixel_features<S, A>(x, p, c, valid, wc, f, col);
-        sweep_step<S, A>(p, c, cur, nxt, f, col);
-        A* tmp = cur; cur = nxt; nxt = tmp;
+        for (int e = 0; e < Oacc * L; ++e) dvn[e * p.cst + col] = A(0);
+        for (int qq = 0; qq < p.qc; ++qq) df[qq * p.cst + col] = A(0);
+        for (int o = 0; o < oc; ++o)
+          for (int l = 0; l < L; ++l)
+            for (int r = 0; r < R; ++r) {
+              const int cbase = ((o * L + l) * R + r) * p.qc;
+              A t = A(0);
+              for (int qq = 0; qq < p.qc; ++qq) t += (A)core[cbase + qq] * f[qq * p.cst + col];
+              A dT = A(0);
+              for (int a = 0; a < Oacc; ++a) {
+                const A g = dv[((a * oc + o) * R + r) * p.cst + col];
+                dT += va[(a * L + l) * p.cst + col] * g;
+                dvn[(a * L + l) * p.cst + col] += t * g;
+              }
+              if (need_dx)
+                for (int qq = 0; qq < p.qc; ++qq) df[qq * p.cst + col] += dT * (A)core[cbase + qq];
+            }
+        if (need_dcore) {
+          // role "element": this lane owns elements e = tid, tid + 64, ... of core c
+          __syncthreads();
+          const int E = oc * L * R * p.qc;
+          for (int e = tid; e < E; e += nthr) {
+            const int qq = e % p.qc;
+            int t2 = e / p.qc;
+            const int r = t2 % R; t2 /= R;
+            const int l = t2 % L;
+            const int o = t2 / L;
+            A acc = A(0);
+            for (int wl = 0; wl < csb; ++wl) {
+              A dT = A(0);
+              for (int a = 0; a < Oacc; ++a)
+                dT += va[(a * L + l) * p.cst + wl] * dv[((a * oc + o) * R + r) * p.cst + wl];
+              acc += dT * f[qq * p.cst + wl];
+            }
+            dacc[p.core_off[c] + e] += acc;
+          }
+          __syncthreads();
+        }
+        if (need_dx && valid && primary) {
+          // d/d x[ch][pixel_c][qv] = sum_{qq: digit_ch(qq) = qv} df[qq] * prod_{ch' != ch} x[ch'][digit]
+          for (int ch = 0; ch < p.C; ++ch)
+            for (int qv = 0; qv < p.q; ++qv) {
+              A g = A(0);
+              for (int qq = 0; qq < p.qc; ++qq) {
+                int t = qq;
+                A pr = A(1);
+                bool hit = false;
+                for (int c2 = p.C - 1; c2 >= 0; --c2) {
+                  const int dg = t % p.q;
+                  t /= p.q;
+                  if (c2 == ch) {
+                    hit = (dg == qv);
+                  } else {
+                    pr *= (A)x[c2 * p.s[0] + wc.b * p.s[1] + (long long)(wc.ho + p.ph[c]) * p.s[2] +
+                               (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4]];
+                  }
+                }
+                if (hit) g += df[qq * p.cst + col] * pr;
+              }
+              A* dst = &gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + w];
+              if (s == 0) *dst = g; else *dst += g;
+            }
+        }
+        A* tmp = dv; dv = dvn; dvn = tmp;
       }
     }
-    // ---- adjoint sweep.  dv: gradient wrt the OUTPUT state of core c, shape [Oacc*oc][R]
-    A* dv = vb;
-    A* dvn = vc;
-    for (int a = 0; a < p.Otot; ++a)
-      for (int r = 0; r < p.l0; ++r)
-        dv[(a * p.l0 + r) * p.cs + col] = (r == s) ? dys[a * p.cs + col] : A(0);
-    for (int c = p.n - 1; c >= 0; --c) {
-      const int L = p.bl[c], R = p.br[c], oc = p.o[c], Oacc = p.oacc[c];
-      const S* core = (const S*)p.core[c];
+  }
+  if (need_dcore) {
+    __syncthreads();
+    for (int c = 0; c < p.n; ++c) {
       A* dcore = (A*)p.dcore[c];
-      for (int e = 0; e < Oacc * L; ++e)
-        va[e * p.cs + col] = valid ? states[(p.st_off[c] + e) * p.Wn + wcol] : A(0);
-      pixel_features<S, A>(x, p, c, valid, wc, f, col);
-      for (int e = 0; e < Oacc * L; ++e) dvn[e * p.cs + col] = A(0);
-      for (int qq = 0; qq < p.qc; ++qq) df[qq * p.cs + col] = A(0);
-      for (int o = 0; o < oc; ++o)
-        for (int l = 0; l < L; ++l)
-          for (int r = 0; r < R; ++r) {
-            const long long cbase = (long long)((o * L + l) * R + r) * p.qc;
-            A t = A(0);
-            for (int qq = 0; qq < p.qc; ++qq) t += (A)core[cbase + qq] * f[qq * p.cs + col];
-            A dT = A(0);
-            for (int a = 0; a < Oacc; ++a) {
-              const A g = dv[((a * oc + o) * R + r) * p.cs + col];
-              dT += va[(a * L + l) * p.cs + col] * g;
-              dvn[(a * L + l) * p.cs + col] += t * g;
-            }
-            for (int qq = 0; qq < p.qc; ++qq) {
-              df[qq * p.cs + col] += dT * (A)core[cbase + qq];
-              if (need_dcore) {
-                const A red = wave_reduce_sum<A>(primary ? dT * f[qq * p.cs + col] : A(0));
-                if (tid == 0) atomicAdd(&dcore[cbase + qq], red);
-              }
-            }
-          }
-      if (need_dx && valid && primary) {
-        // d/d x[ch][pixel_c][qv] = sum_{qq: digit_ch(qq) = qv} df[qq] * prod_{ch' != ch} x[ch'][digit]
-        for (int ch = 0; ch < p.C; ++ch)
-          for (int qv = 0; qv < p.q; ++qv) {
-            A g = A(0);
-            for (int qq = 0; qq < p.qc; ++qq) {
-              int t = qq;
-              A pr = A(1);
-              bool hit = false;
-              for (int c2 = p.C - 1; c2 >= 0; --c2) {
-                const int dg = t % p.q;
-                t /= p.q;
-                if (c2 == ch) {
-                  hit = (dg == qv);
-                } else {
-                  pr *= (A)x[c2 * p.s[0] + wc.b * p.s[1] + (long long)(wc.ho + p.ph[c]) * p.s[2] +
-                             (long long)(wc.wo + p.pw[c]) * p.s[3] + dg * p.s[4]];
-                }
-              }
-              if (hit) g += df[qq * p.cs + col] * pr;
-            }
-            A* dst = &gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + w];
-            if (s == 0) *dst = g; else *dst += g;
-          }
-      }
-      A* tmp = dv; dv = dvn; dvn = tmp;
+      const long long E = p.core_off[c + 1] - p.core_off[c];
+      for (long long e = tid; e < E; e += nthr) atomicAdd(&dcore[e], dacc[p.core_off[c] + e]);
     }
   }
 }
@@ -283,6 +327,12 @@ int fill(SbsP& p, const int64_t xs[5], int n, const int* out_sizes, const int* b
   }
   p.oacc[n] = (int)oacc;
   p.st_off[n] = off;
+  p.cmax = 0;
+  for (int c = 0; c < n; ++c) {
+    const long long e = (long long)p.o[c] * p.bl[c] * p.br[c] * p.qc;
+    if (e > (1 << 20)) return DCTN_ERR_UNSUPPORTED;
+    if ((int)e > p.cmax) p.cmax = (int)e;
+  }
   p.Otot = (int)oacc;
   p.vmax = vmax;
   return DCTN_OK;
@@ -301,6 +351,7 @@ int fwd_launch(const void* x, void* out, SbsP& p, hipStream_t st) {
   while (p.cs > 1 && per_col * p.cs > DCTN_LDS_BUDGET) p.cs >>= 1;
   const size_t lds = per_col * p.cs;
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  p.cst = p.cs;
   const unsigned grid = (unsigned)((p.Wn + p.cs - 1) / p.cs);
   (void)hipFuncSetAttribute((const void*)convsbs_fwd_generic_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -324,10 +375,20 @@ template <typename S, typename A>
 int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, void* ws,
                size_t ws_bytes, SbsP& p, int dtype, hipStream_t st) {
   if (!ws || bwd_ws(p, dtype) > ws_bytes) return DCTN_ERR_WORKSPACE;
+  p.core_off[0] = 0;
+  for (int c = 0; c < p.n; ++c) p.core_off[c + 1] = p.core_off[c] + core_elems(p, c);
+  const int need_dcore_lds = dCores != nullptr;
+  const size_t acc_bytes = need_dcore_lds ? (size_t)p.core_off[p.n] * sizeof(A) : 0;
+  if (acc_bytes > DCTN_LDS_BUDGET / 2) return DCTN_ERR_UNSUPPORTED;
   const size_t per_col = ((size_t)3 * p.vmax + 2 * p.qc + p.Otot) * sizeof(A);
   p.cs = DCTN_WAVE;
-  while (p.cs > 1 && per_col * p.cs > DCTN_LDS_BUDGET) p.cs >>= 1;
-  const size_t lds = per_col * p.cs;
+  while (p.cs > 1 && per_col * (p.cs + 1) + acc_bytes > DCTN_LDS_BUDGET) p.cs >>= 1;
+  int waves = 1;  // several waves share one dCore accumulator when every wave has its 64 columns
+  if (p.cs == DCTN_WAVE && acc_bytes >= 4096)  // small strings: more, smaller workgroups win
+    while (waves < 4 && per_col * (2 * waves * DCTN_WAVE + 1) + acc_bytes <= DCTN_LDS_BUDGET) waves *= 2;
+  const int csb = waves * p.cs;
+  p.cst = csb + 1;
+  const size_t lds = per_col * p.cst + acc_bytes;
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   unsigned char* wsp = (unsigned char*)ws;
   A* states = (A*)wsp;
@@ -348,11 +409,17 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
         return DCTN_ERR_LAUNCH;
     }
   }
-  const unsigned grid = (unsigned)((p.Wn + p.cs - 1) / p.cs);
+  const long long ngroups = (p.Wn + csb - 1) / csb;
+  // persistent workgroups: as many as can be resident (LDS-limited), at most one per window group
+  long long per_cu = (long long)(160 * 1024) / (long long)(lds ? lds : 1);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long long grid = 256 * per_cu;
+  if (grid > ngroups) grid = ngroups;
   (void)hipFuncSetAttribute((const void*)convsbs_bwd_generic_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((convsbs_bwd_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,
-                     (const S*)x, (const S*)dY, states, gxw, p, dX != nullptr, need_dcore);
+  hipLaunchKernelGGL((convsbs_bwd_generic_k<S, A>), dim3((unsigned)grid), dim3(DCTN_WAVE * waves), lds, st,
+                     (const S*)x, (const S*)dY, states, gxw, p, dX != nullptr, need_dcore, ngroups);
   DCTN_CHECK_LAUNCH();
   if (dX) {
     const long long total = (long long)p.C * p.B * p.H * p.W * p.q;
