@@ -146,27 +146,40 @@ def kernel_roofline(model, x, specs, image_size, steps):
         L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),
                                  ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, st), "bwd")
 
-    res = {}
-    for name, fn in (("eps_fwd", fwd), ("eps_bwd_dcore", bwd)):
+    # (a) whole C-ABI call, back to back on torch's current stream (the stream the kernels are
+    # launched on); (b) the call's dominant KERNEL alone (dctn_profile_main_kernel_only), same method
+    def timed(fn, n):
         for _ in range(5):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
-        n = max(steps, 50)
         e0.record()
         for _ in range(n):
             fn()
         e1.record()
         torch.cuda.synchronize(dev)
-        res[name] = (e0.elapsed_time(e1) / n * 1e-3, L.last_kernel())
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    res, single = {}, {}
+    kernel_symbol = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}
+    n = max(steps, 100)
+    for name, fn in (("eps_fwd", fwd), ("eps_bwd_dcore", bwd)):
+        res[name] = (timed(fn, n), L.last_kernel())
+        if "q2reg" in L.last_kernel():
+            lib.dctn_profile_main_kernel_only(1)
+            try:
+                single[name] = timed(fn, n)
+            finally:
+                lib.dctn_profile_main_kernel_only(0)
     wn = B * Ho * Ho
     # algorithmic bytes per launch: read x once, write out (fwd) / read dY (bwd) once, core / dCore once
     bytes_x = C * B * H * W * Q * esz
     bytes_y = wn * O * esz
     bytes_core = core.numel() * esz
     alg = {"eps_fwd": bytes_x + bytes_y + bytes_core, "eps_bwd_dcore": bytes_x + bytes_y + bytes_core}
-    dom = max(res, key=lambda k: res[k][0])
-    sec, kname = res[dom]
+    dom = max(single, key=lambda k: single[k]) if single else max(res, key=lambda k: res[k][0])
+    sec = single.get(dom, res[dom][0])
+    kname = kernel_symbol[dom] if dom in single else res[dom][1]
     achieved = alg[dom] / sec / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -179,7 +192,8 @@ def kernel_roofline(model, x, specs, image_size, steps):
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "kernel": kname, "launch_us": sec * 1e6, "algorithmic_bytes": alg[dom],
         "bytes_per_window": alg[dom] / wn,
-        "all_kernels_us": {k: v[0] * 1e6 for k, v in res.items()},
+        "calls_us": {k: v[0] * 1e6 for k, v in res.items()},
+        "kernels_us": {kernel_symbol[k]: v * 1e6 for k, v in single.items()},
     }
 
 
@@ -192,16 +206,21 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default 1024 for cfg2, 128 for cfg3)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + "
+                    "DCTN_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a single GPU")
     args = ap.parse_args()
 
     from dctn_amd import ddp
     from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
     import dctn_amd
 
-    rank, local_rank, world = ddp.init_from_env()
+    one_device = os.environ.get("DCTN_BENCH_ONE_DEVICE") == "1"
+    if one_device:  # rehearsal only: every rank on cuda:0, collectives through gloo
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    rank, local_rank, world = ddp.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     specs, image_size, q0, dtype = WORKLOADS[args.workload]
     batch = args.batch or (1024 if args.workload.startswith("cfg2") else 128)

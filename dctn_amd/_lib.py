@@ -30,6 +30,7 @@ _PtrP = ctypes.POINTER(c_void)
 # name -> (restype, argtypes); mirrors include/dctn_amd.h one to one
 SIGNATURES = {
     "dctn_version": (c_int, []),
+    "dctn_profile_main_kernel_only": (None, [c_int]),
     "dctn_strerror": (ctypes.c_char_p, [c_int]),
     "dctn_last_kernel": (ctypes.c_char_p, []),
     "dctn_eps_fwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),

@@ -4,9 +4,14 @@
 static const char* volatile g_last_kernel = "none";  // process-wide: autograd runs backward on its own thread
 void dctn_set_last_kernel(const char* name) { g_last_kernel = name; }
 
+static volatile int g_main_only = 0;
+bool dctn_main_kernel_only() { return g_main_only != 0; }
+
 extern "C" {
 
 int dctn_version(void) { return 100; }
+
+void dctn_profile_main_kernel_only(int on) { g_main_only = on; }
 
 const char* dctn_last_kernel(void) { return g_last_kernel; }
 

@@ -21,6 +21,9 @@ template <> struct AccOf<double> { typedef double type; };
 // name of the kernel family the last call dispatched to
 void dctn_set_last_kernel(const char* name);
 
+// measurement aid: launch only the dominant kernel of multi-kernel calls (dctn_profile_main_kernel_only)
+bool dctn_main_kernel_only();
+
 static inline long long ipow_ll(long long b, int e) {
   long long r = 1;
   for (int i = 0; i < e; ++i) r *= b;

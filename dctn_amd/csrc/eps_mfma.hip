@@ -533,6 +533,7 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
     hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false>), g, b, 0, st,
                        (const S*)x, (const S*)dY, (float*)ws, m);
   DCTN_CHECK_LAUNCH();
+  if (dctn_main_kernel_only()) return DCTN_OK;
   hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
                      (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
   DCTN_CHECK_LAUNCH();

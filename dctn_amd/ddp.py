@@ -53,7 +53,13 @@ def broadcast_parameters(params: Iterable[Tensor], src: int = 0) -> None:
 
 
 class FlatGradAllReducer:
-    """Sums (or averages) the gradients of `params` over all ranks through one flat buffer."""
+    """Sums (or averages) the gradients of `params` over all ranks through one flat buffer.
+
+    The messages are tiny (BASELINE cfg2: 29 k values), so the step is latency-bound: the whole
+    exchange is three launches - one `cat` into the bucket, one all-reduce (RCCL `AVG` when
+    available), one multi-tensor copy back.  When all parameters share a dtype the bucket has that
+    dtype (no conversion kernels); mixed dtypes go through an fp32 bucket.
+    """
 
     def __init__(self, params: Iterable[Tensor], average: bool = True):
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
@@ -61,31 +67,45 @@ class FlatGradAllReducer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         numel = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        # fp32 bucket even for bf16 parameters: the sum over ranks must not lose bits
-        self.bucket = torch.zeros(numel, dtype=torch.float32 if ref.dtype != torch.float64 else torch.float64,
-                                  device=ref.device)
+        dtypes = {p.dtype for p in self.params}
+        self.same_dtype = len(dtypes) == 1
+        bucket_dtype = ref.dtype if self.same_dtype else (
+            torch.float64 if torch.float64 in dtypes else torch.float32)
+        self.bucket = torch.zeros(numel, dtype=bucket_dtype, device=ref.device)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.bucket[off : off + p.numel()].view_as(p))
             off += p.numel()
+        backend = dist.get_backend() if dist.is_initialized() else ""
+        self.use_avg = average and backend == "nccl"
 
     @torch.no_grad()
     def __call__(self) -> None:
         if self.world == 1:
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
-        if self.average:
-            self.bucket.div_(self.world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.to(p.dtype).clone()
-            else:
-                p.grad.copy_(v)
+        grads = [p.grad for p in self.params]
+        if self.same_dtype and all(g is not None for g in grads):
+            torch.cat([g.reshape(-1) for g in grads], out=self.bucket)
+        else:
+            for g, v in zip(grads, self.views):
+                if g is None:
+                    v.zero_()
+                else:
+                    v.copy_(g)
+        if self.use_avg:
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+            if self.average:
+                self.bucket.div_(self.world)
+        if self.same_dtype and all(g is not None for g in grads):
+            torch._foreach_copy_(grads, self.views)
+        else:
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    p.grad = v.to(p.dtype).clone()
+                else:
+                    p.grad.copy_(v)
 
 
 @torch.no_grad()

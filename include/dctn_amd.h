@@ -45,6 +45,11 @@ enum {
 };
 
 int dctn_version(void);
+/* Measurement aid (bench.py's roofline leg only): while on, multi-kernel calls launch ONLY their
+ * dominant kernel (dctn_eps_bwd on the q2-reg family: the dCore partial-sum kernel without the
+ * small slice reduction), so back-to-back launches time that single kernel and can be compared
+ * with rocprofv3's per-kernel average.  Results of such calls are incomplete by design. */
+void dctn_profile_main_kernel_only(int on);
 const char* dctn_strerror(int code);
 /* name of the kernel family the last successful call dispatched to
  * (diagnostics / tests: proves which HIP path ran; process-wide, last writer wins) */
