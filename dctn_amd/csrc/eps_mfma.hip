@@ -61,6 +61,12 @@ struct MfmaP {
   unsigned foffb[MFMA_MAXN];  // BYTE offset of factor n relative to the window's top-left pixel
   unsigned s1b, s2b, s3b, s4b;  // byte strides of x (batch, row, column, feature); x spans < 4 GiB
   FastDiv div_hw, div_wo;
+  unsigned rowoffb[MFMA_MAXN];  // row loads: BYTE offset of window row (dh, ch), index dh*C + ch
+  unsigned x_bytes;             // extent of x in bytes (row loads are clamped to stay inside)
+  int rowvec_ok;                // one 16-byte load per window row usable (bf16, Q=2 contiguous, K <= 4)
+  unsigned row_wrap, img_wrap;  // offset corrections when a window walk wraps a row / an image
+  int inc_ok;                   // incremental walk usable (Wo >= 16, Ho*Wo >= 32)
+  long long gpw;                // window groups per wave (contiguous range)
   int vec_ok;             // x: last stride 1, even strides, 4-byte aligned base (bf16 pair loads)
 };
 
@@ -74,18 +80,60 @@ struct RawWindow {
   typedef typename std::conditional<sizeof(S) == 2, unsigned, float2>::type vec_t;
   vec_t v[VEC ? N : 1];
   S e[VEC ? 1 : N][2];
+  uint4 row[MFMA_MAXN / 2];  // row-vector mode (bf16): K pixels of one window row per 16-byte load
+  unsigned shift;            // bit rw set: that row's load was moved back by one pixel (tensor end)
 };
 
-template <typename S, int N, bool VEC>
-__device__ __forceinline__ void issue_window(const S* __restrict__ x, const MfmaP& p, long long w,
-                                             bool valid, RawWindow<S, N, VEC>& raw) {
-  const unsigned wu = valid ? (unsigned)w : 0u;
+// Byte offset of the top-left pixel of a lane's window, advanced by 32 windows per step without
+// divisions or integer multiplies (the wave walks a contiguous range of window groups).
+struct WinIter {
+  unsigned off;   // byte offset of the window's top-left pixel (feature 0)
+  int wo, ho;
+};
+__device__ __forceinline__ WinIter win_begin(const MfmaP& p, long long w) {
+  const unsigned wu = w < p.Wn ? (unsigned)w : 0u;
   const unsigned b = fdiv(wu, p.div_hw);
   const unsigned rem = wu - b * (unsigned)(p.Ho * p.Wo);
   const unsigned ho = fdiv(rem, p.div_wo), wo = rem - ho * (unsigned)p.Wo;
-  const unsigned off0 = b * p.s1b + ho * p.s2b + wo * p.s3b;
+  WinIter it;
+  it.off = b * p.s1b + ho * p.s2b + wo * p.s3b;
+  it.wo = (int)wo;
+  it.ho = (int)ho;
+  return it;
+}
+// requires Wo >= 16 and Ho * Wo >= 32 (host-checked: p.inc_ok): at most two row wraps and one image wrap
+__device__ __forceinline__ void win_advance32(const MfmaP& p, WinIter& it) {
+  it.wo += 32;
+  it.off += 32u * p.s3b;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const bool wrap = it.wo >= p.Wo;
+    it.wo -= wrap ? p.Wo : 0;
+    it.ho += wrap ? 1 : 0;
+    it.off += wrap ? p.row_wrap : 0u;
+  }
+  const bool iw = it.ho >= p.Ho;
+  it.ho -= iw ? p.Ho : 0;
+  it.off += iw ? p.img_wrap : 0u;
+}
+
+// ROWS > 0: row-vector mode with ROWS = K*C rows (one global_load_dwordx4 per row instead of K
+// dword loads: 3x fewer memory requests per window for the 3x3 kernel)
+template <typename S, int N, bool VEC, int ROWS>
+__device__ __forceinline__ void issue_window(const S* __restrict__ x, const MfmaP& p, unsigned off0,
+                                             RawWindow<S, N, VEC>& raw) {
   const char* xb = reinterpret_cast<const char*>(x);
-  if constexpr (VEC) {
+  if constexpr (ROWS > 0) {
+    // a 16-byte load at the last pixel of the tensor would run 4 bytes past its end: move it back
+    // by one pixel there and remember to select the next dword
+    raw.shift = 0;
+#pragma unroll
+    for (int rw = 0; rw < ROWS; ++rw) {
+      unsigned o = off0 + p.rowoffb[rw];
+      if (o + 16u > p.x_bytes) { o -= 4u; raw.shift |= 1u << rw; }
+      raw.row[rw] = *reinterpret_cast<const uint4*>(xb + (size_t)o);
+    }
+  } else if constexpr (VEC) {
 #pragma unroll
     for (int n = 0; n < N; ++n)
       raw.v[n] = *reinterpret_cast<const typename RawWindow<S, N, VEC>::vec_t*>(xb + (size_t)(off0 + p.foffb[n]));
@@ -98,8 +146,30 @@ __device__ __forceinline__ void issue_window(const S* __restrict__ x, const Mfma
   }
 }
 
-template <typename S, int N, bool VEC>
-__device__ __forceinline__ void unpack_window(const RawWindow<S, N, VEC>& raw, float (&xv)[N][2]) {
+template <typename S, int N, bool VEC, int ROWS>
+__device__ __forceinline__ void unpack_window(const RawWindow<S, N, VEC>& raw, const MfmaP& p,
+                                              float (&xv)[N][2]) {
+  if constexpr (ROWS > 0) {
+    constexpr int KK = N / ROWS;  // pixels per row = K
+#pragma unroll
+    for (int rw = 0; rw < ROWS; ++rw) {
+      const bool sh = (raw.shift >> rw) & 1u;
+      const unsigned d[4] = {raw.row[rw].x, raw.row[rw].y, raw.row[rw].z, raw.row[rw].w};
+#pragma unroll
+      for (int dw = 0; dw < KK; ++dw) {
+        // factor n = (dh*K + dw)*C + ch for row rw = dh*C + ch
+        const int dh = rw / p.C, ch = rw - dh * p.C;
+        (void)dh; (void)ch;
+        const unsigned u = sh ? d[dw + 1 < 4 ? dw + 1 : 3] : d[dw];
+        // static factor index needs C at compile time: ROWS = K*C and N = K*K*C give C = ROWS*ROWS/N
+        constexpr int CC = ROWS * ROWS / N;
+        const int n = ((rw / CC) * KK + dw) * CC + (rw % CC);
+        xv[n][0] = __uint_as_float(u << 16);
+        xv[n][1] = __uint_as_float(u & 0xffff0000u);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < N; ++n) {
     if constexpr (VEC && sizeof(S) == 2) {
@@ -171,7 +241,7 @@ __device__ __forceinline__ void build_p0(const float (*xv)[2], int h, bf16x8 (&f
 // ------------------------------------------------------------------------------------ forward
 // Row code of accumulator register v of M-tile t (lane-half bit h excluded):
 //   code = (t << 4) | ((v >> 2) << 2) | (v & 3);   o = code & (OP-1);   b = ((code >> LOGO) << 1) | h
-template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC>
+template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS>
 __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
                                                        const S* __restrict__ core,
                                                        S* __restrict__ out, MfmaP p) {
@@ -209,18 +279,26 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
-  const long long wave = (long long)blockIdx.x * 4 + (tid >> 6);
-  const long long nwaves = (long long)gridDim.x * 4;
+  // XCD-contiguous mapping: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give
+  // each XCD one contiguous eighth of the windows: its L2 then fetches only that part of x.
+  const long long nb = gridDim.x;
+  const long long vb = (nb % 8 == 0) ? (long long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const long long wave = vb * 4 + (tid >> 6);
+  const long long g0 = wave * p.gpw;
+  const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
   RawWindow<S, N, XVEC> raw;
-  if (wave < p.ngroups) issue_window<S, N, XVEC>(x, p, wave * 32 + r, wave * 32 + r < p.Wn, raw);
-  for (long long g = wave; g < p.ngroups; g += nwaves) {
+  WinIter it = win_begin(p, g0 * 32 + r);
+  if (g0 < g1) issue_window<S, N, XVEC, ROWS>(x, p, g0 * 32 + r < p.Wn ? it.off : 0u, raw);
+  for (long long g = g0; g < g1; ++g) {
     const long long w = g * 32 + r;
     const bool valid = w < p.Wn;
     float xv[N][2];
-    unpack_window<S, N, XVEC>(raw, xv);
+    unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
     {  // prefetch the next group of this wave (the last iteration re-reads its own group)
-      const long long gn = g + nwaves < p.ngroups ? g + nwaves : g;
-      issue_window<S, N, XVEC>(x, p, gn * 32 + r, gn * 32 + r < p.Wn, raw);
+      if (g + 1 < g1) {
+        if (p.inc_ok) win_advance32(p, it); else it = win_begin(p, w + 32);
+      }
+      issue_window<S, N, XVEC, ROWS>(x, p, (g + 1 < g1 ? w + 32 : w) < p.Wn ? it.off : 0u, raw);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
     }
     bf16x8 pf[KS];
@@ -262,7 +340,7 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
 // feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
 constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LDS reduction per block)
 
-template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC>
+template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS>
 __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
                                                              const S* __restrict__ dY,
                                                              float* __restrict__ partial, MfmaP p) {
@@ -288,26 +366,32 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[t][a][v] = 0.f;
 
-  const long long wave = (long long)blockIdx.x * BWD_WAVES + wv;
-  const long long nwaves = (long long)gridDim.x * BWD_WAVES;
+  const long long nb = gridDim.x;
+  const long long vb = (nb % 8 == 0) ? (long long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const long long wave = vb * BWD_WAVES + wv;
+  const long long g0 = wave * p.gpw;
+  const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
   RawWindow<S, N, XVEC> raw;
   RowPack<S, OP> rawdy;
-  if (wave < p.ngroups) {
-    const long long w0 = wave * 32 + r;
-    issue_window<S, N, XVEC>(x, p, w0, w0 < p.Wn, raw);
+  WinIter it = win_begin(p, g0 * 32 + r);
+  if (g0 < g1) {
+    const long long w0 = g0 * 32 + r;
+    issue_window<S, N, XVEC, ROWS>(x, p, w0 < p.Wn ? it.off : 0u, raw);
     issue_row<S, OP, OVEC>(dY + (w0 < p.Wn ? w0 : 0) * p.O, p.O, rawdy);
   }
-  for (long long g = wave; g < p.ngroups; g += nwaves) {
+  for (long long g = g0; g < g1; ++g) {
     const long long w = g * 32 + r;
     const bool valid = w < p.Wn;
     float xv[N][2];
-    unpack_window<S, N, XVEC>(raw, xv);
+    unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
     float dy[OP];
     unpack_row<S, OP>(rawdy, p.O, dy);
     {  // prefetch the next group of this wave
-      const long long gn = g + nwaves < p.ngroups ? g + nwaves : g;
-      const long long wn = gn * 32 + r;
-      issue_window<S, N, XVEC>(x, p, wn, wn < p.Wn, raw);
+      const long long wn = g + 1 < g1 ? w + 32 : w;
+      if (g + 1 < g1) {
+        if (p.inc_ok) win_advance32(p, it); else it = win_begin(p, wn);
+      }
+      issue_window<S, N, XVEC, ROWS>(x, p, wn < p.Wn ? it.off : 0u, raw);
       issue_row<S, OP, OVEC>(dY + (wn < p.Wn ? wn : 0) * p.O, p.O, rawdy);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
     }
@@ -473,6 +557,24 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
   }
   m.s1b = (unsigned)(p.s[1] * esz_); m.s2b = (unsigned)(p.s[2] * esz_);
   m.s3b = (unsigned)(p.s[3] * esz_); m.s4b = (unsigned)(p.s[4] * esz_);
+  {
+    long long ext = 0;
+    const long long dims[5] = {p.C, p.B, p.H, p.W, p.Q};
+    for (int i = 0; i < 5; ++i) ext += (dims[i] - 1) * p.s[i];
+    m.x_bytes = (unsigned)((ext + 1) * esz_);
+    const int rows = p.K * p.C;
+    for (int rw = 0; rw < rows && rw < MFMA_MAXN; ++rw) {
+      const int dh = rw / p.C, ch = rw - dh * p.C;
+      m.rowoffb[rw] = (unsigned)((ch * p.s[0] + dh * p.s[2]) * esz_);
+    }
+    // K pixels of a row in one 16-byte load: bf16 pairs (4 bytes per pixel), pixels contiguous
+    m.rowvec_ok = dtype == DCTN_BF16 && p.s[4] == 1 && p.s[3] == 2 && p.K <= 4 && rows <= MFMA_MAXN / 2 &&
+                  ((p.N == 9 && rows == 3) || (p.N == 8 && rows == 4)) && m.x_bytes >= 32;
+  }
+  m.row_wrap = (unsigned)(p.s[2] * esz_) - (unsigned)p.Wo * (unsigned)(p.s[3] * esz_);
+  m.img_wrap = (unsigned)(p.s[1] * esz_) - (unsigned)p.Ho * (unsigned)(p.s[2] * esz_);
+  m.inc_ok = p.Wo >= 16 && p.Ho * p.Wo >= 32;
+  m.gpw = 1;
   m.div_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
   m.div_wo = make_fastdiv((unsigned)p.Wo);
   m.C = p.C; m.B = p.B; m.H = p.H; m.W = p.W; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
@@ -487,29 +589,40 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
 constexpr int FWD_BLOCKS_PER_CU = 4;
 constexpr int NUM_CU = 256;
 
-int bwd_grid(const MfmaP& m) {
+int bwd_grid(MfmaP& m) {
   long long blocks = (m.ngroups + BWD_WAVES - 1) / BWD_WAVES;
-  static const int bdiv = getenv("DCTN_BWD_DIV") ? atoi(getenv("DCTN_BWD_DIV")) : 1;
-  if (blocks > NUM_CU / bdiv) blocks = NUM_CU / bdiv;
+  if (blocks > NUM_CU) blocks = NUM_CU;
   if (blocks < 1) blocks = 1;
+  m.gpw = (m.ngroups + blocks * BWD_WAVES - 1) / (blocks * BWD_WAVES);
+  blocks = (m.ngroups + m.gpw * BWD_WAVES - 1) / (m.gpw * BWD_WAVES);
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+  if (blocks > NUM_CU) blocks = NUM_CU;
   return (int)blocks;
 }
 
 template <typename S, int N0, int N1, int OP>
-int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m, hipStream_t st) {
+int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m_in, hipStream_t st) {
+  MfmaP m = m_in;
   long long blocks = (m.ngroups + 3) / 4;
-  static const int bpc = getenv("DCTN_FWD_BPC") ? atoi(getenv("DCTN_FWD_BPC")) : FWD_BLOCKS_PER_CU;
-  if (blocks > (long long)bpc * NUM_CU) blocks = (long long)bpc * NUM_CU;
+  if (blocks > (long long)FWD_BLOCKS_PER_CU * NUM_CU) blocks = (long long)FWD_BLOCKS_PER_CU * NUM_CU;
+  m.gpw = (m.ngroups + blocks * 4 - 1) / (blocks * 4);
+  blocks = (m.ngroups + m.gpw * 4 - 1) / (m.gpw * 4);   // no idle workgroups at the end
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;        // XCD-contiguous mapping needs a multiple of 8
   const bool ovec = m.O == OP && ((uintptr_t)out % (sizeof(S) * OP)) == 0;
   const dim3 g((unsigned)blocks), b(256);
-  if (m.vec_ok && ovec)
-    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true>), g, b, 0, st, (const S*)x,
+  constexpr int NN = N0 + N1;
+  constexpr int RW = NN == 9 ? 3 : 4;   // K*C window rows: 3x3 single channel, 2x2 two channels
+  if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true, RW>), g, b, 0, st, (const S*)x,
+                       (const S*)core, (S*)out, m);
+  else if (m.vec_ok && ovec)
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true, 0>), g, b, 0, st, (const S*)x,
                        (const S*)core, (S*)out, m);
   else if (m.vec_ok)
-    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, false>), g, b, 0, st, (const S*)x,
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, false, 0>), g, b, 0, st, (const S*)x,
                        (const S*)core, (S*)out, m);
   else
-    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, false, false>), g, b, 0, st, (const S*)x,
+    hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, false, false, 0>), g, b, 0, st, (const S*)x,
                        (const S*)core, (S*)out, m);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_fwd_mfma_q2reg");
@@ -517,20 +630,26 @@ int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m, hip
 }
 
 template <typename S, int N0, int N1, int OP>
-int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const MfmaP& m,
+int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const MfmaP& m_in,
                  hipStream_t st) {
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
+  MfmaP m = m_in;
   const int grid = bwd_grid(m);
   const bool ovec = m.O == OP && ((uintptr_t)dY % (sizeof(S) * OP)) == 0;
   const dim3 g(grid), b(64 * BWD_WAVES);
-  if (m.vec_ok && ovec)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true>), g, b, 0, st,
+  constexpr int NN = N0 + N1;
+  constexpr int RW = NN == 9 ? 3 : 4;
+  if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (float*)ws, m);
+  else if (m.vec_ok && ovec)
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0>), g, b, 0, st,
                        (const S*)x, (const S*)dY, (float*)ws, m);
   else if (m.vec_ok)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false>), g, b, 0, st,
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0>), g, b, 0, st,
                        (const S*)x, (const S*)dY, (float*)ws, m);
   else
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false>), g, b, 0, st,
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0>), g, b, 0, st,
                        (const S*)x, (const S*)dY, (float*)ws, m);
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
