@@ -185,6 +185,87 @@ __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- factored fold, D = 16, float32
+// out[t,i] = a_t + b_i + log( sum_r exp(acc[t,r] - a_t) * exp(M[r,i] - b_i) ),  a_t = max_r acc[t,r],
+// b_i = max_r M[r,i]: 2*256 exps + 256 logs + one 16x16x16 matrix product per step instead of 4096
+// exps.  One wave per window; the product runs on v_mfma_f32_16x16x4_f32 (exact f32) in TRANSPOSED
+// form, out^T = E2^T x E1^T, with the k index ordered r = 4*kq + s: the accumulator layout of one
+// step (lane (t, g) holds acc[t][4g..4g+3]) is then exactly the B-operand layout of the next step,
+// so the whole chain stays in registers (no LDS, no transposes); HBM sees each matrix once.
+// When the dynamic range is unsafe for the factorisation (row / column range > 40, infinities,
+// NaN) the wave takes the exact max-shifted path for that step (same semantics as torch.logsumexp).
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float wave16_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float wave16_min(float v) {
+  v = fminf(v, __shfl_xor(v, 16, 64));
+  return fminf(v, __shfl_xor(v, 32, 64));
+}
+
+__global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __restrict__ mats,
+                                                             float* __restrict__ out, long long Wn,
+                                                             int L) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long w = wave; w < Wn; w += nwaves) {
+    const float* base = mats + w * (long long)L * 256;
+    // state: v[s] = acc[t = c][4g + s]
+    float4 v4 = *reinterpret_cast<const float4*>(base + c * 16 + 4 * g);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float mrow[4];
+    if (L > 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mrow[s] = base[256 + (4 * g + s) * 16 + c];
+    }
+    for (int l = 1; l < L; ++l) {
+      float mnext[4];
+      const float* nb = base + (long long)(l + 1 < L ? l + 1 : l) * 256;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mnext[s] = nb[(4 * g + s) * 16 + c];   // prefetch next matrix
+      const float amax = wave16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      const float amin = wave16_min(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+      const float bmax = wave16_max(fmaxf(fmaxf(mrow[0], mrow[1]), fmaxf(mrow[2], mrow[3])));
+      const float bmin = wave16_min(fminf(fminf(mrow[0], mrow[1]), fminf(mrow[2], mrow[3])));
+      const bool safe = (amax - amin <= 40.f) && (bmax - bmin <= 40.f);   // false for inf / NaN
+      if (__all(safe)) {
+        f32x4_t S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          S = __builtin_amdgcn_mfma_f32_16x16x4f32(expf(mrow[s] - bmax), expf(v[s] - amax), S, 0, 0, 0);
+        // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) v[reg] = logf(S[reg]) + amax + __shfl(bmax, 4 * g + reg, 64);
+      } else {
+        // exact path: gather acc[t][0..15] from the 4 lanes of column t, read M[r][4g..4g+3] directly
+        float arow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) arow[r] = __shfl(v[r & 3], c + 16 * (r >> 2), 64);
+        const float* mb = base + (long long)l * 256;
+        float res[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = 4 * g + reg;
+          float m = neg_inf<float>();
+          for (int r = 0; r < 16; ++r) m = xmax(m, arow[r] + mb[r * 16 + i]);
+          const float mm = xisinf(m) ? 0.f : m;
+          float sacc = 0.f;
+          for (int r = 0; r < 16; ++r) sacc += expf(arow[r] + mb[r * 16 + i] - mm);
+          res[reg] = logf(sacc) + mm;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) v[reg] = res[reg];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mrow[s] = mnext[s];
+    }
+    *reinterpret_cast<float4*>(out + w * 256 + c * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 unsigned grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   if (g > 65536 * 4) g = 65536 * 4;
@@ -299,6 +380,15 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
   if (Wn < 1 || L < 1 || D < 1) return DCTN_ERR_BAD_SHAPE;
   if (D > 32) return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCTN_F32 && D == 16 && ((uintptr_t)mats % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    long long blocks = (Wn + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)mats,
+                       (float*)out, (long long)Wn, L);
+    DCTN_CHECK_LAUNCH();
+    dctn_set_last_kernel("logmatmulexp_fold_fwd_mfma16");
+    return DCTN_OK;
+  }
   switch (dtype) {
     case DCTN_F32: return fold_fwd_launch<float, float>(mats, out, Wn, L, D, st);
     case DCTN_F64: return fold_fwd_launch<double, double>(mats, out, Wn, L, D, st);

@@ -430,3 +430,30 @@ def test_linear_head_vs_torch_reference(B, F, C):
         finally:
             os.environ.pop("DCTN_HEAD_BWD", None)
         assert bf16_close(fd.grad, f64.grad) and bf16_close(wd.grad, w64.grad) and bf16_close(bd.grad, b64.grad)
+
+
+def test_logmatmulexp_fold16_factored_mfma_and_exact_fallback():
+    """D = 16 float32 fold: factored exp -> MFMA -> log forward with the exact path taken per step
+    when the dynamic range is unsafe (large magnitudes, -inf entries)."""
+    torch.manual_seed(16)
+    m = torch.randn(300, 9, 16, 16)
+    m[7] *= 60.0                      # ranges far above 40: exact fallback every step
+    m[11, 3, 5, :] = -float("inf")    # a -inf row in one factor
+    m[13, 0] = -float("inf")          # a whole -inf matrix: result -inf
+    md = m.to(DEV)
+    y = logmatmulexp_fold(md)
+    assert dctn_amd.last_kernel() == "logmatmulexp_fold_fwd_mfma16"
+    want = R.logmatmulexp_fold_batched(m.double())
+    yc = y.cpu().double()
+    assert torch.equal(torch.isinf(yc), torch.isinf(want))
+    fin = torch.isfinite(want)
+    err = ((yc[fin] - want[fin]).abs() / (1.0 + want[fin].abs())).max()
+    assert float(err) < 5e-5, float(err)
+    # backward (exact recomputing kernel) still consistent with the factored forward
+    m2 = torch.randn(40, 9, 16, 16)
+    m2d = m2.to(DEV).requires_grad_(True)
+    y2 = logmatmulexp_fold(m2d)
+    dy = torch.randn(40, 16, 16)
+    y2.backward(dy.to(DEV))
+    (gm,) = R.grads(R.logmatmulexp_fold_batched, [m2.double()], dy.double())
+    assert close(m2d.grad, gm, torch.float32)
