@@ -80,3 +80,12 @@ int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int 
 size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx, int need_dcore);
 int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
                  size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
+
+// MFMA ConvSBS sweep (open chain, uniform bond) — convsbs_mfma.hip
+int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
+                     const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                     int C, int B, int H, int W, int q, int dtype, hipStream_t st);
+int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
+                     float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
+                     const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                     int q, int dtype, hipStream_t st);

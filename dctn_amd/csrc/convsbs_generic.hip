@@ -409,6 +409,27 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
         return DCTN_ERR_LAUNCH;
     }
   }
+  if constexpr (sizeof(S) == 4 && sizeof(A) == 4) {
+    // float32 strings of the MFMA family: register-resident sweep on the matrix cores
+    if (need_dcore) {
+      int outs[SBS_MAXC], bonds[SBS_MAXC];
+      float* dcp[SBS_MAXC];
+      const void* cp[SBS_MAXC];
+      for (int c = 0; c < p.n; ++c) { outs[c] = p.o[c]; bonds[c] = p.bl[c]; dcp[c] = (float*)p.dcore[c]; cp[c] = p.core[c]; }
+      const int rcm = convsbs_bwd_mfma(x, (const int64_t*)p.s, cp, dY, (float*)states, dX ? (float*)gxw : nullptr, dcp, p.n, outs,
+                                       bonds, p.ph, p.pw, p.C, p.B, p.H, p.W, p.q, dtype, st);
+      if (rcm == DCTN_OK) {
+        if (dX) {
+          const long long total = (long long)p.C * p.B * p.H * p.W * p.q;
+          const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+          hipLaunchKernelGGL((convsbs_gather_dx_k<S, A>), dim3(g2), dim3(256), 0, st, gxw, (S*)dX, p);
+          DCTN_CHECK_LAUNCH();
+        }
+        return DCTN_OK;
+      }
+      if (rcm != DCTN_ERR_UNSUPPORTED) return rcm;
+    }
+  }
   const long long ngroups = (p.Wn + csb - 1) / csb;
   // persistent workgroups: as many as can be resident (LDS-limited), at most one per window group
   long long per_cu = (long long)(160 * 1024) / (long long)(lds ? lds : 1);
@@ -470,6 +491,9 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
     p.dcore[c] = nullptr;
   }
   hipStream_t st = (hipStream_t)stream;
+  rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                        dtype, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   switch (dtype) {
     case DCTN_F32: return fwd_launch<float, float>(x, out, p, st);
     case DCTN_F64: return fwd_launch<double, double>(x, out, p, st);

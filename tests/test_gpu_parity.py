@@ -239,11 +239,13 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
     m = many.strings[0].to(DEV)
     x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
     (y,) = many(x)
+    assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32"   # register-resident MFMA sweep
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, snake, x.detach().cpu().double())
     assert close(y, want, torch.float32)
     dy = torch.randn_like(y)
     y.backward(dy)
+    assert dctn_amd.last_kernel() == "convsbs_bwd_mfma_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, snake, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     assert close(x.grad, gr[0], torch.float32)
     for c, gc in zip(m.cores, gr[1:]):
