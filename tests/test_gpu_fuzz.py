@@ -1,0 +1,152 @@
+"""Randomised parity sweep on the GPU: random shapes across the kernel-family boundaries, every
+result (forward, dX, dCore) against the float64 CPU oracle.  Seeds are fixed, so failures repeat."""
+import random
+
+import pytest
+import torch
+
+import dctn_amd
+from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization
+from dctn_amd.conv_sbs_spec import SBSSpecCore, SBSSpecString
+from dctn_amd.eps import eps
+from dctn_amd.logmatmulexp import logmatmulexp, logmatmulexp_batched, logmatmulexp_fold
+from dctn_amd.pos2d import Pos2D
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL = {torch.float64: (1e-9, 1e-11), torch.float32: (3e-4, 3e-5), torch.bfloat16: (3e-2, 3e-2)}
+
+
+def check(got, want, dtype, what):
+    want = want.double()
+    got = got.detach().cpu().double()
+    rtol, atol = TOL[dtype]
+    scale = float(want.abs().max()) or 1.0
+    err = float((got - want).abs().max())
+    bound = atol * scale + rtol * scale
+    assert err <= bound, f"{what}: err {err:.3e} > {bound:.3e} (scale {scale:.3e})"
+
+
+def eps_cases():
+    rng = random.Random(2026)
+    cases = []
+    while len(cases) < 28:
+        C = rng.choice([1, 1, 1, 2, 3])
+        K = rng.choice([1, 2, 2, 3, 3, 4])
+        Q = rng.choice([2, 2, 2, 3, 4, 4, 5, 8])
+        N = K * K * C
+        if Q**N > 2**18 or N > 18:
+            continue
+        O = rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 20])
+        if Q**N * O > 2**21:
+            continue
+        B = rng.choice([1, 2, 3, 5, 17])
+        H, W = K + rng.randrange(0, 9), K + rng.randrange(0, 9)
+        if B * (H - K + 1) * (W - K + 1) * Q**N * O > 3e9:
+            continue
+        dtype = rng.choice([torch.float32, torch.float32, torch.float64, torch.bfloat16])
+        cases.append((C, K, Q, O, B, H, W, dtype, rng.random() < 0.3))
+    return cases
+
+
+@pytest.mark.parametrize("case", eps_cases(), ids=lambda c: "C%dK%dQ%dO%dB%d_%dx%d_%s%s" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], str(c[7]).split(".")[1], "_strided" if c[8] else ""))
+def test_eps_random(case):
+    C, K, Q, O, B, H, W, dtype, strided = case
+    torch.manual_seed(hash(case[:7]) % (2**31))
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q).to(dtype)
+    core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(dtype)
+    xd = x.to(DEV)
+    if strided:  # same values behind a non-contiguous view
+        xd = xd.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    xd = xd.requires_grad_(True)
+    cd = core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    want = R.eps_4step(core.double(), x.double())
+    check(y, want, dtype, f"forward [{dctn_amd.last_kernel()}]")
+    dy = torch.randn(*want.shape).to(dtype)
+    y.backward(dy.to(DEV))
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    check(xd.grad, dx, dtype, "dX")
+    check(cd.grad, dcore, dtype, "dCore")
+
+
+def sbs_cases():
+    rng = random.Random(77)
+    cases = []
+    for _ in range(16):
+        kh, kw = rng.choice([(2, 2), (3, 3), (1, 3), (2, 3)])
+        pos = [(h, w) for h in range(kh) for w in range(kw)]
+        rng.shuffle(pos)
+        n = rng.randrange(2, len(pos) + 1)
+        pos = pos[:n]
+        mh, mw = min(p[0] for p in pos), min(p[1] for p in pos)
+        pos = [(h - mh, w - mw) for h, w in pos]
+        ring = rng.random() < 0.35
+        uniform = rng.random() < 0.5
+        r = rng.choice([2, 3, 4, 8])
+        bonds = [(r if uniform else rng.randrange(1, 6)) for _ in range(n)]
+        if not ring:
+            bonds[0] = 1
+        outs = [1] * n
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            outs[rng.randrange(n)] = rng.choice([2, 3])
+        C, q = rng.choice([(1, 2), (1, 3), (2, 2), (1, 4)])
+        dtype = rng.choice([torch.float32, torch.float32, torch.float64])
+        cases.append((tuple(pos), tuple(bonds), tuple(outs), C, q, dtype))
+    return cases
+
+
+@pytest.mark.parametrize("case", sbs_cases(), ids=lambda c: "n%d_b%s_o%s_C%dq%d_%s" % (
+    len(c[0]), "".join(map(str, c[1])), "".join(map(str, c[2])), c[3], c[4], str(c[5]).split(".")[1]))
+def test_convsbs_random(case):
+    pos, bonds, outs, C, q, dtype = case
+    torch.manual_seed(len(pos) * 100 + sum(bonds))
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
+    m = ConvSBS(spec, DumbNormalInitialization(0.6)).to(dtype).to(DEV)
+    B, H, W = 3, spec.max_height_pos + 4, spec.max_width_pos + 5
+    x = torch.randn(C, B, H, W, q, dtype=dtype, device=DEV, requires_grad=True)
+    y = m(x)
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, list(pos), x.detach().cpu().double())
+    check(y, want, dtype, f"forward [{dctn_amd.last_kernel()}]")
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x.detach().cpu().double()] + cores64,
+                 dy.cpu().double())
+    check(x.grad, gr[0], dtype, "dX")
+    for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
+        check(c.grad, gc, dtype, f"dCore{i}")
+
+
+@pytest.mark.parametrize("T,Rr,I,dtype", [(1, 1, 1, torch.float64), (7, 3, 5, torch.float32), (33, 65, 17, torch.float64),
+                                          (256, 256, 256, torch.float32), (5, 128, 3, torch.float32)])
+def test_logmatmulexp_random(T, Rr, I, dtype):
+    torch.manual_seed(T * 7 + I)
+    a, b = torch.randn(T, Rr, dtype=dtype) * 3, torch.randn(Rr, I, dtype=dtype) * 3
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = logmatmulexp(ad, bd)
+    want = R.logmatmulexp(a.double(), b.double())
+    check(y, want, dtype, "forward")
+    dy = torch.randn(T, I, dtype=dtype)
+    y.backward(dy.to(DEV))
+    ga, gb = R.grads(R.logmatmulexp, [a.double(), b.double()], dy.double())
+    check(ad.grad, ga, dtype, "dA")
+    check(bd.grad, gb, dtype, "dB")
+
+
+@pytest.mark.parametrize("Wn,L,D,dtype", [(1, 1, 16, torch.float32), (5, 2, 16, torch.float32), (130, 9, 16, torch.float32),
+                                          (9, 4, 7, torch.float64), (3, 3, 32, torch.float32), (64, 9, 16, torch.float64)])
+def test_logmatmulexp_fold_random(Wn, L, D, dtype):
+    torch.manual_seed(Wn + L + D)
+    m = torch.randn(Wn, L, D, D, dtype=dtype) * 2
+    md = m.to(DEV).requires_grad_(True)
+    y = logmatmulexp_fold(md)
+    want = R.logmatmulexp_fold_batched(m.double())
+    check(y, want, dtype, f"forward [{dctn_amd.last_kernel()}]")
+    dy = torch.randn(Wn, D, D, dtype=dtype)
+    y.backward(dy.to(DEV))
+    (g,) = R.grads(R.logmatmulexp_fold_batched, [m.double()], dy.double())
+    check(md.grad, g, dtype, "dMats")
