@@ -136,8 +136,23 @@ def ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
     return (c_void * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+_ws_cache: dict = {}
+
+
 def workspace(nbytes: int, dev: torch.device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    """Scratch for one kernel-library call.  Small requests come from the caching allocator; large
+    ones (ConvSBS backward states: tens of MB) reuse one grow-only buffer per (device, stream) —
+    calls on a stream are ordered, so consecutive calls can share it — because re-requesting big
+    blocks every call makes the allocator release and re-map them.  Under graph capture the
+    allocation must come from the graph's pool, so the cache is bypassed."""
+    nbytes = max(int(nbytes), 256)
+    if nbytes < (8 << 20) or torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return buf
 
 
 # precision policy for float32 tensors on the MFMA paths (bf16 tensors always use bf16 MFMA)

@@ -29,6 +29,8 @@ struct SbsMP {
   long long st_off[SBSM_MAXC + 1];  // backward: element offsets of the stored forward states
   float* dcore[SBSM_MAXC];    // backward: global dCore (zero-initialised by the caller)
   int first_off, last_off;    // float offsets of the first / last core tables in LDS
+  int fs_off;                 // float offset of the per-wave feature slices (4 waves x n*4*64)
+  unsigned char digit[4][4];  // digit[qq][ch]: feature index of channel ch in the flat index qq (host-filled)
   const float* core[SBSM_MAXC];
 };
 
@@ -46,19 +48,66 @@ constexpr int ROWP = 65;  // padded length of a packed k-step row (64 lanes + 1)
 // f[qq] = prod_ch x[ch][pixel of core c][digit_ch(qq)] (channel 0 most significant), qq < 4
 __device__ __forceinline__ void features(const float* __restrict__ x, const SbsMP& p, int c,
                                          long long b, int ho, int wo, bool valid, float (&f)[4]) {
+  const float* base = x + b * p.s[1] + (long long)(ho + p.ph[c]) * p.s[2] + (long long)(wo + p.pw[c]) * p.s[3];
+  // per channel the q feature values of this pixel (q <= 4), then the products by table
+  float xv[2][4];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      xv[ch][d] = (valid && ch < p.C && d < p.q) ? base[ch * p.s[0] + d * p.s[4]] : 1.f;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     float pr = (qq < p.qc && valid) ? 1.f : 0.f;
-    int t = qq;
-    for (int ch = p.C - 1; ch >= 0; --ch) {
-      const int dg = t % p.q;
-      t /= p.q;
-      const float* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + p.ph[c]) * p.s[2] +
-                        (long long)(wo + p.pw[c]) * p.s[3] + dg * p.s[4];
-      pr *= (qq < p.qc && valid) ? *px : 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int dg = p.digit[qq][ch];
+      const float xs = dg == 0 ? xv[ch][0] : dg == 1 ? xv[ch][1] : dg == 2 ? xv[ch][2] : xv[ch][3];
+      pr *= ch < p.C ? xs : 1.f;
     }
     f[qq] = pr;
   }
+}
+
+// All feature products of a window (every core of the string) at once: the pixel loads of up to 8
+// cores are issued back to back (one memory round trip per chunk instead of one per core), the
+// products go to the wave's LDS slice fs[(c*4 + qq)*64 + lane] and are read back per core.
+__device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
+                                               int wo, bool valid, float* fs, int lane) {
+  const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
+  for (int c0 = 0; c0 < p.n; c0 += 8) {
+    float raw[8][2][4];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      const int c = c0 + cc < p.n ? c0 + cc : p.n - 1;
+      const float* base = win + (long long)p.ph[c] * p.s[2] + (long long)p.pw[c] * p.s[3];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          raw[cc][ch][d] = (valid && ch < p.C && d < p.q) ? base[ch * p.s[0] + d * p.s[4]] : 1.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      if (c0 + cc < p.n) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float pr = (qq < p.qc && valid) ? 1.f : 0.f;
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const int dg = p.digit[qq][ch];
+            const float xs = dg == 0 ? raw[cc][ch][0] : dg == 1 ? raw[cc][ch][1] : dg == 2 ? raw[cc][ch][2] : raw[cc][ch][3];
+            pr *= ch < p.C ? xs : 1.f;
+          }
+          fs[((c0 + cc) * 4 + qq) * 64 + lane] = pr;
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void load_features(const float* fs, int c, int lane, float (&f)[4]) {
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) f[qq] = fs[(c * 4 + qq) * 64 + lane];
 }
 
 // Pack the cores into LDS.  Middle core c, output o, tile t, k-step s:
@@ -114,9 +163,11 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     const int rem = (int)(ww - b * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     float f[4];
+    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 256;
+    stage_features(x, p, b, ho, wo, valid, fs, lane);
     // ---- first core: v[0][s] = sum_qq core0[r' = 2s + h][qq] * f[qq]
     float v0[SR], v1[SR];
-    features(x, p, 0, b, ho, wo, valid, f);
+    load_features(fs, 0, lane, f);
 #pragma unroll
     for (int s = 0; s < SR; ++s) {
       const float* cp = lds + p.first_off + (2 * s + h) * 4;
@@ -127,7 +178,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     // ---- middle cores on the matrix pipe
     for (int c = 1; c + 1 < p.n; ++c) {
       const int oc = p.o[c];
-      features(x, p, c, b, ho, wo, valid, f);
+      load_features(fs, c, lane, f);
       float n0[SR], n1[SR];
 #pragma unroll
       for (int s = 0; s < SR; ++s) { n0[s] = 0.f; n1[s] = 0.f; }
@@ -161,7 +212,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
       oacc *= oc;
     }
     // ---- last core: out[a] = sum_l v[a][l] * sum_qq coreL[l][qq] f[qq]
-    features(x, p, p.n - 1, b, ho, wo, valid, f);
+    load_features(fs, p.n - 1, lane, f);
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
     for (int s = 0; s < SR; ++s) {
@@ -226,6 +277,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     const float dy0 = valid ? dY[w * p.Otot] : 0.f;
     const float dy1 = (valid && p.Otot > 1) ? dY[w * p.Otot + 1] : 0.f;
     float f[4];
+    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 256;
+    stage_features(x, p, b, ho, wo, valid, fs, lane);
 
     auto write_dx = [&](int c, const float (&df)[4]) {
       if (!need_dx || !valid || h != 0) return;
@@ -259,7 +312,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
 
     // ---------------- forward sweep
     float v0[SR], v1[SR];
-    features(x, p, 0, b, ho, wo, valid, f);
+    load_features(fs, 0, lane, f);
 #pragma unroll
     for (int s = 0; s < SR; ++s) {
       const float* cp = lds + p.first_off + (2 * s + h) * 4;
@@ -270,7 +323,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     for (int c = 1; c + 1 < p.n; ++c) {
       store_state(c, oacc, v0, v1);
       const int oc = p.o[c];
-      features(x, p, c, b, ho, wo, valid, f);
+      load_features(fs, c, lane, f);
       float n0[SR], n1[SR];
 #pragma unroll
       for (int s = 0; s < SR; ++s) { n0[s] = 0.f; n1[s] = 0.f; }
@@ -304,7 +357,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     // ---------------- last core
     float G0[SR], G1[SR];
     {
-      features(x, p, p.n - 1, b, ho, wo, valid, f);
+      load_features(fs, p.n - 1, lane, f);
       float df[4] = {0.f, 0.f, 0.f, 0.f};
       float* dl = lds + p.dacc_off[p.n - 1];
 #pragma unroll
@@ -336,7 +389,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
         v0[s] = valid ? states[(p.st_off[c] + 2 * s + h) * p.Wn + w] : 0.f;
         v1[s] = (valid && oacc_in > 1) ? states[(p.st_off[c] + R + 2 * s + h) * p.Wn + w] : 0.f;
       }
-      features(x, p, c, b, ho, wo, valid, f);
+      load_features(fs, c, lane, f);
       float df[4] = {0.f, 0.f, 0.f, 0.f};
       float d0[SR], d1[SR];
 #pragma unroll
@@ -434,7 +487,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
 
     // ---------------- first core
     {
-      features(x, p, 0, b, ho, wo, valid, f);
+      load_features(fs, 0, lane, f);
       float df[4] = {0.f, 0.f, 0.f, 0.f};
       float* d0p = lds + p.dacc_off[0];
 #pragma unroll
@@ -475,7 +528,12 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
     if (bond_sizes[c] != R) return DCTN_ERR_UNSUPPORTED;
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
-  if (qc > 4) return DCTN_ERR_UNSUPPORTED;
+  if (qc > 4 || C > 2 || q > 4) return DCTN_ERR_UNSUPPORTED;
+  for (int qq = 0; qq < 4; ++qq) {
+    int t = qq;
+    for (int ch = C - 1; ch >= 0; --ch) { p.digit[qq][ch] = (unsigned char)(t % q); t /= q; }
+    for (int ch = C; ch < 4; ++ch) p.digit[qq][ch] = 0;
+  }
   long long otot = 1;
   for (int c = 0; c < n; ++c) {
     if (out_sizes[c] < 1 || out_sizes[c] > 2) return DCTN_ERR_UNSUPPORTED;
@@ -504,6 +562,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   p.first_off = off; off += R * 4;
   p.last_off = off; off += R * 4;
+  p.fs_off = off; off += 4 * n * 256;
   lds_floats = off;
   return DCTN_OK;
 }
@@ -518,7 +577,7 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
   const size_t lds = (size_t)off * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.ngroups + 3) / 4;
-  if (blocks > 256 * 4) blocks = 256 * 4;
+  if (blocks > 256 * 2) blocks = 256 * 2;   // persistent: the core pack is paid once per workgroup
 #define SBS_LAUNCH(RR)                                                                            \
   (void)hipFuncSetAttribute((const void*)convsbs_fwd_mfma_k<RR>,                                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
