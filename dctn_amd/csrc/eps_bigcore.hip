@@ -22,8 +22,8 @@ typedef __attribute__((ext_vector_type(2))) int int2v;
 namespace {
 
 constexpr int BC_WAVES = 4;     // waves per workgroup
-constexpr int BC_NT_FWD = 4;    // column tiles (of 32 windows) per wave, forward
-constexpr int BC_NT_G = 2;      // ... transposed GEMMs (their LDS also holds the factor gradients)
+constexpr int BC_NT_FWD = 2;    // column tiles (of 32 windows) per wave, forward
+constexpr int BC_NT_G = 1;      // ... transposed GEMMs (their LDS also holds the factor gradients)
 constexpr int BC_SROW = 33;     // padded row length of a staged k-row (32 rows + 1: conflict-free both ways)
 constexpr int BC_TBL_MAX = 16;  // generated-operand table entries per lane (k-steps per hi block): 4, 8 or 16
 constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
@@ -375,7 +375,10 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
 // (lo table x hi table, built once per window chunk from the window's features), a lane multiplies
 // the two table entries of its row / column for the 2 windows of the k-step.  A wave owns
 // DC_AT x DC_BT output tiles; window chunks are spread over grid.y and combined with float atomics.
-constexpr int DC_AT = 2, DC_BT = 4;   // tiles per wave (rows, columns); workgroup = 2 x 2 waves
+constexpr int DC_AT = 2, DC_BT = 4;   // tiles per wave (rows, columns)
+constexpr int DC_WR = 2, DC_WC2 = 4;  // waves per workgroup along rows / columns (8 waves: 128 x 512 outputs
+                                      // per table build instead of 128 x 256)
+constexpr int DC_THREADS = 64 * DC_WR * DC_WC2;
 constexpr int DC_WC = 128;            // windows per LDS chunk
 
 struct DcoreP {
@@ -389,7 +392,7 @@ struct DcoreP {
   long long win_per_block;
 };
 
-__global__ __launch_bounds__(256) void eps_bigcore_dcore_k(const float* __restrict__ x,
+__global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* __restrict__ x,
                                                            const float* __restrict__ dY,
                                                            float* __restrict__ dCore, DcoreP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -399,10 +402,10 @@ __global__ __launch_bounds__(256) void eps_bigcore_dcore_k(const float* __restri
   const int o_t0lo = 0, o_t0hi = p.nlo0, o_t1lo = o_t0hi + p.nhi0, o_t1hi = o_t1lo + p.nlo1,
             o_dy = o_t1hi + p.nhi1;
   const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, kk = lane >> 5, wv = tid >> 6;
-  const int ntile_c = (p.cols + 2 * DC_BT * 32 - 1) / (2 * DC_BT * 32);
+  const int ntile_c = (p.cols + DC_WC2 * DC_BT * 32 - 1) / (DC_WC2 * DC_BT * 32);
   const int bt_a = blockIdx.x / ntile_c, bt_c = blockIdx.x % ntile_c;
-  const int a_tile0 = (bt_a * 2 + (wv >> 1)) * DC_AT;      // first row tile of this wave
-  const int c_tile0 = (bt_c * 2 + (wv & 1)) * DC_BT;       // first column tile of this wave
+  const int a_tile0 = (bt_a * DC_WR + wv / DC_WC2) * DC_AT;    // first row tile of this wave
+  const int c_tile0 = (bt_c * DC_WC2 + wv % DC_WC2) * DC_BT;   // first column tile of this wave
 
   // per-lane table offsets of its rows / columns (constant over the whole kernel)
   int offa_lo[DC_AT], offa_hi[DC_AT];
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void eps_bigcore_dcore_k(const float* __restri
   for (long long w0 = w_begin; w0 < w_end; w0 += DC_WC) {
     __syncthreads();
     // window features of the chunk
-    for (int e = tid; e < DC_WC * p.N; e += 256) {
+    for (int e = tid; e < DC_WC * p.N; e += DC_THREADS) {
       const int wl = e % DC_WC, n = e / DC_WC;
       const long long w = w0 + wl;
       const bool valid = w < w_end;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void eps_bigcore_dcore_k(const float* __restri
     __syncthreads();
     // factored Khatri-Rao tables (and dY) of the chunk
     const int nent = o_dy + p.OP;
-    for (int e = tid; e < DC_WC * nent; e += 256) {
+    for (int e = tid; e < DC_WC * nent; e += DC_THREADS) {
       const int wl = e % DC_WC, ent = e / DC_WC;
       const float* xw = xs + wl * (NQ + 1);
       float v;
@@ -787,8 +790,8 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   d.tstride = tstride;
   const size_t lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
-  const int ntile_a = (d.A + 2 * DC_AT * 32 - 1) / (2 * DC_AT * 32);
-  const int ntile_c = (d.cols + 2 * DC_BT * 32 - 1) / (2 * DC_BT * 32);
+  const int ntile_a = (d.A + DC_WR * DC_AT * 32 - 1) / (DC_WR * DC_AT * 32);
+  const int ntile_c = (d.cols + DC_WC2 * DC_BT * 32 - 1) / (DC_WC2 * DC_BT * 32);
   const long long tiles = (long long)ntile_a * ntile_c;
   long long chunks = 1024 / tiles;
   if (chunks < 1) chunks = 1;
@@ -802,7 +805,7 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   if (hipMemsetAsync(dCore, 0, (size_t)p.R * p.O * sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
   (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL(eps_bigcore_dcore_k, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, st,
+  hipLaunchKernelGGL(eps_bigcore_dcore_k, dim3((unsigned)tiles, (unsigned)chunks), dim3(DC_THREADS), lds, st,
                      (const float*)x, (const float*)dY, (float*)dCore, d);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
