@@ -134,7 +134,8 @@ __global__ void lme_fold_fwd_k(const S* __restrict__ mats, S* __restrict__ out, 
 
 template <typename S, typename A>
 __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__ dOut,
-                               S* __restrict__ dMats, long long Wn, int L, int D) {
+                               S* __restrict__ dMats, long long Wn, int L, int D,
+                               const int* __restrict__ only_flagged) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int DD = D * D, DP = D + 1;
   A* pre = reinterpret_cast<A*>(smem);  // [L][D][D+1]  prefix folds, pre[0] = mats[0]
@@ -143,6 +144,7 @@ __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__
   const int tid = threadIdx.x;
   const int t = tid / D, i = tid - t * D;
   for (long long w = blockIdx.x; w < Wn; w += gridDim.x) {
+    if (only_flagged && only_flagged[w] == 0) continue;  // uniform over the workgroup
     const S* base = mats + w * (long long)L * DD;
     __syncthreads();
     A v = (A)base[tid];
@@ -191,79 +193,258 @@ __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__
 // exps.  One wave per window; the product runs on v_mfma_f32_16x16x4_f32 (exact f32) in TRANSPOSED
 // form, out^T = E2^T x E1^T, with the k index ordered r = 4*kq + s: the accumulator layout of one
 // step (lane (t, g) holds acc[t][4g..4g+3]) is then exactly the B-operand layout of the next step,
-// so the whole chain stays in registers (no LDS, no transposes); HBM sees each matrix once.
-// When the dynamic range is unsafe for the factorisation (row / column range > 40, infinities,
-// NaN) the wave takes the exact max-shifted path for that step (same semantics as torch.logsumexp).
+// so the chain of prefixes stays in registers; HBM sees each matrix once.
+//
+// The kernels are bounded by VALU issue, not by HBM or the matrix core, so the arithmetic around the
+// product is kept minimal: the whole chain runs in the base-2 log domain (state and matrices scaled
+// by log2 e once, the result by ln 2 once) so that every exp / log is the single native
+// v_exp_f32 / v_log_f32; the two 16-lane-stride reductions use v_permlane16/32_swap instead of LDS
+// shuffles; and safety of the factorisation is judged on its result: a step is accepted when every
+// S[t,i] >= 2^-100 (terms the shifts could have flushed are then < 2^-26 of the sum); NaN / +inf /
+// all -inf rows make S NaN and fail the test.  A rejected step takes the exact max-shifted path
+// (same semantics as torch.logsumexp) in the forward kernel; the backward kernel flags the window
+// for the exact recomputing kernel.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef int lme_int2v __attribute__((ext_vector_type(2)));
 
+constexpr float LME_LOG2E = 1.4426950408889634f;
+constexpr float LME_LN2 = 0.6931471805599453f;
+constexpr float LME_SMIN = 7.888609052210118e-31f;   // 2^-100
+
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+
+// max over the four lanes (c, 0..3) that share c; result in all four
 __device__ __forceinline__ float wave16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+  int iv = __float_as_int(v);
+  lme_int2v r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  v = fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+  iv = __float_as_int(v);
+  r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
 }
-__device__ __forceinline__ float wave16_min(float v) {
-  v = fminf(v, __shfl_xor(v, 16, 64));
-  return fminf(v, __shfl_xor(v, 32, 64));
+
+constexpr int LME_PST = 20;                 // padded row stride of a 16x16 tile in LDS
+constexpr int LME_TILE = 16 * LME_PST;      // floats per tile
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Matrices are fetched with one coalesced 16-byte load per lane (lane (c, g): row c, columns
+// 4g..4g+3) and turned into the k-major operand layout (lane (c, g): rows 4g..4g+3 of column c) by a
+// b128 write + 4 b32 reads of a per-wave LDS tile (conflict-free at row stride 20).
+__device__ __forceinline__ void lds_transpose16(float* scr, int c, int g, const float4& row, float (&col)[4]) {
+  wave_lds_sync();   // earlier reads of the tile are done
+  *reinterpret_cast<float4*>(scr + c * LME_PST + 4 * g) = row;
+  wave_lds_sync();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) col[s] = scr[(4 * g + s) * LME_PST + c];
+}
+
+// One factored step in the base-2 domain.  v: state (lane (t = c, g): acc'[t][4g + s]); mcol: the
+// right matrix, k-major (lane (i = c, g): M'[4g + s][i]).  Returns S (lane (t = c, g): S[t][4g + reg])
+// and the two shifts (a_t in lane c = t, b_i in lane c = i).
+__device__ __forceinline__ f32x4_t lme_step16(const float (&v)[4], const float (&mcol)[4], float& amax,
+                                              float& bmax) {
+  amax = wave16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+  bmax = wave16_max(fmaxf(fmaxf(mcol[0], mcol[1]), fmaxf(mcol[2], mcol[3])));
+  f32x4_t S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(mcol[s] - bmax), ex2(v[s] - amax), S, 0, 0, 0);
+  return S;
+}
+
+__device__ __forceinline__ bool lme_step_ok(const f32x4_t& S) {
+  return (S[0] >= LME_SMIN) && (S[1] >= LME_SMIN) && (S[2] >= LME_SMIN) && (S[3] >= LME_SMIN);
 }
 
 __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __restrict__ mats,
                                                              float* __restrict__ out, long long Wn,
                                                              int L) {
+  __shared__ __align__(16) float scratch[4][LME_TILE];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  float* scr = scratch[threadIdx.x >> 6];
+  const int gl_off = c * 16 + 4 * g;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
   for (long long w = wave; w < Wn; w += nwaves) {
     const float* base = mats + w * (long long)L * 256;
-    // state: v[s] = acc[t = c][4g + s]
-    float4 v4 = *reinterpret_cast<const float4*>(base + c * 16 + 4 * g);
-    float v[4] = {v4.x, v4.y, v4.z, v4.w};
-    float mrow[4];
-    if (L > 1) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) mrow[s] = base[256 + (4 * g + s) * 16 + c];
-    }
+    const float4 v4 = *reinterpret_cast<const float4*>(base + gl_off);
+    // state (base-2 domain): v[s] = log2(e) * acc[t = c][4g + s]
+    float v[4] = {v4.x * LME_LOG2E, v4.y * LME_LOG2E, v4.z * LME_LOG2E, v4.w * LME_LOG2E};
+    // three matrices in flight per wave
+    float4 q0 = *reinterpret_cast<const float4*>(base + (long long)(1 < L ? 1 : 0) * 256 + gl_off);
+    float4 q1 = *reinterpret_cast<const float4*>(base + (long long)(2 < L ? 2 : L - 1) * 256 + gl_off);
+    float4 q2 = *reinterpret_cast<const float4*>(base + (long long)(3 < L ? 3 : L - 1) * 256 + gl_off);
     for (int l = 1; l < L; ++l) {
-      float mnext[4];
-      const float* nb = base + (long long)(l + 1 < L ? l + 1 : l) * 256;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) mnext[s] = nb[(4 * g + s) * 16 + c];   // prefetch next matrix
-      const float amax = wave16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-      const float amin = wave16_min(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
-      const float bmax = wave16_max(fmaxf(fmaxf(mrow[0], mrow[1]), fmaxf(mrow[2], mrow[3])));
-      const float bmin = wave16_min(fminf(fminf(mrow[0], mrow[1]), fminf(mrow[2], mrow[3])));
-      const bool safe = (amax - amin <= 40.f) && (bmax - bmin <= 40.f);   // false for inf / NaN
-      if (__all(safe)) {
-        f32x4_t S = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          S = __builtin_amdgcn_mfma_f32_16x16x4f32(expf(mrow[s] - bmax), expf(v[s] - amax), S, 0, 0, 0);
+      const float4 q3 = *reinterpret_cast<const float4*>(base + (long long)(l + 3 < L ? l + 3 : L - 1) * 256 + gl_off);
+      float mcol[4];
+      lds_transpose16(scr, c, g, make_float4(q0.x * LME_LOG2E, q0.y * LME_LOG2E, q0.z * LME_LOG2E, q0.w * LME_LOG2E),
+                      mcol);                                              // mcol[s] = M'_l[4g + s][c]
+      float amax, bmax;
+      const f32x4_t S = lme_step16(v, mcol, amax, bmax);
+      if (__all(lme_step_ok(S))) {
         // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) v[reg] = logf(S[reg]) + amax + __shfl(bmax, 4 * g + reg, 64);
+        for (int reg = 0; reg < 4; ++reg) v[reg] = lg2(S[reg]) + amax + __shfl(bmax, 4 * g + reg, 64);
       } else {
-        // exact path: gather acc[t][0..15] from the 4 lanes of column t, read M[r][4g..4g+3] directly
-        float arow[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) arow[r] = __shfl(v[r & 3], c + 16 * (r >> 2), 64);
+        // exact path (rare, natural-log domain, kept small on purpose: rolled loops so that it does not
+        // set the kernel's register budget): acc[t][r] comes from the 4 lanes of row t, M[r][4g..4g+3]
+        // from memory
         const float* mb = base + (long long)l * 256;
-        float res[4];
+        float vn[4], res[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) vn[s2] = v[s2] * LME_LN2;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int i = 4 * g + reg;
           float m = neg_inf<float>();
-          for (int r = 0; r < 16; ++r) m = xmax(m, arow[r] + mb[r * 16 + i]);
+#pragma unroll 1
+          for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              m = xmax(m, __shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i]);
+          }
           const float mm = xisinf(m) ? 0.f : m;
           float sacc = 0.f;
-          for (int r = 0; r < 16; ++r) sacc += expf(arow[r] + mb[r * 16 + i] - mm);
+#pragma unroll 1
+          for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+              sacc += expf(__shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i] - mm);
+          }
           res[reg] = logf(sacc) + mm;
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) v[reg] = res[reg];
+        for (int reg = 0; reg < 4; ++reg) v[reg] = res[reg] * LME_LOG2E;
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) mrow[s] = mnext[s];
+      q0 = q1; q1 = q2; q2 = q3;
     }
-    *reinterpret_cast<float4*>(out + w * 256 + c * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(out + w * 256 + gl_off) =
+        make_float4(v[0] * LME_LN2, v[1] * LME_LN2, v[2] * LME_LN2, v[3] * LME_LN2);
   }
+}
+
+// Factored backward of the same fold (D = 16, float32), one wave per window.  Pass 1 reads every
+// matrix once (all loads in flight together), recomputes the prefix folds P_1..P_{L-1} exactly as the
+// forward kernel does and keeps matrices, prefixes and both shifts of every step in registers
+// (LMAX is the compile-time bound on L); pass 2 walks back with, per step (P = P_{l-1}, M = M_l,
+// Pn = P_l, everything in the base-2 domain):
+//   EP = 2^(P - a_t), EM = 2^(M - b_i), H = G * 2^(a_t + b_i - Pn)               (= G / S)
+//   dP = EP .* (H x EM^T)          dM = EM .* (EP^T x H)
+// i.e. two 16x16x16 products on v_mfma_f32_16x16x4_f32 plus 12 v_exp_f32 per lane instead of
+// 2*4096 exps per window and step.  dP^T comes out of the matrix core in the state layout (lane
+// (t, g) holds columns 4g..4g+3 of row t) so it feeds the next step directly; the operands of dM need
+// t on the k index, so EP and H take one trip through a per-wave LDS scratch tile.  A window with a
+// step the factorisation cannot represent is flagged and left to the exact kernel.
+constexpr int LME_BWD_WAVES = 4;
+
+template <int LMAX>
+__global__ __launch_bounds__(64 * LME_BWD_WAVES) void lme_fold16_bwd_mfma_k(
+    const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
+    int* __restrict__ flags, long long Wn, int L) {
+  __shared__ __align__(16) float scratch[LME_BWD_WAVES][2][LME_TILE];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  float* scrE = scratch[wv][0];
+  float* scrH = scratch[wv][1];
+  const int st_off = c * LME_PST + 4 * g;       // state layout: row c, columns 4g..4g+3
+  const int gl_off = c * 16 + 4 * g;
+  const long long wave = (long long)blockIdx.x * LME_BWD_WAVES + wv;
+  const long long nwaves = (long long)gridDim.x * LME_BWD_WAVES;
+  for (long long w = wave; w < Wn; w += nwaves) {
+    const float* base = mats + w * (long long)L * 256;
+    // ---------------- pass 1
+    float Mr[LMAX][4];     // M'_l[r = c][4g + s]
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      const float4 q = *reinterpret_cast<const float4*>(base + (long long)(l < L ? l : L - 1) * 256 + gl_off);
+      Mr[l][0] = q.x * LME_LOG2E; Mr[l][1] = q.y * LME_LOG2E; Mr[l][2] = q.z * LME_LOG2E; Mr[l][3] = q.w * LME_LOG2E;
+    }
+    float pre[LMAX][4];    // P'_l in the state layout
+    float sa[LMAX], sb[LMAX];   // shifts of step l: a_t (lane c = t), b_i (lane c = i)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pre[0][s] = Mr[0][s];
+    bool ok = true;
+#pragma unroll
+    for (int l = 1; l < LMAX; ++l) {
+      if (l < L) {
+        float mcol[4];
+        lds_transpose16(scrE, c, g, make_float4(Mr[l][0], Mr[l][1], Mr[l][2], Mr[l][3]), mcol);
+        const f32x4_t S = lme_step16(pre[l - 1], mcol, sa[l], sb[l]);
+        ok = ok && lme_step_ok(S);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          pre[l][reg] = lg2(S[reg]) + sa[l] + __shfl(sb[l], 4 * g + reg, 64);
+      }
+    }
+    const bool all_ok = __all(ok);
+    if (lane == 0) flags[w] = all_ok ? 0 : 1;
+    if (!all_ok) continue;
+    // ---------------- pass 2: walk back
+    const float4 g4 = *reinterpret_cast<const float4*>(dOut + w * 256 + gl_off);
+    float G[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int l = LMAX - 1; l >= 1; --l) {
+      if (l < L) {
+        const float* M = Mr[l];
+        const float* P = pre[l - 1];
+        const float* Pn = pre[l];
+        const float a = sa[l];
+        float EP[4], EM[4], H[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float bs = __shfl(sb[l], 4 * g + s, 64);               // b_i, i = 4g + s
+          EP[s] = ex2(P[s] - a);
+          EM[s] = ex2(M[s] - bs);
+          H[s] = G[s] * ex2((a - Pn[s]) + bs);
+        }
+        wave_lds_sync();   // the previous step's reads of the scratch tiles are done
+        *reinterpret_cast<float4*>(scrE + st_off) = make_float4(EP[0], EP[1], EP[2], EP[3]);
+        *reinterpret_cast<float4*>(scrH + st_off) = make_float4(H[0], H[1], H[2], H[3]);
+        f32x4_t T1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) T1 = __builtin_amdgcn_mfma_f32_16x16x4f32(EM[s], H[s], T1, 0, 0, 0);
+        wave_lds_sync();
+        float EPc[4], Hc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          EPc[s] = scrE[(4 * g + s) * LME_PST + c];                    // EP[t = 4g+s][r = c]
+          Hc[s] = scrH[(4 * g + s) * LME_PST + c];                     // H[t = 4g+s][i = c]
+        }
+        f32x4_t T2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) T2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hc[s], EPc[s], T2, 0, 0, 0);
+        *reinterpret_cast<float4*>(dMats + (w * L + l) * 256 + gl_off) =
+            make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) G[s] = T1[s] * EP[s];
+      }
+    }
+    *reinterpret_cast<float4*>(dMats + (w * L) * 256 + gl_off) = make_float4(G[0], G[1], G[2], G[3]);
+  }
+}
+
+// workgroups of `threads` that are resident at once on the whole device (cached per kernel by callers
+// being static functions is not needed: the query is a cheap host-side table lookup)
+long long resident_blocks(const void* fn, int threads) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return (long long)per_cu * cus;
+}
+
+template <int LMAX>
+void fold16_bwd_launch(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, int L,
+                       hipStream_t st) {
+  long long blocks = (Wn + LME_BWD_WAVES - 1) / LME_BWD_WAVES;
+  const long long cap = resident_blocks((const void*)lme_fold16_bwd_mfma_k<LMAX>, 64 * LME_BWD_WAVES);
+  if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
+  hipLaunchKernelGGL((lme_fold16_bwd_mfma_k<LMAX>), dim3((unsigned)blocks), dim3(64 * LME_BWD_WAVES), 0, st,
+                     mats, dOut, dMats, flags, Wn, L);
 }
 
 unsigned grid_for(long long total, int block) {
@@ -318,16 +499,16 @@ int fold_fwd_launch(const void* mats, void* out, long long Wn, int L, int D, hip
 
 template <typename S, typename A>
 int fold_bwd_launch(const void* mats, const void* dOut, void* dMats, long long Wn, int L, int D,
-                    hipStream_t st) {
+                    hipStream_t st, const int* only_flagged = nullptr) {
   const size_t lds = ((size_t)(L + 2) * D * (D + 1)) * sizeof(A);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   (void)hipFuncSetAttribute((const void*)lme_fold_bwd_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)(Wn < 256 * 32 ? Wn : 256 * 32);
   hipLaunchKernelGGL((lme_fold_bwd_k<S, A>), dim3(grid), dim3(D * D), lds, st, (const S*)mats,
-                     (const S*)dOut, (S*)dMats, Wn, L, D);
+                     (const S*)dOut, (S*)dMats, Wn, L, D, only_flagged);
   DCTN_CHECK_LAUNCH();
-  dctn_set_last_kernel("logmatmulexp_fold_bwd");
+  if (!only_flagged) dctn_set_last_kernel("logmatmulexp_fold_bwd");
   return DCTN_OK;
 }
 
@@ -370,8 +551,10 @@ int dctn_logmatmulexp_bwd(const void* logA, const void* logB, const void* out, c
 }
 
 size_t dctn_logmatmulexp_fold_workspace_bytes(int64_t Wn, int L, int D, int dtype, int backward) {
-  (void)Wn; (void)L; (void)D; (void)dtype; (void)backward;
-  return 256;  // every prefix fold lives in LDS
+  (void)L;
+  // prefix folds live in LDS; the factored backward keeps one "needs the exact kernel" flag per window
+  if (backward && dtype == DCTN_F32 && D == 16 && Wn > 0) return 256 + (size_t)Wn * sizeof(int);
+  return 256;
 }
 
 int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, int D, int dtype,
@@ -382,7 +565,8 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCTN_F32 && D == 16 && ((uintptr_t)mats % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
     long long blocks = (Wn + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const long long cap = resident_blocks((const void*)lme_fold16_fwd_mfma_k, 256);
+    if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
     hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)mats,
                        (float*)out, (long long)Wn, L);
     DCTN_CHECK_LAUNCH();
@@ -400,11 +584,27 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
 int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats, void* workspace,
                                size_t workspace_bytes, int64_t Wn, int L, int D, int dtype,
                                void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (!mats || !dOut || !dMats) return DCTN_ERR_NULL;
   if (Wn < 1 || L < 1 || D < 1) return DCTN_ERR_BAD_SHAPE;
   if (D > 32) return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCTN_F32 && D == 16 && L <= 16 && workspace &&
+      workspace_bytes >= 256 + (size_t)Wn * sizeof(int) && ((uintptr_t)mats % 16 == 0) &&
+      ((uintptr_t)dOut % 16 == 0) && ((uintptr_t)dMats % 16 == 0) && ((uintptr_t)workspace % 4 == 0) &&
+      (size_t)(L + 2) * 16 * 17 * sizeof(float) <= DCTN_LDS_BUDGET) {
+    int* flags = reinterpret_cast<int*>(static_cast<unsigned char*>(workspace) + 256);
+    const float* m = (const float*)mats;
+    const float* dy = (const float*)dOut;
+    float* dm = (float*)dMats;
+    if (L <= 5) fold16_bwd_launch<5>(m, dy, dm, flags, Wn, L, st);
+    else if (L <= 9) fold16_bwd_launch<9>(m, dy, dm, flags, Wn, L, st);
+    else fold16_bwd_launch<16>(m, dy, dm, flags, Wn, L, st);
+    DCTN_CHECK_LAUNCH();
+    const int rc = fold_bwd_launch<float, float>(mats, dOut, dMats, Wn, L, D, st, flags);  // flagged windows only
+    if (rc != DCTN_OK) return rc;
+    dctn_set_last_kernel("logmatmulexp_fold_bwd_mfma16");
+    return DCTN_OK;
+  }
   switch (dtype) {
     case DCTN_F32: return fold_bwd_launch<float, float>(mats, dOut, dMats, Wn, L, D, st);
     case DCTN_F64: return fold_bwd_launch<double, double>(mats, dOut, dMats, Wn, L, D, st);

@@ -74,6 +74,9 @@ def bench_convsbs(cpu):
                     many(x)
 
             def fb():
+                x.grad = None
+                for prm in many.parameters():
+                    prm.grad = None
                 many(x)[0].backward(dy)
 
             extra = {}
@@ -104,6 +107,7 @@ def bench_lme(cpu):
                 logmatmulexp_fold(m)
 
         def fb():
+            m.grad = None   # time the op, not a 6 GB accumulate into an old .grad
             logmatmulexp_fold(m).backward(dy)
 
         extra = {"fwd_GBs": None}
@@ -150,6 +154,8 @@ def bench_eps(cpu):
                 eps(core, x)
 
         def fb():
+            x.grad = None
+            core.grad = None
             eps(core, x).backward(dy)
 
         f, b = time_gpu(fwd, 5), time_gpu(fb, 3)
