@@ -7,10 +7,15 @@
 // (A = 2^n0), b over the last n1 (Bn = 2^n1):
 //     T[(b,o), w] = sum_a core[a,b,o] * P0[w,a]      <- MFMA, M = (b,o) rows, N = 32 windows, K = a
 //     out[w,o]    = sum_b P1[w,b] * T[(b,o), w]      <- lane-local epilogue
-// A lane owns ONE window (column of the MFMA tile): it builds its P0 fragment in registers from
-// the window's 2N features, gets 16 rows (b,o) of T back in its accumulator registers, weights
-// them with its own P1 values and reduces over b; one permlane32_swap joins the two lane halves.
-// Nothing but x and out touches HBM; no LDS in the main loop, no barriers.
+// A lane owns ONE window, 64 windows per wave step (the kernels are bounded by VALU issue, so no
+// lane may repeat another lane's loads, address arithmetic or products): it builds the whole P0
+// row of its window in registers; the MFMA tile has only 32 columns, so the step runs as two
+// "sets" (windows of lanes 0-31, then of lanes 32-63) and v_permlane32_swap turns the two k-halves
+// a lane built for its own window into its operand share for set 0 and for set 1.  Each lane gets
+// 16 rows (b,o) of T per tile back, weights them with P1 of the set's window (also handed over by
+// permlane swaps), and one more swap per output joins the two row halves so that every lane ends
+// up with the outputs of its own window.  Nothing but x and out touches HBM; no LDS in the main
+// loop, no barriers.
 //
 // Backward dCore[a,b,o] = sum_w P0[w,a] P1[w,b] dY[w,o]  reduces over windows, so windows must
 // become the MFMA K index while lanes own windows.  The transpose is done ON the matrix core:
@@ -29,6 +34,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) int int2v;
+typedef __attribute__((ext_vector_type(4))) int int4v;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 namespace {
 
@@ -41,6 +48,26 @@ __device__ __forceinline__ float half_sum(float v) {
   const int iv = __float_as_int(v);
   const int2v r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
   return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
+// a <- [a.lo, b.lo], b <- [a.hi, b.hi]  (lo / hi = lanes 0-31 / 32-63): with a, b = the values a lane
+// computed for the first / second lane half's role, a becomes the operand of set 0 (windows of lanes
+// 0-31) and b the operand of set 1 (windows of lanes 32-63).
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  const int2v r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+  a = __int_as_float(r[0]);
+  b = __int_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_halves(bf16x8& a, bf16x8& b) {
+  int4v ia = __builtin_bit_cast(int4v, a), ib = __builtin_bit_cast(int4v, b);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int2v r = __builtin_amdgcn_permlane32_swap(ia[i], ib[i], false, false);
+    ia[i] = r[0];
+    ib[i] = r[1];
+  }
+  a = __builtin_bit_cast(bf16x8, ia);
+  b = __builtin_bit_cast(bf16x8, ib);
 }
 
 // unsigned 32-bit division by an invariant (Granlund-Montgomery, round-up variant):
@@ -56,7 +83,7 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& d) {
 #define MFMA_MAXN 16
 struct MfmaP {
   int C, B, H, W, K, O, Ho, Wo;
-  long long Wn, ngroups;  // groups of 32 windows (Wn < 2^31 in this family)
+  long long Wn, ngroups;  // groups of 64 windows (Wn < 2^31 in this family)
   long long s[5];
   unsigned foffb[MFMA_MAXN];  // BYTE offset of factor n relative to the window's top-left pixel
   unsigned s1b, s2b, s3b, s4b;  // byte strides of x (batch, row, column, feature); x spans < 4 GiB
@@ -65,7 +92,7 @@ struct MfmaP {
   unsigned x_bytes;             // extent of x in bytes (row loads are clamped to stay inside)
   int rowvec_ok;                // one 16-byte load per window row usable (bf16, Q=2 contiguous, K <= 4)
   unsigned row_wrap, img_wrap;  // offset corrections when a window walk wraps a row / an image
-  int inc_ok;                   // incremental walk usable (Wo >= 16, Ho*Wo >= 32)
+  int inc_ok;                   // incremental walk usable (Wo >= 16, Ho >= 4)
   long long gpw;                // window groups per wave (contiguous range)
   int vec_ok;             // x: last stride 1, even strides, 4-byte aligned base (bf16 pair loads)
 };
@@ -74,7 +101,7 @@ struct MfmaP {
 // back to back with no control flow between them and no use of the data, so a whole group's
 // loads are in flight together and the next group's can be issued before this one is consumed.
 // Addresses are uniform base + 32-bit lane offset (+ uniform per-factor offset).
-// Lanes l and l+32 load the same window; lanes without a window read window 0 (masked later).
+// Lanes without a window read window 0 (masked later).
 template <typename S, int N, bool VEC>
 struct RawWindow {
   typedef typename std::conditional<sizeof(S) == 2, unsigned, float2>::type vec_t;
@@ -84,7 +111,7 @@ struct RawWindow {
   unsigned shift;            // bit rw set: that row's load was moved back by one pixel (tensor end)
 };
 
-// Byte offset of the top-left pixel of a lane's window, advanced by 32 windows per step without
+// Byte offset of the top-left pixel of a lane's window, advanced by 64 windows per step without
 // divisions or integer multiplies (the wave walks a contiguous range of window groups).
 struct WinIter {
   unsigned off;   // byte offset of the window's top-left pixel (feature 0)
@@ -101,12 +128,12 @@ __device__ __forceinline__ WinIter win_begin(const MfmaP& p, long long w) {
   it.ho = (int)ho;
   return it;
 }
-// requires Wo >= 16 and Ho * Wo >= 32 (host-checked: p.inc_ok): at most two row wraps and one image wrap
-__device__ __forceinline__ void win_advance32(const MfmaP& p, WinIter& it) {
-  it.wo += 32;
-  it.off += 32u * p.s3b;
+// requires Wo >= 16 and Ho >= 4 (host-checked: p.inc_ok): at most four row wraps and one image wrap
+__device__ __forceinline__ void win_advance64(const MfmaP& p, WinIter& it) {
+  it.wo += 64;
+  it.off += 64u * p.s3b;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 4; ++k) {
     const bool wrap = it.wo >= p.Wo;
     it.wo -= wrap ? p.Wo : 0;
     it.ho += wrap ? 1 : 0;
@@ -219,22 +246,28 @@ __device__ __forceinline__ void store_row(S* __restrict__ dst, int O, const floa
   }
 }
 
-// P0 fragments of this lane's window: frag[s][j] = P0[w][a = 16 s + 8 h + j], a's MSB = factor 0.
+// The whole P0 row of this lane's window, as the two k-halves of every 16-wide k-step:
+// X[s][j] = P0[w][a = 16 s + j], Y[s][j] = P0[w][a = 16 s + 8 + j]; a's MSB = factor 0.
 template <int N0>
-__device__ __forceinline__ void build_p0(const float (*xv)[2], int h, bf16x8 (&frag)[(1 << N0) / 16]) {
+__device__ __forceinline__ void build_p0(const float (*xv)[2], bf16x8 (&X)[(1 << N0) / 16],
+                                         bf16x8 (&Y)[(1 << N0) / 16]) {
   constexpr int KS = (1 << N0) / 16;
   float lo8[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     lo8[j] = xv[N0 - 3][(j >> 2) & 1] * xv[N0 - 2][(j >> 1) & 1] * xv[N0 - 1][j & 1];
-  const float xh = h ? xv[N0 - 4][1] : xv[N0 - 4][0];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    float hi = xh;
+    float hi = 1.f;
 #pragma unroll
-    for (int t = 0; t < N0 - 4; ++t) hi *= xv[N0 - 5 - t][(s >> t) & 1];
+    for (int t = 0; t < N0 - 4; ++t) hi = t == 0 ? xv[N0 - 5][s & 1] : hi * xv[N0 - 5 - t][(s >> t) & 1];
+    const float h0 = N0 > 4 ? hi * xv[N0 - 4][0] : xv[N0 - 4][0];
+    const float h1 = N0 > 4 ? hi * xv[N0 - 4][1] : xv[N0 - 4][1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) frag[s][j] = (bf16_t)(hi * lo8[j]);
+    for (int j = 0; j < 8; ++j) {
+      X[s][j] = (bf16_t)(h0 * lo8[j]);
+      Y[s][j] = (bf16_t)(h1 * lo8[j]);
+    }
   }
 }
 
@@ -254,7 +287,7 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
   constexpr int TOT = A * BN * OP, PER = TOT / 256;
   static_assert(TOT % 256 == 0, "core staging assumes a multiple of 256 elements");
   __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
   {
     S tmp[PER];
 #pragma unroll
@@ -287,52 +320,68 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
   const long long g0 = wave * p.gpw;
   const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
   RawWindow<S, N, XVEC> raw;
-  WinIter it = win_begin(p, g0 * 32 + r);
-  if (g0 < g1) issue_window<S, N, XVEC, ROWS>(x, p, g0 * 32 + r < p.Wn ? it.off : 0u, raw);
+  WinIter it = win_begin(p, g0 * 64 + lane);
+  if (g0 < g1) issue_window<S, N, XVEC, ROWS>(x, p, g0 * 64 + lane < p.Wn ? it.off : 0u, raw);
   for (long long g = g0; g < g1; ++g) {
-    const long long w = g * 32 + r;
+    const long long w = g * 64 + lane;
     const bool valid = w < p.Wn;
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
     {  // prefetch the next group of this wave (the last iteration re-reads its own group)
       if (g + 1 < g1) {
-        if (p.inc_ok) win_advance32(p, it); else it = win_begin(p, w + 32);
+        if (p.inc_ok) win_advance64(p, it); else it = win_begin(p, w + 64);
       }
-      issue_window<S, N, XVEC, ROWS>(x, p, (g + 1 < g1 ? w + 32 : w) < p.Wn ? it.off : 0u, raw);
+      issue_window<S, N, XVEC, ROWS>(x, p, (g + 1 < g1 ? w + 64 : w) < p.Wn ? it.off : 0u, raw);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
     }
-    bf16x8 pf[KS];
-    build_p0<N0>(xv, h, pf);
-    // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 is the lane half
-    float p1hi[BN / 2];
+    bf16x8 pf0[KS], pf1[KS];   // after the swaps: B operands of set 0 / set 1
+    build_p0<N0>(xv, pf0, pf1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) swap_halves(pf0[s], pf1[s]);
+    // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 (factor N-1) is the lane half of
+    // the accumulator row.  m0 / m1: multipliers this lane applies in set 0 / set 1.
+    float m0[BN / 2], m1[BN / 2];
 #pragma unroll
     for (int bh = 0; bh < BN / 2; ++bh) {
       float v = 1.f;
 #pragma unroll
-      for (int u = 1; u < N1; ++u) v *= xv[N - 1 - u][(bh >> (u - 1)) & 1];
-      p1hi[bh] = v;
+      for (int u = 1; u < N1; ++u) v = u == 1 ? xv[N - 2][bh & 1] : v * xv[N - 1 - u][(bh >> (u - 1)) & 1];
+      m0[bh] = v * xv[N - 1][0];
+      m1[bh] = v * xv[N - 1][1];
+      swap_halves(m0[bh], m1[bh]);
     }
-    const float xl = h ? xv[N - 1][1] : xv[N - 1][0];
-    float res[OP];
+    f32x2 res0[OP / 2], res1[OP / 2];
 #pragma unroll
-    for (int o = 0; o < OP; ++o) res[o] = 0.f;
+    for (int o = 0; o < OP / 2; ++o) { res0[o] = f32x2{0.f, 0.f}; res1[o] = f32x2{0.f, 0.f}; }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      f32x16 acc;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+      for (int set = 0; set < 2; ++set) {
+        f32x16 acc;
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], pf[s], acc, 0, 0, 0);
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
-        res[code & (OP - 1)] += acc[v] * p1hi[code >> LOGO];
+        for (int s = 0; s < KS; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], set ? pf1[s] : pf0[s], acc, 0, 0, 0);
+        // rows v, v+1 (v even) are outputs o, o+1 of the same b: one packed FMA
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+          const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
+          const float mm = set ? m1[code >> LOGO] : m0[code >> LOGO];
+          f32x2& dst = set ? res1[(code & (OP - 1)) >> 1] : res0[(code & (OP - 1)) >> 1];
+          dst = __builtin_elementwise_fma(f32x2{acc[v], acc[v + 1]}, f32x2{mm, mm}, dst);
+        }
       }
     }
+    // join the two row halves: lanes 0-31 end up with set 0 (their own windows), lanes 32-63 with set 1
+    float res[OP];
 #pragma unroll
-    for (int o = 0; o < OP; ++o) res[o] = half_sum(res[o] * xl);
-    if (valid && h == 0) store_row<S, OP, OVEC>(out + w * p.O, p.O, res);
+    for (int o = 0; o < OP; ++o) {
+      float a0 = res0[o >> 1][o & 1], a1 = res1[o >> 1][o & 1];
+      swap_halves(a0, a1);
+      res[o] = a0 + a1;
+    }
+    if (valid) store_row<S, OP, OVEC>(out + w * p.O, p.O, res);
   }
 }
 
@@ -373,23 +422,23 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
   RawWindow<S, N, XVEC> raw;
   RowPack<S, OP> rawdy;
-  WinIter it = win_begin(p, g0 * 32 + r);
+  WinIter it = win_begin(p, g0 * 64 + lane);
   if (g0 < g1) {
-    const long long w0 = g0 * 32 + r;
+    const long long w0 = g0 * 64 + lane;
     issue_window<S, N, XVEC, ROWS>(x, p, w0 < p.Wn ? it.off : 0u, raw);
     issue_row<S, OP, OVEC>(dY + (w0 < p.Wn ? w0 : 0) * p.O, p.O, rawdy);
   }
   for (long long g = g0; g < g1; ++g) {
-    const long long w = g * 32 + r;
+    const long long w = g * 64 + lane;
     const bool valid = w < p.Wn;
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
     float dy[OP];
     unpack_row<S, OP>(rawdy, p.O, dy);
     {  // prefetch the next group of this wave
-      const long long wn = g + 1 < g1 ? w + 32 : w;
+      const long long wn = g + 1 < g1 ? w + 64 : w;
       if (g + 1 < g1) {
-        if (p.inc_ok) win_advance32(p, it); else it = win_begin(p, wn);
+        if (p.inc_ok) win_advance64(p, it); else it = win_begin(p, wn);
       }
       issue_window<S, N, XVEC, ROWS>(x, p, wn < p.Wn ? it.off : 0u, raw);
       issue_row<S, OP, OVEC>(dY + (wn < p.Wn ? wn : 0) * p.O, p.O, rawdy);
@@ -400,57 +449,68 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       xv[0][1] = 0.f;
     }
 
-    // P0 transposed: features on lanes, windows in registers -> B operand fragments
-    bf16x8 pf[KS];
-    build_p0<N0>(xv, h, pf);
-    bf16x8 p0t[AT][2];
+    // P0 of the lane's own window -> A operands of set 0 / set 1 -> transposed on the matrix core:
+    // features on lanes, windows in registers = B operand fragments summing over windows
+    bf16x8 pf[2][KS];
+    build_p0<N0>(xv, pf[0], pf[1]);
 #pragma unroll
-    for (int a = 0; a < AT; ++a) {
-      f32x16 d;
+    for (int s = 0; s < KS; ++s) swap_halves(pf[0][s], pf[1][s]);
+    bf16x8 p0t[2][AT][2];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) d[v] = 0.f;
+    for (int set = 0; set < 2; ++set)
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp)
-        if (2 * a + sp < KS)
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[2 * a + sp], ident[sp], d, 0, 0, 0);
+      for (int a = 0; a < AT; ++a) {
+        f32x16 d;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) p0t[a][v >> 3][v & 7] = (bf16_t)d[v];
-    }
+        for (int v = 0; v < 16; ++v) d[v] = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+          if (2 * a + sp < KS)
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[set][2 * a + sp], ident[sp], d, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) p0t[set][a][v >> 3][v & 7] = (bf16_t)d[v];
+      }
     // full P1 table of this window (b bit u <-> factor N-1-u)
     float p1[BN];
 #pragma unroll
     for (int b = 0; b < BN; ++b) {
       float v = 1.f;
 #pragma unroll
-      for (int u = 0; u < N1; ++u) v *= xv[N - 1 - u][(b >> u) & 1];
+      for (int u = 0; u < N1; ++u) v = u == 0 ? xv[N - 1][b & 1] : v * xv[N - 1 - u][(b >> u) & 1];
       p1[b] = v;
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      f32x16 d;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) d[v] = 0.f;
+      // Z of the own window for both k-halves, then the same hand-over as for P0
+      bf16x8 zf[2][2];   // [set after the swap][sp]
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
-        bf16x8 zf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int m0 = (t << 5) | (sp << 4) | j;        // h == 0
-          const int m1 = m0 | 8;                           // h == 1
-          const float z0 = p1[m0 >> LOGO] * dy[m0 & (OP - 1)];
-          const float z1 = p1[m1 >> LOGO] * dy[m1 & (OP - 1)];
-          zf[j] = (bf16_t)(h ? z1 : z0);
+          const int ma = (t << 5) | (sp << 4) | j;        // first k-half
+          const int mb = ma | 8;                           // second k-half
+          zf[0][sp][j] = (bf16_t)(p1[ma >> LOGO] * dy[ma & (OP - 1)]);
+          zf[1][sp][j] = (bf16_t)(p1[mb >> LOGO] * dy[mb & (OP - 1)]);
         }
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, ident[sp], d, 0, 0, 0);
+        swap_halves(zf[0][sp], zf[1][sp]);
       }
-      bf16x8 zt[2];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) zt[v >> 3][v & 7] = (bf16_t)d[v];
+      for (int set = 0; set < 2; ++set) {
+        f32x16 d;
 #pragma unroll
-      for (int a = 0; a < AT; ++a)
+        for (int v = 0; v < 16; ++v) d[v] = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-          acc[t][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt[s2], p0t[a][s2], acc[t][a], 0, 0, 0);
+        for (int sp = 0; sp < 2; ++sp)
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[set][sp], ident[sp], d, 0, 0, 0);
+        bf16x8 zt[2];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) zt[v >> 3][v & 7] = (bf16_t)d[v];
+#pragma unroll
+        for (int a = 0; a < AT; ++a)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            acc[t][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt[s2], p0t[set][a][s2], acc[t][a], 0, 0, 0);
+      }
     }
   }
 
@@ -573,13 +633,13 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
   }
   m.row_wrap = (unsigned)(p.s[2] * esz_) - (unsigned)p.Wo * (unsigned)(p.s[3] * esz_);
   m.img_wrap = (unsigned)(p.s[1] * esz_) - (unsigned)p.Ho * (unsigned)(p.s[2] * esz_);
-  m.inc_ok = p.Wo >= 16 && p.Ho * p.Wo >= 32;
+  m.inc_ok = p.Wo >= 16 && p.Ho >= 4;
   m.gpw = 1;
   m.div_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
   m.div_wo = make_fastdiv((unsigned)p.Wo);
   m.C = p.C; m.B = p.B; m.H = p.H; m.W = p.W; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
   m.Wn = p.Wn;
-  m.ngroups = (p.Wn + 31) / 32;
+  m.ngroups = (p.Wn + 63) / 64;
   for (int i = 0; i < 5; ++i) m.s[i] = p.s[i];
   const size_t esz = dtype == DCTN_BF16 ? 2 : 4;
   m.vec_ok = p.s[4] == 1 && p.s[0] % 2 == 0 && p.s[1] % 2 == 0 && p.s[2] % 2 == 0 &&
