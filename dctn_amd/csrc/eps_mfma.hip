@@ -17,6 +17,15 @@
 // up with the outputs of its own window.  Nothing but x and out touches HBM; no LDS in the main
 // loop, no barriers.
 //
+// Work decomposition: a wave owns 64 consecutive window POSITIONS of the image (lane = position) and
+// loops over a chunk of samples.  All addressing then is "per-lane constant + per-sample scalar":
+// x, dY and out are accessed through raw buffer descriptors (buffer_load / buffer_store with the lane
+// part in the VGPR offset and the sample / row part in the scalar offset), so the main loop holds no
+// address arithmetic at all, lanes without a position and the 16-byte row load that would run past
+// the end of x are handled by the hardware range check (probe: tools/bufprobe.hip), and everything
+// that depends only on the position (in the fused-head backward: the lane's slice of the classifier
+// weight) is loaded once per wave.
+//
 // Backward dCore[a,b,o] = sum_w P0[w,a] P1[w,b] dY[w,o]  reduces over windows, so windows must
 // become the MFMA K index while lanes own windows.  The transpose is done ON the matrix core:
 // multiplying the lane-owns-window fragment (as A operand) by an identity B operand returns the
@@ -82,168 +91,221 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& d) {
 
 #define MFMA_MAXN 16
 struct MfmaP {
-  int C, B, H, W, K, O, Ho, Wo;
-  long long Wn, ngroups;  // groups of 64 windows (Wn < 2^31 in this family)
-  long long s[5];
-  unsigned foffb[MFMA_MAXN];  // BYTE offset of factor n relative to the window's top-left pixel
-  unsigned s1b, s2b, s3b, s4b;  // byte strides of x (batch, row, column, feature); x spans < 4 GiB
-  FastDiv div_hw, div_wo;
+  int C, B, K, O, Ho, Wo;
+  int P;                        // window positions per sample = Ho * Wo
+  int npg;                      // position groups of 64
+  int spc, nchunks;             // samples per wave, number of sample chunks
+  unsigned foffb[MFMA_MAXN];    // BYTE offset of factor n relative to the window's top-left pixel
   unsigned rowoffb[MFMA_MAXN];  // row loads: BYTE offset of window row (dh, ch), index dh*C + ch
-  unsigned x_bytes;             // extent of x in bytes (row loads are clamped to stay inside)
+  unsigned s1b, s2b, s3b, s4b;  // byte strides of x (batch, row, column, feature)
+  unsigned x_bytes;             // extent of x in bytes (< 2^31: buffer range check, 32-bit offsets)
+  unsigned o_bytes, o_s1b;      // extent of out / dY in bytes (< 2^31), bytes per sample
+  FastDiv div_wo;
   int rowvec_ok;                // one 16-byte load per window row usable (bf16, Q=2 contiguous, K <= 4)
-  unsigned row_wrap, img_wrap;  // offset corrections when a window walk wraps a row / an image
-  int inc_ok;                   // incremental walk usable (Wo >= 16, Ho >= 4)
-  long long gpw;                // window groups per wave (contiguous range)
-  int vec_ok;             // x: last stride 1, even strides, 4-byte aligned base (bf16 pair loads)
+  int vec_ok;                   // x: last stride 1, even strides, 4-byte aligned base (pair loads)
+  int Cout;                     // fused-head backward: number of classes (rows of the head weight)
+  unsigned hw_rowb, hw_bytes;   //   bytes per row (P * O * 2) and in total
 };
 
-// Raw features of one window, as loaded (2 values of type S per factor): the loads are issued
-// back to back with no control flow between them and no use of the data, so a whole group's
-// loads are in flight together and the next group's can be issued before this one is consumed.
-// Addresses are uniform base + 32-bit lane offset (+ uniform per-factor offset).
-// Lanes without a window read window 0 (masked later).
-template <typename S, int N, bool VEC>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, (int)bytes, 0x00020000);
+}
+
+// Raw features of one window, as loaded: the loads are issued back to back with no control flow
+// between them and no use of the data, so a whole step's loads are in flight together and the next
+// step's can be issued before this one is consumed.  Lanes without a window position carry an
+// out-of-range offset and read zeros.
+template <typename S, int N, bool VEC, int ROWS>
 struct RawWindow {
-  typedef typename std::conditional<sizeof(S) == 2, unsigned, float2>::type vec_t;
-  vec_t v[VEC ? N : 1];
-  S e[VEC ? 1 : N][2];
-  uint4 row[MFMA_MAXN / 2];  // row-vector mode (bf16): K pixels of one window row per 16-byte load
-  unsigned shift;            // bit rw set: that row's load was moved back by one pixel (tensor end)
+  u32x4 row[ROWS > 0 ? ROWS : 1];  // row-vector mode (bf16): K pixels of one window row per 16-byte load
+  unsigned v[(ROWS == 0 && VEC) ? N * (int)(sizeof(S) / 2) : 1];  // pair mode: both features of a factor
+  unsigned e[(ROWS == 0 && !VEC) ? 2 * N : 1];                    // scalar mode: raw bits per feature
 };
 
-// Byte offset of the top-left pixel of a lane's window, advanced by 64 windows per step without
-// divisions or integer multiplies (the wave walks a contiguous range of window groups).
-struct WinIter {
-  unsigned off;   // byte offset of the window's top-left pixel (feature 0)
-  int wo, ho;
-};
-__device__ __forceinline__ WinIter win_begin(const MfmaP& p, long long w) {
-  const unsigned wu = w < p.Wn ? (unsigned)w : 0u;
-  const unsigned b = fdiv(wu, p.div_hw);
-  const unsigned rem = wu - b * (unsigned)(p.Ho * p.Wo);
-  const unsigned ho = fdiv(rem, p.div_wo), wo = rem - ho * (unsigned)p.Wo;
-  WinIter it;
-  it.off = b * p.s1b + ho * p.s2b + wo * p.s3b;
-  it.wo = (int)wo;
-  it.ho = (int)ho;
-  return it;
-}
-// requires Wo >= 16 and Ho >= 4 (host-checked: p.inc_ok): at most four row wraps and one image wrap
-__device__ __forceinline__ void win_advance64(const MfmaP& p, WinIter& it) {
-  it.wo += 64;
-  it.off += 64u * p.s3b;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool wrap = it.wo >= p.Wo;
-    it.wo -= wrap ? p.Wo : 0;
-    it.ho += wrap ? 1 : 0;
-    it.off += wrap ? p.row_wrap : 0u;
-  }
-  const bool iw = it.ho >= p.Ho;
-  it.ho -= iw ? p.Ho : 0;
-  it.off += iw ? p.img_wrap : 0u;
-}
-
-// ROWS > 0: row-vector mode with ROWS = K*C rows (one global_load_dwordx4 per row instead of K
+// ROWS > 0: row-vector mode with ROWS = K*C rows (one buffer_load_dwordx4 per row instead of K
 // dword loads: 3x fewer memory requests per window for the 3x3 kernel)
 template <typename S, int N, bool VEC, int ROWS>
-__device__ __forceinline__ void issue_window(const S* __restrict__ x, const MfmaP& p, unsigned off0,
-                                             RawWindow<S, N, VEC>& raw) {
-  const char* xb = reinterpret_cast<const char*>(x);
+__device__ __forceinline__ void issue_window(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff,
+                                             const MfmaP& p, RawWindow<S, N, VEC, ROWS>& raw) {
   if constexpr (ROWS > 0) {
-    // a 16-byte load at the last pixel of the tensor would run 4 bytes past its end: move it back
-    // by one pixel there and remember to select the next dword
-    raw.shift = 0;
 #pragma unroll
-    for (int rw = 0; rw < ROWS; ++rw) {
-      unsigned o = off0 + p.rowoffb[rw];
-      if (o + 16u > p.x_bytes) { o -= 4u; raw.shift |= 1u << rw; }
-      raw.row[rw] = *reinterpret_cast<const uint4*>(xb + (size_t)o);
-    }
+    for (int rw = 0; rw < ROWS; ++rw)
+      raw.row[rw] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + p.rowoffb[rw], 0);
   } else if constexpr (VEC) {
 #pragma unroll
-    for (int n = 0; n < N; ++n)
-      raw.v[n] = *reinterpret_cast<const typename RawWindow<S, N, VEC>::vec_t*>(xb + (size_t)(off0 + p.foffb[n]));
+    for (int n = 0; n < N; ++n) {
+      if constexpr (sizeof(S) == 2) {
+        raw.v[n] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + p.foffb[n], 0);
+      } else {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff + p.foffb[n], 0);
+        raw.v[2 * n] = t.x;
+        raw.v[2 * n + 1] = t.y;
+      }
+    }
   } else {
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      raw.e[n][0] = *reinterpret_cast<const S*>(xb + (size_t)(off0 + p.foffb[n]));
-      raw.e[n][1] = *reinterpret_cast<const S*>(xb + (size_t)(off0 + p.foffb[n] + p.s4b));
-    }
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if constexpr (sizeof(S) == 2)
+          raw.e[2 * n + q] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+              rs, voff, soff + p.foffb[n] + q * p.s4b, 0);
+        else
+          raw.e[2 * n + q] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + p.foffb[n] + q * p.s4b, 0);
+      }
   }
 }
 
 template <typename S, int N, bool VEC, int ROWS>
-__device__ __forceinline__ void unpack_window(const RawWindow<S, N, VEC>& raw, const MfmaP& p,
-                                              float (&xv)[N][2]) {
+__device__ __forceinline__ void unpack_window(const RawWindow<S, N, VEC, ROWS>& raw, float (&xv)[N][2]) {
   if constexpr (ROWS > 0) {
-    constexpr int KK = N / ROWS;  // pixels per row = K
+    constexpr int KK = N / ROWS;          // pixels per row = K
+    constexpr int CC = ROWS * ROWS / N;   // channels: ROWS = K*C and N = K*K*C
 #pragma unroll
     for (int rw = 0; rw < ROWS; ++rw) {
-      const bool sh = (raw.shift >> rw) & 1u;
       const unsigned d[4] = {raw.row[rw].x, raw.row[rw].y, raw.row[rw].z, raw.row[rw].w};
 #pragma unroll
       for (int dw = 0; dw < KK; ++dw) {
         // factor n = (dh*K + dw)*C + ch for row rw = dh*C + ch
-        const int dh = rw / p.C, ch = rw - dh * p.C;
-        (void)dh; (void)ch;
-        const unsigned u = sh ? d[dw + 1 < 4 ? dw + 1 : 3] : d[dw];
-        // static factor index needs C at compile time: ROWS = K*C and N = K*K*C give C = ROWS*ROWS/N
-        constexpr int CC = ROWS * ROWS / N;
         const int n = ((rw / CC) * KK + dw) * CC + (rw % CC);
-        xv[n][0] = __uint_as_float(u << 16);
-        xv[n][1] = __uint_as_float(u & 0xffff0000u);
+        xv[n][0] = __uint_as_float(d[dw] << 16);
+        xv[n][1] = __uint_as_float(d[dw] & 0xffff0000u);
       }
     }
-    return;
-  }
+  } else if constexpr (VEC) {
 #pragma unroll
-  for (int n = 0; n < N; ++n) {
-    if constexpr (VEC && sizeof(S) == 2) {
-      xv[n][0] = __uint_as_float(raw.v[n] << 16);
-      xv[n][1] = __uint_as_float(raw.v[n] & 0xffff0000u);
-    } else if constexpr (VEC) {
-      xv[n][0] = raw.v[n].x;
-      xv[n][1] = raw.v[n].y;
-    } else {
-      xv[n][0] = to_f32(raw.e[n][0]);
-      xv[n][1] = to_f32(raw.e[n][1]);
+    for (int n = 0; n < N; ++n) {
+      if constexpr (sizeof(S) == 2) {
+        xv[n][0] = __uint_as_float(raw.v[n] << 16);
+        xv[n][1] = __uint_as_float(raw.v[n] & 0xffff0000u);
+      } else {
+        xv[n][0] = __uint_as_float(raw.v[2 * n]);
+        xv[n][1] = __uint_as_float(raw.v[2 * n + 1]);
+      }
     }
+  } else {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        xv[n][q] = sizeof(S) == 2 ? __uint_as_float(raw.e[2 * n + q] << 16) : __uint_as_float(raw.e[2 * n + q]);
   }
 }
 
-// OP consecutive values of one window (dY row / out row), as one vector access when VEC
+// OP consecutive values of one window (dY row / out row): DW dwords when VEC, element accesses else
 template <typename S, int OP>
-struct alignas(sizeof(S) * OP) RowPack {
-  S e[OP];
+struct RawRow {
+  static constexpr int DW = OP * (int)sizeof(S) / 4;
+  unsigned d[DW];     // VEC
+  unsigned e[OP];     // !VEC: raw bits per element (unused elements zero)
 };
 template <typename S, int OP, bool VEC>
-__device__ __forceinline__ void issue_row(const S* __restrict__ src, int O, RowPack<S, OP>& pk) {
+__device__ __forceinline__ void issue_row(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int O,
+                                          RawRow<S, OP>& r) {
+  constexpr int DW = RawRow<S, OP>::DW;
   if constexpr (VEC) {
-    pk = *reinterpret_cast<const RowPack<S, OP>*>(src);
+    if constexpr (DW == 1) {
+      r.d[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    } else if constexpr (DW == 2) {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+      r.d[0] = t.x; r.d[1] = t.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < DW / 4; ++i) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + 16u * i, 0);
+        r.d[4 * i] = t.x; r.d[4 * i + 1] = t.y; r.d[4 * i + 2] = t.z; r.d[4 * i + 3] = t.w;
+      }
+    }
   } else {
 #pragma unroll
-    for (int o = 0; o < OP; ++o) pk.e[o] = src[o < O ? o : 0];
+    for (int o = 0; o < OP; ++o) {
+      r.e[o] = 0u;
+      if (o < O) {
+        if constexpr (sizeof(S) == 2)
+          r.e[o] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff + 2u * o, 0);
+        else
+          r.e[o] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + 4u * o, 0);
+      }
+    }
   }
 }
-template <typename S, int OP>
-__device__ __forceinline__ void unpack_row(const RowPack<S, OP>& pk, int O, float (&v)[OP]) {
+template <typename S, int OP, bool VEC>
+__device__ __forceinline__ void unpack_row(const RawRow<S, OP>& r, float (&v)[OP]) {
 #pragma unroll
-  for (int o = 0; o < OP; ++o) v[o] = o < O ? to_f32(pk.e[o]) : 0.f;
+  for (int o = 0; o < OP; ++o) {
+    if constexpr (!VEC) {
+      v[o] = sizeof(S) == 2 ? __uint_as_float(r.e[o] << 16) : __uint_as_float(r.e[o]);
+    } else if constexpr (sizeof(S) == 2) {
+      v[o] = (o & 1) ? __uint_as_float(r.d[o >> 1] & 0xffff0000u) : __uint_as_float(r.d[o >> 1] << 16);
+    } else {
+      v[o] = __uint_as_float(r.d[o]);
+    }
+  }
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 template <typename S, int OP, bool VEC>
-__device__ __forceinline__ void store_row(S* __restrict__ dst, int O, const float (&v)[OP]) {
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int O,
+                                          const float (&v)[OP]) {
+  constexpr int DW = RawRow<S, OP>::DW;
   if constexpr (VEC) {
-    struct alignas(sizeof(S) * OP) Pack { S e[OP]; };
-    Pack pk;
+    unsigned d[DW];
 #pragma unroll
-    for (int o = 0; o < OP; ++o) pk.e[o] = (S)v[o];
-    *reinterpret_cast<Pack*>(dst) = pk;
+    for (int i = 0; i < DW; ++i)
+      d[i] = sizeof(S) == 2 ? pack_bf16(v[2 * i], v[2 * i + 1]) : __float_as_uint(v[i * (OP / DW)]);
+    if constexpr (DW == 1) {
+      __builtin_amdgcn_raw_buffer_store_b32(d[0], rs, voff, soff, 0);
+    } else if constexpr (DW == 2) {
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{d[0], d[1]}, rs, voff, soff, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < DW / 4; ++i)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]}, rs, voff,
+                                               soff + 16u * i, 0);
+    }
   } else {
 #pragma unroll
     for (int o = 0; o < OP; ++o)
-      if (o < O) dst[o] = (S)v[o];
+      if (o < O) {
+        if constexpr (sizeof(S) == 2)
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack_bf16(v[o], 0.f) & 0xffffu), rs, voff,
+                                                soff + 2u * o, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[o]), rs, voff, soff + 4u * o, 0);
+      }
   }
+}
+
+// Which samples and which window positions a wave works on (see the header comment).
+struct WaveJob {
+  int b0, b1;          // samples [b0, b1)
+  unsigned voff_x;     // byte offset of the lane's window inside a sample of x (x_bytes: no window)
+  unsigned voff_o;     // byte offset of the lane's row inside a sample of out / dY (o_bytes: no window)
+  int pos;
+  bool valid;
+};
+__device__ __forceinline__ WaveJob wave_job(const MfmaP& p, int waves_per_block, int esz) {
+  // XCD-contiguous mapping: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give each
+  // XCD one contiguous eighth of the waves: the position groups of a sample chunk then meet in one L2.
+  const int nb = gridDim.x;
+  const int vb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(vb * waves_per_block + (int)(threadIdx.x >> 6));
+  const int chunk = wave / p.npg, pg = wave - chunk * p.npg;
+  WaveJob j;
+  j.b0 = chunk < p.nchunks ? chunk * p.spc : 0;
+  j.b1 = chunk < p.nchunks ? (j.b0 + p.spc < p.B ? j.b0 + p.spc : p.B) : 0;
+  j.pos = pg * 64 + (int)(threadIdx.x & 63);
+  j.valid = j.pos < p.P;
+  const unsigned pu = j.valid ? (unsigned)j.pos : 0u;
+  const unsigned ho = fdiv(pu, p.div_wo), wo = pu - ho * (unsigned)p.Wo;
+  j.voff_x = j.valid ? ho * p.s2b + wo * p.s3b : p.x_bytes;
+  j.voff_o = j.valid ? pu * (unsigned)(p.O * esz) : p.o_bytes;
+  return j;
 }
 
 // The whole P0 row of this lane's window, as the two k-halves of every 16-wide k-step:
@@ -275,7 +337,7 @@ __device__ __forceinline__ void build_p0(const float (*xv)[2], bf16x8 (&X)[(1 <<
 // Row code of accumulator register v of M-tile t (lane-half bit h excluded):
 //   code = (t << 4) | ((v >> 2) << 2) | (v & 3);   o = code & (OP-1);   b = ((code >> LOGO) << 1) | h
 template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS>
-__global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4 : 2))) void eps_fwd_q2reg_k(const S* __restrict__ x,
                                                        const S* __restrict__ core,
                                                        S* __restrict__ out, MfmaP p) {
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
@@ -312,27 +374,17 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
-  // XCD-contiguous mapping: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give
-  // each XCD one contiguous eighth of the windows: its L2 then fetches only that part of x.
-  const long long nb = gridDim.x;
-  const long long vb = (nb % 8 == 0) ? (long long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
-  const long long wave = vb * 4 + (tid >> 6);
-  const long long g0 = wave * p.gpw;
-  const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
-  RawWindow<S, N, XVEC> raw;
-  WinIter it = win_begin(p, g0 * 64 + lane);
-  if (g0 < g1) issue_window<S, N, XVEC, ROWS>(x, p, g0 * 64 + lane < p.Wn ? it.off : 0u, raw);
-  for (long long g = g0; g < g1; ++g) {
-    const long long w = g * 64 + lane;
-    const bool valid = w < p.Wn;
+  const WaveJob job = wave_job(p, 4, (int)sizeof(S));
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
+  RawWindow<S, N, XVEC, ROWS> raw;
+  if (job.b0 < job.b1) issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, raw);
+  for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
-    unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
-    {  // prefetch the next group of this wave (the last iteration re-reads its own group)
-      if (g + 1 < g1) {
-        if (p.inc_ok) win_advance64(p, it); else it = win_begin(p, w + 64);
-      }
-      issue_window<S, N, XVEC, ROWS>(x, p, (g + 1 < g1 ? w + 64 : w) < p.Wn ? it.off : 0u, raw);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
+    unpack_window<S, N, XVEC, ROWS>(raw, xv);
+    {  // prefetch the next sample of this wave (the last iteration re-reads its own)
+      const int bn = b + 1 < job.b1 ? b + 1 : b;
+      issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)bn * p.s1b, p, raw);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's arithmetic
     }
     bf16x8 pf0[KS], pf1[KS];   // after the swaps: B operands of set 0 / set 1
     build_p0<N0>(xv, pf0, pf1);
@@ -350,9 +402,11 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
       m1[bh] = v * xv[N - 1][1];
       swap_halves(m0[bh], m1[bh]);
     }
-    f32x2 res0[OP / 2], res1[OP / 2];
+    // (scalar FMAs on purpose: packed f32 VALU issues slower than two scalar ones on gfx950 — see
+    // MI355X_MICROARCH.md, 'price of one filler beside MFMAs' — the build also disables SLP packing)
+    float res0[OP], res1[OP];
 #pragma unroll
-    for (int o = 0; o < OP / 2; ++o) { res0[o] = f32x2{0.f, 0.f}; res1[o] = f32x2{0.f, 0.f}; }
+    for (int o = 0; o < OP; ++o) { res0[o] = 0.f; res1[o] = 0.f; }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -363,13 +417,12 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
 #pragma unroll
         for (int s = 0; s < KS; ++s)
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], set ? pf1[s] : pf0[s], acc, 0, 0, 0);
-        // rows v, v+1 (v even) are outputs o, o+1 of the same b: one packed FMA
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) {
+        for (int v = 0; v < 16; ++v) {
           const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
           const float mm = set ? m1[code >> LOGO] : m0[code >> LOGO];
-          f32x2& dst = set ? res1[(code & (OP - 1)) >> 1] : res0[(code & (OP - 1)) >> 1];
-          dst = __builtin_elementwise_fma(f32x2{acc[v], acc[v + 1]}, f32x2{mm, mm}, dst);
+          float& dst = set ? res1[code & (OP - 1)] : res0[code & (OP - 1)];
+          dst = __builtin_fmaf(acc[v], mm, dst);
         }
       }
     }
@@ -377,11 +430,11 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
     float res[OP];
 #pragma unroll
     for (int o = 0; o < OP; ++o) {
-      float a0 = res0[o >> 1][o & 1], a1 = res1[o >> 1][o & 1];
+      float a0 = res0[o], a1 = res1[o];
       swap_halves(a0, a1);
       res[o] = a0 + a1;
     }
-    if (valid) store_row<S, OP, OVEC>(out + w * p.O, p.O, res);
+    store_row<S, OP, OVEC>(rs_o, job.voff_o, (unsigned)b * p.o_s1b, p.O, res);  // no position: out of range
   }
 }
 
@@ -389,9 +442,14 @@ __global__ __launch_bounds__(256) void eps_fwd_q2reg_k(const S* __restrict__ x,
 // feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
 constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LDS reduction per block)
 
-template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS>
+// HEADC > 0: fused classifier-head backward.  dY is not read; instead `dY` points at dLogits
+// (B, Cout) and `hw` at the head weight (Cout, P*O), both bf16, and the wave forms
+// dY[w, o] = sum_c dLogits[b, c] * hw[c, pos*O + o] itself: the lane's weight slice is loaded once
+// (HEADC = Cout padded to the instantiated bound), dLogits of the sample is wave-uniform.
+template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS, int HEADC>
 __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
                                                              const S* __restrict__ dY,
+                                                             const S* __restrict__ hw,
                                                              float* __restrict__ partial, MfmaP p) {
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int AT = A >= 32 ? A / 32 : 1;
@@ -415,39 +473,62 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[t][a][v] = 0.f;
 
-  const long long nb = gridDim.x;
-  const long long vb = (nb % 8 == 0) ? (long long)(blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
-  const long long wave = vb * BWD_WAVES + wv;
-  const long long g0 = wave * p.gpw;
-  const long long g1 = g0 + p.gpw < p.ngroups ? g0 + p.gpw : p.ngroups;
-  RawWindow<S, N, XVEC> raw;
-  RowPack<S, OP> rawdy;
-  WinIter it = win_begin(p, g0 * 64 + lane);
-  if (g0 < g1) {
-    const long long w0 = g0 * 64 + lane;
-    issue_window<S, N, XVEC, ROWS>(x, p, w0 < p.Wn ? it.off : 0u, raw);
-    issue_row<S, OP, OVEC>(dY + (w0 < p.Wn ? w0 : 0) * p.O, p.O, rawdy);
+  const WaveJob job = wave_job(p, BWD_WAVES, (int)sizeof(S));
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dY, HEADC > 0 ? 0u : p.o_bytes);
+  float hwf[HEADC > 0 ? HEADC : 1][OP];
+  constexpr int DLW = HEADC > 0 ? HEADC / 2 : 1;   // dwords of one row of dLogits (bf16 pairs)
+  const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
+  unsigned dlraw[DLW];
+  if constexpr (HEADC > 0) {
+    const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
+    const unsigned voff_hw = job.valid ? (unsigned)job.pos * (unsigned)(OP * 2) : p.hw_bytes;
+    RawRow<S, OP> rr[HEADC];
+#pragma unroll
+    for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
+      issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
+#pragma unroll
+    for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
   }
-  for (long long g = g0; g < g1; ++g) {
-    const long long w = g * 64 + lane;
-    const bool valid = w < p.Wn;
+  RawWindow<S, N, XVEC, ROWS> raw;
+  RawRow<S, OP> rawdy;
+  if (job.b0 < job.b1) {
+    issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, raw);
+    if constexpr (HEADC > 0) {
+#pragma unroll
+      for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)job.b0 * (p.Cout / 2) + i] : 0u;
+    } else {
+      issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)job.b0 * p.o_s1b, p.O, rawdy);
+    }
+  }
+  for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
-    unpack_window<S, N, XVEC, ROWS>(raw, p, xv);
+    unpack_window<S, N, XVEC, ROWS>(raw, xv);
     float dy[OP];
-    unpack_row<S, OP>(rawdy, p.O, dy);
-    {  // prefetch the next group of this wave
-      const long long wn = g + 1 < g1 ? w + 64 : w;
-      if (g + 1 < g1) {
-        if (p.inc_ok) win_advance64(p, it); else it = win_begin(p, wn);
+    if constexpr (HEADC > 0) {
+#pragma unroll
+      for (int o = 0; o < OP; ++o) dy[o] = 0.f;
+#pragma unroll
+      for (int c = 0; c < HEADC; ++c) {
+        const float dl = (c & 1) ? __uint_as_float(dlraw[c >> 1] & 0xffff0000u) : __uint_as_float(dlraw[c >> 1] << 16);
+#pragma unroll
+        for (int o = 0; o < OP; ++o) dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
       }
-      issue_window<S, N, XVEC, ROWS>(x, p, wn < p.Wn ? it.off : 0u, raw);
-      issue_row<S, OP, OVEC>(dY + (wn < p.Wn ? wn : 0) * p.O, p.O, rawdy);
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's arithmetic
+    } else {
+      unpack_row<S, OP, OVEC>(rawdy, dy);
     }
-    if (!valid) {  // lanes past the last window contribute nothing: P0 carries factor 0
-      xv[0][0] = 0.f;
-      xv[0][1] = 0.f;
+    {  // prefetch the next sample of this wave
+      const int bn = b + 1 < job.b1 ? b + 1 : b;
+      issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)bn * p.s1b, p, raw);
+      if constexpr (HEADC > 0) {
+#pragma unroll
+        for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)bn * (p.Cout / 2) + i] : 0u;
+      } else {
+        issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)bn * p.o_s1b, p.O, rawdy);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's arithmetic
     }
+    // lanes without a window position read zeros for x: their P0 is 0 and they contribute nothing
 
     // P0 of the lane's own window -> A operands of set 0 / set 1 -> transposed on the matrix core:
     // features on lanes, windows in registers = B operand fragments summing over windows
@@ -580,15 +661,16 @@ bool family_ok(const EpsP& p, int dtype, int precision) {
   if (dtype == DCTN_F64) return false;
   if (dtype == DCTN_F32 && precision != DCTN_PREC_BF16) return false;
   if (p.N != 8 && p.N != 9) return false;
-  if (p.Wn >= (1LL << 31) - 64) return false;
-  {  // 32-bit byte offsets: non-negative strides and an extent below 4 GiB
+  const long long esz = dtype == DCTN_BF16 ? 2 : 4;
+  {  // 32-bit byte offsets with the hardware range check: non-negative strides, extents below 2 GiB
     long long ext = 0;
     const long long dims[5] = {p.C, p.B, p.H, p.W, p.Q};
     for (int i = 0; i < 5; ++i) {
       if (p.s[i] < 0) return false;
       ext += (dims[i] - 1) * p.s[i];
     }
-    if ((ext + 1) * 4 >= (1LL << 32)) return false;
+    if ((ext + 1) * esz >= (1LL << 31)) return false;
+    if (p.Wn * p.O * esz >= (1LL << 31)) return false;
   }
   const int op = next_pow2(p.O);
   return op >= 2 ? op <= 16 : true;
@@ -609,66 +691,67 @@ FastDiv make_fastdiv(unsigned d) {
 }
 
 void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
-  const long long esz_ = dtype == DCTN_BF16 ? 2 : 4;
+  const long long esz = dtype == DCTN_BF16 ? 2 : 4;
   for (int n = 0; n < p.N && n < MFMA_MAXN; ++n) {
     const int pos = n / p.C, ch = n - pos * p.C;
     const int dh = pos / p.K, dw = pos - dh * p.K;
-    m.foffb[n] = (unsigned)((ch * p.s[0] + dh * p.s[2] + dw * p.s[3]) * esz_);
+    m.foffb[n] = (unsigned)((ch * p.s[0] + dh * p.s[2] + dw * p.s[3]) * esz);
   }
-  m.s1b = (unsigned)(p.s[1] * esz_); m.s2b = (unsigned)(p.s[2] * esz_);
-  m.s3b = (unsigned)(p.s[3] * esz_); m.s4b = (unsigned)(p.s[4] * esz_);
-  {
-    long long ext = 0;
-    const long long dims[5] = {p.C, p.B, p.H, p.W, p.Q};
-    for (int i = 0; i < 5; ++i) ext += (dims[i] - 1) * p.s[i];
-    m.x_bytes = (unsigned)((ext + 1) * esz_);
-    const int rows = p.K * p.C;
-    for (int rw = 0; rw < rows && rw < MFMA_MAXN; ++rw) {
-      const int dh = rw / p.C, ch = rw - dh * p.C;
-      m.rowoffb[rw] = (unsigned)((ch * p.s[0] + dh * p.s[2]) * esz_);
-    }
-    // K pixels of a row in one 16-byte load: bf16 pairs (4 bytes per pixel), pixels contiguous
-    m.rowvec_ok = dtype == DCTN_BF16 && p.s[4] == 1 && p.s[3] == 2 && p.K <= 4 && rows <= MFMA_MAXN / 2 &&
-                  ((p.N == 9 && rows == 3) || (p.N == 8 && rows == 4)) && m.x_bytes >= 32;
+  m.s1b = (unsigned)(p.s[1] * esz); m.s2b = (unsigned)(p.s[2] * esz);
+  m.s3b = (unsigned)(p.s[3] * esz); m.s4b = (unsigned)(p.s[4] * esz);
+  long long ext = 0;
+  const long long dims[5] = {p.C, p.B, p.H, p.W, p.Q};
+  for (int i = 0; i < 5; ++i) ext += (dims[i] - 1) * p.s[i];
+  m.x_bytes = (unsigned)((ext + 1) * esz);
+  const int rows = p.K * p.C;
+  for (int rw = 0; rw < MFMA_MAXN; ++rw) m.rowoffb[rw] = 0;
+  for (int rw = 0; rw < rows && rw < MFMA_MAXN; ++rw) {
+    const int dh = rw / p.C, ch = rw - dh * p.C;
+    m.rowoffb[rw] = (unsigned)((ch * p.s[0] + dh * p.s[2]) * esz);
   }
-  m.row_wrap = (unsigned)(p.s[2] * esz_) - (unsigned)p.Wo * (unsigned)(p.s[3] * esz_);
-  m.img_wrap = (unsigned)(p.s[1] * esz_) - (unsigned)p.Ho * (unsigned)(p.s[2] * esz_);
-  m.inc_ok = p.Wo >= 16 && p.Ho >= 4;
-  m.gpw = 1;
-  m.div_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+  // K pixels of a row in one 16-byte load: bf16 pairs (4 bytes per pixel), pixels contiguous
+  m.rowvec_ok = dtype == DCTN_BF16 && p.s[4] == 1 && p.s[3] == 2 && p.K <= 4 && rows <= MFMA_MAXN / 2 &&
+                ((p.N == 9 && rows == 3) || (p.N == 8 && rows == 4));
   m.div_wo = make_fastdiv((unsigned)p.Wo);
-  m.C = p.C; m.B = p.B; m.H = p.H; m.W = p.W; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
-  m.Wn = p.Wn;
-  m.ngroups = (p.Wn + 63) / 64;
-  for (int i = 0; i < 5; ++i) m.s[i] = p.s[i];
-  const size_t esz = dtype == DCTN_BF16 ? 2 : 4;
+  m.C = p.C; m.B = p.B; m.K = p.K; m.O = p.O; m.Ho = p.Ho; m.Wo = p.Wo;
+  m.P = p.Ho * p.Wo;
+  m.npg = (m.P + 63) / 64;
+  m.spc = 1; m.nchunks = p.B;
+  m.o_s1b = (unsigned)((long long)m.P * p.O * esz);
+  m.o_bytes = (unsigned)(p.Wn * p.O * esz);
   m.vec_ok = p.s[4] == 1 && p.s[0] % 2 == 0 && p.s[1] % 2 == 0 && p.s[2] % 2 == 0 &&
-             p.s[3] % 2 == 0 && ((uintptr_t)x % (2 * esz)) == 0;
+             p.s[3] % 2 == 0 && ((uintptr_t)x % 4) == 0;
+  m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0;
 }
 
 constexpr int FWD_BLOCKS_PER_CU = 4;
 constexpr int NUM_CU = 256;
 
-int bwd_grid(MfmaP& m) {
-  long long blocks = (m.ngroups + BWD_WAVES - 1) / BWD_WAVES;
-  if (blocks > NUM_CU) blocks = NUM_CU;
-  if (blocks < 1) blocks = 1;
-  m.gpw = (m.ngroups + blocks * BWD_WAVES - 1) / (blocks * BWD_WAVES);
-  blocks = (m.ngroups + m.gpw * BWD_WAVES - 1) / (m.gpw * BWD_WAVES);
+// Split the batch into sample chunks so that (chunks x position groups) is about `target` waves;
+// returns the number of workgroups of `wpb` waves (a multiple of 8 for the XCD-contiguous mapping).
+int plan_waves(MfmaP& m, int wpb, long long target) {
+  long long chunks = target / m.npg;
+  if (chunks < 1) chunks = 1;
+  if (chunks > m.B) chunks = m.B;
+  m.spc = (int)((m.B + chunks - 1) / chunks);
+  m.nchunks = (m.B + m.spc - 1) / m.spc;
+  const long long waves = (long long)m.nchunks * m.npg;
+  long long blocks = (waves + wpb - 1) / wpb;
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-  if (blocks > NUM_CU) blocks = NUM_CU;
   return (int)blocks;
+}
+
+// vector row accesses of out / dY: O already a power of two and a dword-aligned base
+template <typename S>
+bool row_vec_ok(const MfmaP& m, int OP, const void* ptr) {
+  return m.O == OP && ((uintptr_t)ptr % 4) == 0 && (OP * sizeof(S)) % 4 == 0;
 }
 
 template <typename S, int N0, int N1, int OP>
 int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m_in, hipStream_t st) {
   MfmaP m = m_in;
-  long long blocks = (m.ngroups + 3) / 4;
-  if (blocks > (long long)FWD_BLOCKS_PER_CU * NUM_CU) blocks = (long long)FWD_BLOCKS_PER_CU * NUM_CU;
-  m.gpw = (m.ngroups + blocks * 4 - 1) / (blocks * 4);
-  blocks = (m.ngroups + m.gpw * 4 - 1) / (m.gpw * 4);   // no idle workgroups at the end
-  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;        // XCD-contiguous mapping needs a multiple of 8
-  const bool ovec = m.O == OP && ((uintptr_t)out % (sizeof(S) * OP)) == 0;
+  const int blocks = plan_waves(m, 4, (long long)FWD_BLOCKS_PER_CU * NUM_CU * 4);
+  const bool ovec = row_vec_ok<S>(m, OP, out);
   const dim3 g((unsigned)blocks), b(256);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;   // K*C window rows: 3x3 single channel, 2x2 two channels
@@ -694,29 +777,62 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
                  hipStream_t st) {
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
   MfmaP m = m_in;
-  const int grid = bwd_grid(m);
-  const bool ovec = m.O == OP && ((uintptr_t)dY % (sizeof(S) * OP)) == 0;
+  const int grid = plan_waves(m, BWD_WAVES, (long long)NUM_CU * BWD_WAVES);   // <= NUM_CU partial tiles
+  const bool ovec = row_vec_ok<S>(m, OP, dY);
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
   if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (float*)ws, m);
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW, 0>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
   else if (m.vec_ok && ovec)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (float*)ws, m);
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0, 0>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
   else if (m.vec_ok)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (float*)ws, m);
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0, 0>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
   else
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (float*)ws, m);
+    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, 0, st,
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
   hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
                      (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_q2reg");
+  return DCTN_OK;
+}
+
+// fused classifier-head backward (bf16 only): dLogits (B, Cout), head weight (Cout, P*O)
+template <int N0, int N1, int OP>
+int bwd_head_launch_t(const void* x, const void* dL, const void* hw, void* dCore, void* ws, const MfmaP& m_in,
+                      hipStream_t st) {
+  typedef bf16_t S;
+  constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
+  MfmaP m = m_in;
+  if (m.O != OP || m.Cout < 2 || m.Cout > 16 || m.Cout % 2 != 0) return DCTN_ERR_UNSUPPORTED;
+  if (((uintptr_t)dL % 4) != 0 || ((uintptr_t)hw % 4) != 0) return DCTN_ERR_UNSUPPORTED;
+  const int grid = plan_waves(m, BWD_WAVES, (long long)NUM_CU * BWD_WAVES);
+  const dim3 g(grid), b(64 * BWD_WAVES);
+  constexpr int NN = N0 + N1;
+  constexpr int RW = NN == 9 ? 3 : 4;
+#define DCTN_HEAD_LAUNCH(XV, ROWSV, HC)                                                                        \
+  hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, 0, st, (const S*)x, \
+                     (const S*)dL, (const S*)hw, (float*)ws, m)
+  if (m.rowvec_ok && m.vec_ok) {
+    if (m.Cout <= 10) DCTN_HEAD_LAUNCH(true, RW, 10); else DCTN_HEAD_LAUNCH(true, RW, 16);
+  } else if (m.vec_ok) {
+    if (m.Cout <= 10) DCTN_HEAD_LAUNCH(true, 0, 10); else DCTN_HEAD_LAUNCH(true, 0, 16);
+  } else {
+    if (m.Cout <= 10) DCTN_HEAD_LAUNCH(false, 0, 10); else DCTN_HEAD_LAUNCH(false, 0, 16);
+  }
+#undef DCTN_HEAD_LAUNCH
+  DCTN_CHECK_LAUNCH();
+  if (dctn_main_kernel_only()) return DCTN_OK;
+  hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
+                     (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_bwd_mfma_q2reg_head");
   return DCTN_OK;
 }
 
@@ -777,4 +893,28 @@ int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void
   const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
   if (dtype == DCTN_BF16) return bwd_dispatch<bf16_t>(x, dY, dCore, ws, m, p.N, op, st);
   return bwd_dispatch<float>(x, dY, dCore, ws, m, p.N, op, st);
+}
+
+// dCore of an EPS layer whose output feeds the linear classifier head directly: dY is never
+// materialised, the kernel forms it from dLogits and the head weight (see eps_bwd_dcore_q2reg_k).
+int eps_bwd_mfma_head(const void* x, const void* dLogits, const void* head_w, void* dCore, void* ws,
+                      size_t ws_bytes, const EpsP& p, int Cout, int dtype, int precision, hipStream_t st) {
+  if (dtype != DCTN_BF16 || !dCore) return DCTN_ERR_UNSUPPORTED;
+  if (!family_ok(p, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < eps_bwd_mfma_workspace(p, dtype, precision, 0, 1)) return DCTN_ERR_WORKSPACE;
+  const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
+  if (op != p.O || op > 4) return DCTN_ERR_UNSUPPORTED;   // the weight slice lives in registers
+  MfmaP m;
+  fill_mp(m, p, x, dtype);
+  m.Cout = Cout;
+  const long long rowb = (long long)m.P * p.O * 2;
+  if (rowb * Cout >= (1LL << 31)) return DCTN_ERR_UNSUPPORTED;
+  m.hw_rowb = (unsigned)rowb;
+  m.hw_bytes = (unsigned)(rowb * Cout);
+  if (p.N == 9) {
+    if (op == 2) return bwd_head_launch_t<5, 4, 2>(x, dLogits, head_w, dCore, ws, m, st);
+    return bwd_head_launch_t<5, 4, 4>(x, dLogits, head_w, dCore, ws, m, st);
+  }
+  if (op == 2) return bwd_head_launch_t<4, 4, 2>(x, dLogits, head_w, dCore, ws, m, st);
+  return bwd_head_launch_t<4, 4, 4>(x, dLogits, head_w, dCore, ws, m, st);
 }

@@ -98,6 +98,74 @@ class _LinearHeadFunction(torch.autograd.Function):
         return d_f, (d_w if need_w else None), (d_b if need_b else None)
 
 
+class _EpsLinearHeadFunction(torch.autograd.Function):
+    """The last EPS layer, the flatten and the linear head as ONE autograd node (reference:
+    dctn/eps_plus_linear.py:144-147).  Forward is the EPS kernel followed by the head kernel; in the
+    backward the gradient of the features is never materialised: `dctn_eps_head_bwd_dcore` forms it
+    inside the dCore kernel from dLogits and the head weight (one GEMM launch and a write + read of
+    the (B, H'*W'*O) gradient less per step).  Used when the layer's input needs no gradient (it is
+    the dataset tensor for a single-EPS model) and the shape is in the register-resident MFMA
+    family; anything else takes the two separate nodes."""
+
+    @staticmethod
+    def supported(core: Tensor, x: Tensor, weight: Tensor, bias) -> bool:
+        if not (x.is_cuda and bias is not None and not x.requires_grad):
+            return False
+        if not (x.dtype == core.dtype == weight.dtype == bias.dtype == torch.bfloat16):
+            return False
+        n, o, cout = core.ndim - 1, core.shape[-1], weight.shape[0]
+        return (x.shape[-1] == 2 and n in (8, 9) and o in (2, 4) and cout <= 16 and cout % 2 == 0
+                and weight.shape[1] % 8 == 0 and os.environ.get("DCTN_FUSED_HEAD", "1") == "1")
+
+    @staticmethod
+    def forward(ctx, core: Tensor, x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+        dev = L.require_device(core, x, weight, bias)
+        C, B, H, W, Q = x.shape
+        K = math.isqrt((core.ndim - 1) // C)
+        O = core.shape[-1]
+        core_c, w, b = core.contiguous(), weight.contiguous(), bias.contiguous()
+        prec, code = L.precision(), L.dtype_code(x)
+        feat = torch.empty((B, (H - K + 1) * (W - K + 1) * O), dtype=x.dtype, device=dev)
+        ws = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
+        L.check(
+            L.lib().dctn_eps_fwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), feat.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
+            "eps forward",
+        )
+        assert w.shape[1] == feat.shape[1]
+        cout = w.shape[0]
+        out = torch.empty((B, cout), dtype=x.dtype, device=dev)
+        L.check(L.lib().dctn_linear_head_fwd(feat.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B,
+                                             feat.shape[1], cout, code, L.stream_ptr(dev)), "linear head forward")
+        ctx.save_for_backward(core_c, x, feat, w)
+        ctx.dims = (C, B, H, W, Q, K, O, prec)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        core_c, x, feat, w = ctx.saved_tensors
+        C, B, H, W, Q, K, O, prec = ctx.dims
+        need_core, _, need_w, need_b = ctx.needs_input_grad
+        dev, code = x.device, L.dtype_code(x)
+        g = d_out.contiguous()
+        d_w = g.t() @ feat if need_w else None
+        d_b = g.sum(0) if need_b else None
+        d_core = None
+        if need_core:
+            d_core = torch.empty_like(core_c)
+            ws = L.workspace(L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1), dev)
+            rc = L.lib().dctn_eps_head_bwd_dcore(
+                x.data_ptr(), L.strides5(x), g.data_ptr(), w.data_ptr(), d_core.data_ptr(), ws.data_ptr(),
+                ws.numel(), C, B, H, W, Q, K, O, w.shape[0], code, prec, L.stream_ptr(dev))
+            if rc == L.ERR_UNSUPPORTED:   # outside the fused family: the two separate device kernels
+                d_feat = (g @ w).contiguous()
+                rc = L.lib().dctn_eps_bwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), d_feat.data_ptr(), None,
+                                          d_core.data_ptr(), ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code,
+                                          prec, L.stream_ptr(dev))
+            L.check(rc, "eps + linear head backward")
+        return d_core, None, d_w, d_b
+
+
 class EPSesPlusLinear(nn.Module):
     def __init__(
         self,
@@ -162,7 +230,13 @@ class EPSesPlusLinear(nn.Module):
             cores = tuple(self.p.expand_as(core).bernoulli() * core / self.p for core in self.epses)
         else:
             cores = tuple(self.epses)
-        features = epses_composition.contract_with_input(cores, input)
+        x = input
+        for core in cores[:-1]:   # as epses_composition.contract_with_input
+            x = eps.eps(core, x).unsqueeze(0)
+        if _EpsLinearHeadFunction.supported(cores[-1], x, self.linear.weight, self.linear.bias):
+            eps._check_core(cores[-1], x)
+            return _EpsLinearHeadFunction.apply(cores[-1], x, self.linear.weight, self.linear.bias)
+        features = eps.eps(cores[-1], x)
         flat = features.reshape(features.shape[0], -1)
         if _LinearHeadFunction.supported(flat, self.linear.weight, self.linear.bias):
             return _LinearHeadFunction.apply(flat, self.linear.weight, self.linear.bias)
