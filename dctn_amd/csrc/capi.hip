@@ -68,18 +68,26 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   return a + b + 256;
 }
 
-int dctn_eps_head_bwd_dcore(const void* x, const int64_t x_strides[5], const void* dLogits,
-                            const void* head_weight, void* dCore, void* workspace, size_t workspace_bytes,
-                            int C, int B, int H, int W, int Q, int K, int O, int Cout, int dtype,
-                            int precision, void* stream) {
-  if (!x || !dLogits || !head_weight || !dCore || !x_strides) return DCTN_ERR_NULL;
+size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout, int dtype,
+                                         int precision) {
+  EpsP p;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  return eps_head_bwd_mfma_workspace(p, Cout, dtype, precision) + 256;
+}
+
+int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features, const void* dLogits,
+                      const void* head_weight, void* dCore, void* dWeight, void* dBias, void* workspace,
+                      size_t workspace_bytes, int C, int B, int H, int W, int Q, int K, int O, int Cout,
+                      int dtype, int precision, void* stream) {
+  if (!x || !features || !dLogits || !head_weight || !dCore || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   if (Cout < 1) return DCTN_ERR_BAD_SHAPE;
   EpsP p;
   const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
   if (rc != DCTN_OK) return rc;
-  return eps_bwd_mfma_head(x, dLogits, head_weight, dCore, workspace, workspace_bytes, p, Cout, dtype,
-                           precision, (hipStream_t)stream);
+  return eps_head_bwd_mfma(x, features, dLogits, head_weight, dCore, dWeight, dBias, workspace, workspace_bytes, p,
+                           Cout, dtype, precision, (hipStream_t)stream);
 }
 
 int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,

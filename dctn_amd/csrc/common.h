@@ -80,8 +80,10 @@ int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int 
 size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx, int need_dcore);
 int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
                  size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
-int eps_bwd_mfma_head(const void* x, const void* dLogits, const void* head_w, void* dCore, void* ws,
-                      size_t ws_bytes, const EpsP& p, int Cout, int dtype, int precision, hipStream_t st);
+size_t eps_head_bwd_mfma_workspace(const EpsP& p, int Cout, int dtype, int precision);
+int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, const void* head_w, void* dCore,
+                      void* dW, void* dBias, void* ws, size_t ws_bytes, const EpsP& p, int Cout, int dtype,
+                      int precision, hipStream_t st);
 
 // MFMA ConvSBS sweep (open chain, uniform bond) — convsbs_mfma.hip
 int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,

@@ -105,6 +105,7 @@ struct MfmaP {
   int vec_ok;                   // x: last stride 1, even strides, 4-byte aligned base (pair loads)
   int Cout;                     // fused-head backward: number of classes (rows of the head weight)
   unsigned hw_rowb, hw_bytes;   //   bytes per row (P * O * 2) and in total
+  int ncb;                      //   chunk blocks (8 sample chunks each) of the grouped wave mapping
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -249,6 +250,17 @@ __device__ __forceinline__ void unpack_row(const RawRow<S, OP>& r, float (&v)[OP
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
+// 8 floats -> one MFMA operand fragment: exactly four v_cvt_pk_bf16_f32 (element-wise casts into a
+// bf16x8 make the compiler convert singly and re-pack with shifts and ors)
+__device__ __forceinline__ bf16x8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6,
+                                        float f7) {
+  int4v r;
+  r[0] = (int)pack_bf16(f0, f1);
+  r[1] = (int)pack_bf16(f2, f3);
+  r[2] = (int)pack_bf16(f4, f5);
+  r[3] = (int)pack_bf16(f6, f7);
+  return __builtin_bit_cast(bf16x8, r);
+}
 template <typename S, int OP, bool VEC>
 __device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, int O,
                                           const float (&v)[OP]) {
@@ -289,13 +301,22 @@ struct WaveJob {
   int pos;
   bool valid;
 };
-__device__ __forceinline__ WaveJob wave_job(const MfmaP& p, int waves_per_block, int esz) {
+// grouped = true (fused-head backward): a workgroup is (chunk block cb, position group pg) and its
+// waves are the 8 sample chunks of cb at the SAME positions, so that their per-position sums can
+// meet in LDS; consecutive workgroups walk pg first, keeping the samples of a chunk block on one XCD.
+__device__ __forceinline__ WaveJob wave_job(const MfmaP& p, int waves_per_block, int esz, bool grouped = false) {
   // XCD-contiguous mapping: workgroups b, b+8, ... share an XCD (round-robin dispatch), so give each
   // XCD one contiguous eighth of the waves: the position groups of a sample chunk then meet in one L2.
   const int nb = gridDim.x;
   const int vb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(vb * waves_per_block + (int)(threadIdx.x >> 6));
-  const int chunk = wave / p.npg, pg = wave - chunk * p.npg;
+  int chunk = wave / p.npg, pg = wave - chunk * p.npg;
+  if (grouped) {
+    const int cb = vb / p.npg;
+    pg = vb - cb * p.npg;
+    chunk = __builtin_amdgcn_readfirstlane(cb * waves_per_block + (int)(threadIdx.x >> 6));
+    if (cb >= p.ncb) chunk = p.nchunks;   // padding workgroups: no samples
+  }
   WaveJob j;
   j.b0 = chunk < p.nchunks ? chunk * p.spc : 0;
   j.b1 = chunk < p.nchunks ? (j.b0 + p.spc < p.B ? j.b0 + p.spc : p.B) : 0;
@@ -325,11 +346,10 @@ __device__ __forceinline__ void build_p0(const float (*xv)[2], bf16x8 (&X)[(1 <<
     for (int t = 0; t < N0 - 4; ++t) hi = t == 0 ? xv[N0 - 5][s & 1] : hi * xv[N0 - 5 - t][(s >> t) & 1];
     const float h0 = N0 > 4 ? hi * xv[N0 - 4][0] : xv[N0 - 4][0];
     const float h1 = N0 > 4 ? hi * xv[N0 - 4][1] : xv[N0 - 4][1];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      X[s][j] = (bf16_t)(h0 * lo8[j]);
-      Y[s][j] = (bf16_t)(h1 * lo8[j]);
-    }
+    X[s] = pack8(h0 * lo8[0], h0 * lo8[1], h0 * lo8[2], h0 * lo8[3], h0 * lo8[4], h0 * lo8[5], h0 * lo8[6],
+                 h0 * lo8[7]);
+    Y[s] = pack8(h1 * lo8[0], h1 * lo8[1], h1 * lo8[2], h1 * lo8[3], h1 * lo8[4], h1 * lo8[5], h1 * lo8[6],
+                 h1 * lo8[7]);
   }
 }
 
@@ -445,12 +465,18 @@ constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LD
 // HEADC > 0: fused classifier-head backward.  dY is not read; instead `dY` points at dLogits
 // (B, Cout) and `hw` at the head weight (Cout, P*O), both bf16, and the wave forms
 // dY[w, o] = sum_c dLogits[b, c] * hw[c, pos*O + o] itself: the lane's weight slice is loaded once
-// (HEADC = Cout padded to the instantiated bound), dLogits of the sample is wave-uniform.
+// (HEADC = Cout padded to the instantiated bound), dLogits of the sample is wave-uniform.  The same
+// loop accumulates the head-weight gradient of the lane's position,
+// dW[c, pos*O + o] += dLogits[b, c] * feat[b, pos, o]  (`feat` = the layer's forward output), reduced
+// over the workgroup's 8 sample chunks in LDS and written as one partial tile per chunk block to
+// `dwpart` [ncb][Cout][P*O]; eps_head_reduce_k sums the tiles (and dLogits into dBias).
 template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS, int HEADC>
 __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
                                                              const S* __restrict__ dY,
                                                              const S* __restrict__ hw,
-                                                             float* __restrict__ partial, MfmaP p) {
+                                                             const S* __restrict__ feat,
+                                                             float* __restrict__ partial,
+                                                             float* __restrict__ dwpart, MfmaP p) {
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int AT = A >= 32 ? A / 32 : 1;
   constexpr int LOGO = ilog2(OP);
@@ -473,10 +499,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[t][a][v] = 0.f;
 
-  const WaveJob job = wave_job(p, BWD_WAVES, (int)sizeof(S));
+  const WaveJob job = wave_job(p, BWD_WAVES, (int)sizeof(S), HEADC > 0);
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes);
-  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(dY, HEADC > 0 ? 0u : p.o_bytes);
+  // non-head: rows of dY; head: rows of the forward output (same layout)
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(HEADC > 0 ? feat : dY, p.o_bytes);
   float hwf[HEADC > 0 ? HEADC : 1][OP];
+  float dwacc[HEADC > 0 ? HEADC : 1][OP];
+#pragma unroll
+  for (int c = 0; c < (HEADC > 0 ? HEADC : 1); ++c)
+#pragma unroll
+    for (int o = 0; o < OP; ++o) dwacc[c][o] = 0.f;
   constexpr int DLW = HEADC > 0 ? HEADC / 2 : 1;   // dwords of one row of dLogits (bf16 pairs)
   const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
   unsigned dlraw[DLW];
@@ -497,22 +529,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     if constexpr (HEADC > 0) {
 #pragma unroll
       for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)job.b0 * (p.Cout / 2) + i] : 0u;
-    } else {
-      issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)job.b0 * p.o_s1b, p.O, rawdy);
     }
+    issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)job.b0 * p.o_s1b, p.O, rawdy);
   }
   for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, xv);
     float dy[OP];
     if constexpr (HEADC > 0) {
+      float ft[OP];   // forward output of the window (zeros for lanes without a position)
+      unpack_row<S, OP, OVEC>(rawdy, ft);
 #pragma unroll
       for (int o = 0; o < OP; ++o) dy[o] = 0.f;
 #pragma unroll
       for (int c = 0; c < HEADC; ++c) {
         const float dl = (c & 1) ? __uint_as_float(dlraw[c >> 1] & 0xffff0000u) : __uint_as_float(dlraw[c >> 1] << 16);
 #pragma unroll
-        for (int o = 0; o < OP; ++o) dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
+        for (int o = 0; o < OP; ++o) {
+          dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
+          dwacc[c][o] = __builtin_fmaf(dl, ft[o], dwacc[c][o]);
+        }
       }
     } else {
       unpack_row<S, OP, OVEC>(rawdy, dy);
@@ -523,9 +559,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       if constexpr (HEADC > 0) {
 #pragma unroll
         for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)bn * (p.Cout / 2) + i] : 0u;
-      } else {
-        issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)bn * p.o_s1b, p.O, rawdy);
       }
+      issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)bn * p.o_s1b, p.O, rawdy);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's arithmetic
     }
     // lanes without a window position read zeros for x: their P0 is 0 and they contribute nothing
@@ -548,8 +583,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         for (int sp = 0; sp < 2; ++sp)
           if (2 * a + sp < KS)
             d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[set][2 * a + sp], ident[sp], d, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) p0t[set][a][v >> 3][v & 7] = (bf16_t)d[v];
+        p0t[set][a][0] = pack8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        p0t[set][a][1] = pack8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
       }
     // full P1 table of this window (b bit u <-> factor N-1-u)
     float p1[BN];
@@ -566,13 +601,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       bf16x8 zf[2][2];   // [set after the swap][sp]
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
+        float za[8], zb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int ma = (t << 5) | (sp << 4) | j;        // first k-half
           const int mb = ma | 8;                           // second k-half
-          zf[0][sp][j] = (bf16_t)(p1[ma >> LOGO] * dy[ma & (OP - 1)]);
-          zf[1][sp][j] = (bf16_t)(p1[mb >> LOGO] * dy[mb & (OP - 1)]);
+          za[j] = p1[ma >> LOGO] * dy[ma & (OP - 1)];
+          zb[j] = p1[mb >> LOGO] * dy[mb & (OP - 1)];
         }
+        zf[0][sp] = pack8(za[0], za[1], za[2], za[3], za[4], za[5], za[6], za[7]);
+        zf[1][sp] = pack8(zb[0], zb[1], zb[2], zb[3], zb[4], zb[5], zb[6], zb[7]);
         swap_halves(zf[0][sp], zf[1][sp]);
       }
 #pragma unroll
@@ -584,8 +622,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         for (int sp = 0; sp < 2; ++sp)
           d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[set][sp], ident[sp], d, 0, 0, 0);
         bf16x8 zt[2];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) zt[v >> 3][v & 7] = (bf16_t)d[v];
+        zt[0] = pack8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        zt[1] = pack8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
 #pragma unroll
         for (int a = 0; a < AT; ++a)
 #pragma unroll
@@ -616,6 +654,41 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         dst[(long long)(t * 32 + row) * (AT * 32) + a * 32 + col] = sum;
       }
     }
+
+  if constexpr (HEADC > 0) {
+    // head-weight gradient: sum the 8 waves (same positions, different sample chunks) in LDS, a few
+    // classes per round (the 32 KiB tile buffer holds 8 x 1024 floats), and store the workgroup's
+    // partial tile; LDS index (cc*64 + lane)*OP + o makes the stores run along the feature index
+    constexpr int CPR = 1024 / (64 * OP);   // classes per round
+    float* red1 = &red[0][0];
+    const int nbk = gridDim.x;
+    const int vbk = (nbk % 8 == 0) ? (int)(blockIdx.x % 8) * (nbk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int cb = vbk / p.npg, pg = vbk - cb * p.npg;
+    const int F = p.P * OP;
+#pragma unroll
+    for (int c0 = 0; c0 < HEADC; c0 += CPR) {
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < CPR; ++cc)
+#pragma unroll
+        for (int o = 0; o < OP; ++o) {
+          // static register index: unrolled over every (c0, cc) pair that can occur
+          float v = 0.f;
+#pragma unroll
+          for (int c = 0; c < HEADC; ++c) v = (c == c0 + cc) ? dwacc[c][o] : v;
+          red1[wv * 1024 + (cc * 64 + lane) * OP + o] = v;
+        }
+      __syncthreads();
+      for (int e = tid; e < CPR * 64 * OP; e += 64 * BWD_WAVES) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < BWD_WAVES; ++k) sum += red1[k * 1024 + e];
+        const int cc = e / (64 * OP), rem = e - cc * (64 * OP);   // rem = lane*OP + o
+        const int c = c0 + cc, f = pg * 64 * OP + rem;
+        if (cb < p.ncb && c < p.Cout && f < F) dwpart[((long long)cb * p.Cout + c) * F + f] = sum;
+      }
+    }
+  }
 }
 
 // dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a].  One workgroup per 32 consecutive
@@ -647,6 +720,70 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
     const int m = (int)(e / ACOLS), a = (int)(e % ACOLS);
     const int b = m / OP, o = m % OP;
     if (a < A && o < O) dCore[((long long)a * BN + b) * O + o] = (S)t;
+  }
+}
+
+// Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
+// as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
+// (256 consecutive features each), the last one sums dLogits over the batch into dBias.
+__global__ __launch_bounds__(256) void eps_head_reduce_k(const float* __restrict__ partial,
+                                                         bf16_t* __restrict__ dCore, int nblk, int A, int BN,
+                                                         int O, int OP, int ACOLS, int n_core,
+                                                         const float* __restrict__ dwpart,
+                                                         bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
+                                                         const bf16_t* __restrict__ dL, bf16_t* __restrict__ dBias,
+                                                         int B, int Cout) {
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < n_core) {
+    const int c = tid & 31, k8 = tid >> 5;
+    const long long stride = (long long)BN * OP * ACOLS;
+    const long long e = (long long)blockIdx.x * 32 + c;  // flat (m, a) index
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    int k = k8;
+    for (; k + 56 < nblk; k += 64) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += partial[(k + 8 * i) * stride + e];
+    }
+    for (; k < nblk; k += 8) acc[0] += partial[k * stride + e];
+    red[k8][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (k8 == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += red[i][c];
+      const int m = (int)(e / ACOLS), a = (int)(e % ACOLS);
+      const int b = m / OP, o = m % OP;
+      if (a < A && o < O) dCore[((long long)a * BN + b) * O + o] = (bf16_t)t;
+    }
+    return;
+  }
+  if ((int)blockIdx.x < n_core + n_dw) {
+    if (!dW) return;
+    const long long e = (long long)((int)blockIdx.x - n_core) * 256 + tid;
+    if (e >= nW) return;
+    float t = 0.f;
+    for (int k = 0; k < ncb; ++k) t += dwpart[(long long)k * nW + e];
+    dW[e] = (bf16_t)t;
+    return;
+  }
+  if (!dBias) return;
+  {  // dBias[c] = sum_b dLogits[b, c]: thread (c = tid % 16, lane16 = tid / 16) strides over b
+    const int c = tid & 15, l16 = tid >> 4;
+    float t = 0.f;
+    if (c < Cout)
+      for (int b = l16; b < B; b += 16) t += (float)dL[(long long)b * Cout + c];
+    __shared__ float rb[16][17];
+    rb[l16][c] = t;
+    __syncthreads();
+    if (tid < 16 && tid < Cout) {
+      float u = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) u += rb[i][tid];
+      dBias[tid] = (bf16_t)u;
+    }
   }
 }
 
@@ -721,7 +858,7 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
   m.o_bytes = (unsigned)(p.Wn * p.O * esz);
   m.vec_ok = p.s[4] == 1 && p.s[0] % 2 == 0 && p.s[1] % 2 == 0 && p.s[2] % 2 == 0 &&
              p.s[3] % 2 == 0 && ((uintptr_t)x % 4) == 0;
-  m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0;
+  m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0; m.ncb = 0;
 }
 
 constexpr int FWD_BLOCKS_PER_CU = 4;
@@ -784,16 +921,16 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
   constexpr int RW = NN == 9 ? 3 : 4;
   if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
     hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else if (m.vec_ok && ovec)
     hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else if (m.vec_ok)
     hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else
     hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, 0, st,
-                       (const S*)x, (const S*)dY, (const S*)nullptr, (float*)ws, m);
+                       (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
   hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
@@ -803,22 +940,45 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
   return DCTN_OK;
 }
 
-// fused classifier-head backward (bf16 only): dLogits (B, Cout), head weight (Cout, P*O)
+// grouped wave mapping of the fused head backward: ncb chunk blocks x npg position groups workgroups
+// (<= NUM_CU: one dCore partial tile per workgroup), 8 sample chunks per chunk block
+int plan_grouped(MfmaP& m) {
+  if (m.npg > NUM_CU) return 0;
+  long long ncb = NUM_CU / m.npg;
+  const long long need = (m.B + BWD_WAVES - 1) / BWD_WAVES;
+  if (ncb > need) ncb = need;
+  m.spc = (int)((m.B + ncb * BWD_WAVES - 1) / (ncb * BWD_WAVES));
+  m.nchunks = (m.B + m.spc - 1) / m.spc;
+  m.ncb = (m.nchunks + BWD_WAVES - 1) / BWD_WAVES;
+  long long blocks = (long long)m.ncb * m.npg;
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+  return blocks <= NUM_CU ? (int)blocks : 0;
+}
+
+size_t head_dw_partial_bytes(const EpsP& p, int Cout) {
+  const long long P = (long long)p.Ho * p.Wo, npg = (P + 63) / 64;
+  if (npg > NUM_CU) return 0;
+  return (size_t)(NUM_CU / npg) * (size_t)Cout * (size_t)(P * p.O) * sizeof(float);
+}
+
+// fused classifier-head backward (bf16 only): dLogits (B, Cout), head weight (Cout, P*O), feat (B, P*O)
 template <int N0, int N1, int OP>
-int bwd_head_launch_t(const void* x, const void* dL, const void* hw, void* dCore, void* ws, const MfmaP& m_in,
-                      hipStream_t st) {
+int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void* feat, void* dCore, void* dW,
+                      void* dBias, void* ws, size_t core_ws_bytes, const MfmaP& m_in, hipStream_t st) {
   typedef bf16_t S;
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
   MfmaP m = m_in;
   if (m.O != OP || m.Cout < 2 || m.Cout > 16 || m.Cout % 2 != 0) return DCTN_ERR_UNSUPPORTED;
-  if (((uintptr_t)dL % 4) != 0 || ((uintptr_t)hw % 4) != 0) return DCTN_ERR_UNSUPPORTED;
-  const int grid = plan_waves(m, BWD_WAVES, (long long)NUM_CU * BWD_WAVES);
+  if (((uintptr_t)dL % 4) != 0 || ((uintptr_t)hw % 4) != 0 || ((uintptr_t)feat % 4) != 0) return DCTN_ERR_UNSUPPORTED;
+  const int grid = plan_grouped(m);
+  if (grid == 0) return DCTN_ERR_UNSUPPORTED;
+  float* dwpart = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + core_ws_bytes);
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
 #define DCTN_HEAD_LAUNCH(XV, ROWSV, HC)                                                                        \
   hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, 0, st, (const S*)x, \
-                     (const S*)dL, (const S*)hw, (float*)ws, m)
+                     (const S*)dL, (const S*)hw, (const S*)feat, (float*)ws, dwpart, m)
   if (m.rowvec_ok && m.vec_ok) {
     if (m.Cout <= 10) DCTN_HEAD_LAUNCH(true, RW, 10); else DCTN_HEAD_LAUNCH(true, RW, 16);
   } else if (m.vec_ok) {
@@ -829,10 +989,13 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, void* dCore
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
-  hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
-                     (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
+  const long long nW = (long long)m.Cout * m.P * OP;
+  const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
+  hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(256), 0, st, (const float*)ws, (S*)dCore,
+                     grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,
+                     (const S*)dL, (S*)dBias, m.B, m.Cout);
   DCTN_CHECK_LAUNCH();
-  dctn_set_last_kernel("eps_bwd_mfma_q2reg_head");
+  dctn_set_last_kernel("eps_head_bwd_mfma_q2reg");
   return DCTN_OK;
 }
 
@@ -895,26 +1058,42 @@ int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void
   return bwd_dispatch<float>(x, dY, dCore, ws, m, p.N, op, st);
 }
 
-// dCore of an EPS layer whose output feeds the linear classifier head directly: dY is never
-// materialised, the kernel forms it from dLogits and the head weight (see eps_bwd_dcore_q2reg_k).
-int eps_bwd_mfma_head(const void* x, const void* dLogits, const void* head_w, void* dCore, void* ws,
-                      size_t ws_bytes, const EpsP& p, int Cout, int dtype, int precision, hipStream_t st) {
-  if (dtype != DCTN_BF16 || !dCore) return DCTN_ERR_UNSUPPORTED;
-  if (!family_ok(p, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
-  if (!ws || ws_bytes < eps_bwd_mfma_workspace(p, dtype, precision, 0, 1)) return DCTN_ERR_WORKSPACE;
+// Backward of (EPS layer -> flatten -> linear head) in one pass over x: dCore, dW and dBias from
+// dLogits, the head weight and the layer's forward output; dY is never materialised (see
+// eps_bwd_dcore_q2reg_k).
+static bool head_family_ok(const EpsP& p, int Cout, int dtype, int precision) {
+  if (dtype != DCTN_BF16 || !family_ok(p, dtype, precision)) return false;
   const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
-  if (op != p.O || op > 4) return DCTN_ERR_UNSUPPORTED;   // the weight slice lives in registers
+  if (op != p.O || op > 4) return false;   // the weight slice and its gradient live in registers
+  if (Cout < 2 || Cout > 16 || Cout % 2 != 0) return false;
+  const long long P = (long long)p.Ho * p.Wo;
+  if ((P + 63) / 64 > NUM_CU) return false;
+  return P * p.O * 2 * Cout < (1LL << 31);
+}
+
+size_t eps_head_bwd_mfma_workspace(const EpsP& p, int Cout, int dtype, int precision) {
+  if (!head_family_ok(p, Cout, dtype, precision)) return 0;
+  const size_t a = (eps_bwd_mfma_workspace(p, dtype, precision, 0, 1) + 255) / 256 * 256;
+  return a + head_dw_partial_bytes(p, Cout);
+}
+
+int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, const void* head_w, void* dCore,
+                      void* dW, void* dBias, void* ws, size_t ws_bytes, const EpsP& p, int Cout, int dtype,
+                      int precision, hipStream_t st) {
+  if (!dCore) return DCTN_ERR_UNSUPPORTED;
+  if (!head_family_ok(p, Cout, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < eps_head_bwd_mfma_workspace(p, Cout, dtype, precision)) return DCTN_ERR_WORKSPACE;
+  const size_t core_ws = (eps_bwd_mfma_workspace(p, dtype, precision, 0, 1) + 255) / 256 * 256;
   MfmaP m;
   fill_mp(m, p, x, dtype);
   m.Cout = Cout;
   const long long rowb = (long long)m.P * p.O * 2;
-  if (rowb * Cout >= (1LL << 31)) return DCTN_ERR_UNSUPPORTED;
   m.hw_rowb = (unsigned)rowb;
   m.hw_bytes = (unsigned)(rowb * Cout);
   if (p.N == 9) {
-    if (op == 2) return bwd_head_launch_t<5, 4, 2>(x, dLogits, head_w, dCore, ws, m, st);
-    return bwd_head_launch_t<5, 4, 4>(x, dLogits, head_w, dCore, ws, m, st);
+    if (p.O == 2) return bwd_head_launch_t<5, 4, 2>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
+    return bwd_head_launch_t<5, 4, 4>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
   }
-  if (op == 2) return bwd_head_launch_t<4, 4, 2>(x, dLogits, head_w, dCore, ws, m, st);
-  return bwd_head_launch_t<4, 4, 4>(x, dLogits, head_w, dCore, ws, m, st);
+  if (p.O == 2) return bwd_head_launch_t<4, 4, 2>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
+  return bwd_head_launch_t<4, 4, 4>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
 }

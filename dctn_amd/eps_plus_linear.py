@@ -101,9 +101,10 @@ class _LinearHeadFunction(torch.autograd.Function):
 class _EpsLinearHeadFunction(torch.autograd.Function):
     """The last EPS layer, the flatten and the linear head as ONE autograd node (reference:
     dctn/eps_plus_linear.py:144-147).  Forward is the EPS kernel followed by the head kernel; in the
-    backward the gradient of the features is never materialised: `dctn_eps_head_bwd_dcore` forms it
-    inside the dCore kernel from dLogits and the head weight (one GEMM launch and a write + read of
-    the (B, H'*W'*O) gradient less per step).  Used when the layer's input needs no gradient (it is
+    backward the gradient of the features is never materialised: `dctn_eps_head_bwd` forms it inside
+    the dCore kernel from dLogits and the head weight and accumulates dWeight / dBias in the same pass
+    (two kernels instead of three library GEMM / reduction launches + two EPS kernels, and no write +
+    read of the (B, H'*W'*O) gradient).  Used when the layer's input needs no gradient (it is
     the dataset tensor for a single-EPS model) and the shape is in the register-resident MFMA
     family; anything else takes the two separate nodes."""
 
@@ -148,21 +149,27 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
         need_core, _, need_w, need_b = ctx.needs_input_grad
         dev, code = x.device, L.dtype_code(x)
         g = d_out.contiguous()
-        d_w = g.t() @ feat if need_w else None
-        d_b = g.sum(0) if need_b else None
-        d_core = None
-        if need_core:
-            d_core = torch.empty_like(core_c)
-            ws = L.workspace(L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1), dev)
-            rc = L.lib().dctn_eps_head_bwd_dcore(
-                x.data_ptr(), L.strides5(x), g.data_ptr(), w.data_ptr(), d_core.data_ptr(), ws.data_ptr(),
-                ws.numel(), C, B, H, W, Q, K, O, w.shape[0], code, prec, L.stream_ptr(dev))
-            if rc == L.ERR_UNSUPPORTED:   # outside the fused family: the two separate device kernels
-                d_feat = (g @ w).contiguous()
-                rc = L.lib().dctn_eps_bwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), d_feat.data_ptr(), None,
-                                          d_core.data_ptr(), ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code,
-                                          prec, L.stream_ptr(dev))
-            L.check(rc, "eps + linear head backward")
+        if not need_core:
+            return None, None, (g.t() @ feat if need_w else None), (g.sum(0) if need_b else None)
+        d_core = torch.empty_like(core_c)
+        d_w = torch.empty_like(w) if need_w else None
+        d_b = torch.empty((w.shape[0],), dtype=w.dtype, device=dev) if need_b else None
+        cout = w.shape[0]
+        nbytes = max(L.lib().dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, prec),
+                     L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1))
+        ws = L.workspace(nbytes, dev)
+        rc = L.lib().dctn_eps_head_bwd(
+            x.data_ptr(), L.strides5(x), feat.data_ptr(), g.data_ptr(), w.data_ptr(), d_core.data_ptr(),
+            None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(), ws.data_ptr(),
+            ws.numel(), C, B, H, W, Q, K, O, cout, code, prec, L.stream_ptr(dev))
+        if rc == L.ERR_UNSUPPORTED:   # outside the fused family: library GEMMs + the plain EPS backward
+            d_w = g.t() @ feat if need_w else None
+            d_b = g.sum(0) if need_b else None
+            d_feat = (g @ w).contiguous()
+            rc = L.lib().dctn_eps_bwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), d_feat.data_ptr(), None,
+                                      d_core.data_ptr(), ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code,
+                                      prec, L.stream_ptr(dev))
+        L.check(rc, "eps + linear head backward")
         return d_core, None, d_w, d_b
 
 

@@ -84,18 +84,25 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
                  int C, int B, int H, int W, int Q, int K, int O,
                  int dtype, int precision, void* stream);
 
-/* dCore of an EPS layer whose output feeds the linear classifier head directly (reference:
- * dctn/eps_plus_linear.py:145-147, features -> "b h w q -> b (h w q)" -> nn.Linear): the kernel
- * forms dY[b,h,w,o] = sum_c dLogits[b,c] * head_weight[c, (h*W'+w)*O + o] on the fly, so the
- * gradient of the features is never written to or read from HBM.
+/* Backward of (EPS layer -> "b h w q -> b (h w q)" -> nn.Linear), the tail of
+ * EPSesPlusLinear.forward (reference: dctn/eps_plus_linear.py:144-147), in one pass over x: the
+ * kernel forms dY[b,h,w,o] = sum_c dLogits[b,c] * head_weight[c, (h*W'+w)*O + o] on the fly, so the
+ * gradient of the features is never written to or read from HBM, and accumulates the head's own
+ * gradients beside dCore.
+ *   features    : (B, H'*W'*O) contiguous, the layer's forward output (input of the linear head)
  *   dLogits     : (B, Cout) contiguous;  head_weight : (Cout, H'*W'*O) contiguous
- *   dCore       : same layout as core, OVERWRITTEN; workspace: dctn_eps_bwd_workspace_bytes(need_dx=0, need_dcore=1)
- * bfloat16 only.  Returns DCTN_ERR_UNSUPPORTED for shapes outside the register-resident MFMA family
- * (the caller then composes dctn_linear_head_bwd with dctn_eps_bwd; there is no CPU fallback). */
-int dctn_eps_head_bwd_dcore(const void* x, const int64_t x_strides[5], const void* dLogits,
-                            const void* head_weight, void* dCore, void* workspace, size_t workspace_bytes,
-                            int C, int B, int H, int W, int Q, int K, int O, int Cout,
-                            int dtype, int precision, void* stream);
+ *   dCore       : same layout as core;  dWeight : like head_weight, or NULL;  dBias : (Cout), or NULL
+ *   all three OVERWRITTEN; `workspace` must hold dctn_eps_head_bwd_workspace_bytes().
+ * bfloat16 only, the layer's input gets no gradient.  Returns DCTN_ERR_UNSUPPORTED for shapes
+ * outside the register-resident MFMA family (the caller then composes dctn_linear_head_bwd or
+ * library GEMMs with dctn_eps_bwd; there is no CPU fallback). */
+size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout,
+                                         int dtype, int precision);
+int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features,
+                      const void* dLogits, const void* head_weight, void* dCore, void* dWeight,
+                      void* dBias, void* workspace, size_t workspace_bytes,
+                      int C, int B, int H, int W, int Q, int K, int O, int Cout,
+                      int dtype, int precision, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConvSBS — replaces dctn/conv_sbs.py:258-304 `ConvSBS.forward`

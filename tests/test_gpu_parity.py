@@ -434,6 +434,48 @@ def test_linear_head_vs_torch_reference(B, F, C):
         assert bf16_close(fd.grad, f64.grad) and bf16_close(wd.grad, w64.grad) and bf16_close(bd.grad, b64.grad)
 
 
+@pytest.mark.parametrize("K,O,size,B", [(3, 4, 28, 5), (3, 4, 8, 19), (3, 2, 12, 9), (3, 4, 40, 3)])
+def test_eps_plus_linear_fused_head_backward(K, O, size, B):
+    """bf16 single-EPS model (BASELINE config 2's shape family): the last EPS + flatten + linear head
+    run as one autograd node whose backward (`dctn_eps_head_bwd`) forms dY on the fly and produces
+    dCore, dWeight and dBias in one pass; checked against the float64 oracle and against the unfused
+    composition (library GEMMs + dctn_eps_bwd)."""
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    torch.manual_seed(100 * K + 10 * O + size)
+    m = EPSesPlusLinear(((K, O),), UnitTheoreticalOutputStd(), 1.0, DEV, torch.bfloat16, image_size=size)
+    with torch.no_grad():
+        m.linear.weight.mul_(8.0)
+    u = torch.rand(B, size, size)
+    x = torch.stack([torch.sin(u * 1.5707963) ** 2, torch.cos(u * 1.5707963) ** 2], dim=-1)[None].to(torch.bfloat16).to(DEV)
+    g = torch.randn(B, 10).to(torch.bfloat16)
+
+    def run(fused):
+        os.environ["DCTN_FUSED_HEAD"] = "1" if fused else "0"
+        try:
+            for prm in m.parameters():
+                prm.grad = None
+            out = m(x)
+            out.backward(g.to(DEV))
+            return out.detach().cpu(), [prm.grad.detach().cpu().double() for prm in (m.epses[0], m.linear.weight, m.linear.bias)], dctn_amd.last_kernel()
+        finally:
+            os.environ.pop("DCTN_FUSED_HEAD", None)
+
+    out_f, grads_f, kern_f = run(True)
+    out_u, grads_u, kern_u = run(False)
+    assert kern_f == "eps_head_bwd_mfma_q2reg" and kern_u != kern_f
+    assert torch.equal(out_f, out_u)
+    core64 = m.epses[0].detach().cpu().double().requires_grad_(True)
+    w64 = m.linear.weight.detach().cpu().double().requires_grad_(True)
+    b64 = m.linear.bias.detach().cpu().double().requires_grad_(True)
+    want = R.eps_plus_linear_forward([core64], w64, b64, x.cpu().double())
+    assert bf16_close(out_f, want.detach())
+    want.backward(g.double())
+    for name, got_f, got_u, ref in zip(("dCore", "dWeight", "dBias"), grads_f, grads_u, (core64.grad, w64.grad, b64.grad)):
+        assert bf16_close(got_f, ref), name
+        assert bf16_close(got_u, ref), name + " (unfused)"
+
+
 def test_logmatmulexp_fold16_factored_mfma_and_exact_fallback():
     """D = 16 float32 fold: factored exp -> MFMA -> log forward with the exact path taken per step
     when the dynamic range is unsafe (large magnitudes, -inf entries)."""
