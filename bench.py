@@ -27,6 +27,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md: dense MFMA peaks (no sparsity): bf16 ~2.5 PFLOP/s; exact f32 157.3 TFLOP/s
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3, "float64": 78.6}
 
 WORKLOADS = {
     # name: (epses_specs, image_size, Q0, dtype)
@@ -120,7 +122,8 @@ def cpu_baseline(specs, image_size, q0, target_seconds=12.0):
 
 def kernel_roofline(model, x, specs, image_size, steps):
     """Times the EPS kernels of the first layer alone with HIP events on the stream they are
-    launched on (torch's current stream) and prices the dominant one against the HBM roofline."""
+    launched on (torch's current stream) and prices the dominant one against the compute (MFMA)
+    roofline SURVEY 8(d) assigns to this path; the HBM figures ride along."""
     from dctn_amd import _lib as L
 
     dev = x.device
@@ -140,14 +143,37 @@ def kernel_roofline(model, x, specs, image_size, steps):
 
     def fwd():
         L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), wsf.data_ptr(),
-                                 wsf.numel(), C, B, H, W, Q, K, O, code, prec, st), "fwd")
+                                 wsf.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)), "fwd")
 
-    def bwd():
-        L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, st), "bwd")
+    # The model's own backward for this shape: when the layer feeds the linear head directly and is in
+    # the fused family (bf16 cfg2), that is dctn_eps_head_bwd (dCore + dWeight + dBias, dY formed on the
+    # fly); otherwise the plain dctn_eps_bwd.
+    from dctn_amd.eps_plus_linear import _EpsLinearHeadFunction
+
+    w_head, b_head = model.linear.weight.detach().contiguous(), model.linear.bias.detach().contiguous()
+    fused = len(specs) == 1 and _EpsLinearHeadFunction.supported(core, x, w_head, b_head)
+    cout = w_head.shape[0]
+    if fused:
+        feat = out.view(B, -1)
+        dl = (torch.randn((B, cout), device=dev) * 0.1).to(x.dtype)
+        dw, db = torch.empty_like(w_head), torch.empty_like(b_head)
+        wsh = L.workspace(lib.dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, prec), dev)
+
+        def bwd():
+            L.check(lib.dctn_eps_head_bwd(x.data_ptr(), L.strides5(x), feat.data_ptr(), dl.data_ptr(), w_head.data_ptr(),
+                                          dcore.data_ptr(), dw.data_ptr(), db.data_ptr(), wsh.data_ptr(), wsh.numel(),
+                                          C, B, H, W, Q, K, O, cout, code, prec, L.stream_ptr(dev)), "head bwd")
+    else:
+        def bwd():
+            L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)), "bwd")
 
     # (a) whole C-ABI call, back to back on torch's current stream (the stream the kernels are
-    # launched on); (b) the call's dominant KERNEL alone (dctn_profile_main_kernel_only), same method
+    # launched on): a THROUGHPUT figure, successive launches may overlap head and tail;
+    # (b) the call's dominant KERNEL alone (dctn_profile_main_kernel_only) as a chain of CHAIN dependent
+    # launches captured in a HIP graph and replayed: each launch waits for the previous one to drain, as
+    # it does inside the real step, which is the per-launch duration rocprofv3 reports (plus the
+    # ~1 us boundary between two graph nodes).
     def timed(fn, n):
         for _ in range(5):
             fn()
@@ -160,6 +186,18 @@ def kernel_roofline(model, x, specs, image_size, steps):
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / n * 1e-3
 
+    CHAIN = 20
+
+    def timed_chain(fn, n):
+        fn()
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(CHAIN):
+                fn()
+        reps = max(1, n // CHAIN)
+        return timed(graph.replay, reps) / CHAIN
+
     res, single = {}, {}
     kernel_symbol = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}
     n = max(steps, 100)
@@ -168,19 +206,27 @@ def kernel_roofline(model, x, specs, image_size, steps):
         if "q2reg" in L.last_kernel():
             lib.dctn_profile_main_kernel_only(1)
             try:
-                single[name] = timed(fn, n)
+                single[name] = timed_chain(fn, n)
             finally:
                 lib.dctn_profile_main_kernel_only(0)
     wn = B * Ho * Ho
-    # algorithmic bytes per launch: read x once, write out (fwd) / read dY (bwd) once, core / dCore once
+    n_in = core.numel() // O
+    # this path is compute bound (MFMA for the core GEMM, VALU for the Khatri-Rao halves);
+    # algorithmic flops per window: forward 2*Q^N*O (GEMM) + the two halves and the final dot; dCore the
+    # same GEMM size transposed (+ forming dY and dWeight when the head is fused: 4*Cout*O)
+    half = 2 * (Q ** ((K * K * C + 1) // 2) + Q ** ((K * K * C) // 2)) + 2 * Q ** ((K * K * C) // 2) * O
+    flops = {"eps_fwd": wn * (2 * n_in * O + half),
+             "eps_bwd_dcore": wn * (2 * n_in * O + half + (4 * cout * O if fused else 0))}
+    # algorithmic bytes per launch: read x once, write out (fwd) / read dY or the features (bwd) once,
+    # core / dCore once (+ dLogits, head weight and its gradient when fused)
     bytes_x = C * B * H * W * Q * esz
     bytes_y = wn * O * esz
     bytes_core = core.numel() * esz
-    alg = {"eps_fwd": bytes_x + bytes_y + bytes_core, "eps_bwd_dcore": bytes_x + bytes_y + bytes_core}
+    alg = {"eps_fwd": bytes_x + bytes_y + bytes_core,
+           "eps_bwd_dcore": bytes_x + bytes_y + bytes_core + ((B * cout + 2 * w_head.numel() + cout) * esz if fused else 0)}
     dom = max(single, key=lambda k: single[k]) if single else max(res, key=lambda k: res[k][0])
     sec = single.get(dom, res[dom][0])
     kname = kernel_symbol[dom] if dom in single else res[dom][1]
-    achieved = alg[dom] / sec / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -188,10 +234,13 @@ def kernel_roofline(model, x, specs, image_size, steps):
             traffic = json.load(open(tpath)).get(f"{kname}:B{B}")
         except Exception:
             traffic = None
+    peak = MFMA_PEAK_TFLOPS[str(x.dtype).replace("torch.", "")]
+    achieved = flops[dom] / sec / 1e12
     return {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic, "kernel": kname, "launch_us": sec * 1e6, "algorithmic_bytes": alg[dom],
-        "bytes_per_window": alg[dom] / wn,
+        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+        "traffic": traffic, "kernel": kname, "launch_us": sec * 1e6, "algorithmic_flops": flops[dom],
+        "flops_per_window": flops[dom] / wn, "algorithmic_bytes": alg[dom], "bytes_per_window": alg[dom] / wn,
+        "hbm_gbs": alg[dom] / sec / 1e9, "hbm_frac": alg[dom] / sec / 1e9 / HBM_PEAK_GBS, "fused_head": bool(fused),
         "calls_us": {k: v[0] * 1e6 for k, v in res.items()},
         "kernels_us": {kernel_symbol[k]: v * 1e6 for k, v in single.items()},
     }

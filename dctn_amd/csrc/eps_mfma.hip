@@ -413,14 +413,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
     // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 (factor N-1) is the lane half of
     // the accumulator row.  m0 / m1: multipliers this lane applies in set 0 / set 1.
     float m0[BN / 2], m1[BN / 2];
+    {
+      float ph[BN / 2];   // P1 without its last factor, built by doubling
+      ph[0] = xv[N - 2][0];
+      ph[1] = xv[N - 2][1];
 #pragma unroll
-    for (int bh = 0; bh < BN / 2; ++bh) {
-      float v = 1.f;
+      for (int u = 2; u < N1; ++u)
 #pragma unroll
-      for (int u = 1; u < N1; ++u) v = u == 1 ? xv[N - 2][bh & 1] : v * xv[N - 1 - u][(bh >> (u - 1)) & 1];
-      m0[bh] = v * xv[N - 1][0];
-      m1[bh] = v * xv[N - 1][1];
-      swap_halves(m0[bh], m1[bh]);
+        for (int bh = (1 << (u - 1)) - 1; bh >= 0; --bh) {
+          const float lo = ph[bh];
+          ph[bh | (1 << (u - 1))] = lo * xv[N - 1 - u][1];
+          ph[bh] = lo * xv[N - 1 - u][0];
+        }
+#pragma unroll
+      for (int bh = 0; bh < BN / 2; ++bh) {
+        m0[bh] = ph[bh] * xv[N - 1][0];
+        m1[bh] = ph[bh] * xv[N - 1][1];
+        swap_halves(m0[bh], m1[bh]);
+      }
     }
     // (scalar FMAs on purpose: packed f32 VALU issues slower than two scalar ones on gfx950 — see
     // MI355X_MICROARCH.md, 'price of one filler beside MFMAs' — the build also disables SLP packing)
@@ -512,25 +522,33 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   constexpr int DLW = HEADC > 0 ? HEADC / 2 : 1;   // dwords of one row of dLogits (bf16 pairs)
   const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
   unsigned dlraw[DLW];
+  RawRow<S, OP> rr[HEADC > 0 ? HEADC : 1];
   if constexpr (HEADC > 0) {
     const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
     const unsigned voff_hw = job.valid ? (unsigned)job.pos * (unsigned)(OP * 2) : p.hw_bytes;
-    RawRow<S, OP> rr[HEADC];
 #pragma unroll
     for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
       issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
-#pragma unroll
-    for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
   }
+  float dbacc[HEADC > 0 ? HEADC : 1];   // sum of dLogits over the wave's samples (wave-uniform)
+#pragma unroll
+  for (int c = 0; c < (HEADC > 0 ? HEADC : 1); ++c) dbacc[c] = 0.f;
   RawWindow<S, N, XVEC, ROWS> raw;
   RawRow<S, OP> rawdy;
   if (job.b0 < job.b1) {
     issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, raw);
     if constexpr (HEADC > 0) {
 #pragma unroll
-      for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)job.b0 * (p.Cout / 2) + i] : 0u;
+      for (int i = 0; i < DLW; ++i) {   // clamped index + select: no control flow around the scalar loads
+        const unsigned v = dl32[(long long)job.b0 * (p.Cout / 2) + (2 * i < p.Cout ? i : 0)];
+        dlraw[i] = 2 * i < p.Cout ? v : 0u;
+      }
     }
     issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)job.b0 * p.o_s1b, p.O, rawdy);
+  }
+  if constexpr (HEADC > 0) {   // the weight slice arrives together with the first sample's loads
+#pragma unroll
+    for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
   }
   for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
       for (int c = 0; c < HEADC; ++c) {
         const float dl = (c & 1) ? __uint_as_float(dlraw[c >> 1] & 0xffff0000u) : __uint_as_float(dlraw[c >> 1] << 16);
+        dbacc[c] += dl;
 #pragma unroll
         for (int o = 0; o < OP; ++o) {
           dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
@@ -558,7 +577,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)bn * p.s1b, p, raw);
       if constexpr (HEADC > 0) {
 #pragma unroll
-        for (int i = 0; i < DLW; ++i) dlraw[i] = 2 * i < p.Cout ? dl32[(long long)bn * (p.Cout / 2) + i] : 0u;
+        for (int i = 0; i < DLW; ++i) {
+          const unsigned v = dl32[(long long)bn * (p.Cout / 2) + (2 * i < p.Cout ? i : 0)];
+          dlraw[i] = 2 * i < p.Cout ? v : 0u;
+        }
       }
       issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)bn * p.o_s1b, p.O, rawdy);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's arithmetic
@@ -587,14 +609,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         p0t[set][a][1] = pack8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
       }
     // full P1 table of this window (b bit u <-> factor N-1-u)
-    float p1[BN];
+    float p1[BN];   // built by doubling: 2 + 4 + ... + BN multiplies instead of (N1 - 1) * BN
+    p1[0] = xv[N - 1][0];
+    p1[1] = xv[N - 1][1];
 #pragma unroll
-    for (int b = 0; b < BN; ++b) {
-      float v = 1.f;
+    for (int u = 1; u < N1; ++u)
 #pragma unroll
-      for (int u = 0; u < N1; ++u) v = u == 0 ? xv[N - 1][b & 1] : v * xv[N - 1 - u][(b >> u) & 1];
-      p1[b] = v;
-    }
+      for (int b = (1 << u) - 1; b >= 0; --b) {
+        const float lo = p1[b];
+        p1[b | (1 << u)] = lo * xv[N - 1 - u][1];
+        p1[b] = lo * xv[N - 1 - u][0];
+      }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       // Z of the own window for both k-halves, then the same hand-over as for P0
@@ -688,6 +713,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         if (cb < p.ncb && c < p.Cout && f < F) dwpart[((long long)cb * p.Cout + c) * F + f] = sum;
       }
     }
+    // dBias: the chunk block's sum of dLogits, once (position group 0), after the dW tiles [ncb][Cout][F]
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < HEADC; ++c) red1[wv * 16 + c] = dbacc[c];
+    }
+    __syncthreads();
+    if (pg == 0 && cb < p.ncb && tid < 16) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < BWD_WAVES; ++k) sum += tid < HEADC ? red1[k * 16 + tid] : 0.f;
+      dwpart[(long long)p.ncb * p.Cout * F + cb * 16 + tid] = sum;
+    }
   }
 }
 
@@ -725,14 +763,14 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 
 // Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
 // as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
-// (256 consecutive features each), the last one sums dLogits over the batch into dBias.
+// (256 consecutive features each), the last one sums the chunk blocks' partial dBias.
 __global__ __launch_bounds__(256) void eps_head_reduce_k(const float* __restrict__ partial,
                                                          bf16_t* __restrict__ dCore, int nblk, int A, int BN,
                                                          int O, int OP, int ACOLS, int n_core,
                                                          const float* __restrict__ dwpart,
                                                          bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
-                                                         const bf16_t* __restrict__ dL, bf16_t* __restrict__ dBias,
-                                                         int B, int Cout) {
+                                                         const float* __restrict__ dbpart,
+                                                         bf16_t* __restrict__ dBias, int Cout) {
   __shared__ float red[8][32];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < n_core) {
@@ -764,26 +802,21 @@ __global__ __launch_bounds__(256) void eps_head_reduce_k(const float* __restrict
     if (!dW) return;
     const long long e = (long long)((int)blockIdx.x - n_core) * 256 + tid;
     if (e >= nW) return;
-    float t = 0.f;
-    for (int k = 0; k < ncb; ++k) t += dwpart[(long long)k * nW + e];
-    dW[e] = (bf16_t)t;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < ncb; k += 4) {   // independent loads: all partial tiles of this element in flight together
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] += dwpart[(long long)(k + i) * nW + e];
+    }
+    for (; k < ncb; ++k) t[0] += dwpart[(long long)k * nW + e];
+    dW[e] = (bf16_t)((t[0] + t[1]) + (t[2] + t[3]));
     return;
   }
   if (!dBias) return;
-  {  // dBias[c] = sum_b dLogits[b, c]: thread (c = tid % 16, lane16 = tid / 16) strides over b
-    const int c = tid & 15, l16 = tid >> 4;
-    float t = 0.f;
-    if (c < Cout)
-      for (int b = l16; b < B; b += 16) t += (float)dL[(long long)b * Cout + c];
-    __shared__ float rb[16][17];
-    rb[l16][c] = t;
-    __syncthreads();
-    if (tid < 16 && tid < Cout) {
-      float u = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) u += rb[i][tid];
-      dBias[tid] = (bf16_t)u;
-    }
+  if (tid < Cout) {   // dBias[c] = sum over the chunk blocks' partial sums of dLogits (written by the main kernel)
+    float u = 0.f;
+    for (int k = 0; k < ncb; ++k) u += dbpart[k * 16 + tid];
+    dBias[tid] = (bf16_t)u;
   }
 }
 
@@ -958,7 +991,7 @@ int plan_grouped(MfmaP& m) {
 size_t head_dw_partial_bytes(const EpsP& p, int Cout) {
   const long long P = (long long)p.Ho * p.Wo, npg = (P + 63) / 64;
   if (npg > NUM_CU) return 0;
-  return (size_t)(NUM_CU / npg) * (size_t)Cout * (size_t)(P * p.O) * sizeof(float);
+  return (size_t)(NUM_CU / npg) * ((size_t)Cout * (size_t)(P * p.O) + 16) * sizeof(float);
 }
 
 // fused classifier-head backward (bf16 only): dLogits (B, Cout), head weight (Cout, P*O), feat (B, P*O)
@@ -973,6 +1006,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   const int grid = plan_grouped(m);
   if (grid == 0) return DCTN_ERR_UNSUPPORTED;
   float* dwpart = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + core_ws_bytes);
+  const long long nW = (long long)m.Cout * m.P * OP;   // dwpart: [ncb][Cout][P*O] then dBias partials [ncb][16]
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
@@ -989,11 +1023,10 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
-  const long long nW = (long long)m.Cout * m.P * OP;
   const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
   hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(256), 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,
-                     (const S*)dL, (S*)dBias, m.B, m.Cout);
+                     (const float*)(dwpart + (size_t)m.ncb * nW), (S*)dBias, m.Cout);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_head_bwd_mfma_q2reg");
   return DCTN_OK;
