@@ -14,21 +14,28 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+import dctn_amd  # noqa: E402
 
 DEV = torch.device("cuda:0")
 
 
 def time_gpu(fn, iters):
+    """Median over `iters` rounds of 3 back-to-back calls (an occasional allocator stall of tens of
+    milliseconds otherwise lands in a mean)."""
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    rounds = []
     for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        rounds.append(e0.elapsed_time(e1) / 3 * 1e-3)
+    rounds.sort()
+    return rounds[len(rounds) // 2]
 
 
 def time_cpu(fn, budget=6.0):
@@ -89,7 +96,9 @@ def bench_convsbs(cpu):
                 torch.set_num_threads(min(16, os.cpu_count() or 1))
                 t = time_cpu(lambda: R.convsbs_forward(cc, snake, xc).backward(dyc))
                 extra["cpu_fwd_bwd_Mwin_s"] = round(windows * Bc / B / t / 1e6, 3)
-            report(f"ConvSBS snake r={r} {tag} B={B} f32", windows, time_gpu(fwd, 20), time_gpu(fb, 10), extra)
+            tf, tb = time_gpu(fwd, 20), time_gpu(fb, 10)
+            extra["bwd_kernel"] = dctn_amd.last_kernel()
+            report(f"ConvSBS snake r={r} {tag} B={B} f32", windows, tf, tb, extra)
 
 
 def bench_lme(cpu):
