@@ -354,6 +354,9 @@ def main():
             "parallelism": f"dp{world}",
             "hip_graph": graph is not None,
             "last_kernel": kernel_used,
+            "grad_allreduce": None if reducer is None else (
+                "in place on the backward's flat gradient buffer (1 launch)" if getattr(reducer, "_flat_key", None)
+                else "gather -> all_reduce -> scatter (3 launches)"),
         },
     }
     if rank == 0:

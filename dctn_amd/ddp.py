@@ -79,11 +79,38 @@ class FlatGradAllReducer:
         backend = dist.get_backend() if dist.is_initialized() else ""
         self.use_avg = average and backend == "nccl"
 
+    def _contiguous_flat(self, grads) -> Optional[Tensor]:
+        """One 1-D tensor aliasing all gradients when they already sit back to back, in parameter
+        order, in a single storage (the fused EPS + head backward allocates them like that)."""
+        if not self.same_dtype or any(g is None or not g.is_contiguous() for g in grads):
+            return None
+        g0 = grads[0]
+        esz, base, off = g0.element_size(), g0.data_ptr(), 0
+        st = g0.untyped_storage()
+        for g in grads:
+            if g.untyped_storage().data_ptr() != st.data_ptr() or g.data_ptr() != base + off * esz:
+                return None
+            off += g.numel()
+        key = (base, off)
+        if getattr(self, "_flat_key", None) != key:
+            self._flat = g0.new_empty(0).set_(st, g0.storage_offset(), (off,), (1,))
+            self._flat_key = key
+        return self._flat
+
     @torch.no_grad()
     def __call__(self) -> None:
         if self.world == 1:
             return
         grads = [p.grad for p in self.params]
+        flat = self._contiguous_flat(grads)
+        if flat is not None:   # the backward already laid the gradients out as one bucket: one launch
+            if self.use_avg:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                if self.average:
+                    flat.div_(self.world)
+            return
         if self.same_dtype and all(g is not None for g in grads):
             torch.cat([g.reshape(-1) for g in grads], out=self.bucket)
         else:

@@ -151,10 +151,14 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
         g = d_out.contiguous()
         if not need_core:
             return None, None, (g.t() @ feat if need_w else None), (g.sum(0) if need_b else None)
-        d_core = torch.empty_like(core_c)
-        d_w = torch.empty_like(w) if need_w else None
-        d_b = torch.empty((w.shape[0],), dtype=w.dtype, device=dev) if need_b else None
         cout = w.shape[0]
+        # the three gradients are carved out of ONE buffer, in parameter order (epses[-1], linear.weight,
+        # linear.bias): ddp.FlatGradAllReducer then all-reduces that buffer in place, with no gather /
+        # scatter kernels around the collective
+        flat = torch.empty(core_c.numel() + w.numel() + cout, dtype=w.dtype, device=dev)
+        d_core = flat[: core_c.numel()].view_as(core_c)
+        d_w = flat[core_c.numel() : core_c.numel() + w.numel()].view_as(w) if need_w else None
+        d_b = flat[core_c.numel() + w.numel() :] if need_b else None
         nbytes = max(L.lib().dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, prec),
                      L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1))
         ws = L.workspace(nbytes, dev)

@@ -44,6 +44,20 @@ def _worker(rank, world, port, q):
     ((ref(x[0].reshape(8, 6)) - y) ** 2).sum().backward()
     for p, pr in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, pr.grad, atol=1e-5)
+    # gradients that already sit back to back in one storage (what the fused EPS + head backward
+    # produces) are all-reduced in place through one aliasing view: no gather / scatter
+    params = [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(1))]
+    bucket = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    params[0].grad, params[1].grad, params[2].grad = bucket[:6].view(2, 3), bucket[6:10], bucket[10:]
+    red2 = ddp.FlatGradAllReducer(params, average=True)
+    assert red2._contiguous_flat([p.grad for p in params]) is not None
+    red2()
+    assert torch.allclose(bucket, torch.arange(11, dtype=torch.float32) * 1.5)      # mean of x1 and x2, in place
+    assert params[1].grad.data_ptr() == bucket[6:].data_ptr()
+    params[1].grad = torch.ones(4)                                                   # no longer one storage: bucket path
+    assert red2._contiguous_flat([p.grad for p in params]) is None
+    red2()
+    assert torch.allclose(params[1].grad, torch.ones(4))
     tot, cnt = ddp.all_reduce_scalar_sums(torch.tensor(float(rank + 1)), torch.tensor(4.0))
     assert float(tot) == 3.0 and float(cnt) == 8.0
     dist.barrier()
