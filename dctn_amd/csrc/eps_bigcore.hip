@@ -573,20 +573,41 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   return true;
 }
 
-// split the row tiles over grid.y so that the grid has ~8 workgroups per CU (tail balance)
-void choose_row_groups(BigP& b, int nt, int max_rg) {
+// Split the row tiles over grid.y.  The grid runs in "rounds" of as many workgroups as are resident
+// at once, each taking (row tiles per group + a fixed part for staging the window features) tile
+// times: pick the split that minimises rounds x that time (a split that leaves the last round almost
+// empty costs a whole round: 133 window blocks x 16 groups on 512 slots was 4.2 -> 5 rounds).
+void choose_row_groups(BigP& b, int nt, int max_rg, size_t lds_bytes) {
   const long long wpb = (long long)BC_WAVES * nt * 32;
   const long long wblocks = (b.Wn + wpb - 1) / wpb;
   const int mtiles = (b.rows + 31) / 32;
-  long long rg = (8 * 256 + wblocks - 1) / wblocks;
-  if (rg > mtiles) rg = mtiles;
-  if (rg > max_rg) rg = max_rg;
-  if (rg < 1) rg = 1;
-  b.mt_per_rg = (int)((mtiles + rg - 1) / rg);
-  b.rg_count = (mtiles + b.mt_per_rg - 1) / b.mt_per_rg;
+  long long per_cu = lds_bytes > 0 ? (long long)(160 * 1024) / (long long)lds_bytes : 8;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  const long long capacity = 256 * per_cu;
+  int top = mtiles < max_rg ? mtiles : max_rg;
+  if (top < 1) top = 1;
+  // rough cycle model: a row tile = kdim/2 k-steps x nt column tiles x 64 cycles at ~60 % matrix-pipe
+  // efficiency; per workgroup ~8k cycles to stage the window features; per slice one write + read of
+  // the partial result at ~1.2 KB/cycle
+  const double tile = (double)(b.kdim / 2) * nt * 64.0 / 0.6;
+  const double ovh = 8000.0;
+  const double slice_bytes = b.mode == MODE_FWD ? (double)b.Wn * b.O * 4.0 : (double)b.Wn * b.N * b.Q * 4.0;
+  const double slice = 2.0 * slice_bytes / 1200.0;
+  double best = 1e300;
+  int best_mt = mtiles;
+  for (int rg = 1; rg <= top; ++rg) {
+    const int mt_per = (mtiles + rg - 1) / rg;
+    const int groups = (mtiles + mt_per - 1) / mt_per;
+    const long long rounds = (wblocks * groups + capacity - 1) / capacity;
+    const double cost = (double)rounds * ((double)mt_per * tile + ovh) + (groups > 1 ? slice * groups : 0.0);
+    if (cost < best) { best = cost; best_mt = mt_per; }
+  }
+  b.mt_per_rg = best_mt;
+  b.rg_count = (mtiles + best_mt - 1) / best_mt;
 }
 
-constexpr int BC_MAX_RG = 16;
+constexpr int BC_MAX_RG = 32;
 
 // out[i] = sum_g part[g][i], fixed order
 __global__ void bigcore_sum_slices_k(const float* __restrict__ part, float* __restrict__ out,
@@ -676,7 +697,7 @@ size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
   BigP b;
   if (!fill_big(b, p, MODE_FWD)) return 0;
-  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG);
+  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG, big_lds(b));
   return b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
 }
 
@@ -687,7 +708,7 @@ int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t
   if (!fill_big(b, p, MODE_FWD)) return DCTN_ERR_UNSUPPORTED;
   const size_t lds = big_lds(b);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
-  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG);
+  choose_row_groups(b, BC_NT_FWD, BC_MAX_RG, lds);
   const size_t need = b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
   if (need > 0 && (!ws || ws_bytes < need)) {  // no scratch: keep every row tile in one workgroup
     b.rg_count = 1;
@@ -723,8 +744,8 @@ static bool dfactor_plan(const EpsP& p, BigP& b0, BigP& b1) {
   const int mt0 = (b0.rows + 31) / 32, mt1 = (b1.rows + 31) / 32;
   int cap = mt0 < mt1 ? mt0 : mt1;
   if (cap > BC_MAX_RG) cap = BC_MAX_RG;
-  choose_row_groups(b0, BC_NT_G, cap);
-  choose_row_groups(b1, BC_NT_G, cap);
+  choose_row_groups(b0, BC_NT_G, cap, big_lds(b0));
+  choose_row_groups(b1, BC_NT_G, cap, big_lds(b1));
   // both halves must fill the same number of slices: take the smaller count for both
   const int rg = b0.rg_count < b1.rg_count ? b0.rg_count : b1.rg_count;
   b0.mt_per_rg = (mt0 + rg - 1) / rg; b0.rg_count = (mt0 + b0.mt_per_rg - 1) / b0.mt_per_rg;
