@@ -45,6 +45,13 @@ struct BigP {
   int rhalf_first, rhalf_n;   // factors of the half indexing the rows
   int rg_count, mt_per_rg;    // row tiles are split over grid.y (deterministic partial slices)
   int BnO;                    // Bn * O: stride of `a` in the core
+  // xo = 1 (O not a power of two): EXACT out size, no padded rows / k-values.
+  //   FWD rows R = b*O + o in the core's memory order (b = R / O by multiply-shift);
+  //   G0 / G1 put o OUTERMOST in k: k = o*Kh + kh with kh = b (G0) or a (G1), Kh = 2^lkh, so the
+  //   generated operand keeps a power-of-two table over the low digits of kh and the hi product
+  //   of block hb is dY[w, o = hb >> lnhbo] * KR(high digits, hb & (2^lnhbo - 1)).
+  int xo, lkh, lnhbo;
+  unsigned odiv_m;            // ceil(2^32 / O)
 };
 
 __device__ __forceinline__ float half_sum(float v) {
@@ -156,6 +163,8 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
       const int kin = 2 * t + h;
       if (MODE == MODE_FWD) {
         tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
+      } else if (p.xo) {
+        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
       } else {
         tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
                      dys[(kin & (p.OP - 1)) * BC_WPB + wl];
@@ -187,7 +196,12 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
     const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
     int o;
-    if (MODE == MODE_FWD) {
+    if (p.xo) {
+      o = 0;  // every staged element is real: validity is row < rows, k < kdim
+      if (MODE == MODE_FWD) coff[i] = (unsigned)kl * p.BnO + row;
+      else if (MODE == MODE_G0) coff[i] = (unsigned)row * p.BnO + (kl & ((1 << p.lkh) - 1)) * p.O + (kl >> p.lkh);
+      else coff[i] = (unsigned)(kl & ((1 << p.lkh) - 1)) * p.BnO + row * p.O + (kl >> p.lkh);
+    } else if (MODE == MODE_FWD) {
       o = row & (p.OP - 1);
       coff[i] = (unsigned)kl * p.BnO + (row >> p.LOGO) * p.O + o;
     } else if (MODE == MODE_G0) {
@@ -201,7 +215,13 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   }
   auto stage_fetch = [&](int mt, int st) {
     unsigned u;
-    if (MODE == MODE_FWD) u = (unsigned)st * 128u * p.BnO + (unsigned)mt * (32 >> p.LOGO) * p.O;
+    if (p.xo) {
+      // k0 = 128 st = o0 * Kh + kh0 (128 and Kh are powers of two: no carry into the per-thread part)
+      const unsigned k0 = (unsigned)st * 128u, kh0 = k0 & ((1u << p.lkh) - 1u), o0 = k0 >> p.lkh;
+      if (MODE == MODE_FWD) u = k0 * p.BnO + (unsigned)mt * 32u;
+      else if (MODE == MODE_G0) u = (unsigned)mt * 32u * p.BnO + kh0 * p.O + o0;
+      else u = kh0 * p.BnO + (unsigned)mt * 32u * p.O + o0;
+    } else if (MODE == MODE_FWD) u = (unsigned)st * 128u * p.BnO + (unsigned)mt * (32 >> p.LOGO) * p.O;
     else if (MODE == MODE_G0) u = (unsigned)mt * 32u * p.BnO + (unsigned)st * (128 >> p.LOGO) * p.O;
     else u = (unsigned)st * (128 >> p.LOGO) * p.BnO + (unsigned)mt * 32u * p.O;
 #pragma unroll
@@ -235,10 +255,17 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     stage_fetch(mt, 0);
     __syncthreads();  // previous tile's readers are done with both buffers
     stage_commit(0);
+    // hi product of block hb (xo, G modes: times dY[w, o] of the block's o)
+    auto hi_of = [&](int hb, int nt) {
+      const int wl = (wv * BC_NT + nt) * 32 + wl32;
+      if (MODE != MODE_FWD && p.xo)
+        return kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hb & ((1 << p.lnhbo) - 1), wl, NQ) *
+               dys[(hb >> p.lnhbo) * BC_WPB + wl];
+      return kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hb, wl, NQ);
+    };
     float hi[BC_NT];
 #pragma unroll
-    for (int nt = 0; nt < BC_NT; ++nt)
-      hi[nt] = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, 0, (wv * BC_NT + nt) * 32 + wl32, NQ);
+    for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hi_of(0, nt);
     for (int st = 0; st < nstage; ++st) {
       __syncthreads();  // stage st visible; buffer (st+1)&1 free
       if (st + 1 < nstage) stage_fetch(mt, st + 1);
@@ -262,9 +289,7 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
         }
 #pragma unroll
-        for (int nt = 0; nt < BC_NT; ++nt)
-          hin[nt] = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hbn,
-                                    (wv * BC_NT + nt) * 32 + wl32, NQ);
+        for (int nt = 0; nt < BC_NT; ++nt) hin[nt] = hi_of(hbn, nt);
 #pragma unroll
         for (int t = 0; t < BC_TBL; ++t) avn[t] = sb[2 * (hbl * BC_TBL + t) * BC_SROW];
 #pragma unroll
@@ -282,7 +307,23 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     }
 
     // ---- epilogue of this row tile
-    if (MODE == MODE_FWD) {
+    if (MODE == MODE_FWD && p.xo) {
+      // rows are (b, o) in memory order: slot = o = R mod O picked by a select chain (no dynamic
+      // register indexing); both lane halves hold partial sums of every o
+      constexpr int OPT = (1 << LOGO_T) < 16 ? (1 << LOGO_T) : 16;
+#pragma unroll
+      for (int nt = 0; nt < BC_NT; ++nt) {
+        const int wl = (wv * BC_NT + nt) * 32 + wl32;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
+          const int bq = (int)__umulhi((unsigned)R, p.odiv_m), oq = R - bq * p.O;
+          const float val = R < p.rows ? acc[nt][v] * kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, bq, wl) : 0.f;
+#pragma unroll
+          for (int oo = 0; oo < OPT; ++oo) oacc[nt][oo] += oo == oq ? val : 0.f;
+        }
+      }
+    } else if (MODE == MODE_FWD) {
       constexpr int OPT = 1 << LOGO_T;
       constexpr int STEPV = OPT <= 4 ? OPT : OPT / 2;
 #pragma unroll
@@ -339,7 +380,14 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     for (int nt = 0; nt < BC_NT; ++nt) {
       const long long w = w_block + (wv * BC_NT + nt) * 32 + wl32;
       constexpr int OPT = 1 << LOGO_T;
-      if constexpr (OPT <= 4) {
+      if (p.xo) {
+        constexpr int OS = OPT < 16 ? OPT : 16;
+#pragma unroll
+        for (int s2 = 0; s2 < OS; ++s2) {
+          const float r = half_sum(oacc[nt][s2]);
+          if (s2 < p.O && h == 0 && w < p.Wn) out[w * p.O + s2] = r;
+        }
+      } else if constexpr (OPT <= 4) {
 #pragma unroll
         for (int s = 0; s < OPT; ++s) {
           const float r = half_sum(oacc[nt][s]);
@@ -385,7 +433,7 @@ struct DcoreP {
   int C, B, H, W, K, O, Q, LQ, N, n0, n1, Ho, Wo, OP, LOGO;
   long long Wn;
   long long s[5];
-  int A, BN, cols;                 // cols = BN * OP
+  int A, BN, cols;                 // cols = BN * O: column (b, o) = memory order of the core row
   int lb0, lb1;                    // bits of the lo tables of half 0 / half 1 (multiples of LQ)
   int nlo0, nhi0, nlo1, nhi1;      // table sizes
   int tstride;                     // floats per window in the table image (odd: conflict-free)
@@ -423,8 +471,8 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
 #pragma unroll
   for (int bt = 0; bt < DC_BT; ++bt) {
     const int col = (c_tile0 + bt) * 32 + il;
-    const int o = col & (p.OP - 1), b = col >> p.LOGO;
-    c_ok[bt] = col < p.cols && o < p.O;
+    const int b = col / p.O, o = col - b * p.O;
+    c_ok[bt] = col < p.cols;
     const int bc = col < p.cols ? b : 0;
     offb_lo[bt] = o_t1lo + (bc & ((1 << p.lb1) - 1));
     offb_hi[bt] = o_t1hi + (bc >> p.lb1);
@@ -509,12 +557,11 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
 #pragma unroll
     for (int bt = 0; bt < DC_BT; ++bt) {
       const int col = (c_tile0 + bt) * 32 + il;
-      const int o = col & (p.OP - 1), b = col >> p.LOGO;
-      if (col < p.cols && o < p.O) {
+      if (col < p.cols) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int a = (a_tile0 + at) * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-          if (a < p.A) atomicAdd(&dCore[((long long)a * p.BN + b) * p.O + o], acc[at][bt][v]);
+          if (a < p.A) atomicAdd(&dCore[(long long)a * p.cols + col], acc[at][bt][v]);
         }
       }
     }
@@ -543,8 +590,22 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   b.LOGO = ilog2i(b.OP);
   b.mode = mode;
   const int A = 1 << (b.n0 * b.LQ), BN = 1 << (b.n1 * b.LQ);
+  b.xo = (p.O >= 3 && (p.O & (p.O - 1)) != 0 && p.O <= 16) ? 1 : 0;
+  b.odiv_m = (unsigned)(((1ull << 32) + p.O - 1) / p.O);
+  b.lkh = 0; b.lnhbo = 0;
   int khalf_bits;
-  if (mode == MODE_FWD) {
+  if (b.xo) {
+    if (mode == MODE_FWD) {
+      b.rows = BN * p.O; b.kdim = A;
+      b.khalf_first = 0; b.khalf_n = b.n0; b.rhalf_first = b.n0; b.rhalf_n = b.n1;
+    } else if (mode == MODE_G0) {
+      b.rows = A; b.kdim = p.O * BN; b.lkh = b.n1 * b.LQ;
+      b.khalf_first = b.n0; b.khalf_n = b.n1; b.rhalf_first = 0; b.rhalf_n = b.n0;
+    } else {
+      b.rows = BN; b.kdim = p.O * A; b.lkh = b.n0 * b.LQ;
+      b.khalf_first = 0; b.khalf_n = b.n0; b.rhalf_first = b.n0; b.rhalf_n = b.n1;
+    }
+  } else if (mode == MODE_FWD) {
     b.rows = BN * b.OP; b.kdim = A;
     b.khalf_first = 0; b.khalf_n = b.n0; b.rhalf_first = b.n0; b.rhalf_n = b.n1;
   } else if (mode == MODE_G0) {
@@ -557,7 +618,7 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   khalf_bits = b.khalf_n * b.LQ;
   (void)khalf_bits;
   // inner block: ID = Q^mk * (FWD ? 1 : OP) k-values, ID/2 <= BC_TBL table entries, mk >= 0 digits
-  const int opk = mode == MODE_FWD ? 1 : b.OP;
+  const int opk = (mode == MODE_FWD || b.xo) ? 1 : b.OP;
   int mk = 0;
   while (mk + 1 <= b.khalf_n && ((1 << ((mk + 1) * b.LQ)) * opk) / 2 <= BC_TBL_MAX) ++mk;
   b.mk = mk;
@@ -566,6 +627,11 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   b.tbl = b.ID / 2;
   if (b.tbl != 4 && b.tbl != 8 && b.tbl != 16) return false;
   b.nhb = b.kdim / b.ID;
+  if (b.xo && mode != MODE_FWD) {
+    if ((1 << b.lkh) < 128 && (128 % (1 << b.lkh)) != 0) return false;
+    b.lnhbo = b.lkh - ilog2i(b.ID);   // hi blocks per o = Kh / ID
+    if (b.lnhbo < 0) return false;
+  }
   b.BnO = BN * p.O;
   if (p.R * p.O >= (1LL << 31)) return false;  // 32-bit core offsets
   b.rg_count = 1;
@@ -796,7 +862,7 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   while (d.OP < p.O) d.OP <<= 1;
   if (d.OP > 32) return DCTN_ERR_UNSUPPORTED;
   d.LOGO = ilog2i(d.OP);
-  d.A = 1 << (d.n0 * d.LQ); d.BN = 1 << (d.n1 * d.LQ); d.cols = d.BN * d.OP;
+  d.A = 1 << (d.n0 * d.LQ); d.BN = 1 << (d.n1 * d.LQ); d.cols = d.BN * p.O;
   // lo tables: as many whole digits as fit in 5 bits (32 entries), at least one digit
   auto lo_bits = [&](int nfac) {
     int m = 5 / d.LQ;
