@@ -109,9 +109,27 @@ __device__ __forceinline__ float kr_flat(const float* xs, const BigP& p, int fir
   return ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
 }
 
+// The same with the number of factors at compile time (ND = 1..4, chosen by the launcher: no control
+// flow in the main loop): no reads of the ones row and no index arithmetic for absent digits, which
+// were 2/3 of the VALU instructions of the main loop.
+template <int WPB, int ND>
+__device__ __forceinline__ float kr_exact(const float* xs, const BigP& p, int first, int idx, int wl) {
+  float f[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const int dg = (idx >> ((ND - 1 - d) * p.LQ)) & (p.Q - 1);
+    f[d] = xs[((first + d) * p.Q + dg) * WPB + wl];
+  }
+  float v = f[0];
+#pragma unroll
+  for (int d = 1; d < ND; ++d) v *= f[d];
+  return v;
+}
+
 // LOGO_T: log2 of the padded out size (compile time for FWD, whose epilogue selects output slots
 // statically); ignored (0) by the G modes.
-template <int MODE, int BC_NT, int LOGO_T, int BC_TBL>
+// ND: number of hi digits of the generated operand (khalf_n - mk) when in 1..4, else -1 (generic).
+template <int MODE, int BC_NT, int LOGO_T, int BC_TBL, int ND>
 __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __restrict__ x,
                                                                 const float* __restrict__ core,
                                                                 const float* __restrict__ dY,
@@ -258,10 +276,12 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     // hi product of block hb (xo, G modes: times dY[w, o] of the block's o)
     auto hi_of = [&](int hb, int nt) {
       const int wl = (wv * BC_NT + nt) * 32 + wl32;
-      if (MODE != MODE_FWD && p.xo)
-        return kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hb & ((1 << p.lnhbo) - 1), wl, NQ) *
-               dys[(hb >> p.lnhbo) * BC_WPB + wl];
-      return kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hb, wl, NQ);
+      const int hidx = (MODE != MODE_FWD && p.xo) ? (hb & ((1 << p.lnhbo) - 1)) : hb;
+      float v;
+      if constexpr (ND > 0) v = kr_exact<BC_WPB, ND>(xs, p, p.khalf_first, hidx, wl);
+      else v = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hidx, wl, NQ);
+      if (MODE != MODE_FWD && p.xo) v *= dys[(hb >> p.lnhbo) * BC_WPB + wl];
+      return v;
     };
     float hi[BC_NT];
 #pragma unroll
@@ -723,17 +743,27 @@ size_t big_lds(const BigP& b) {
   return f * sizeof(float);
 }
 
+template <int MODE, int NT, int LOGO_T, int TBL, int ND>
+int launch_nd(const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
+              hipStream_t st) {
+  constexpr int WPB = BC_WAVES * NT * 32;
+  const unsigned grid = (unsigned)((b.Wn + WPB - 1) / WPB);
+  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE, NT, LOGO_T, TBL, ND>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((eps_bigcore_k<MODE, NT, LOGO_T, TBL, ND>), dim3(grid, b.rg_count), dim3(64 * BC_WAVES), lds,
+                     st, (const float*)x, (const float*)core, (const float*)dY, (float*)out, b);
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
 template <int MODE, int NT, int LOGO_T, int TBL>
 int launch_one(const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
                hipStream_t st) {
-  constexpr int WPB = BC_WAVES * NT * 32;
-  const unsigned grid = (unsigned)((b.Wn + WPB - 1) / WPB);
-  (void)hipFuncSetAttribute((const void*)eps_bigcore_k<MODE, NT, LOGO_T, TBL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((eps_bigcore_k<MODE, NT, LOGO_T, TBL>), dim3(grid, b.rg_count), dim3(64 * BC_WAVES), lds, st,
-                     (const float*)x, (const float*)core, (const float*)dY, (float*)out, b);
-  DCTN_CHECK_LAUNCH();
-  return DCTN_OK;
+  switch (b.khalf_n - b.mk) {   // hi digits of the generated operand
+    case 2: return launch_nd<MODE, NT, LOGO_T, TBL, 2>(x, core, dY, out, b, lds, st);
+    case 3: return launch_nd<MODE, NT, LOGO_T, TBL, 3>(x, core, dY, out, b, lds, st);
+  }
+  return launch_nd<MODE, NT, LOGO_T, TBL, -1>(x, core, dY, out, b, lds, st);
 }
 
 template <int MODE, int NT, int LOGO_T>
