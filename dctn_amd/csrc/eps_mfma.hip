@@ -764,34 +764,37 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 // Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
 // as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
 // (256 consecutive features each), the last one sums the chunk blocks' partial dBias.
-__global__ __launch_bounds__(256) void eps_head_reduce_k(const float* __restrict__ partial,
-                                                         bf16_t* __restrict__ dCore, int nblk, int A, int BN,
-                                                         int O, int OP, int ACOLS, int n_core,
-                                                         const float* __restrict__ dwpart,
-                                                         bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
-                                                         const float* __restrict__ dbpart,
-                                                         bf16_t* __restrict__ dBias, int Cout) {
-  __shared__ float red[8][32];
+__global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restrict__ partial,
+                                                          bf16_t* __restrict__ dCore, int nblk, int A, int BN,
+                                                          int O, int OP, int ACOLS, int n_core,
+                                                          const float* __restrict__ dwpart,
+                                                          bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
+                                                          const float* __restrict__ dbpart,
+                                                          bf16_t* __restrict__ dBias, int Cout) {
+  // The kernel is a latency chain, not a bandwidth problem: 1024 threads per workgroup so that every
+  // partial tile of an element is fetched in ONE round of independent loads.
+  __shared__ float red[32][33];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < n_core) {
-    const int c = tid & 31, k8 = tid >> 5;
+    const int c = tid & 31, k32 = tid >> 5;
     const long long stride = (long long)BN * OP * ACOLS;
     const long long e = (long long)blockIdx.x * 32 + c;  // flat (m, a) index
-    float acc[8];
+    float acc = 0.f;
+    for (int k0 = 0; k0 < nblk; k0 += 256) {   // nblk <= 256: one trip
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    int k = k8;
-    for (; k + 56 < nblk; k += 64) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += partial[(k + 8 * i) * stride + e];
+      for (int i = 0; i < 8; ++i) {
+        const int k = k0 + k32 + 32 * i;
+        v[i] = k < nblk ? partial[k * stride + e] : 0.f;
+      }
+      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (; k < nblk; k += 8) acc[0] += partial[k * stride + e];
-    red[k8][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    red[k32][c] = acc;
     __syncthreads();
-    if (k8 == 0) {
+    if (k32 == 0) {
       float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t += red[i][c];
+      for (int i = 0; i < 32; ++i) t += red[i][c];
       const int m = (int)(e / ACOLS), a = (int)(e % ACOLS);
       const int b = m / OP, o = m % OP;
       if (a < A && o < O) dCore[((long long)a * BN + b) * O + o] = (bf16_t)t;
@@ -800,16 +803,20 @@ __global__ __launch_bounds__(256) void eps_head_reduce_k(const float* __restrict
   }
   if ((int)blockIdx.x < n_core + n_dw) {
     if (!dW) return;
-    const long long e = (long long)((int)blockIdx.x - n_core) * 256 + tid;
-    if (e >= nW) return;
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < ncb; k += 4) {   // independent loads: all partial tiles of this element in flight together
+    // 4 threads per element, each up to 8 independent loads (ncb <= 32), joined by two lane shuffles
+    const long long e = (long long)((int)blockIdx.x - n_core) * 256 + (tid >> 2);
+    const int sub = tid & 3;
+    float v[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] += dwpart[(long long)(k + i) * nW + e];
+    for (int i = 0; i < 8; ++i) {
+      const int k = sub + 4 * i;
+      v[i] = (k < ncb && e < nW) ? dwpart[(long long)k * nW + e] : 0.f;
     }
-    for (; k < ncb; ++k) t[0] += dwpart[(long long)k * nW + e];
-    dW[e] = (bf16_t)((t[0] + t[1]) + (t[2] + t[3]));
+    float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int k = 32 + sub; k < ncb; k += 4) t += e < nW ? dwpart[(long long)k * nW + e] : 0.f;
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    if (sub == 0 && e < nW) dW[e] = (bf16_t)t;
     return;
   }
   if (!dBias) return;
@@ -1024,7 +1031,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
   const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
-  hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(256), 0, st, (const float*)ws, (S*)dCore,
+  hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,
                      (const float*)(dwpart + (size_t)m.ncb * nW), (S*)dBias, m.Cout);
   DCTN_CHECK_LAUNCH();
