@@ -79,6 +79,50 @@ __device__ __forceinline__ void swap_halves(bf16x8& a, bf16x8& b) {
   b = __builtin_bit_cast(bf16x8, ib);
 }
 
+// LDS hand-over inside one wave (writes of all lanes visible to the reads of all lanes)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Transposition tiles of the dCore kernel: [64 windows][32 features] bf16, 64-byte rows, the four
+// 16-byte chunks of row w rotated by (w >> 1) & 3.  With that rotation both sides are conflict-free:
+// the row writes (ds_write_b128, 32-bank rule: 8 consecutive lanes cover 8 distinct 4-bank sets) and
+// the hardware transpose reads (ds_read_b64_tr_b16, 64-bank rule: the 4 rows of a block are 16 banks
+// apart and the 8 eight-byte units of a row keep distinct chunks), and every address is a per-lane
+// constant plus a compile-time offset.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int LROW = 32;   // shorts per row
+struct TrLane {
+  int wr[4];      // short offset inside a tile of logical chunk c of the lane's own row
+  int rd_lo, rd_hi;   // short offsets of the lane's two transpose-read addresses at k-step 0
+};
+__device__ __forceinline__ TrLane tr_lane(int lane) {
+  TrLane t;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) t.wr[c] = lane * LROW + (((c + (lane >> 1)) & 3) << 3);
+  // reader: 16-lane group g, lane 4q + p of it supplies row q, columns 4p..4p+3 of the block whose
+  // rows are windows 16 ks + 8 (g >> 1) + {0..3} (lo) / {4..7} (hi), columns features 16 (g & 1) + ..
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int lc = 2 * (g & 1) + (pp >> 1), half = pp & 1;
+  const int row = 8 * (g >> 1) + q;
+  t.rd_lo = row * LROW + (((lc + (row >> 1)) & 3) << 3) + 4 * half;
+  t.rd_hi = (row + 4) * LROW + (((lc + ((row + 4) >> 1)) & 3) << 3) + 4 * half;
+  return t;
+}
+// One 32x32x16 bf16 operand fragment with the hardware transpose read (cdna_hip_programming.md T10):
+// lane (r, h) gets feature r of windows 16 ks + 8 h + j, j = 0..7 - the windows on the MFMA k index.
+// Lane i of a 16-lane group receives column i of the group's 4 rows.  EXEC must be all ones.
+__device__ __forceinline__ bf16x8 tr_frag(const short* tile, int ks, const TrLane& t) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + t.rd_lo + ks * 16 * LROW));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + t.rd_hi + ks * 16 * LROW));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // unsigned 32-bit division by an invariant (Granlund-Montgomery, round-up variant):
 //   q = (t + ((n - t) >> s1)) >> s2,  t = umulhi(M, n)
 struct FastDiv {
@@ -490,8 +534,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int AT = A >= 32 ? A / 32 : 1;
   constexpr int LOGO = ilog2(OP);
+  // LDST: windows reach the MFMA k index through LDS with the hardware transpose read instead of
+  // through identity MFMAs (3 tiles of [64 windows][32 features] per wave; the cfg2 shape).  It
+  // removes, per 64 windows, 12 of the 20 MFMAs, the 48 bf16 conversions behind them and all 24
+  // lane swaps from a kernel that is bound by VALU + MFMA issue.
+  constexpr bool LDST = A == 32 && MT <= 2;
   __shared__ float red[BWD_WAVES][32 * 32];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wv = tid >> 6;
+  short* tiles = reinterpret_cast<short*>(dsm) + wv * ((1 + MT) * 64 * LROW);
+  const TrLane trl = tr_lane(lane);
 
   // identity B operands of the transposing MFMA: element j of k-step parity sp is
   // [16*sp + 8*h + j == r]
@@ -530,9 +582,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
       issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
   }
-  float dbacc[HEADC > 0 ? HEADC : 1];   // sum of dLogits over the wave's samples (wave-uniform)
-#pragma unroll
-  for (int c = 0; c < (HEADC > 0 ? HEADC : 1); ++c) dbacc[c] = 0.f;
   RawWindow<S, N, XVEC, ROWS> raw;
   RawRow<S, OP> rawdy;
   if (job.b0 < job.b1) {
@@ -562,7 +611,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
       for (int c = 0; c < HEADC; ++c) {
         const float dl = (c & 1) ? __uint_as_float(dlraw[c >> 1] & 0xffff0000u) : __uint_as_float(dlraw[c >> 1] << 16);
-        dbacc[c] += dl;
 #pragma unroll
         for (int o = 0; o < OP; ++o) {
           dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
@@ -586,6 +634,53 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's arithmetic
     }
     // lanes without a window position read zeros for x: their P0 is 0 and they contribute nothing
+
+    if constexpr (LDST) {
+      bf16x8 X[KS], Y[KS];
+      build_p0<N0>(xv, X, Y);
+      float p1[BN];   // built by doubling: 2 + 4 + ... + BN multiplies instead of (N1 - 1) * BN
+      p1[0] = xv[N - 1][0];
+      p1[1] = xv[N - 1][1];
+#pragma unroll
+      for (int u = 1; u < N1; ++u)
+#pragma unroll
+        for (int bb = (1 << u) - 1; bb >= 0; --bb) {
+          const float lo = p1[bb];
+          p1[bb | (1 << u)] = lo * xv[N - 1 - u][1];
+          p1[bb] = lo * xv[N - 1 - u][0];
+        }
+      wave_lds_sync();   // the previous step's transposed reads are done
+      // the lane's window = its row of every tile; features in natural a order: 16 s + j, 16 s + 8 + j
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2]) = X[s2];
+        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2 + 1]) = Y[s2];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          float z[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int m = (t << 5) | (c4 << 3) | j;
+            z[j] = p1[m >> LOGO] * dy[m & (OP - 1)];
+          }
+          *reinterpret_cast<bf16x8*>(tiles + (1 + t) * 64 * LROW + trl.wr[c4]) =
+              pack8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        }
+      wave_lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 p0t = tr_frag(tiles, ks, trl);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const bf16x8 zt = tr_frag(tiles + (1 + t) * 64 * LROW, ks, trl);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt, p0t, acc[t][0], 0, 0, 0);
+        }
+      }
+      continue;
+    }
 
     // P0 of the lane's own window -> A operands of set 0 / set 1 -> transposed on the matrix core:
     // features on lanes, windows in registers = B operand fragments summing over windows
@@ -713,19 +808,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         if (cb < p.ncb && c < p.Cout && f < F) dwpart[((long long)cb * p.Cout + c) * F + f] = sum;
       }
     }
-    // dBias: the chunk block's sum of dLogits, once (position group 0), after the dW tiles [ncb][Cout][F]
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < HEADC; ++c) red1[wv * 16 + c] = dbacc[c];
-    }
-    __syncthreads();
-    if (pg == 0 && cb < p.ncb && tid < 16) {
-      float sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < BWD_WAVES; ++k) sum += tid < HEADC ? red1[k * 16 + tid] : 0.f;
-      dwpart[(long long)p.ncb * p.Cout * F + cb * 16 + tid] = sum;
-    }
   }
 }
 
@@ -763,14 +845,14 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 
 // Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
 // as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
-// (256 consecutive features each), the last one sums the chunk blocks' partial dBias.
+// (256 consecutive features each), the last one sums dLogits over the batch into dBias.
 __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restrict__ partial,
                                                           bf16_t* __restrict__ dCore, int nblk, int A, int BN,
                                                           int O, int OP, int ACOLS, int n_core,
                                                           const float* __restrict__ dwpart,
                                                           bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
-                                                          const float* __restrict__ dbpart,
-                                                          bf16_t* __restrict__ dBias, int Cout) {
+                                                          const bf16_t* __restrict__ dL,
+                                                          bf16_t* __restrict__ dBias, int B, int Cout) {
   // The kernel is a latency chain, not a bandwidth problem: 1024 threads per workgroup so that every
   // partial tile of an element is fetched in ONE round of independent loads.
   __shared__ float red[32][33];
@@ -820,10 +902,20 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
     return;
   }
   if (!dBias) return;
-  if (tid < Cout) {   // dBias[c] = sum over the chunk blocks' partial sums of dLogits (written by the main kernel)
-    float u = 0.f;
-    for (int k = 0; k < ncb; ++k) u += dbpart[k * 16 + tid];
-    dBias[tid] = (bf16_t)u;
+  {  // dBias[c] = sum_b dLogits[b, c]: thread (c = tid % 16, j = tid / 16) takes every 64th sample
+    const int c = tid & 15, j = tid >> 4;
+    float t = 0.f;
+    if (c < Cout)
+      for (int b = j; b < B; b += 64) t += (float)dL[(long long)b * Cout + c];
+    __shared__ float rb[64][17];
+    rb[j][c] = t;
+    __syncthreads();
+    if (tid < 16 && tid < Cout) {
+      float u = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) u += rb[i][tid];
+      dBias[tid] = (bf16_t)u;
+    }
   }
 }
 
@@ -904,6 +996,19 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
 constexpr int FWD_BLOCKS_PER_CU = 4;
 constexpr int NUM_CU = 256;
 
+// dynamic LDS of the dCore kernel: the per-wave transposition tiles of its LDST path, else nothing
+template <int N0, int N1, int OP>
+constexpr size_t dcore_dyn_lds() {
+  constexpr int A = 1 << N0, MT = (1 << N1) * OP / 32;
+  return (A == 32 && MT <= 2) ? (size_t)BWD_WAVES * (1 + MT) * 64 * LROW * sizeof(short) : 0;
+}
+#define DCTN_DCORE_LAUNCH(KERNEL, G, B, DYN, ST, ...)                                                  \
+  do {                                                                                                 \
+    if ((DYN) > 0)                                                                                     \
+      (void)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DYN)); \
+    hipLaunchKernelGGL(KERNEL, G, B, DYN, ST, __VA_ARGS__);                                            \
+  } while (0)
+
 // Split the batch into sample chunks so that (chunks x position groups) is about `target` waves;
 // returns the number of workgroups of `wpb` waves (a multiple of 8 for the XCD-contiguous mapping).
 int plan_waves(MfmaP& m, int wpb, long long target) {
@@ -953,6 +1058,7 @@ template <typename S, int N0, int N1, int OP>
 int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const MfmaP& m_in,
                  hipStream_t st) {
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
+  constexpr size_t DYN = dcore_dyn_lds<N0, N1, OP>();
   MfmaP m = m_in;
   const int grid = plan_waves(m, BWD_WAVES, (long long)NUM_CU * BWD_WAVES);   // <= NUM_CU partial tiles
   const bool ovec = row_vec_ok<S>(m, OP, dY);
@@ -960,16 +1066,16 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
   if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW, 0>), g, b, 0, st,
+    DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, RW, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else if (m.vec_ok && ovec)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0, 0>), g, b, 0, st,
+    DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, true, 0, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else if (m.vec_ok)
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0, 0>), g, b, 0, st,
+    DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, true, false, 0, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   else
-    hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, 0, st,
+    DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   DCTN_CHECK_LAUNCH();
   if (dctn_main_kernel_only()) return DCTN_OK;
@@ -1007,18 +1113,19 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
                       void* dBias, void* ws, size_t core_ws_bytes, const MfmaP& m_in, hipStream_t st) {
   typedef bf16_t S;
   constexpr int A = 1 << N0, BN = 1 << N1, AT = A >= 32 ? A / 32 : 1;
+  constexpr size_t DYN = dcore_dyn_lds<N0, N1, OP>();
   MfmaP m = m_in;
   if (m.O != OP || m.Cout < 2 || m.Cout > 16 || m.Cout % 2 != 0) return DCTN_ERR_UNSUPPORTED;
   if (((uintptr_t)dL % 4) != 0 || ((uintptr_t)hw % 4) != 0 || ((uintptr_t)feat % 4) != 0) return DCTN_ERR_UNSUPPORTED;
   const int grid = plan_grouped(m);
   if (grid == 0) return DCTN_ERR_UNSUPPORTED;
   float* dwpart = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + core_ws_bytes);
-  const long long nW = (long long)m.Cout * m.P * OP;   // dwpart: [ncb][Cout][P*O] then dBias partials [ncb][16]
+  const long long nW = (long long)m.Cout * m.P * OP;   // dwpart: [ncb][Cout][P*O]
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
 #define DCTN_HEAD_LAUNCH(XV, ROWSV, HC)                                                                        \
-  hipLaunchKernelGGL((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, 0, st, (const S*)x, \
+  DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, DYN, st, (const S*)x, \
                      (const S*)dL, (const S*)hw, (const S*)feat, (float*)ws, dwpart, m)
   if (m.rowvec_ok && m.vec_ok) {
     if (m.Cout <= 10) DCTN_HEAD_LAUNCH(true, RW, 10); else DCTN_HEAD_LAUNCH(true, RW, 16);
@@ -1033,7 +1140,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
   hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,
-                     (const float*)(dwpart + (size_t)m.ncb * nW), (S*)dBias, m.Cout);
+                     (const S*)dL, (S*)dBias, m.B, m.Cout);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_head_bwd_mfma_q2reg");
   return DCTN_OK;
