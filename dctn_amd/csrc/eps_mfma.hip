@@ -905,8 +905,16 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
   {  // dBias[c] = sum_b dLogits[b, c]: thread (c = tid % 16, j = tid / 16) takes every 64th sample
     const int c = tid & 15, j = tid >> 4;
     float t = 0.f;
-    if (c < Cout)
-      for (int b = j; b < B; b += 64) t += (float)dL[(long long)b * Cout + c];
+    if (c < Cout) {
+      int b = j;
+      for (; b + 64 * 7 < B; b += 64 * 8) {   // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)dL[(long long)(b + 64 * i) * Cout + c];
+        t += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+      for (; b < B; b += 64) t += (float)dL[(long long)b * Cout + c];
+    }
     __shared__ float rb[64][17];
     rb[j][c] = t;
     __syncthreads();
