@@ -19,17 +19,14 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) int int2v;
 
-namespace {
+// The file is compiled three times (Makefile: -DBC_PART=0/1/2) so that its 60-odd kernel
+// instantiations build in parallel: part 1 owns the forward launchers for LOGO_T >= 3, part 2 the
+// transposed-GEMM launchers, part 0 everything else (dCore kernel, planning, the entry points).
+#ifndef BC_PART
+#define BC_PART 0
+#endif
 
-constexpr int BC_WAVES = 4;     // waves per workgroup
-constexpr int BC_NT_FWD = 2;    // column tiles (of 32 windows) per wave, forward
-constexpr int BC_NT_G = 1;      // ... transposed GEMMs (their LDS also holds the factor gradients)
-constexpr int BC_SROW = 33;     // padded row length of a staged k-row (32 rows + 1: conflict-free both ways)
-constexpr int BC_TBL_MAX = 16;  // generated-operand table entries per lane (k-steps per hi block): 4, 8 or 16
-constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
-
-enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
-
+namespace dctn_bc {
 struct BigP {
   int C, B, H, W, K, O, Q, LQ, N, n0, n1, Ho, Wo;
   int OP, LOGO;       // O padded to a power of two
@@ -53,6 +50,23 @@ struct BigP {
   int xo, lkh, lnhbo;
   unsigned odiv_m;            // ceil(2^32 / O)
 };
+int launch_fwd_hi(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st);
+int launch_g(int mode, const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
+             hipStream_t st);
+}  // namespace dctn_bc
+
+namespace {
+
+constexpr int BC_WAVES = 4;     // waves per workgroup
+constexpr int BC_NT_FWD = 2;    // column tiles (of 32 windows) per wave, forward
+constexpr int BC_NT_G = 1;      // ... transposed GEMMs (their LDS also holds the factor gradients)
+constexpr int BC_SROW = 33;     // padded row length of a staged k-row (32 rows + 1: conflict-free both ways)
+constexpr int BC_TBL_MAX = 16;  // generated-operand table entries per lane (k-steps per hi block): 4, 8 or 16
+constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
+
+enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
+
+using dctn_bc::BigP;
 
 __device__ __forceinline__ float half_sum(float v) {
   const int iv = __float_as_int(v);
@@ -784,6 +798,23 @@ int launch_fwd(const void* x, const void* core, void* out, const BigP& b, size_t
 
 }  // namespace
 
+#if BC_PART == 1
+int dctn_bc::launch_fwd_hi(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st) {
+  switch (b.LOGO) {
+    case 3: return launch_fwd<3>(x, core, out, b, lds, st);
+    case 4: return launch_fwd<4>(x, core, out, b, lds, st);
+    case 5: return launch_fwd<5>(x, core, out, b, lds, st);
+  }
+  return DCTN_ERR_UNSUPPORTED;
+}
+#elif BC_PART == 2
+int dctn_bc::launch_g(int mode, const void* x, const void* core, const void* dY, void* out, const BigP& b,
+                      size_t lds, hipStream_t st) {
+  if (mode == MODE_G0) return launch_tbl<MODE_G0, BC_NT_G, 0>(x, core, dY, out, b, lds, st);
+  return launch_tbl<MODE_G1, BC_NT_G, 0>(x, core, dY, out, b, lds, st);
+}
+#else
+
 // worthwhile only when the core is large: small cores stay on the register family / generic path
 static bool bigcore_wanted(const EpsP& p) {
   return p.R * p.O >= 1024;
@@ -815,9 +846,7 @@ int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t
   switch (b.LOGO) {
     case 1: rc = launch_fwd<1>(x, core, dst, b, lds, st); break;
     case 2: rc = launch_fwd<2>(x, core, dst, b, lds, st); break;
-    case 3: rc = launch_fwd<3>(x, core, dst, b, lds, st); break;
-    case 4: rc = launch_fwd<4>(x, core, dst, b, lds, st); break;
-    case 5: rc = launch_fwd<5>(x, core, dst, b, lds, st); break;
+    case 3: case 4: case 5: rc = dctn_bc::launch_fwd_hi(x, core, dst, b, lds, st); break;
   }
   if (rc != DCTN_OK) return rc;
   if (b.rg_count > 1) {
@@ -864,9 +893,9 @@ int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX
   const size_t need = (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
   if (!ws || ws_bytes < need) return DCTN_ERR_WORKSPACE;
   float* gxw = (float*)ws;
-  int rc = launch_tbl<MODE_G0, BC_NT_G, 0>(x, core, dY, gxw, b0, big_lds(b0), st);
+  int rc = dctn_bc::launch_g(MODE_G0, x, core, dY, gxw, b0, big_lds(b0), st);
   if (rc != DCTN_OK) return rc;
-  rc = launch_tbl<MODE_G1, BC_NT_G, 0>(x, core, dY, gxw, b1, big_lds(b1), st);
+  rc = dctn_bc::launch_g(MODE_G1, x, core, dY, gxw, b1, big_lds(b1), st);
   if (rc != DCTN_OK) return rc;
   const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
   const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -928,3 +957,4 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
   return DCTN_OK;
 }
+#endif  // BC_PART
