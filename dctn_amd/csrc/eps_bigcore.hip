@@ -474,6 +474,9 @@ struct DcoreP {
   long long win_per_block;
 };
 
+// PERX / PERY: register slots of the chunk prefetch (x features / dY values per thread): NQ <= 4 PERX,
+// O <= 4 PERY.
+template <int PERX, int PERY>
 __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* __restrict__ x,
                                                            const float* __restrict__ dY,
                                                            float* __restrict__ dCore, DcoreP p) {
@@ -525,58 +528,99 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
   long long w_end = w_begin + p.win_per_block;
   if (w_end > p.Wn) w_end = p.Wn;
 
+  // ---- staging plan of this thread (constant over the kernel): window slot wl_s of every chunk,
+  // elements nq = role + 4 i of its NQ features; role r also owns table r of that window
+  constexpr int ROLES = DC_THREADS / DC_WC;      // 4
+  const int wl_s = tid % DC_WC, role = tid / DC_WC;
+  int foff[PERX];
+  unsigned okx = 0;   // bit i: element i exists
+#pragma unroll
+  for (int i = 0; i < PERX; ++i) {
+    const int nq = role + ROLES * i;
+    const int n = nq / p.Q, q = nq - n * p.Q;
+    const int pos = n / p.C, ch = n - pos * p.C;
+    const int dh = pos / p.K, dw = pos - dh * p.K;
+    foff[i] = nq < NQ ? (int)(ch * p.s[0] + dh * p.s[2] + dw * p.s[3] + q * p.s[4]) : 0;
+    if (nq < NQ) okx |= 1u << i;
+  }
+  float prex[PERX], prey[PERY];
+  auto fetch_chunk = [&](long long w0) {   // global loads of chunk w0 into registers (consumed a chunk later)
+    const long long w = w0 + wl_s;
+    const bool valid = w < w_end;
+    const long long ww = valid ? w : 0;
+    const int hw = p.Ho * p.Wo;
+    const long long bb = ww / hw;
+    const int rem = (int)(ww - bb * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const float* px = x + bb * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
+#pragma unroll
+    for (int i = 0; i < PERX; ++i) prex[i] = (valid && ((okx >> i) & 1u)) ? px[foff[i]] : 0.f;
+#pragma unroll
+    for (int i = 0; i < PERY; ++i) {
+      const int o = role + ROLES * i;
+      prey[i] = (valid && o < p.O) ? dY[ww * p.O + o] : 0.f;
+    }
+  };
+  const int o_zero = o_dy + p.OP;   // one entry that is always 0: rows / columns outside the core point at it
+#pragma unroll
+  for (int at = 0; at < DC_AT; ++at)
+    if (!a_ok[at]) { offa_lo[at] = o_zero; offa_hi[at] = o_zero; }
+#pragma unroll
+  for (int bt = 0; bt < DC_BT; ++bt)
+    if (!c_ok[bt]) { offb_lo[bt] = o_zero; offb_hi[bt] = o_zero; offb_dy[bt] = o_zero; }
+
+  fetch_chunk(w_begin);
   for (long long w0 = w_begin; w0 < w_end; w0 += DC_WC) {
-    __syncthreads();
-    // window features of the chunk
-    for (int e = tid; e < DC_WC * p.N; e += DC_THREADS) {
-      const int wl = e % DC_WC, n = e / DC_WC;
-      const long long w = w0 + wl;
-      const bool valid = w < w_end;
-      const long long ww = valid ? w : 0;
-      const int hw = p.Ho * p.Wo;
-      const long long bb = ww / hw;
-      const int rem = (int)(ww - bb * hw);
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      const int pos = n / p.C, ch = n - pos * p.C;
-      const int dh = pos / p.K, dw = pos - dh * p.K;
-      const float* px = x + ch * p.s[0] + bb * p.s[1] + (long long)(ho + dh) * p.s[2] +
-                        (long long)(wo + dw) * p.s[3];
-      for (int q = 0; q < p.Q; ++q) xs[wl * (NQ + 1) + n * p.Q + q] = valid ? px[q * p.s[4]] : 0.f;
+    __syncthreads();   // the previous chunk's MFMA loop is done with xs / tb
+    {
+      float* xw = xs + wl_s * (NQ + 1);
+      float* tw = tb + wl_s * p.tstride;
+#pragma unroll
+      for (int i = 0; i < PERX; ++i)
+        if ((okx >> i) & 1u) xw[role + ROLES * i] = prex[i];
+#pragma unroll
+      for (int i = 0; i < PERY; ++i) {
+        const int o = role + ROLES * i;
+        if (o < p.OP) tw[o_dy + o] = prey[i];
+      }
+      if (role == 0) tw[o_zero] = 0.f;
     }
     __syncthreads();
-    // factored Khatri-Rao tables (and dY) of the chunk
-    const int nent = o_dy + p.OP;
-    for (int e = tid; e < DC_WC * nent; e += DC_THREADS) {
-      const int wl = e % DC_WC, ent = e / DC_WC;
-      const float* xw = xs + wl * (NQ + 1);
-      float v;
-      if (ent >= o_dy) {
-        const int o = ent - o_dy;
-        const long long w = w0 + wl;
-        v = (w < w_end && o < p.O) ? dY[w * p.O + o] : 0.f;
+    if (w0 + DC_WC < w_end) fetch_chunk(w0 + DC_WC);   // in flight during the table build and the MFMA loop
+    {
+      // factored Khatri-Rao table `role` of window wl_s, built by doubling in place (most significant
+      // digit first): Q + Q^2 + ... multiplies instead of (digits - 1) per entry plus index arithmetic
+      int first, nf, off;
+      if (role == 0) { nf = p.lb0 / p.LQ; first = p.n0 - nf; off = o_t0lo; }
+      else if (role == 1) { nf = p.n0 - p.lb0 / p.LQ; first = 0; off = o_t0hi; }
+      else if (role == 2) { nf = p.lb1 / p.LQ; first = p.N - nf; off = o_t1lo; }
+      else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; off = o_t1hi; }
+      float* T = tb + wl_s * p.tstride + off;
+      const float* xw = xs + wl_s * (NQ + 1) + first * p.Q;
+      if (nf == 0) {
+        T[0] = 1.f;
       } else {
-        int first, nf, idx;
-        if (ent < o_t0hi) { nf = p.lb0 / p.LQ; first = p.n0 - nf; idx = ent - o_t0lo; }
-        else if (ent < o_t1lo) { nf = p.n0 - p.lb0 / p.LQ; first = 0; idx = ent - o_t0hi; }
-        else if (ent < o_t1hi) { nf = p.lb1 / p.LQ; first = p.N - nf; idx = ent - o_t1lo; }
-        else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; idx = ent - o_t1hi; }
-        v = 1.f;
-        for (int d = 0; d < nf; ++d) {
-          const int dg = (idx >> ((nf - 1 - d) * p.LQ)) & (p.Q - 1);
-          v *= xw[(first + d) * p.Q + dg];
+        for (int q = 0; q < p.Q; ++q) T[q] = xw[q];
+        int S = p.Q;
+        for (int d = 1; d < nf; ++d) {
+          const float* xd = xw + d * p.Q;
+          for (int j = S - 1; j >= 0; --j) {
+            const float old = T[j];
+            for (int q = p.Q - 1; q >= 0; --q) T[j * p.Q + q] = old * xd[q];
+          }
+          S *= p.Q;
         }
       }
-      tb[wl * p.tstride + ent] = v;
     }
     __syncthreads();
-    for (int ks = 0; ks < DC_WC / 2; ++ks) {
-      const float* tw = tb + (2 * ks + kk) * p.tstride;
+    const float* tw = tb + kk * p.tstride;
+#pragma unroll 2
+    for (int ks = 0; ks < DC_WC / 2; ++ks, tw += 2 * p.tstride) {
       float pa[DC_AT], pz[DC_BT];
 #pragma unroll
-      for (int at = 0; at < DC_AT; ++at) pa[at] = a_ok[at] ? tw[offa_lo[at]] * tw[offa_hi[at]] : 0.f;
+      for (int at = 0; at < DC_AT; ++at) pa[at] = tw[offa_lo[at]] * tw[offa_hi[at]];
 #pragma unroll
-      for (int bt = 0; bt < DC_BT; ++bt)
-        pz[bt] = c_ok[bt] ? tw[offb_lo[bt]] * tw[offb_hi[bt]] * tw[offb_dy[bt]] : 0.f;
+      for (int bt = 0; bt < DC_BT; ++bt) pz[bt] = tw[offb_lo[bt]] * tw[offb_hi[bt]] * tw[offb_dy[bt]];
 #pragma unroll
       for (int at = 0; at < DC_AT; ++at)
 #pragma unroll
@@ -931,7 +975,8 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   };
   d.lb0 = lo_bits(d.n0); d.lb1 = lo_bits(d.n1);
   d.nlo0 = 1 << d.lb0; d.nhi0 = d.A >> d.lb0; d.nlo1 = 1 << d.lb1; d.nhi1 = d.BN >> d.lb1;
-  int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP;
+  if (p.N * p.Q > 80 || d.OP > 32) return DCTN_ERR_UNSUPPORTED;   // register staging plan of the kernel
+  int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP + 1;   // + the always-zero entry
   if (tstride % 2 == 0) ++tstride;
   d.tstride = tstride;
   const size_t lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
@@ -949,10 +994,16 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   chunks = (p.Wn + wpb - 1) / wpb;
   d.win_per_block = wpb;
   if (hipMemsetAsync(dCore, 0, (size_t)p.R * p.O * sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
-  (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  hipLaunchKernelGGL(eps_bigcore_dcore_k, dim3((unsigned)tiles, (unsigned)chunks), dim3(DC_THREADS), lds, st,
-                     (const float*)x, (const float*)dY, (float*)dCore, d);
+#define DC_LAUNCH(PX, PY)                                                                                  \
+  do {                                                                                                     \
+    (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k<PX, PY>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    hipLaunchKernelGGL((eps_bigcore_dcore_k<PX, PY>), dim3((unsigned)tiles, (unsigned)chunks),            \
+                       dim3(DC_THREADS), lds, st, (const float*)x, (const float*)dY, (float*)dCore, d);   \
+  } while (0)
+  if (p.N * p.Q <= 40 && d.OP <= 8) DC_LAUNCH(10, 2);
+  else DC_LAUNCH(20, 8);
+#undef DC_LAUNCH
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
   return DCTN_OK;
