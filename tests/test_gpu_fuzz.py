@@ -150,3 +150,65 @@ def test_logmatmulexp_fold_random(Wn, L, D, dtype):
     y.backward(dy.to(DEV))
     (g,) = R.grads(R.logmatmulexp_fold_batched, [m.double()], dy.double())
     check(md.grad, g, dtype, "dMats")
+
+
+# (C, K, size, B, O, Cout): fused EPS + head backward across its shape family — position groups with
+# idle lanes (P < 64, P not a multiple of 64), fewer samples than waves, odd batches, both core
+# splits (N = 9: LDS transpose path, N = 8: identity-MFMA path), several class counts
+HEAD_CASES = [(1, 3, 10, 1, 4, 10), (1, 3, 12, 7, 2, 4), (2, 2, 9, 13, 4, 16), (1, 3, 12, 70, 4, 2),
+              (1, 3, 70, 2, 4, 10), (2, 2, 13, 33, 2, 10), (1, 3, 30, 19, 4, 6), (1, 3, 28, 9, 2, 16)]
+
+
+@pytest.mark.parametrize("C,K,size,B,O,Cout", HEAD_CASES)
+def test_eps_head_fused_backward_random(C, K, size, B, O, Cout):
+    from dctn_amd.eps_plus_linear import _EpsLinearHeadFunction
+
+    torch.manual_seed(C * 1000 + K * 100 + size + B + O + Cout)
+    N = K * K * C
+    side = size - K + 1
+    F = side * side * O
+    assert F % 8 == 0
+    core = (torch.randn(*(2,) * N, O) * 2.0 ** (-N / 2) * 4).to(torch.bfloat16)
+    u = torch.rand(C, B, size, size)
+    x = torch.stack([torch.sin(u * 1.5707963) ** 2, torch.cos(u * 1.5707963) ** 2], dim=-1).to(torch.bfloat16)
+    w = (torch.randn(Cout, F) * F ** -0.5 * 4).to(torch.bfloat16)
+    bias = (torch.randn(Cout) * 0.1).to(torch.bfloat16)
+    g = torch.randn(B, Cout).to(torch.bfloat16)
+    cd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (core, w, bias))
+    xd = x.to(DEV)
+    assert _EpsLinearHeadFunction.supported(cd, xd, wd, bd)
+    out = _EpsLinearHeadFunction.apply(cd, xd, wd, bd)
+    out.backward(g.to(DEV))
+    assert dctn_amd.last_kernel() == "eps_head_bwd_mfma_q2reg"
+    c64, w64, b64 = (t.double().requires_grad_(True) for t in (core, w, bias))
+    want = R.eps_plus_linear_forward([c64], w64, b64, x.double())
+    check(out, want.detach(), torch.bfloat16, "logits")
+    want.backward(g.double())
+    check(cd.grad, c64.grad, torch.bfloat16, "dCore")
+    check(wd.grad, w64.grad, torch.bfloat16, "dWeight")
+    check(bd.grad, b64.grad, torch.bfloat16, "dBias")
+
+
+# (C, B, H, W, Q, K, O): large-core exact-f32 MFMA family with out sizes that are NOT powers of two
+# (rows in memory order, o outermost in the transposed GEMMs' k, exact dCore columns), row halves of
+# 16 .. 256 entries, one and two input channels
+BIGCORE_XO_CASES = [(1, 2, 7, 7, 4, 2, 5), (1, 2, 6, 6, 2, 3, 6), (1, 2, 9, 9, 4, 3, 6), (2, 3, 6, 6, 2, 2, 7),
+                    (1, 1, 5, 5, 8, 2, 3), (1, 2, 6, 6, 4, 2, 12), (1, 5, 11, 8, 2, 4, 3)]
+
+
+@pytest.mark.parametrize("C,B,H,W,Q,K,O", BIGCORE_XO_CASES)
+def test_eps_bigcore_exact_out_size(C, B, H, W, Q, K, O):
+    torch.manual_seed(C + 10 * B + 100 * H + Q + K + O)
+    N = K * K * C
+    core = torch.randn(*(Q,) * N, O) * Q ** (-N / 2) * 3
+    x = torch.rand(C, B, H, W, Q) + 0.1
+    cd, xd = core.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+    want = R.eps_4step(core.double(), x.double())
+    check(y, want, torch.float32, "forward")
+    dy = torch.randn(y.shape)
+    y.backward(dy.to(DEV))
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    check(cd.grad, dcore, torch.float32, "dCore")
+    check(xd.grad, dx, torch.float32, "dX")
