@@ -65,7 +65,8 @@ __device__ __forceinline__ void build_plo(const EpsP& p, const A* xs, A* plo, in
 template <typename S, typename A, int OT>
 __global__ __launch_bounds__(DCTN_WAVE) void eps_fwd_generic_k(const S* __restrict__ x,
                                                                const S* __restrict__ core,
-                                                               S* __restrict__ out, EpsP p) {
+                                                               S* __restrict__ out, EpsP p,
+                                                               long long hi_per_slice) {
   extern __shared__ __align__(16) unsigned char smem[];
   A* xs = reinterpret_cast<A*>(smem);               // [N*Q][64]
   A* plo = xs + (size_t)p.N * p.Q * DCTN_WAVE;      // [LO][64]
@@ -77,11 +78,15 @@ __global__ __launch_bounds__(DCTN_WAVE) void eps_fwd_generic_k(const S* __restri
   stage_window<S, A>(x, p, valid, c, xs, tid);
   build_plo<A>(p, xs, plo, tid);
 
+  // gridDim.y > 1: the high half of the core rows is split over grid.y (few windows would leave
+  // most SIMDs idle behind one serial loop per wave); slices meet by atomic adds on a zeroed `out`
+  const long long hi_begin = (long long)blockIdx.y * hi_per_slice;
+  const long long hi_end = hi_begin + hi_per_slice < p.HI ? hi_begin + hi_per_slice : p.HI;
   for (int o0 = 0; o0 < p.O; o0 += OT) {
     A acc[OT];
 #pragma unroll
     for (int j = 0; j < OT; ++j) acc[j] = A(0);
-    for (long long hi = 0; hi < p.HI; ++hi) {
+    for (long long hi = hi_begin; hi < hi_end; ++hi) {
       long long t = hi;
       A phi = A(1);
       for (int d = p.NH - 1; d >= 0; --d) {
@@ -100,7 +105,15 @@ __global__ __launch_bounds__(DCTN_WAVE) void eps_fwd_generic_k(const S* __restri
     if (valid) {
 #pragma unroll
       for (int j = 0; j < OT; ++j)
-        if (o0 + j < p.O) out[w * p.O + o0 + j] = (S)acc[j];
+        if (o0 + j < p.O) {
+          if constexpr (sizeof(S) == sizeof(A)) {
+            if (gridDim.y > 1) {
+              atomicAdd(reinterpret_cast<A*>(out) + w * p.O + o0 + j, acc[j]);
+              continue;
+            }
+          }
+          out[w * p.O + o0 + j] = (S)acc[j];
+        }
     }
   }
 }
@@ -112,9 +125,11 @@ __global__ __launch_bounds__(DCTN_WAVE) void eps_fwd_generic_k(const S* __restri
 template <typename S, typename A>
 __global__ __launch_bounds__(DCTN_WAVE) void eps_bwd_dfactor_generic_k(
     const S* __restrict__ x, const S* __restrict__ core, const S* __restrict__ dY,
-    A* __restrict__ gxw, EpsP p) {
+    A* __restrict__ gxw, EpsP p, long long hi_per_slice) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int NQ = p.N * p.Q;
+  const long long hi_begin = (long long)blockIdx.y * hi_per_slice;   // split as in the forward kernel
+  const long long hi_end = hi_begin + hi_per_slice < p.HI ? hi_begin + hi_per_slice : p.HI;
   A* xs = reinterpret_cast<A*>(smem);      // [NQ][64]
   A* gx = xs + (size_t)NQ * DCTN_WAVE;     // [NQ][64]
   A* plo = gx + (size_t)NQ * DCTN_WAVE;    // [LO][64]
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(DCTN_WAVE) void eps_bwd_dfactor_generic_k(
   long long pw_top = 1;
   for (int d = 0; d + 1 < p.NH; ++d) pw_top *= p.Q;
 
-  for (long long hi = 0; hi < p.HI; ++hi) {
+  for (long long hi = hi_begin; hi < hi_end; ++hi) {
     // suffix products over the high factors
     {
       long long t = hi;
@@ -185,8 +200,13 @@ __global__ __launch_bounds__(DCTN_WAVE) void eps_bwd_dfactor_generic_k(
       gx[((p.NH + e) * p.Q + de) * DCTN_WAVE + tid] += u * pr;
     }
   }
-  if (valid)
-    for (int e = 0; e < NQ; ++e) gxw[(long long)e * p.Wn + w] = gx[e * DCTN_WAVE + tid];
+  if (valid) {
+    if (gridDim.y > 1) {
+      for (int e = 0; e < NQ; ++e) atomicAdd(&gxw[(long long)e * p.Wn + w], gx[e * DCTN_WAVE + tid]);
+    } else {
+      for (int e = 0; e < NQ; ++e) gxw[(long long)e * p.Wn + w] = gx[e * DCTN_WAVE + tid];
+    }
+  }
 }
 
 }  // namespace
@@ -349,21 +369,33 @@ static size_t dcore_lds(const EpsP& p, size_t asz) {
   return ((size_t)DC_WB * (p.N * p.Q + p.O)) * asz;
 }
 
+// number of grid.y slices of the high half of the core rows: enough waves for ~4 per SIMD
+static long long hi_slices(const EpsP& p, unsigned window_blocks) {
+  long long sl = 4096 / (long long)(window_blocks ? window_blocks : 1);
+  if (sl > p.HI) sl = p.HI;
+  if (sl > 64) sl = 64;
+  return sl < 1 ? 1 : sl;
+}
+
 template <typename S, typename A>
 static int fwd_launch(const void* x, const void* core, void* out, const EpsP& p, hipStream_t st) {
   const size_t lds = fwd_lds(p, sizeof(A));
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+  const long long slices = sizeof(S) == sizeof(A) ? hi_slices(p, grid) : 1;
+  const long long hps = (p.HI + slices - 1) / slices;
+  const dim3 g2(grid, (unsigned)((p.HI + hps - 1) / hps));
+  if (g2.y > 1 && hipMemsetAsync(out, 0, (size_t)p.Wn * p.O * sizeof(S), st) != hipSuccess) return DCTN_ERR_LAUNCH;
   if (p.O <= 4) {
     (void)hipFuncSetAttribute((const void*)eps_fwd_generic_k<S, A, 4>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((eps_fwd_generic_k<S, A, 4>), dim3(grid), dim3(DCTN_WAVE), lds, st,
-                       (const S*)x, (const S*)core, (S*)out, p);
+    hipLaunchKernelGGL((eps_fwd_generic_k<S, A, 4>), g2, dim3(DCTN_WAVE), lds, st,
+                       (const S*)x, (const S*)core, (S*)out, p, hps);
   } else {
     (void)hipFuncSetAttribute((const void*)eps_fwd_generic_k<S, A, 8>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((eps_fwd_generic_k<S, A, 8>), dim3(grid), dim3(DCTN_WAVE), lds, st,
-                       (const S*)x, (const S*)core, (S*)out, p);
+    hipLaunchKernelGGL((eps_fwd_generic_k<S, A, 8>), g2, dim3(DCTN_WAVE), lds, st,
+                       (const S*)x, (const S*)core, (S*)out, p, hps);
   }
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_fwd_generic");
@@ -401,10 +433,15 @@ static int bwd_launch(const void* x, const void* core, const void* dY, void* dX,
     A* gxw = (A*)wsp;
     wsp += align256((size_t)p.Wn * p.N * p.Q * sizeof(A));
     const unsigned grid = (unsigned)((p.Wn + DCTN_WAVE - 1) / DCTN_WAVE);
+    const long long slices = hi_slices(p, grid);
+    const long long hps = (p.HI + slices - 1) / slices;
+    const dim3 g3(grid, (unsigned)((p.HI + hps - 1) / hps));
+    if (g3.y > 1 && hipMemsetAsync(gxw, 0, (size_t)p.Wn * p.N * p.Q * sizeof(A), st) != hipSuccess)
+      return DCTN_ERR_LAUNCH;
     (void)hipFuncSetAttribute((const void*)eps_bwd_dfactor_generic_k<S, A>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((eps_bwd_dfactor_generic_k<S, A>), dim3(grid), dim3(DCTN_WAVE), lds, st,
-                       (const S*)x, (const S*)core, (const S*)dY, gxw, p);
+    hipLaunchKernelGGL((eps_bwd_dfactor_generic_k<S, A>), g3, dim3(DCTN_WAVE), lds, st,
+                       (const S*)x, (const S*)core, (const S*)dY, gxw, p, hps);
     DCTN_CHECK_LAUNCH();
     const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
     const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
