@@ -34,3 +34,19 @@ def align(input: Tensor, kernel_size: int) -> Iterator[Tensor]:
     return align_with_positions(
         input, tuple(Pos2D(i // kernel_size, i % kernel_size) for i in range(kernel_size**2))
     )
+
+
+def make_windows(x: Tensor, kernel_size: int):
+    """``x``: (num_channels, batch, height, width, in_size).  The K*K*channels aligned views stacked
+    on a new leading dim, as a batch of rank-one tensors (factors on dim 0, coordinates on dim 4):
+    the reference's dctn/align.py:49-61.  This MATERIALISES K*K copies of ``x`` and exists for API
+    parity and the tests; the statistics the reference reads off it come from
+    ``dctn_amd.window_stats`` without any copy."""
+    import torch
+
+    from .rank_one_tensor import RankOneTensorsBatch
+
+    stacked = torch.cat(
+        tuple(torch.stack(tuple(align(part, kernel_size)), dim=0) for part in x.split(128, dim=1)), dim=1
+    )
+    return RankOneTensorsBatch(stacked, factors_dim=0, coordinates_dim=4)

@@ -1,0 +1,123 @@
+// Window statistics of the input feature map — the step just before the EPS path.
+//
+// Reference: dctn/dataset_loading.py:79-94 `calc_scaling_factor` builds, for 10 880 samples, the
+// tensor of all K x K windows (`make_windows`, dctn/align.py:49-61: K*K shifted views stacked, i.e.
+// K*K copies of the data set) and asks `RankOneTensorsBatch` (dctn/rank_one_tensor.py:53-100) for
+// the mean and the variance of the rank-one tensors  T_w = (x)_n x_n[w, :]  over all windows w:
+//     sum(T_w)   = prod_n sum_q x_n[w,q]          ||T_w||^2 = prod_n sum_q x_n[w,q]^2
+// Here one lane owns a window, forms the two products from the window's N*Q features read in
+// place (no window tensor is ever materialised) and the workgroup adds its float64 partial sums
+// to the two global accumulators.  HBM: x once (plus the K*K-fold overlap served by the caches).
+#include "common.h"
+
+namespace {
+
+template <typename S>
+__global__ __launch_bounds__(256) void window_stats_k(const S* __restrict__ x, double* __restrict__ sums, EpsP p) {
+  __shared__ double red[2][4];
+  double s_sum = 0.0, s_sq = 0.0;
+  const int hw = p.Ho * p.Wo;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < p.Wn;
+       w += (long long)gridDim.x * blockDim.x) {
+    const long long b = w / hw;
+    const int rem = (int)(w - b * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    double ps = 1.0, pq = 1.0;
+    for (int n = 0; n < p.N; ++n) {
+      const int pos = n / p.C, ch = n - pos * p.C;
+      const int dh = pos / p.K, dw = pos - dh * p.K;
+      const S* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3];
+      double t = 0.0, u = 0.0;
+      for (int q = 0; q < p.Q; ++q) {
+        const double v = (double)(float)px[q * p.s[4]];
+        t += v;
+        u += v * v;
+      }
+      ps *= t;
+      pq *= u;
+    }
+    s_sum += ps;
+    s_sq += pq;
+  }
+  // wave reduction, then one atomic pair per workgroup
+  for (int off = 32; off > 0; off >>= 1) {
+    s_sum += __shfl_down(s_sum, off, 64);
+    s_sq += __shfl_down(s_sq, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = s_sum; red[1][wv] = s_sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&sums[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+template <>
+__global__ __launch_bounds__(256) void window_stats_k<double>(const double* __restrict__ x, double* __restrict__ sums,
+                                                               EpsP p) {
+  __shared__ double red[2][4];
+  double s_sum = 0.0, s_sq = 0.0;
+  const int hw = p.Ho * p.Wo;
+  for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < p.Wn;
+       w += (long long)gridDim.x * blockDim.x) {
+    const long long b = w / hw;
+    const int rem = (int)(w - b * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    double ps = 1.0, pq = 1.0;
+    for (int n = 0; n < p.N; ++n) {
+      const int pos = n / p.C, ch = n - pos * p.C;
+      const int dh = pos / p.K, dw = pos - dh * p.K;
+      const double* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3];
+      double t = 0.0, u = 0.0;
+      for (int q = 0; q < p.Q; ++q) {
+        const double v = px[q * p.s[4]];
+        t += v;
+        u += v * v;
+      }
+      ps *= t;
+      pq *= u;
+    }
+    s_sum += ps;
+    s_sq += pq;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s_sum += __shfl_down(s_sum, off, 64);
+    s_sq += __shfl_down(s_sq, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = s_sum; red[1][wv] = s_sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&sums[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+}  // namespace
+
+extern "C" int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums, int C, int B, int H, int W,
+                                 int Q, int K, int dtype, void* stream) {
+  if (!x || !x_strides || !sums) return DCTN_ERR_NULL;
+  if (C < 1 || B < 1 || Q < 1 || K < 1 || H < K || W < K) return DCTN_ERR_BAD_SHAPE;
+  EpsP p = {};   // only the window geometry is used (no core: any number of factors)
+  p.C = C; p.B = B; p.H = H; p.W = W; p.Q = Q; p.K = K; p.O = 1;
+  p.N = K * K * C;
+  p.Ho = H - K + 1; p.Wo = W - K + 1;
+  p.Wn = (long long)B * p.Ho * p.Wo;
+  for (int i = 0; i < 5; ++i) p.s[i] = x_strides[i];
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  long long blocks = (p.Wn + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 g((unsigned)blocks), b(256);
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(window_stats_k<float>, g, b, 0, st, (const float*)x, (double*)sums, p); break;
+    case DCTN_F64: hipLaunchKernelGGL(window_stats_k<double>, g, b, 0, st, (const double*)x, (double*)sums, p); break;
+    case DCTN_BF16: hipLaunchKernelGGL(window_stats_k<bf16_t>, g, b, 0, st, (const bf16_t*)x, (double*)sums, p); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("window_stats");
+  return DCTN_OK;
+}

@@ -176,6 +176,19 @@ int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut,
                          void* dWeight, void* dBias, void* workspace, size_t workspace_bytes,
                          int64_t B, int F, int Cout, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Window statistics of the input feature map (reference: calc_scaling_factor,
+ * dctn/dataset_loading.py:79-94 = make_windows (dctn/align.py:49-61) + RankOneTensorsBatch
+ * .mean_over_batch / .var_over_batch (dctn/rank_one_tensor.py:53-100)).  For the rank-one tensor
+ * T_w = (x)_n x_n[w,:] of every K x K window w of x (C,B,H,W,Q):
+ *   sums[0] = sum_w sum(T_w)   = sum_w prod_n sum_q x_n[w,q]
+ *   sums[1] = sum_w ||T_w||^2  = sum_w prod_n sum_q x_n[w,q]^2
+ * `sums`: two float64 values on the device, OVERWRITTEN.  The K*K-fold window tensor of the
+ * reference is never materialised.
+ * ------------------------------------------------------------------------------------------ */
+int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums,
+                      int C, int B, int H, int W, int Q, int K, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

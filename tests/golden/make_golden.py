@@ -294,5 +294,41 @@ def main():
     npz("logmatmulexp", **cases)
 
 
+def window_stats_fixture():
+    """Window statistics: the reference's own make_windows (dctn/align.py:49-61) and
+    RankOneTensorsBatch (dctn/rank_one_tensor.py) on seeded inputs; the scaling factor is the last
+    line of calc_scaling_factor (dctn/dataset_loading.py:94) applied to those two numbers (the function
+    itself needs torchvision, which is not installed)."""
+    assert os.path.isdir(REF)
+    sys.path.insert(0, REF)
+    from dctn.align import make_windows
+    from dctn.rank_one_tensor import RankOneTensorsBatch
+
+    torch.manual_seed(zlib.crc32(b"window_stats"))
+    out = {}
+    for tag, (C, B, H, W, Q, K) in {"a": (1, 6, 7, 7, 2, 2), "b": (1, 5, 8, 9, 2, 3), "c": (2, 4, 6, 6, 3, 2),
+                                    "d": (1, 3, 9, 9, 2, 4)}.items():
+        if Q == 2 and C == 1:
+            x = 2 * phi(torch.rand(B, H, W, dtype=torch.float64)).unsqueeze(0)   # the reference's feature map
+        else:
+            x = torch.rand(C, B, H, W, Q, dtype=torch.float64) + 0.25
+        r1 = make_windows(x, K)
+        mean, var = r1.mean_over_batch(), r1.var_over_batch()
+        out.update({f"x_{tag}": x, f"K_{tag}": K, f"mean_{tag}": mean, f"var_{tag}": var,
+                    f"sum_{tag}": r1.sum_over_batch(), f"sq_{tag}": r1.squared_fro_norm_over_batch(),
+                    f"factor_{tag}": (mean**2 + var) ** (-1 / (2 * K**2))})
+    basic = RankOneTensorsBatch(
+        array=torch.tensor([[[[1.0], [2.0]], [[2.0], [-3.0]]], [[[4.0], [2.0]], [[-5.0], [-10.0]]]]),
+        factors_dim=1, coordinates_dim=2)
+    out.update(basic_array=basic.array, basic_sum_per_tensor=basic.sum_per_tensor(),
+               basic_sq_per_tensor=basic.squared_fro_norm_per_tensor(), basic_var=basic.var_over_batch(),
+               basic_std=basic.std_over_batch(), basic_mean=basic.mean_over_batch())
+    npz("window_stats", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "window_stats":
+        window_stats_fixture()
+    else:
+        main()
+        window_stats_fixture()

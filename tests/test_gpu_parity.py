@@ -510,3 +510,50 @@ def test_logmatmulexp_fold16_factored_mfma_and_exact_fallback():
     for wdw in range(70):
         scale = gm[wdw].abs().max().clamp_min(1.0)
         assert float((got[wdw] - gm[wdw]).abs().max() / scale) < 2e-4, wdw
+
+
+# ------------------------------------------------------------------ window statistics
+def test_window_statistics_kernel_against_reference_fixture_and_oracle():
+    """`dctn_window_stats` (one pass over the images, no window tensor) against the numbers the
+    reference's make_windows + RankOneTensorsBatch produced, then dtype / stride variants against the
+    oracle, then the defining property of calc_scaling_factor."""
+    from dctn_amd.align import make_windows
+    from dctn_amd.window_stats import (apply_feature_map, calc_scaling_factor, window_mean_var, window_sums)
+
+    g = load("window_stats")
+    for tag in "abcd":
+        x, K = dev(g[f"x_{tag}"]), int(g[f"K_{tag}"])
+        sums = window_sums(x, K).cpu()
+        assert dctn_amd.last_kernel() == "window_stats"
+        assert np.isclose(float(sums[0]), float(g[f"sum_{tag}"]), rtol=1e-12)
+        assert np.isclose(float(sums[1]), float(g[f"sq_{tag}"]), rtol=1e-12)
+        mean, var = window_mean_var(x, K)
+        assert np.isclose(float(mean), float(g[f"mean_{tag}"]), rtol=1e-11)
+        assert np.isclose(float(var), float(g[f"var_{tag}"]), rtol=1e-9)
+        assert np.isclose(calc_scaling_factor(x, K), float(g[f"factor_{tag}"]), rtol=1e-10)
+    torch.manual_seed(33)
+    images = torch.rand(300, 28, 28)
+    x = apply_feature_map(images)                               # (1, 300, 28, 28, 2), the reference's layout
+    assert x.shape == (1, 300, 28, 28, 2)
+    for K in (3, 4):
+        want = R.window_mean_var_factor(x, K)
+        for dtype, rtol in ((torch.float64, 1e-11), (torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+            xd = x.to(dtype).to(DEV)
+            mean, var = window_mean_var(xd, K)
+            ref = R.window_mean_var_factor(x.to(dtype), K) if dtype != torch.float64 else want
+            assert np.isclose(float(mean), float(ref[0]), rtol=rtol) and np.isclose(float(var), float(ref[1]), rtol=10 * rtol)
+        # strided view (every other sample, a crop): strides go through the C-ABI
+        big = torch.rand(2, 9, 12, 13, 3, dtype=torch.float64)
+        view = big[:, ::2, 1:11, 2:12]
+        s_view = window_sums(big.to(DEV)[:, ::2, 1:11, 2:12], K)
+        t, q = R.window_sums(view, K)
+        assert np.isclose(float(s_view[0]), float(t), rtol=1e-12) and np.isclose(float(s_view[1]), float(q), rtol=1e-12)
+        # after scaling, the windows' rank-one tensors have mean^2 + variance == 1
+        f = calc_scaling_factor(x, K, DEV)
+        m2, v2 = window_mean_var((x.double() * f).to(DEV), K)
+        assert abs(float(m2**2 + v2) - 1.0) < 1e-9
+        # and the materialising host mirror agrees (K*K copies of the data)
+        w = make_windows(x.double(), K)
+        assert np.isclose(float(w.mean_over_batch()), float(want[0]), rtol=1e-11)
+    with pytest.raises(RuntimeError):
+        window_sums(x, 3)                                        # CPU tensor: no fallback

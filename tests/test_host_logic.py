@@ -248,3 +248,29 @@ def test_eps_plus_linear_ctor_state_dict_and_manual_init():  # cf. reference tes
         assert float(m.p) == pytest.approx(p)
     with pytest.raises(ValueError):
         EPSesPlusLinear(((2, 3),), object(), 1.0, torch.device("cpu"), torch.float32)
+
+
+def test_rank_one_tensors_batch_and_make_windows():
+    """Host mirror of dctn/rank_one_tensor.py and dctn/align.py:49-61 against the fixture produced by
+    the reference (incl. the values of its own tests/test_rank_one_tensor.py:8-45)."""
+    import numpy as np
+
+    from dctn.rank_one_tensor import RankOneTensorsBatch      # alias package path
+    from dctn_amd.align import make_windows
+
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_stats.npz")))
+    b = RankOneTensorsBatch(torch.from_numpy(g["basic_array"]), factors_dim=1, coordinates_dim=2)
+    assert b.batch_shape == (2, 1) and b.ntensors == 2 and b.ncoordinates == 4
+    assert torch.allclose(b.sum_per_tensor(), torch.from_numpy(g["basic_sum_per_tensor"]))
+    assert torch.allclose(b.squared_fro_norm_per_tensor(), torch.from_numpy(g["basic_sq_per_tensor"]))
+    assert torch.allclose(b.sum_over_batch(), torch.tensor(-93.0)) and torch.allclose(b.mean_over_batch(), torch.tensor(-11.625))
+    assert torch.allclose(b.var_over_batch(), torch.from_numpy(g["basic_var"])) and torch.allclose(b.std_over_batch(), torch.from_numpy(g["basic_std"]))
+    assert torch.allclose(b.std_over_batch(unbiased=False), b.std_over_batch())    # as in the reference
+    with pytest.raises(AssertionError):
+        RankOneTensorsBatch(torch.zeros(2, 2), 1, 1)
+    for tag in "abcd":
+        x, K = torch.from_numpy(g[f"x_{tag}"]), int(g[f"K_{tag}"])
+        w = make_windows(x, K)
+        assert w.array.shape[0] == K * K * x.shape[0] and w.factors_dim == 0 and w.coordinates_dim == 4
+        assert np.isclose(float(w.mean_over_batch()), float(g[f"mean_{tag}"]), rtol=1e-12)
+        assert np.isclose(float(w.var_over_batch()), float(g[f"var_{tag}"]), rtol=1e-10)

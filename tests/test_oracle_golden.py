@@ -129,3 +129,17 @@ def test_logmatmulexp():
     mats = t(g["fold_mats"])
     assert torch.allclose(R.logmatmulexp_fold(list(mats)), t(g["fold_y"]), rtol=1e-5, atol=1e-5)
     assert torch.allclose(R.logmatmulexp_fold_batched(mats[None])[0], t(g["fold_y"]), rtol=1e-5, atol=1e-5)
+
+
+def test_window_statistics_against_the_reference_fixture():
+    """make_windows + RankOneTensorsBatch of the reference vs the oracle's loops."""
+    g = dict(np.load(os.path.join(GOLDEN, "window_stats.npz")))
+    for tag in "abcd":
+        x, K = torch.from_numpy(g[f"x_{tag}"]), int(g[f"K_{tag}"])
+        total, sq = R.window_sums(x, K)
+        assert np.isclose(float(total), float(g[f"sum_{tag}"]), rtol=1e-12)
+        assert np.isclose(float(sq), float(g[f"sq_{tag}"]), rtol=1e-12)
+        mean, var, factor = R.window_mean_var_factor(x, K)
+        assert np.isclose(float(mean), float(g[f"mean_{tag}"]), rtol=1e-11)
+        assert np.isclose(float(var), float(g[f"var_{tag}"]), rtol=1e-9)
+        assert np.isclose(float(factor), float(g[f"factor_{tag}"]), rtol=1e-10)

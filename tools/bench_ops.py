@@ -172,11 +172,42 @@ def bench_eps(cpu):
                                                 "fwd_bwd_TFLOPs": round(3 * flops / b / 1e12, 2)})
 
 
+def bench_window_stats(cpu):
+    """calc_scaling_factor's statistics at the reference's size (10 880 MNIST samples,
+    float64): the one-pass HIP kernel, the reference's materialising formulation run on the GPU with
+    torch (make_windows: K*K copies of the data), and the CPU oracle."""
+    from dctn_amd.align import make_windows
+    from dctn_amd.window_stats import apply_feature_map, window_mean_var
+    from oracle import ref_cpu as R
+
+    torch.manual_seed(0)
+    x = apply_feature_map(torch.rand(10880, 28, 28, dtype=torch.float64)).to(DEV)
+    for K in (3, 4):
+        windows = 10880 * (29 - K) ** 2
+        t_kernel = time_gpu(lambda: window_mean_var(x, K), 10)
+
+        def materialise():
+            w = make_windows(x, K)
+            return w.mean_over_batch(), w.var_over_batch()
+
+        t_torch = time_gpu(materialise, 3)
+        row = {"op": f"window statistics K={K} f64, 10880x28x28x2 (calc_scaling_factor)", "windows": windows,
+               "hip_kernel_us": round(t_kernel * 1e6, 1), "torch_materialising_gpu_us": round(t_torch * 1e6, 1),
+               "hip_GBs": round(x.numel() * 8 / t_kernel / 1e9, 1)}
+        if cpu:
+            xc = x.cpu()
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            row["cpu_oracle_us"] = round(time_cpu(lambda: R.window_mean_var_factor(xc, K), 4.0) * 1e6, 1)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
+    if a.only in ("", "stats"):
+        bench_window_stats(a.cpu)
     if a.only in ("", "eps"):
         bench_eps(a.cpu)
     if a.only in ("", "convsbs"):
