@@ -58,6 +58,41 @@ def _worker(rank, world, port, q):
     assert red2._contiguous_flat([p.grad for p in params]) is None
     red2()
     assert torch.allclose(params[1].grad, torch.ones(4))
+    # evaluation.score: every rank scores its shard, all ranks report the global mean CE / accuracy;
+    # training.train_step: identical parameters after an update from different shards
+    from dctn_amd import evaluation, training
+
+    torch.manual_seed(99)
+    clf = torch.nn.Linear(6, 3)
+    ddp.broadcast_parameters(clf.parameters())
+    feats, labels = torch.randn(1, 8, 1, 2, 3), torch.randint(0, 3, (8,))
+    wrap = lambda xb: clf(xb[0].reshape(xb.shape[1], 6))          # (C, B, ...) input layout
+    shard = [(feats[:, rank * 4 : rank * 4 + 2], labels[rank * 4 : rank * 4 + 2], None),
+             (feats[:, rank * 4 + 2 : rank * 4 + 4], labels[rank * 4 + 2 : rank * 4 + 4], None)]
+    loss_g, acc_g = evaluation.score(wrap, shard, torch.device("cpu"))
+    full = clf(feats[0].reshape(8, 6))
+    assert abs(loss_g - float(torch.nn.functional.cross_entropy(full, labels))) < 1e-6
+    assert abs(acc_g - float((full.argmax(1) == labels).float().mean())) < 1e-9
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.clf = clf
+
+        def forward(self, xb):
+            return self.clf(xb[0].reshape(xb.shape[1], 6))
+
+    net = Wrapped()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    red3 = ddp.FlatGradAllReducer(net.parameters(), average=True)
+    res = training.train_step(net, feats[:, rank * 4 : rank * 4 + 4], labels[rank * 4 : rank * 4 + 4],
+                              torch.nn.functional.cross_entropy, opt,
+                              reg_fn=lambda m: m.clf.weight.norm() ** 2, reg_coeff=1e-3, reducer=red3)
+    assert res["output"].shape == (4, 3)
+    flat2 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered2 = [torch.empty_like(flat2) for _ in range(world)]
+    dist.all_gather(gathered2, flat2)
+    assert all(torch.equal(t, gathered2[0]) for t in gathered2)
     tot, cnt = ddp.all_reduce_scalar_sums(torch.tensor(float(rank + 1)), torch.tensor(4.0))
     assert float(tot) == 3.0 and float(cnt) == 8.0
     dist.barrier()
