@@ -41,6 +41,10 @@ SIGNATURES = {
     "dctn_eps_head_bwd_workspace_bytes": (c_size, [c_int] * 8 + [c_int, c_int]),
     "dctn_eps_head_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_size]
                           + [c_int] * 8 + [c_int, c_int, c_void]),
+    "dctn_ce_loss_fwd": (c_int, [c_void, c_void, c_void, c_i64, c_int, c_int, c_void]),
+    "dctn_ce_loss_bwd": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_void]),
+    "dctn_sgd_l2_step": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, c_int, c_int, c_void]),
     "dctn_window_stats": (c_int, [c_void, _I64x5, c_void] + [c_int] * 6 + [c_int, c_void]),
     "dctn_convsbs_workspace_bytes": (c_size, [c_int, _IntP, _IntP] + [c_int] * 5 + [_IntP, _IntP, c_int, c_int]),
     "dctn_convsbs_fwd": (c_int, [c_void, _I64x5, _PtrP, c_void, c_int, _IntP, _IntP, _IntP, _IntP]

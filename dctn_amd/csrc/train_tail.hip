@@ -1,0 +1,135 @@
+// The tail of a training iteration: everything around the contraction
+// path that the reference's loop runs per iteration (dctn/training.py:77-84) — cross-entropy on the
+// (batch, classes) logits, the L2 regulariser (dctn/eps_plus_linear.py:149-159,
+// dctn/epses_composition.py:144-146) and the optimizer update — is a few kilobytes of data, but as
+// library calls it is ~30 launches of 4-5 us each, 3x the time of the forward + backward kernels of
+// BASELINE config 2.  Three kernels replace them:
+//   ce_fwd_k   : mean cross-entropy of bf16/f32 logits (max-shifted log-sum-exp, float32)
+//   ce_bwd_k   : dLogits = (softmax - onehot) * dLoss / B, in the logits' dtype
+//   sgd_l2_k   : over ONE flat buffer holding all parameters: g += 2 * l2 * w on the regularised
+//                prefix, buf = momentum * buf + g, w -= lr * buf; the regulariser's value
+//                sum w^2 is accumulated on the way (float32 master arithmetic, storage dtype kept)
+#include "common.h"
+
+namespace {
+
+template <typename S>
+__global__ __launch_bounds__(256) void ce_fwd_k(const S* __restrict__ logits, const long long* __restrict__ labels,
+                                                float* __restrict__ loss, long long B, int C) {
+  __shared__ float red[4];
+  float part = 0.f;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
+    const S* row = logits + b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, (float)row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
+    const long long y = labels[b];
+    part += (m + logf(s)) - (float)row[y >= 0 && y < C ? y : 0];
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, ((red[0] + red[1]) + (red[2] + red[3])) / (float)B);
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void ce_bwd_k(const S* __restrict__ logits, const long long* __restrict__ labels,
+                                                const float* __restrict__ dloss, S* __restrict__ dlogits, long long B,
+                                                int C) {
+  const float scale = dloss[0] / (float)B;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
+    const S* row = logits + b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, (float)row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
+    const float inv = 1.f / s;
+    const long long y = labels[b];
+    for (int c = 0; c < C; ++c) {
+      const float p = expf((float)row[c] - m) * inv;
+      dlogits[b * C + c] = (S)((p - (c == y ? 1.f : 0.f)) * scale);
+    }
+  }
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void sgd_l2_k(S* __restrict__ w, const S* __restrict__ g, float* __restrict__ buf,
+                                                float* __restrict__ sq_sum, long long n, long long n_reg, float lr,
+                                                float momentum, float l2, int first_step) {
+  __shared__ float red[4];
+  float part = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float wi = (float)w[i];
+    float gi = (float)g[i];
+    if (i < n_reg) {
+      gi += 2.f * l2 * wi;
+      part += wi * wi;
+    }
+    const float bi = first_step ? gi : momentum * buf[i] + gi;   // torch.optim.SGD: the first step copies g
+    buf[i] = bi;
+    w[i] = (S)(wi - lr * bi);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0 && sq_sum) atomicAdd(sq_sum, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+unsigned blocks_for(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream) {
+  if (!logits || !labels || !loss) return DCTN_ERR_NULL;
+  if (B < 1 || C < 1) return DCTN_ERR_BAD_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  const dim3 g(blocks_for(B)), b(256);
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(ce_fwd_k<float>, g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C); break;
+    case DCTN_BF16: hipLaunchKernelGGL(ce_fwd_k<bf16_t>, g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, void* dlogits, int64_t B, int C,
+                     int dtype, void* stream) {
+  if (!logits || !labels || !dloss || !dlogits) return DCTN_ERR_NULL;
+  if (B < 1 || C < 1) return DCTN_ERR_BAD_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(blocks_for(B)), b(256);
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(ce_bwd_k<float>, g, b, 0, st, (const float*)logits, (const long long*)labels, (const float*)dloss, (float*)dlogits, (long long)B, C); break;
+    case DCTN_BF16: hipLaunchKernelGGL(ce_bwd_k<bf16_t>, g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (const float*)dloss, (bf16_t*)dlogits, (long long)B, C); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+int dctn_sgd_l2_step(void* params, const void* grads, void* momentum_buf, void* sq_sum, int64_t n, int64_t n_reg,
+                     float lr, float momentum, float l2, int first_step, int dtype, void* stream) {
+  if (!params || !grads || !momentum_buf) return DCTN_ERR_NULL;
+  if (n < 1 || n_reg < 0 || n_reg > n) return DCTN_ERR_BAD_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (sq_sum && hipMemsetAsync(sq_sum, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  const dim3 g(blocks_for(n)), b(256);
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(sgd_l2_k<float>, g, b, 0, st, (float*)params, (const float*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step); break;
+    case DCTN_BF16: hipLaunchKernelGGL(sgd_l2_k<bf16_t>, g, b, 0, st, (bf16_t*)params, (const bf16_t*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+}  // extern "C"

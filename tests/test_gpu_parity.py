@@ -609,3 +609,73 @@ def test_train_step_end_to_end_loss_goes_down(dtype):
     assert last < 0.7 * first, (first, last)
     loss, acc = score(model, [(x, yd, None)], DEV)
     assert acc > 0.8 and abs(loss - last) < 0.5
+
+
+def test_graphed_train_step_matches_eager():
+    """`GraphedTrainStep` (forward, CE, regulariser, backward, SGD step replayed from one HIP graph)
+    leaves the parameters where the eager iteration leaves them."""
+    import copy
+
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    from dctn_amd.training import GraphedTrainStep, train_step
+
+    torch.manual_seed(11)
+    a = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, torch.float32, image_size=10)
+    b = copy.deepcopy(a)
+    xs = [torch.rand(1, 32, 10, 10, 2, device=DEV) for _ in range(6)]
+    ys = [torch.randint(0, 10, (32,), device=DEV) for _ in range(6)]
+    reg = lambda m: m.epswise_l2_regularizer()
+    oa = torch.optim.SGD(a.parameters(), lr=0.05, momentum=0.9)
+    ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9)
+    # the graphed step warms up with three real iterations on the example batch: give model `a` the same
+    graphed = GraphedTrainStep(b, xs[0], ys[0], torch.nn.functional.cross_entropy, ob, reg_fn=reg, reg_coeff=1e-3,
+                               warmup=3)
+    for _ in range(3):
+        train_step(a, xs[0], ys[0], torch.nn.functional.cross_entropy, oa, reg_fn=reg, reg_coeff=1e-3)
+    for x, y in zip(xs, ys):
+        ra = train_step(a, x, y, torch.nn.functional.cross_entropy, oa, reg_fn=reg, reg_coeff=1e-3)
+        rb = graphed(x, y)
+        assert torch.allclose(ra["loss"], rb["loss"], rtol=1e-5, atol=1e-6)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_training_tail_matches_torch(dtype):
+    """`fused_cross_entropy` against F.cross_entropy (value and gradient), and `FlatSGD` (momentum + the
+    L2 regulariser folded into the update, one kernel over a flat parameter buffer) against
+    torch.optim.SGD driven by loss + l2 * epswise_l2_regularizer through autograd."""
+    import copy
+
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    from dctn_amd.training import FlatSGD, fused_cross_entropy, train_step
+
+    torch.manual_seed(21)
+    logits = (torch.randn(77, 10) * 3).to(dtype).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, 10, (77,), device=DEV)
+    loss = fused_cross_entropy(logits, labels)
+    (loss * 1.7).backward()
+    ref_logits = logits.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_logits, labels)
+    (ref * 1.7).backward()
+    assert loss.dtype == torch.float32 and abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    tol = 1e-6 if dtype == torch.float32 else 2e-2 * float(ref_logits.grad.abs().max())
+    assert float((logits.grad.float() - ref_logits.grad).abs().max()) <= tol
+
+    if dtype == torch.bfloat16:
+        return   # the optimizer comparison below needs float32 weights on the torch side
+    a = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, dtype, image_size=10)
+    b = copy.deepcopy(a)
+    l2, lr, mom = 1e-2, 0.05, 0.9
+    oa = torch.optim.SGD(a.parameters(), lr=lr, momentum=mom)
+    ob = FlatSGD(list(b.epses) + [b.linear.weight], [b.linear.bias], lr=lr, momentum=mom, l2=l2)
+    for it in range(5):
+        x = torch.rand(1, 16, 10, 10, 2, device=DEV)
+        y = torch.randint(0, 10, (16,), device=DEV)
+        ra = train_step(a, x, y, torch.nn.functional.cross_entropy, oa, reg_fn=lambda m: m.epswise_l2_regularizer(),
+                        reg_coeff=l2)
+        rb = train_step(b, x, y, fused_cross_entropy, ob)
+        assert abs(float(ra["loss"]) - float(rb["loss"])) < 1e-4
+        assert abs(float(ra["reg_term"]) * l2 - float(ob.reg_value())) < 1e-4 * max(1.0, float(ra["reg_term"]) * l2)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=2e-4, atol=2e-6)

@@ -172,6 +172,37 @@ def bench_eps(cpu):
                                                 "fwd_bwd_TFLOPs": round(3 * flops / b / 1e12, 2)})
 
 
+def bench_train():
+    """A whole training iteration of BASELINE cfg2 (forward, CE loss, L2 regulariser, backward, SGD with
+    momentum; B = 1024): eager launches vs the HIP-graph replay of dctn_amd.training.GraphedTrainStep."""
+    import torch.nn.functional as F
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    from dctn_amd.training import GraphedTrainStep, train_step
+
+    for dtype in (torch.bfloat16, torch.float32):
+        torch.manual_seed(0)
+        model = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, dtype)
+        u = torch.rand(1, 1024, 28, 28)
+        x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1).to(dtype).to(DEV)
+        y = torch.randint(0, 10, (1024,), device=DEV)
+        reg = lambda m: m.epswise_l2_regularizer()
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+        eager = time_gpu(lambda: train_step(model, x, y, F.cross_entropy, opt, reg_fn=reg, reg_coeff=1e-4), 20)
+        graphed = GraphedTrainStep(model, x, y, F.cross_entropy, opt, reg_fn=reg, reg_coeff=1e-4)
+        replay = time_gpu(lambda: graphed(x, y), 50)
+        # fused tail: one CE forward + one CE backward kernel, regulariser + momentum update in one kernel
+        from dctn_amd.training import FlatSGD, fused_cross_entropy
+        torch.manual_seed(0)
+        model2 = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, dtype)
+        opt2 = FlatSGD(list(model2.epses) + [model2.linear.weight], [model2.linear.bias], lr=1e-3, momentum=0.9, l2=1e-4)
+        graphed2 = GraphedTrainStep(model2, x, y, fused_cross_entropy, opt2)
+        fused = time_gpu(lambda: graphed2(x, y), 50)
+        print(json.dumps({"op": f"training iteration cfg2 B=1024 {str(dtype).replace('torch.', '')} (fwd + CE + L2 reg + bwd + SGD)",
+                          "windows": 692224, "eager_us": round(eager * 1e6, 1), "hip_graph_us": round(replay * 1e6, 1),
+                          "hip_graph_fused_tail_us": round(fused * 1e6, 1),
+                          "fused_tail_Gwin_s": round(692224 / fused / 1e9, 2)}), flush=True)
+
+
 def bench_window_stats(cpu):
     """calc_scaling_factor's statistics at the reference's size (10 880 MNIST samples,
     float64): the one-pass HIP kernel, the reference's materialising formulation run on the GPU with
@@ -206,6 +237,8 @@ if __name__ == "__main__":
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
+    if a.only in ("", "train"):
+        bench_train()
     if a.only in ("", "stats"):
         bench_window_stats(a.cpu)
     if a.only in ("", "eps"):
