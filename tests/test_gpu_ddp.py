@@ -1,0 +1,90 @@
+"""Two data-parallel ranks sharing ONE MI355X (gloo collectives on device tensors): the complete
+training iteration — forward + fused backward replayed from a HIP graph, the in-place all-reduce of
+the backward's flat gradient buffer, the optimizer graph — must leave both ranks with the parameters
+a single process gets from the concatenated batch.  (RCCL needs one GPU per rank; on the one-GPU test
+box the same code path runs over gloo.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(dtype, dev):
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    torch.manual_seed(5)
+    return EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=12)
+
+
+def _data(dtype, dev):
+    g = torch.Generator().manual_seed(17)
+    u = torch.rand(1, 32, 12, 12, generator=g)
+    x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1).to(dtype).to(dev)
+    y = torch.randint(0, 10, (32,), generator=g).to(dev)
+    return x, y
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+    from dctn_amd.training import FlatSGD, GraphedTrainStep, fused_cross_entropy
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("gloo")
+    dtype = torch.bfloat16
+    model = _make(dtype, dev)
+    ddp.broadcast_parameters(model.parameters())
+    x, y = _data(dtype, dev)
+    xs, ys = ddp.shard_batch(x, rank, world), y[rank * 16 : rank * 16 + 16]
+    opt = FlatSGD(list(model.epses) + [model.linear.weight], [model.linear.bias], lr=0.05, momentum=0.9, l2=1e-3)
+    red = ddp.FlatGradAllReducer(model.parameters(), average=True)
+    step = GraphedTrainStep(model, xs, ys, fused_cross_entropy, opt, reducer=red, warmup=1)
+    for _ in range(3):
+        step(xs, ys)
+    torch.cuda.synchronize(dev)
+    assert step.g_opt is not None and red._flat_key is not None       # split graphs, in-place all-reduce
+    q.put((rank, [p.detach().float().cpu() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_iteration():
+    from dctn_amd.training import FlatSGD, GraphedTrainStep, fused_cross_entropy
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+    # single process, whole batch: 1 warm-up + 3 iterations, same optimizer
+    dev = torch.device("cuda", 0)
+    model = _make(torch.bfloat16, dev)
+    x, y = _data(torch.bfloat16, dev)
+    opt = FlatSGD(list(model.epses) + [model.linear.weight], [model.linear.bias], lr=0.05, momentum=0.9, l2=1e-3)
+    step = GraphedTrainStep(model, x, y, fused_cross_entropy, opt, warmup=1)
+    for _ in range(3):
+        step(x, y)
+    for a, p in zip(got[0], model.parameters()):
+        ref = p.detach().float().cpu()
+        assert float((a - ref).abs().max()) <= 3e-2 * float(ref.abs().max()), "ranks vs single process"
