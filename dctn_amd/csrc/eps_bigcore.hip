@@ -389,17 +389,25 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
           const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
           if (R < p.rows) {
             const float g = acc[nt][v];
-            // prefix products on the fly, suffix by recomputation (nf <= 8)
-            float pre_p = 1.f;
-            for (int d = 0; d < nf; ++d) {
-              const int dg = (R >> ((nf - 1 - d) * p.LQ)) & (p.Q - 1);
-              float suf = 1.f;
-              for (int d2 = d + 1; d2 < nf; ++d2) {
-                const int dg2 = (R >> ((nf - 1 - d2) * p.LQ)) & (p.Q - 1);
-                suf *= xs[((p.rhalf_first + d2) * p.Q + dg2) * BC_WPB + wl];
-              }
-              gcol[(d * p.Q + dg) * gstride] += g * pre_p * suf;
-              pre_p *= xs[((p.rhalf_first + d) * p.Q + dg) * BC_WPB + wl];
+            // leave-one-out products from one read per factor: suffix products stored, prefix running
+            // (nf <= BC_MAXD; absent digits read the ones row, so every loop bound is compile time)
+            float xv[BC_MAXD], suf[BC_MAXD + 1];
+            int slot[BC_MAXD];
+#pragma unroll
+            for (int d = 0; d < BC_MAXD; ++d) {
+              const int sh = d < nf ? (nf - 1 - d) * p.LQ : 0;
+              const int dg = (R >> sh) & (p.Q - 1);
+              slot[d] = d * p.Q + dg;
+              xv[d] = xs[(d < nf ? (p.rhalf_first + d) * p.Q + dg : NQ) * BC_WPB + wl];
+            }
+            suf[BC_MAXD] = 1.f;
+#pragma unroll
+            for (int d = BC_MAXD - 1; d >= 0; --d) suf[d] = suf[d + 1] * xv[d];
+            float pre_p = g;
+#pragma unroll
+            for (int d = 0; d < BC_MAXD; ++d) {
+              if (d < nf) gcol[slot[d] * gstride] += pre_p * suf[d + 1];
+              pre_p *= xv[d];
             }
           }
         }
