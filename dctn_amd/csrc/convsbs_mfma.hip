@@ -29,7 +29,7 @@ struct SbsMP {
   long long st_off[SBSM_MAXC + 1];  // backward: element offsets of the stored forward states
   float* dcore[SBSM_MAXC];    // backward: global dCore (zero-initialised by the caller)
   int first_off, last_off;    // float offsets of the first / last core tables in LDS
-  int fs_off;                 // float offset of the per-wave feature slices (4 waves x n*4*64)
+  int fs_off;                 // float offset of the per-wave feature slices (4 waves x n*4*32)
   unsigned char digit[4][4];  // digit[qq][ch]: feature index of channel ch in the flat index qq (host-filled)
   const float* core[SBSM_MAXC];
 };
@@ -71,7 +71,7 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 
 // All feature products of a window (every core of the string) at once: the pixel loads of up to 8
 // cores are issued back to back (one memory round trip per chunk instead of one per core), the
-// products go to the wave's LDS slice fs[(c*4 + qq)*64 + lane] and are read back per core.
+// products go to the wave's LDS slice fs[(c*4 + qq)*32 + window] and are read back per core.
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
@@ -99,7 +99,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
             const float xs = dg == 0 ? raw[cc][ch][0] : dg == 1 ? raw[cc][ch][1] : dg == 2 ? raw[cc][ch][2] : raw[cc][ch][3];
             pr *= ch < p.C ? xs : 1.f;
           }
-          fs[((c0 + cc) * 4 + qq) * 64 + lane] = pr;
+          fs[((c0 + cc) * 4 + qq) * 32 + (lane & 31)] = pr;   // both lane halves hold the same window
         }
       }
     }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
 }
 __device__ __forceinline__ void load_features(const float* fs, int c, int lane, float (&f)[4]) {
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq) f[qq] = fs[(c * 4 + qq) * 64 + lane];
+  for (int qq = 0; qq < 4; ++qq) f[qq] = fs[(c * 4 + qq) * 32 + (lane & 31)];
 }
 
 // Pack the cores into LDS.  Middle core c, output o, tile t, k-step s:
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     const int rem = (int)(ww - b * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     float f[4];
-    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 256;
+    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 128;
     stage_features(x, p, b, ho, wo, valid, fs, lane);
     // ---- first core: v[0][s] = sum_qq core0[r' = 2s + h][qq] * f[qq]
     float v0[SR], v1[SR];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     const float dy0 = valid ? dY[w * p.Otot] : 0.f;
     const float dy1 = (valid && p.Otot > 1) ? dY[w * p.Otot + 1] : 0.f;
     float f[4];
-    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 256;
+    float* fs = lds + p.fs_off + (tid >> 6) * p.n * 128;
     stage_features(x, p, b, ho, wo, valid, fs, lane);
 
     auto write_dx = [&](int c, const float (&df)[4]) {
@@ -562,7 +562,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   p.first_off = off; off += R * 4;
   p.last_off = off; off += R * 4;
-  p.fs_off = off; off += 4 * n * 256;
+  p.fs_off = off; off += 4 * n * 128;
   lds_floats = off;
   return DCTN_OK;
 }
