@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default 1024 for cfg2, 128 for cfg3)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch samples per GPU whatever N; strong: --batch is the GLOBAL batch, split over the N GPUs")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + "
@@ -273,6 +275,8 @@ def main():
     torch.cuda.set_device(dev)
     specs, image_size, q0, dtype = WORKLOADS[args.workload]
     batch = args.batch or (1024 if args.workload.startswith("cfg2") else 128)
+    if args.scaling == "strong":
+        batch = max(1, batch // world)
 
     torch.manual_seed(0)
     model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
@@ -342,7 +346,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": {torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
         "data": "synthetic",
