@@ -212,3 +212,30 @@ def test_eps_bigcore_exact_out_size(C, B, H, W, Q, K, O):
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
     check(cd.grad, dcore, torch.float32, "dCore")
     check(xd.grad, dx, torch.float32, "dX")
+
+
+@pytest.mark.parametrize("Wn,L", [(7, 3), (33, 5), (20, 6), (9, 10), (5, 16), (4, 17), (257, 9)])
+def test_logmatmulexp_fold16_all_chain_lengths(Wn, L):
+    """D = 16 float32 fold: every template bound of the factored backward (L <= 5, <= 9, <= 16), the
+    exact recomputing kernel beyond 16, and windows flagged for the exact path in the middle of a batch."""
+    torch.manual_seed(Wn * 31 + L)
+    m = torch.randn(Wn, L, 16, 16) * 1.5
+    if Wn > 4:
+        m[2] *= 40.0                                  # range far beyond what the factorisation accepts
+        m[Wn - 1, L // 2, 3, :] = -float("inf")       # a -inf row in one factor
+    md = m.to(DEV).requires_grad_(True)
+    y = logmatmulexp_fold(md)
+    want = R.logmatmulexp_fold_batched(m.double())
+    yc = y.detach().cpu().double()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(yc), fin)
+    assert float(((yc[fin] - want[fin]).abs() / (1.0 + want[fin].abs())).max()) < 5e-5
+    dy = torch.randn(Wn, 16, 16)
+    y.backward(dy.to(DEV))
+    assert ("mfma16" in dctn_amd.last_kernel()) == (L <= 16)
+    (g,) = R.grads(R.logmatmulexp_fold_batched, [m.double()], dy.double())
+    got = md.grad.cpu().double()
+    assert torch.isfinite(got).all()
+    for w in range(Wn):
+        scale = float(g[w].abs().max().clamp_min(1.0))
+        assert float((got[w] - g[w]).abs().max()) < 3e-4 * scale, w
