@@ -82,14 +82,14 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main):
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.out, self.loss, self.reg = fwd_bwd()
             if not split:
                 optimizer.step()
         self.g_opt = None
         if split:
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
                 optimizer.step()
 
     def __call__(self, x: Tensor, y: Tensor) -> Dict[str, Tensor]:
