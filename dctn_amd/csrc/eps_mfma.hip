@@ -414,6 +414,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
   static_assert(TOT % 256 == 0, "core staging assumes a multiple of 256 elements");
   __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
   const int tid = threadIdx.x, lane = tid & 63;
+  // the first sample's window loads go out before the core is staged: both memory round trips overlap
+  const WaveJob job = wave_job(p, 4, (int)sizeof(S));
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
+  RawWindow<S, N, XVEC, ROWS> raw;
+  if (job.b0 < job.b1) issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, raw);
   {
     S tmp[PER];
 #pragma unroll
@@ -438,10 +443,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
-  const WaveJob job = wave_job(p, 4, (int)sizeof(S));
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
-  RawWindow<S, N, XVEC, ROWS> raw;
-  if (job.b0 < job.b1) issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, raw);
   for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, xv);
