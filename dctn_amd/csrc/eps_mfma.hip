@@ -27,14 +27,19 @@
 // weight) is loaded once per wave.
 //
 // Backward dCore[a,b,o] = sum_w P0[w,a] P1[w,b] dY[w,o]  reduces over windows, so windows must
-// become the MFMA K index while lanes own windows.  The transpose is done ON the matrix core:
-// multiplying the lane-owns-window fragment (as A operand) by an identity B operand returns the
-// tile with the feature index on the lane and 16 windows in the accumulator registers — exactly
-// the layout the next MFMA consumes as an operand summing over windows (no LDS round trip).
+// become the MFMA K index while lanes own windows: both operands of
 //     Z[w,(b,o)] = P1[w,b] dY[w,o];   dCoreT[(b,o), a] += Zt (A operand) x P0t (B operand)
-// Per-wave partial sums stay in registers over all of the wave's windows, are reduced over the
+// need a transpose.  For the 3x3 shape (A = 32, <= 64 rows (b,o)) every lane writes the bf16 row of
+// its own window into a per-wave LDS tile and the operand fragments come back through the hardware
+// transpose read ds_read_b64_tr_b16 (swizzled 64-byte rows: conflict-free both ways).  The wider
+// shapes transpose ON the matrix core instead: multiplying the lane-owns-window fragment (as A
+// operand) by an identity B operand returns the tile with the feature index on the lane and 16
+// windows in the accumulator registers - the layout the next MFMA consumes as an operand summing over
+// windows (more MFMAs, conversions and lane swaps, but no LDS tiles).
+// Per-wave partial sums stay in registers over all of the wave's samples, are reduced over the
 // workgroup's waves in LDS, written to a workspace and summed by a second small kernel
-// (deterministic: no float atomics).
+// (deterministic: no float atomics).  With the classifier head fused (HEADC > 0) the same pass forms
+// dY from dLogits and the head weight and accumulates the head's own gradients.
 #include "common.h"
 
 #include <cstdlib>
