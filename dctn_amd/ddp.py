@@ -79,6 +79,19 @@ class FlatGradAllReducer:
         backend = dist.get_backend() if dist.is_initialized() else ""
         self.use_avg = average and backend == "nccl"
 
+    def _reduce(self, buf: Tensor) -> None:
+        """In-place sum / mean of ``buf`` over the ranks.  RCCL's AVG is one launch; if the backend or
+        the dtype refuses it (raised synchronously at enqueue), fall back to SUM + divide for good."""
+        if self.use_avg:
+            try:
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+                return
+            except (RuntimeError, ValueError):
+                self.use_avg = False
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if self.average:
+            buf.div_(self.world)
+
     def _contiguous_flat(self, grads) -> Optional[Tensor]:
         """One 1-D tensor aliasing all gradients when they already sit back to back, in parameter
         order, in a single storage (the fused EPS + head backward allocates them like that)."""
@@ -104,12 +117,7 @@ class FlatGradAllReducer:
         grads = [p.grad for p in self.params]
         flat = self._contiguous_flat(grads)
         if flat is not None:   # the backward already laid the gradients out as one bucket: one launch
-            if self.use_avg:
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                if self.average:
-                    flat.div_(self.world)
+            self._reduce(flat)
             return
         if self.same_dtype and all(g is not None for g in grads):
             torch.cat([g.reshape(-1) for g in grads], out=self.bucket)
@@ -119,12 +127,7 @@ class FlatGradAllReducer:
                     v.zero_()
                 else:
                     v.copy_(g)
-        if self.use_avg:
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
-            if self.average:
-                self.bucket.div_(self.world)
+        self._reduce(self.bucket)
         if self.same_dtype and all(g is not None for g in grads):
             torch._foreach_copy_(grads, self.views)
         else:
