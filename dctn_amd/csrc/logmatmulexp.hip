@@ -54,7 +54,7 @@ template <typename S, typename A>
 __global__ void lme_bwd_dA_k(const S* __restrict__ lA, const S* __restrict__ lB,
                              const S* __restrict__ out, const S* __restrict__ dO,
                              S* __restrict__ dA, long long batch, int T, int R, int I,
-                             long long sA, long long sB) {
+                             long long sA, long long sB, const int* __restrict__ only_batch) {
   const long long nbA = sA == 0 ? 1 : batch;
   const long long total = nbA * T * R;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -63,6 +63,7 @@ __global__ void lme_bwd_dA_k(const S* __restrict__ lA, const S* __restrict__ lB,
     const long long t2 = idx / R;
     const int th = (int)(t2 % T);
     const long long bA = t2 / T;
+    if (only_batch && !only_batch[bA]) continue;   // (never combined with a broadcast operand)
     const long long b0 = sA == 0 ? 0 : bA, b1 = sA == 0 ? batch : bA + 1;
     A acc = A(0);
     for (long long b = b0; b < b1; ++b) {
@@ -80,7 +81,7 @@ template <typename S, typename A>
 __global__ void lme_bwd_dB_k(const S* __restrict__ lA, const S* __restrict__ lB,
                              const S* __restrict__ out, const S* __restrict__ dO,
                              S* __restrict__ dB, long long batch, int T, int R, int I,
-                             long long sA, long long sB) {
+                             long long sA, long long sB, const int* __restrict__ only_batch) {
   const long long nbB = sB == 0 ? 1 : batch;
   const long long total = nbB * R * I;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -89,6 +90,7 @@ __global__ void lme_bwd_dB_k(const S* __restrict__ lA, const S* __restrict__ lB,
     const long long t2 = idx / I;
     const int r = (int)(t2 % R);
     const long long bB = t2 / R;
+    if (only_batch && !only_batch[bB]) continue;
     const long long b0 = sB == 0 ? 0 : bB, b1 = sB == 0 ? batch : bB + 1;
     A acc = A(0);
     for (long long b = b0; b < b1; ++b) {
@@ -467,22 +469,23 @@ int fwd_launch(const void* lA, const void* lB, void* out, long long batch, int T
 
 template <typename S, typename A>
 int bwd_launch(const void* lA, const void* lB, const void* out, const void* dO, void* dA, void* dB,
-               long long batch, int T, int R, int I, long long sA, long long sB, hipStream_t st) {
+               long long batch, int T, int R, int I, long long sA, long long sB, hipStream_t st,
+               const int* only_batch = nullptr) {
   if (dA) {
     const long long total = (sA == 0 ? 1 : batch) * T * R;
     hipLaunchKernelGGL((lme_bwd_dA_k<S, A>), dim3(grid_for(total, 256)), dim3(256), 0, st,
                        (const S*)lA, (const S*)lB, (const S*)out, (const S*)dO, (S*)dA, batch, T, R,
-                       I, sA, sB);
+                       I, sA, sB, only_batch);
     DCTN_CHECK_LAUNCH();
   }
   if (dB) {
     const long long total = (sB == 0 ? 1 : batch) * R * I;
     hipLaunchKernelGGL((lme_bwd_dB_k<S, A>), dim3(grid_for(total, 256)), dim3(256), 0, st,
                        (const S*)lA, (const S*)lB, (const S*)out, (const S*)dO, (S*)dB, batch, T, R,
-                       I, sA, sB);
+                       I, sA, sB, only_batch);
     DCTN_CHECK_LAUNCH();
   }
-  dctn_set_last_kernel("logmatmulexp_bwd");
+  if (!only_batch) dctn_set_last_kernel("logmatmulexp_bwd");
   return DCTN_OK;
 }
 
@@ -514,14 +517,33 @@ int fold_bwd_launch(const void* mats, const void* dOut, void* dMats, long long W
 
 }  // namespace
 
+// logmatmulexp_gemm.hip
+bool lme_gemm_wanted(long long batch, int T, int R, int I, long long sA, long long sB, int dtype);
+size_t lme_gemm_workspace(long long batch, int T, int R, int I);
+int lme_gemm_fwd(const void* A, const void* B, void* out, void* ws, long long batch, int T, int R, int I,
+                 long long sA, long long sB, hipStream_t st);
+int lme_gemm_bwd(const void* A, const void* B, const void* out, const void* dO, void* dA, void* dB, void* ws,
+                 long long batch, int T, int R, int I, long long sA, long long sB, hipStream_t st,
+                 const int** unsafe_out);
+
 extern "C" {
 
-int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out, int64_t batch, int Theta,
-                          int R, int I, int64_t strideA_batch, int64_t strideB_batch, int dtype,
-                          void* stream) {
+size_t dctn_logmatmulexp_workspace_bytes(int64_t batch, int Theta, int R, int I, int64_t strideA_batch,
+                                         int64_t strideB_batch, int dtype) {
+  if (batch < 1 || Theta < 1 || R < 1 || I < 1) return 0;
+  if (!lme_gemm_wanted(batch, Theta, R, I, strideA_batch, strideB_batch, dtype)) return 0;
+  return lme_gemm_workspace(batch, Theta, R, I);
+}
+
+int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out, void* workspace,
+                          size_t workspace_bytes, int64_t batch, int Theta, int R, int I,
+                          int64_t strideA_batch, int64_t strideB_batch, int dtype, void* stream) {
   if (!logA || !logB || !out) return DCTN_ERR_NULL;
   if (batch < 1 || Theta < 1 || R < 1 || I < 1) return DCTN_ERR_BAD_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && lme_gemm_wanted(batch, Theta, R, I, strideA_batch, strideB_batch, dtype) &&
+      workspace_bytes >= lme_gemm_workspace(batch, Theta, R, I))
+    return lme_gemm_fwd(logA, logB, out, workspace, batch, Theta, R, I, strideA_batch, strideB_batch, st);
   switch (dtype) {
     case DCTN_F32:
       return fwd_launch<float, float>(logA, logB, out, batch, Theta, R, I, strideA_batch, strideB_batch, st);
@@ -534,11 +556,22 @@ int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out, int64_t
 }
 
 int dctn_logmatmulexp_bwd(const void* logA, const void* logB, const void* out, const void* dOut,
-                          void* dA, void* dB, int64_t batch, int Theta, int R, int I,
-                          int64_t strideA_batch, int64_t strideB_batch, int dtype, void* stream) {
+                          void* dA, void* dB, void* workspace, size_t workspace_bytes, int64_t batch,
+                          int Theta, int R, int I, int64_t strideA_batch, int64_t strideB_batch, int dtype,
+                          void* stream) {
   if (!logA || !logB || !out || !dOut) return DCTN_ERR_NULL;
   if (batch < 1 || Theta < 1 || R < 1 || I < 1) return DCTN_ERR_BAD_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && lme_gemm_wanted(batch, Theta, R, I, strideA_batch, strideB_batch, dtype) &&
+      workspace_bytes >= lme_gemm_workspace(batch, Theta, R, I)) {
+    const int* unsafe = nullptr;
+    const int rc = lme_gemm_bwd(logA, logB, out, dOut, dA, dB, workspace, batch, Theta, R, I, strideA_batch,
+                                strideB_batch, st, &unsafe);
+    if (rc != DCTN_OK) return rc;
+    // batch elements whose factored form would overflow: exact kernels, those elements only
+    return bwd_launch<float, float>(logA, logB, out, dOut, dA, dB, batch, Theta, R, I, strideA_batch,
+                                    strideB_batch, st, unsafe);
+  }
   switch (dtype) {
     case DCTN_F32:
       return bwd_launch<float, float>(logA, logB, out, dOut, dA, dB, batch, Theta, R, I, strideA_batch, strideB_batch, st);

@@ -17,13 +17,14 @@ import torch.distributed as dist
 from torch import Tensor
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False) -> tuple:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and creates the
-    process group.  Returns (rank, local_rank, world_size)."""
+    process group (for one rank only when `single_rank_group`: a rehearsal of the RCCL path on a
+    one-GPU machine).  Returns (rank, local_rank, world_size)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -61,9 +62,11 @@ class FlatGradAllReducer:
     dtype (no conversion kernels); mixed dtypes go through an fp32 bucket.
     """
 
-    def __init__(self, params: Iterable[Tensor], average: bool = True):
+    def __init__(self, params: Iterable[Tensor], average: bool = True, skip_single_rank: bool = True):
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         self.average = average
+        self.skip_single_rank = skip_single_rank   # False: issue the collective even for one rank (rehearsal)
+        self._seen_grads: List[Optional[Tensor]] = []
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         numel = sum(p.numel() for p in self.params)
         ref = self.params[0]
@@ -112,10 +115,15 @@ class FlatGradAllReducer:
 
     @torch.no_grad()
     def __call__(self) -> None:
-        if self.world == 1:
+        if self.world == 1 and self.skip_single_rank:
             return
         grads = [p.grad for p in self.params]
-        flat = self._contiguous_flat(grads)
+        # a replayed HIP graph leaves the very same gradient tensors in place: skip the layout checks
+        if len(grads) == len(self._seen_grads) and all(a is b for a, b in zip(grads, self._seen_grads)):
+            flat = self._flat
+        else:
+            flat = self._contiguous_flat(grads)
+            self._seen_grads = grads if flat is not None else []
         if flat is not None:   # the backward already laid the gradients out as one bucket: one launch
             self._reduce(flat)
             return

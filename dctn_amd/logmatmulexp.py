@@ -14,6 +14,14 @@ from torch import Tensor
 from . import _lib as L
 
 
+def _workspace(dev, nb, T, R, I, sA, sB, code):
+    """Scratch for the factored (exp -> MFMA GEMM -> log) kernels; (None, 0) where the direct kernels run."""
+    nbytes = L.lib().dctn_logmatmulexp_workspace_bytes(nb, T, R, I, sA, sB, code)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
 class _LME(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_A: Tensor, log_B: Tensor) -> Tensor:
@@ -27,8 +35,10 @@ class _LME(torch.autograd.Function):
         sA = 0 if (a.shape[0] == 1 and nb > 1) else T * R
         sB = 0 if (b.shape[0] == 1 and nb > 1) else R * I
         out = torch.empty((nb, T, I), dtype=a.dtype, device=dev)
+        ws, nbytes = _workspace(dev, nb, T, R, I, sA, sB, L.dtype_code(a))
         L.check(
-            L.lib().dctn_logmatmulexp_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), nb, T, R, I, sA, sB,
+            L.lib().dctn_logmatmulexp_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                          None if ws is None else ws.data_ptr(), nbytes, nb, T, R, I, sA, sB,
                                           L.dtype_code(a), L.stream_ptr(dev)),
             "logmatmulexp forward",
         )
@@ -44,11 +54,12 @@ class _LME(torch.autograd.Function):
         g = d_out.contiguous()
         dA = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         dB = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        ws, nbytes = _workspace(dev, nb, T, R, I, sA, sB, L.dtype_code(a))
         L.check(
             L.lib().dctn_logmatmulexp_bwd(
                 a.data_ptr(), b.data_ptr(), out.data_ptr(), g.data_ptr(),
                 None if dA is None else dA.data_ptr(), None if dB is None else dB.data_ptr(),
-                nb, T, R, I, sA, sB, L.dtype_code(a), L.stream_ptr(dev)),
+                None if ws is None else ws.data_ptr(), nbytes, nb, T, R, I, sA, sB, L.dtype_code(a), L.stream_ptr(dev)),
             "logmatmulexp backward",
         )
         return dA, dB

@@ -136,7 +136,15 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
  *   batched: logA (batch, Theta, R), logB (batch, R, I), out (batch, Theta, I), all contiguous;
  *   the reference's strictly 2-D call is batch == 1.  stride_*_batch in elements (0 = broadcast).
  * ------------------------------------------------------------------------------------------ */
+/* Products that are not tiny run as "exp -> GEMM on the matrix cores -> log" (one exp per input
+ * element, float32 MFMA) and need scratch: `workspace` of dctn_logmatmulexp_workspace_bytes() bytes
+ * (0 = this shape uses the direct kernels; workspace may then be NULL).  With workspace == NULL the
+ * direct kernels are always used.  Results keep torch.logsumexp semantics either way: output tiles
+ * / batch elements where the factored form is not safe are recomputed by the direct kernels. */
+size_t dctn_logmatmulexp_workspace_bytes(int64_t batch, int Theta, int R, int I,
+                                         int64_t strideA_batch, int64_t strideB_batch, int dtype);
 int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out,
+                          void* workspace, size_t workspace_bytes,
                           int64_t batch, int Theta, int R, int I,
                           int64_t strideA_batch, int64_t strideB_batch,
                           int dtype, void* stream);
@@ -144,6 +152,7 @@ int dctn_logmatmulexp_fwd(const void* logA, const void* logB, void* out,
  * gradient is summed over the batch. */
 int dctn_logmatmulexp_bwd(const void* logA, const void* logB, const void* out, const void* dOut,
                           void* dA, void* dB,
+                          void* workspace, size_t workspace_bytes,
                           int64_t batch, int Theta, int R, int I,
                           int64_t strideA_batch, int64_t strideB_batch,
                           int dtype, void* stream);

@@ -512,6 +512,58 @@ def test_logmatmulexp_fold16_factored_mfma_and_exact_fallback():
         assert float((got[wdw] - gm[wdw]).abs().max() / scale) < 2e-4, wdw
 
 
+@pytest.mark.parametrize("nb,T,Rr,I", [(1, 256, 256, 256), (3, 100, 70, 130), (2, 64, 16, 64), (5, 33, 40, 65)])
+def test_logmatmulexp_factored_gemm_and_exact_fallback(nb, T, Rr, I):
+    """float32 products that are not tiny: exp -> MFMA GEMM -> log.  Ragged tiles, -inf rows / columns,
+    dynamic ranges the factorisation cannot hold (output tiles / batch elements redone by the direct
+    kernels) — torch.logsumexp semantics throughout."""
+    from dctn_amd.logmatmulexp import logmatmulexp_batched
+    torch.manual_seed(nb * 1000 + T)
+    a, b = torch.randn(nb, T, Rr) * 3, torch.randn(nb, Rr, I) * 3
+    a[0, 5, 3] = -float("inf")              # isolated -inf entries
+    b[0, 4, 7] = -float("inf")
+    if nb > 1:
+        a[1, :, 0] += 300.0                  # one dominant term per row, far beyond the factored range
+        b[1, 0, :] -= 300.0
+        b[1, 1, ::2] += 250.0
+    a64, b64 = a.double(), b.double()
+
+    def reference(a64, b64):
+        return torch.stack([R.logmatmulexp(a64[n], b64[n]) for n in range(nb)])
+
+    # forward, with a -inf row and a -inf column on top (-inf outputs; their gradient is NaN in the
+    # reference as well, so the backward comparison below runs without them)
+    af, bf = a.clone(), b.clone()
+    af[0, 1, :] = -float("inf")
+    bf[0, :, 2] = -float("inf")
+    yf = logmatmulexp_batched(af.to(DEV), bf.to(DEV)).cpu().double()
+    assert dctn_amd.last_kernel() == "logmatmulexp_fwd_mfma_gemm"
+    wf = reference(af.double(), bf.double())
+    assert torch.equal(torch.isinf(yf), torch.isinf(wf)) and not torch.isnan(yf).any()
+    fin = torch.isfinite(wf)
+    assert float(((yf[fin] - wf[fin]).abs() / (1.0 + wf[fin].abs())).max()) < 2e-6
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = logmatmulexp_batched(ad, bd)
+    want = reference(a64, b64)
+    assert float(((y.detach().cpu().double() - want).abs() / (1.0 + want.abs())).max()) < 2e-6
+    dy = torch.randn(nb, T, I)
+    y.backward(dy.to(DEV))
+    assert dctn_amd.last_kernel() == "logmatmulexp_bwd_mfma_gemm"
+    # float64 gradients from the closed form
+    wgt = torch.exp(a64.unsqueeze(3) + b64.unsqueeze(1) - want.unsqueeze(2)) * dy.double().unsqueeze(2)
+    ga, gb = wgt.sum(3), wgt.sum(1)
+    for name, got, ref in (("dA", ad.grad, ga), ("dB", bd.grad, gb)):
+        got = got.cpu().double()
+        assert torch.isfinite(got).all(), name
+        for n in range(nb):
+            assert float((got[n] - ref[n]).abs().max()) < 2e-5 * float(ref[n].abs().max().clamp_min(1.0)), (name, n)
+    # NaN propagates like logsumexp's: only the outputs that see it
+    a2 = a.clone()
+    a2[0, 9, 4] = float("nan")
+    y2 = logmatmulexp_batched(a2.to(DEV), bd.detach()).cpu()
+    assert torch.isnan(y2[0, 9]).all() and int(torch.isnan(y2).sum()) == I
+
+
 # ------------------------------------------------------------------ window statistics (SURVEY 8(f) f3)
 def test_window_statistics_kernel_against_reference_fixture_and_oracle():
     """`dctn_window_stats` (one pass over the images, no window tensor) against the numbers the

@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu():
     assert lib.dctn_eps_fwd(8, s, 8, 8, None, 0, 1, 1, 2, 2, 2, 3, 4, 0, 0, None) == _lib.ERR_BAD_SHAPE  # H < K
     assert lib.dctn_eps_fwd(8, s, 8, 8, None, 0, 1, 1, 4, 4, 2, 3, 4, 7, 0, None) == _lib.ERR_BAD_DTYPE
     assert lib.dctn_eps_bwd_workspace_bytes(1, 2, 8, 8, 2, 3, 4, 0, 0, 1, 1) > 0
-    assert lib.dctn_logmatmulexp_fwd(8, 8, 8, 1, 0, 3, 3, 0, 0, 0, None) == _lib.ERR_BAD_SHAPE
+    assert lib.dctn_logmatmulexp_fwd(8, 8, 8, None, 0, 1, 0, 3, 3, 0, 0, 0, None) == _lib.ERR_BAD_SHAPE
 
 
 def test_product_path_has_no_cpu_fallback():
