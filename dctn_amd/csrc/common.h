@@ -73,6 +73,15 @@ size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision
 int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
                        size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
 
+// float64 two-halves path on v_mfma_f64_16x16x4_f64 — eps_f64.hip
+bool eps_f64_wanted(const EpsP& p, int dtype);
+size_t eps_fwd_f64_workspace(const EpsP& p, int dtype);
+int eps_fwd_f64(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
+                hipStream_t st);
+size_t eps_bwd_f64_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore);
+int eps_bwd_f64(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
+                const EpsP& p, int dtype, hipStream_t st);
+
 // MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
 // is outside the family so that the dispatcher can take the generic kernels.
 int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int dtype,

@@ -43,6 +43,38 @@ def rel_err(got, want):
     return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
 
 
+def test_cfg1_full_batch_64_f64():
+    """BASELINE configs[0]: the reference's own EPS micro-benchmark shape (small_experiments/eps2d_benchmark/
+    benchmark.py:45-64): B = 64, 28x28, K = 4, Q = 2, O = 2, float64, core and input both with gradients."""
+    torch.manual_seed(1)
+    x = mnist_like(64, 28, torch.float64, 11)
+    core = (torch.randn(*(2,) * 16, 2, dtype=torch.float64) * 2.0 ** -4).to(DEV)
+    y = eps(core, x)
+    assert y.shape == (64, 25, 25, 2) and dctn_amd.last_kernel() == "eps_fwd_mfma_f64_halves"
+    # batch independence (the windows of a sample never meet those of another one; GEMM tiles do change)
+    for lo, hi in ((0, 1), (5, 40), (63, 64)):
+        assert rel_err(eps(core, x[:, lo:hi]), y[lo:hi].cpu()) < 1e-13
+    assert torch.equal(eps(core * 4, x), y * 4)                      # exact homogeneity (powers of two)
+    idx = [0, 31, 63]
+    want = R.eps_4step(core.cpu(), x[:, idx].cpu())
+    assert rel_err(y[idx], want) < 1e-12
+    # gradients: oracle on a slice of the batch, additivity of dCore over batch slices, dX per sample
+    dy = torch.randn(64, 25, 25, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(12)).to(DEV)
+
+    def grads(lo, hi):
+        c, xs = core.clone().requires_grad_(True), x[:, lo:hi].clone().requires_grad_(True)
+        eps(c, xs).backward(dy[lo:hi])
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves"
+        return c.grad.cpu(), xs.grad.cpu()
+
+    dc_whole, dx_whole = grads(0, 64)
+    parts = [grads(0, 3), grads(3, 40), grads(40, 64)]
+    assert rel_err(sum(p[0] for p in parts), dc_whole) < 1e-12
+    assert rel_err(torch.cat([p[1] for p in parts], dim=1), dx_whole) < 1e-12
+    gc, gx = R.grads(R.eps_4step, [core.cpu(), x[:, 0:3].cpu()], dy[0:3].cpu())
+    assert rel_err(parts[0][0], gc) < 1e-11 and rel_err(parts[0][1], gx) < 1e-11
+
+
 def test_cfg2_full_batch_1024_bf16():
     """BASELINE configs[1]: EPSesPlusLinear(((3,4),)), x (1,1024,28,28,2) bf16 — the bench workload."""
     torch.manual_seed(2)

@@ -121,6 +121,43 @@ def test_convsbs_random(case):
         check(c.grad, gc, dtype, f"dCore{i}")
 
 
+# (C, K, Q, O, B, H, W, strided): float64 on the f64 matrix cores (two-halves GEMM path): power-of-two and odd Q,
+# odd numbers of factors (n0 != n1), O that does not divide the tile, ragged window counts, strided input
+F64_CASES = [(1, 3, 2, 4, 5, 9, 8, False), (2, 2, 3, 3, 3, 7, 9, True), (1, 2, 8, 5, 7, 6, 6, False),
+             (1, 4, 2, 2, 2, 10, 9, False), (3, 2, 2, 6, 3, 8, 5, True), (1, 3, 3, 1, 2, 8, 9, False)]
+
+
+@pytest.mark.parametrize("case", F64_CASES, ids=lambda c: "C%dK%dQ%dO%dB%d_%dx%d%s" % (c[:7] + ("_strided" if c[7] else "",)))
+def test_eps_f64_matrix_core_path(case):
+    C, K, Q, O, B, H, W, strided = case
+    torch.manual_seed(sum(case[:7]))
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q, dtype=torch.float64)
+    core = torch.randn(*(Q,) * N, O, dtype=torch.float64) * Q ** (-N / 4)
+    xd = x.to(DEV)
+    if strided:
+        xd = xd.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    xd = xd.requires_grad_(True)
+    cd = core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f64_halves"
+    want = R.eps_4step(core, x)
+    check(y, want, torch.float64, "forward")
+    dy = torch.randn(*want.shape, dtype=torch.float64)
+    y.backward(dy.to(DEV))
+    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves"
+    dcore, dx = R.grads(R.eps_4step, [core, x], dy)
+    check(xd.grad, dx, torch.float64, "dX")
+    check(cd.grad, dcore, torch.float64, "dCore")
+    # each gradient alone (other buffers absent)
+    x3 = xd.detach().clone().requires_grad_(True)
+    eps(cd.detach(), x3).backward(dy.to(DEV))
+    check(x3.grad, dx, torch.float64, "dX alone")
+    c3 = cd.detach().clone().requires_grad_(True)
+    eps(c3, xd.detach()).backward(dy.to(DEV))
+    check(c3.grad, dcore, torch.float64, "dCore alone")
+
+
 @pytest.mark.parametrize("T,Rr,I,dtype", [(1, 1, 1, torch.float64), (7, 3, 5, torch.float32), (33, 65, 17, torch.float64),
                                           (256, 256, 256, torch.float32), (5, 128, 3, torch.float32)])
 def test_logmatmulexp_random(T, Rr, I, dtype):

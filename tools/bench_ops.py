@@ -138,6 +138,17 @@ def bench_lme(cpu):
                       "fwd_bwd_ms": round(fb * 1e3, 3),
                       "reference_published_ms": {"fwd": 5.51, "fwd_bwd": 11.08, "hardware": "unnamed CUDA GPU"}}),
           flush=True)
+    # the other rows the reference publishes (results.json:372-381 and :822-831)
+    for dim, dt, pub in ((128, torch.float32, {"fwd": 0.815, "fwd_bwd": 1.676}), (280, torch.float64, {"fwd_bwd": 41.1})):
+        mats = [torch.randn(dim, dim, device=DEV, dtype=dt, requires_grad=True) for _ in range(6)]
+        y = functools.reduce(logmatmulexp, mats)
+        dy = torch.randn_like(y)
+        f = time_gpu(lambda: functools.reduce(logmatmulexp, [t.detach() for t in mats]), 20)
+        fb = time_gpu(lambda: functools.reduce(logmatmulexp, mats).backward(dy), 10)
+        print(json.dumps({"op": f"reduce(logmatmulexp, 6x({dim}x{dim})) {str(dt).split('.')[-1]}",
+                          "fwd_ms": round(f * 1e3, 3), "fwd_bwd_ms": round(fb * 1e3, 3),
+                          "fwd_kernel": dctn_amd.last_kernel(),
+                          "reference_published_ms": dict(pub, hardware="unnamed CUDA GPU")}), flush=True)
 
 
 def bench_eps(cpu):
