@@ -18,12 +18,13 @@
 // tools/mfma64probe.hip): register v of lane l is D[4 v + l / 16][l % 16].
 #include "common.h"
 
+#include <type_traits>
+
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 
 namespace {
 
 constexpr int GT = 64, GK = 16;                 // tile, k chunk
-constexpr int AP = GK + 1, BP = GT + 1;         // padded LDS rows
 constexpr size_t CHUNK_BYTES = (size_t)1 << 30; // bound of the per-chunk buffers
 
 struct HalfP {
@@ -59,42 +60,52 @@ HalfP make_half(const EpsP& p) {
   return h;
 }
 
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------ P0 / P1 of a chunk of windows
+// one wave per window (4 per workgroup), the window's N x Q features in the wave's LDS
 template <int LOGQ>
 __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x, double* __restrict__ P0,
                                                     double* __restrict__ P1, HalfP h, long long w0, long long nw) {
-  extern __shared__ double xs[];   // [N][Q]
+  extern __shared__ double sm[];
   const EpsP& p = h.p;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* xs = sm + (size_t)wv * p.N * p.Q;   // [N][Q]
   const int hw = p.Ho * p.Wo;
-  for (long long wl = blockIdx.x; wl < nw; wl += gridDim.x) {
+  const int A = (int)h.A, E2 = (int)(h.A + h.Bn);
+  for (long long wl = (long long)blockIdx.x * 4 + wv; wl < nw; wl += (long long)gridDim.x * 4) {
     const long long w = w0 + wl;
     const long long b = w / hw;
     const int rem = (int)(w - b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    __syncthreads();
-    for (int e = threadIdx.x; e < p.N * p.Q; e += 256) {
+    wave_sync_lds();
+    for (int e = lane; e < p.N * p.Q; e += 64) {
       const int n = e / p.Q, q = e - n * p.Q;
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
       xs[e] = x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
-    __syncthreads();
-    for (long long e = threadIdx.x; e < h.A + h.Bn; e += 256) {
-      const bool second = e >= h.A;
-      long long t = second ? e - h.A : e;
+    wave_sync_lds();
+    for (int e = lane; e < E2; e += 64) {
+      const bool second = e >= A;
+      int t = second ? e - A : e;
       const int base = second ? h.n0 : 0, nd = second ? h.n1 : h.n0;
       double pr = 1.0;
       for (int d = nd - 1; d >= 0; --d) {
         int digit;
         if (LOGQ > 0) {
-          digit = (int)(t & ((1 << LOGQ) - 1));
+          digit = t & ((1 << LOGQ) - 1);
           t >>= LOGQ;
         } else {
-          digit = (int)(t % p.Q);
+          digit = t % p.Q;
           t /= p.Q;
         }
         pr *= xs[(base + d) * p.Q + digit];
       }
       if (second)
-        P1[wl * h.Bn + (e - h.A)] = pr;
+        P1[wl * h.Bn + (e - A)] = pr;
       else
         P0[wl * h.A + e] = pr;
     }
@@ -114,123 +125,203 @@ struct GemmD {
   const double* dy;
   long long Bn;
   int O;
+  int slices;             // k slices (set by gemm_launch)
 };
 
-template <int LA, int LB>
+// WTM MFMA tiles per wave along m (block tile 32 WTM x 64), KC = k chunk
+template <int LA, int LB, int WTM, int KC>
 __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag, const double* __restrict__ Bg,
                                                   double* __restrict__ Cg, GemmD g) {
-  __shared__ double As[GT * AP];
-  __shared__ double Bs[GK * BP];
+  constexpr int BM = 32 * WTM, BN = GT;
+  constexpr int APk = KC + 1, BPn = BN + 1;
+  constexpr int UA = BM * KC / 256, UB = BN * KC / 256;   // staged elements per thread
+  constexpr int LOGK = KC == 16 ? 4 : 5, LOGBM = BM == 64 ? 6 : 7;
+  __shared__ double As[BM * APk];
+  __shared__ double Bs[KC * BPn];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-  const long long kbeg = (long long)blockIdx.z * g.kslice;
+  // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2.  XCD x takes
+  // the contiguous tile range [x per, (x+1) per) with the n tile fastest, so the workgroups that share an A
+  // row block (and are resident together) hit the same L2 instead of fetching it 8 times from memory.
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int total = tiles_n * tiles_m * g.slices, per = (total + 7) / 8;
+  const int t = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;
+  if (t >= total) return;
+  const int bz = t / (tiles_n * tiles_m), trem = t - bz * tiles_n * tiles_m;
+  const int m0 = (trem / tiles_n) * BM, n0 = (trem % tiles_n) * BN;
+  const long long kbeg = (long long)bz * g.kslice;
   const long long kend = kbeg + g.kslice < g.K ? kbeg + g.kslice : g.K;
   constexpr bool AKF = LA != A_MFAST, BKF = LB == B_KFAST;
-  // element e = tid + 256 u of a 64 x 16 operand tile: k fastest: k = e & 15, x = e >> 4 (+16 u); x fastest: x = e & 63, k = e >> 6 (+4 u)
-  const int kf_k = tid & 15, kf_x = tid >> 4, xf_x = tid & 63, xf_k = tid >> 6;
-  double ra[4], rb[4], ra2[4], rb2[4];
-  // T operand on the B side: this thread's column n = (i1, o) is fixed
-  int bt_i1 = 0, bt_o = 0;
+  // element e = tid + 256 u of an X x KC operand tile: k fastest: k = e & (KC-1), x = e >> LOGK; x fastest: x = e & (X-1), k = e / X
+  const int kf_k = tid & (KC - 1), kf_x = tid >> LOGK;                     // x step 256 / KC
+  const int axf_x = tid & (BM - 1), axf_k = tid >> LOGBM;                  // k step 256 / BM
+  const int bxf_x = tid & (BN - 1), bxf_k = tid >> 6;                      // k step 4
+  constexpr int KFS = 256 / KC, AXS = 256 / BM;
+  double ra[UA], rb[UB], ra2[LA == A_T ? UA : 1], rb2[LB == B_T ? UB : 1];
+  // The k-invariant part of every load address is formed once per lane (rows / columns clamped into range:
+  // what the clamped rows produce lands in rows / columns of C that are never stored, so nothing is masked
+  // outside the last, partial k chunk); inside the loop the wave-uniform k0 term is all that changes.
+  long long aoff[UA], boff[UB];
+  long long aoff2[LA == A_T ? UA : 1];
+  long long boff2[LB == B_T ? UB : 1];
+  int bt_i1 = 0, bt_o = 0;   // T operand on the B side: this thread's column n = (i1, o) is fixed
   if (LB == B_T) {
-    const int n = min(n0 + xf_x, g.N - 1);
+    const int n = min(n0 + bxf_x, g.N - 1);
     bt_i1 = n / g.O;
     bt_o = n - bt_i1 * g.O;
   }
-  auto fetch = [&](long long k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (LA == A_KFAST) {
-        const long long m = min(m0 + kf_x + 16 * u, g.M - 1), k = min(k0 + kf_k, (long long)g.K - 1);
-        ra[u] = Ag[m * g.lda + k];
-      } else if (LA == A_MFAST) {
-        const long long m = min(m0 + xf_x, g.M - 1), k = min(k0 + xf_k + 4 * u, (long long)g.K - 1);
-        ra[u] = Ag[k * g.lda + m];
-      } else {   // T[m = w][k = (i1, o)]
-        const long long m = min(m0 + kf_x + 16 * u, g.M - 1);
-        const int k = (int)min(k0 + kf_k, (long long)g.K - 1);
-        const int i1 = k / g.O, o = k - i1 * g.O;
-        ra[u] = g.p1[m * g.Bn + i1];
-        ra2[u] = g.dy[m * g.O + o];
+  for (int u = 0; u < UA; ++u) {
+    if (LA == A_KFAST) {
+      aoff[u] = (long long)min(m0 + kf_x + KFS * u, g.M - 1) * g.lda + kf_k;            // + k0
+    } else if (LA == A_MFAST) {
+      aoff[u] = (long long)(axf_k + AXS * u) * g.lda + min(m0 + axf_x, g.M - 1);       // + k0 lda
+    } else {
+      const long long m = min(m0 + kf_x + KFS * u, g.M - 1);
+      aoff[u] = m * g.Bn;                                                               // + (k0 + kf_k) / O
+      aoff2[LA == A_T ? u : 0] = m * g.O;                                               // + (k0 + kf_k) % O
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    if (LB == B_NFAST) {
+      boff[u] = (long long)(bxf_k + 4 * u) * g.ldb + min(n0 + bxf_x, g.N - 1);          // + k0 ldb
+    } else if (LB == B_KFAST) {
+      boff[u] = (long long)min(n0 + kf_x + KFS * u, g.N - 1) * g.ldb + kf_k;            // + k0
+    } else {
+      boff[u] = (long long)(bxf_k + 4 * u) * g.Bn + bt_i1;                              // + k0 Bn
+      boff2[LB == B_T ? u : 0] = (long long)(bxf_k + 4 * u) * g.O + bt_o;               // + k0 O
+    }
+  }
+  auto fetch = [&](long long k0, auto tailc) {
+    constexpr bool tail = decltype(tailc)::value;
+    // tail: the chunk crosses kend — clamp k into [0, K) (the staged value is zeroed afterwards)
+    if (LA == A_T) {
+      const int k = (int)(tail ? min(k0 + kf_k, (long long)g.K - 1) : k0 + kf_k);
+      const int i1 = k / g.O, o = k - i1 * g.O;
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        ra[u] = g.p1[aoff[u] + i1];
+        ra2[LA == A_T ? u : 0] = g.dy[aoff2[LA == A_T ? u : 0] + o];
       }
+    } else {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        if (LA == A_KFAST) {
+          const long long kc = tail ? min(k0, (long long)g.K - 1 - kf_k) : k0;
+          ra[u] = Ag[aoff[u] + kc];
+        } else {
+          const long long kc = tail ? min(k0, (long long)g.K - 1 - (axf_k + AXS * u)) : k0;
+          ra[u] = Ag[aoff[u] + kc * g.lda];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
       if (LB == B_NFAST) {
-        const long long k = min(k0 + xf_k + 4 * u, (long long)g.K - 1), n = min(n0 + xf_x, g.N - 1);
-        rb[u] = Bg[k * g.ldb + n];
+        const long long kc = tail ? min(k0, (long long)g.K - 1 - (bxf_k + 4 * u)) : k0;
+        rb[u] = Bg[boff[u] + kc * g.ldb];
       } else if (LB == B_KFAST) {
-        const long long n = min(n0 + kf_x + 16 * u, g.N - 1), k = min(k0 + kf_k, (long long)g.K - 1);
-        rb[u] = Bg[n * g.ldb + k];
-      } else {   // T[k = w][n = (i1, o)]
-        const long long k = min(k0 + xf_k + 4 * u, (long long)g.K - 1);
-        rb[u] = g.p1[k * g.Bn + bt_i1];
-        rb2[u] = g.dy[k * g.O + bt_o];
+        const long long kc = tail ? min(k0, (long long)g.K - 1 - kf_k) : k0;
+        rb[u] = Bg[boff[u] + kc];
+      } else {
+        const long long kc = tail ? min(k0, (long long)g.K - 1 - (bxf_k + 4 * u)) : k0;
+        rb[u] = g.p1[boff[u] + kc * g.Bn];
+        rb2[LB == B_T ? u : 0] = g.dy[boff2[LB == B_T ? u : 0] + kc * g.O];
       }
     }
   };
-  auto stage = [&](long long k0) {
+  auto stage = [&](long long k0, auto tailc) {
+    constexpr bool tail = decltype(tailc)::value;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      double va = LA == A_T ? ra[u] * ra2[u] : ra[u];
-      double vb = LB == B_T ? rb[u] * rb2[u] : rb[u];
+    for (int u = 0; u < UA; ++u) {
+      double va = LA == A_T ? ra[u] * ra2[LA == A_T ? u : 0] : ra[u];
       if (AKF) {
-        const int m = kf_x + 16 * u;
-        if (!((m0 + m < g.M) & (k0 + kf_k < kend))) va = 0.0;
-        As[m * AP + kf_k] = va;
+        if (tail && !(k0 + kf_k < kend)) va = 0.0;
+        As[(kf_x + KFS * u) * APk + kf_k] = va;
       } else {
-        const int k = xf_k + 4 * u;
-        if (!((m0 + xf_x < g.M) & (k0 + k < kend))) va = 0.0;
-        As[xf_x * AP + k] = va;
+        const int k = axf_k + AXS * u;
+        if (tail && !(k0 + k < kend)) va = 0.0;
+        As[axf_x * APk + k] = va;
       }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      double vb = LB == B_T ? rb[u] * rb2[LB == B_T ? u : 0] : rb[u];
       if (BKF) {
-        const int n = kf_x + 16 * u;
-        if (!((n0 + n < g.N) & (k0 + kf_k < kend))) vb = 0.0;
-        Bs[kf_k * BP + n] = vb;
+        if (tail && !(k0 + kf_k < kend)) vb = 0.0;
+        Bs[kf_k * BPn + kf_x + KFS * u] = vb;
       } else {
-        const int k = xf_k + 4 * u;
-        if (!((n0 + xf_x < g.N) & (k0 + k < kend))) vb = 0.0;
-        Bs[k * BP + xf_x] = vb;
+        const int k = bxf_k + 4 * u;
+        if (tail && !(k0 + k < kend)) vb = 0.0;
+        Bs[k * BPn + bxf_x] = vb;
       }
     }
   };
-  f64x4 acc[2][2];
+  f64x4 acc[WTM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-  if (kbeg < kend) fetch(kbeg);
-  for (long long k0 = kbeg; k0 < kend; k0 += GK) {
-    __syncthreads();
-    stage(k0);
-    __syncthreads();
-    if (k0 + GK < kend) fetch(k0 + GK);
+  // Full chunks run the mask-free code; only the last, partial chunk of the k range clamps its loads (a clamped
+  // k re-reads an element of the same row / column) and zeroes what lies beyond kend.
+  auto mma = [&]() {
 #pragma unroll
-    for (int kk = 0; kk < GK / 4; ++kk) {
-      double a[2], b[2];
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      double a[WTM], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = As[(32 * wm + 16 * i + lr) * AP + 4 * kk + lk];
+      for (int i = 0; i < WTM; ++i) a[i] = As[(16 * WTM * wm + 16 * i + lr) * APk + 4 * kk + lk];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[(4 * kk + lk) * BP + 32 * wn + 16 * j + lr];
+      for (int j = 0; j < 2; ++j) b[j] = Bs[(4 * kk + lk) * BPn + 32 * wn + 16 * j + lr];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+  const std::integral_constant<bool, false> FULL;
+  const std::integral_constant<bool, true> TAIL;
+  const long long kfull = kbeg + (kend - kbeg) / KC * KC;   // end of the full chunks
+  if (kbeg < kfull)
+    fetch(kbeg, FULL);
+  else if (kbeg < kend)
+    fetch(kbeg, TAIL);
+  for (long long k0 = kbeg; k0 < kfull; k0 += KC) {
+    __syncthreads();
+    stage(k0, FULL);
+    __syncthreads();
+    if (k0 + KC < kfull)
+      fetch(k0 + KC, FULL);
+    else if (k0 + KC < kend)
+      fetch(k0 + KC, TAIL);
+    mma();
   }
-  double* C = Cg + (long long)blockIdx.z * g.cslice;
+  if (kfull < kend) {
+    __syncthreads();
+    stage(kfull, TAIL);
+    __syncthreads();
+    mma();
+  }
+  double* C = Cg + (long long)bz * g.cslice;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int m = m0 + 32 * wm + 16 * i + 4 * v + lk, n = n0 + 32 * wn + 16 * j + lr;
+        const int m = m0 + 16 * WTM * wm + 16 * i + 4 * v + lk, n = n0 + 32 * wn + 16 * j + lr;
         if (m < g.M && n < g.N) C[(long long)m * g.ldc + n] = acc[i][j][v];
       }
 }
 
+// 64 x 64 tiles, k chunks of 16: 128-row tiles or 32-deep chunks measured the same or slower (cfg1: 348 / 379 /
+// 343 / 405 us forward for <2,16> / <2,32> / <4,16> / <4,32>), so the variant with the most workgroups is kept.
 template <int LA, int LB>
-void gemm_launch(const double* A, const double* B, double* C, const GemmD& g, int slices, hipStream_t st) {
-  const dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, slices);
-  hipLaunchKernelGGL((f64_gemm_k<LA, LB>), grid, dim3(256), 0, st, A, B, C, g);
+void gemm_launch(const double* A, const double* B, double* C, GemmD g, int slices, hipStream_t st) {
+  constexpr int WTM = 2, KC = 16;
+  g.slices = slices;
+  const int total = ((g.N + GT - 1) / GT) * ((g.M + 32 * WTM - 1) / (32 * WTM)) * slices;
+  hipLaunchKernelGGL((f64_gemm_k<LA, LB, WTM, KC>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
 
 // --------------------------------------------------------------------- contractions around the GEMMs
@@ -265,68 +356,108 @@ __global__ __launch_bounds__(256) void f64_dp1_k(const double* __restrict__ Z, c
 }
 
 // gxw[(n Q + q)][w] = sum over the entries i of the factor's half whose digit of factor n is q of
-// dP[w, i] * prod_{other factors d of the half} x_d[w, digit_d(i)].  One workgroup per window; thread
-// t owns the pair (factor, q) = t % (nd Q) and the slice t / (nd Q) of the half's entries.
+// dP[w, i] * prod_{other factors d of the half} x_d[w, digit_d(i)].
+// One WAVE per window (4 windows per workgroup, no workgroup barriers).  With factor f of the half at digit
+// stride S_f = Q^(nd-1-f), i = (u Q + q) S_f + l and the product splits into PRE_f[u] (factors above f) and
+// SUF_f[l] (factors below f): both families of Kronecker prefix / suffix products are built level by level in
+// the wave's LDS (sum over levels < E entries each), so a term costs three LDS reads and two multiplies.
+// Lane -> (pair (f, q), slice of the (u, l) range); slices are summed through LDS.
 template <int LOGQ>
 __global__ __launch_bounds__(256) void f64_dx_half_k(const double* __restrict__ x, const double* __restrict__ dP,
                                                      double* __restrict__ gxw, HalfP h, int second, long long w0,
                                                      long long nw) {
   extern __shared__ double sm[];
   const EpsP& p = h.p;
+  const int Q = p.Q;
   const int base = second ? h.n0 : 0, nd = second ? h.n1 : h.n0;
-  const long long E = second ? h.Bn : h.A;
-  double* xs = sm;                    // [nd][Q]
-  double* dps = xs + nd * p.Q;        // [E]
-  double* red = dps + E;              // [256]
-  const int np = nd * p.Q;            // (factor, q) pairs
-  const int nsl = 256 / np;           // slices
-  const int pr = threadIdx.x % np, sl = threadIdx.x / np;
-  const int fd = pr / p.Q, fq = pr - fd * p.Q;
-  const long long EQ = E / p.Q;       // entries with a given digit at factor fd
-  // stride of factor fd's digit inside the half's index (factor 0 of the half is the most significant)
-  long long stride = 1;
-  for (int d = nd - 1; d > fd; --d) stride *= p.Q;
+  const int E = (int)(second ? h.Bn : h.A);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int per_wave = nd * Q + 3 * E + 64;
+  double* xs = sm + (size_t)wv * per_wave;   // [nd][Q]
+  double* dps = xs + nd * Q;                 // [E]
+  double* pre = dps + E;                     // levels 0 .. nd-1, level f has Q^f entries
+  double* suf = pre + E;                     // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
+  double* red = suf + E;                     // [64]
+  const int np = nd * Q;
+  const int ppl = np < 64 ? np : 64, nsl = 64 / ppl;
   const int hw = p.Ho * p.Wo;
-  for (long long wl = blockIdx.x; wl < nw; wl += gridDim.x) {
+  const int EQ = E / Q;
+  for (long long wl = (long long)blockIdx.x * 4 + wv; wl < nw; wl += (long long)gridDim.x * 4) {
     const long long w = w0 + wl;
     const long long b = w / hw;
     const int rem = (int)(w - b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nd * p.Q; e += 256) {
-      const int n = base + e / p.Q, q = e % p.Q;
+    wave_sync_lds();   // the previous window's reads are done
+    for (int e = lane; e < np; e += 64) {
+      const int n = base + e / Q, q = e % Q;
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
       xs[e] = x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
-    for (long long e = threadIdx.x; e < E; e += 256) dps[e] = dP[wl * E + e];
-    __syncthreads();
-    double acc = 0.0;
-    if (sl < nsl) {
-      for (long long j = sl; j < EQ; j += nsl) {
-        // i = j with the digit fq inserted at factor fd: i = (j / stride) * stride * Q + fq * stride + j % stride
-        const long long jh = j / stride, jl = j - jh * stride;
-        const long long i = (jh * p.Q + fq) * stride + jl;
-        long long t = i;
-        double prd = 1.0;
-        for (int d = nd - 1; d >= 0; --d) {
-          int digit;
+    for (int e = lane; e < E; e += 64) dps[e] = dP[wl * E + e];
+    if (lane == 0) pre[0] = 1.0, suf[0] = 1.0;   // level 0 of PRE (factor 0), level nd-1 of SUF (last factor)
+    wave_sync_lds();
+    // PRE level f (offset (Q^f - 1)/(Q - 1)): pre_f[u Q + q'] = pre_{f-1}[u] x_{f-1}[q']
+    // SUF level g counted from the last factor (offset likewise): suf_g[q' Q^(g-1) + l] = x_{nd-g}[q'] suf_{g-1}[l]
+    {
+      int off_prev = 0, size_prev = 1;
+      for (int f = 1; f < nd; ++f) {
+        const int off = off_prev + size_prev, size = size_prev * Q;
+        for (int e = lane; e < size; e += 64) {
+          int u, qq;
           if (LOGQ > 0) {
-            digit = (int)(t & ((1 << LOGQ) - 1));
-            t >>= LOGQ;
+            u = e >> LOGQ;
+            qq = e & ((1 << LOGQ) - 1);
           } else {
-            digit = (int)(t % p.Q);
-            t /= p.Q;
+            u = e / Q;
+            qq = e - u * Q;
           }
-          if (d != fd) prd *= xs[d * p.Q + digit];
+          pre[off + e] = pre[off_prev + u] * xs[(f - 1) * Q + qq];
+          const int q2 = e / size_prev, l = e - q2 * size_prev;
+          suf[off + e] = xs[(nd - f) * Q + q2] * suf[off_prev + l];
         }
-        acc += dps[i] * prd;
+        off_prev = off;
+        size_prev = size;
+        wave_sync_lds();
       }
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < np) {
-      double s = 0.0;
-      for (int k = 0; k < nsl; ++k) s += red[k * np + threadIdx.x];
-      gxw[(long long)((base + fd) * p.Q + fq) * p.Wn + w] = s;
+    for (int pbase = 0; pbase < np; pbase += ppl) {
+      const int pr = pbase + lane % ppl, sl = lane / ppl;
+      double acc = 0.0;
+      if (pr < np && sl < nsl) {
+        const int fd = pr / Q, fq = pr - fd * Q;
+        // stride of factor fd, offsets of its PRE level (fd) and SUF level (nd-1-fd)
+        int stride = 1, off_suf = 0;
+        for (int d = nd - 1; d > fd; --d) {
+          off_suf += stride;
+          stride *= Q;
+        }
+        int off_pre = 0, sz = 1;
+        for (int d = 0; d < fd; ++d) {
+          off_pre += sz;
+          sz *= Q;
+        }
+        int lstride = 0;
+        if (LOGQ > 0) lstride = LOGQ * (nd - 1 - fd);
+        for (int j = sl; j < EQ; j += nsl) {
+          int u, l;
+          if (LOGQ > 0) {
+            u = j >> lstride;
+            l = j & (stride - 1);
+          } else {
+            u = j / stride;
+            l = j - u * stride;
+          }
+          acc += dps[(u * Q + fq) * stride + l] * pre[off_pre + u] * suf[off_suf + l];
+        }
+      }
+      wave_sync_lds();
+      red[lane] = acc;
+      wave_sync_lds();
+      if (lane < ppl && pbase + lane < np) {
+        double s = 0.0;
+        for (int k = 0; k < nsl; ++k) s += red[k * ppl + lane];
+        const int prr = pbase + lane;
+        gxw[(long long)(base * Q + prr) * p.Wn + w] = s;
+      }
     }
   }
 }
@@ -355,8 +486,8 @@ unsigned blocks_for(long long n, int per) {
 }
 
 int launch_halves(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
-  const size_t lds = (size_t)h.p.N * h.p.Q * sizeof(double);
-  const unsigned grid = blocks_for(nw, 1);
+  const size_t lds = (size_t)4 * h.p.N * h.p.Q * sizeof(double);
+  const unsigned grid = blocks_for(nw, 4);
   switch (ilog2_pow2(h.p.Q)) {
     case 1: hipLaunchKernelGGL(f64_halves_k<1>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
     case 2: hipLaunchKernelGGL(f64_halves_k<2>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
@@ -367,20 +498,31 @@ int launch_halves(const double* x, double* P0, double* P1, const HalfP& h, long 
   return DCTN_OK;
 }
 
-int launch_dx_half(const double* x, const double* dP, double* gxw, const HalfP& h, int second, long long w0,
-                   long long nw, hipStream_t st) {
+size_t dx_half_lds(const HalfP& h, int second) {
   const int nd = second ? h.n1 : h.n0;
   const long long E = second ? h.Bn : h.A;
-  const size_t lds = ((size_t)nd * h.p.Q + (size_t)E + 256) * sizeof(double);
-  const unsigned grid = blocks_for(nw, 1);
-  switch (ilog2_pow2(h.p.Q)) {
-    case 1: hipLaunchKernelGGL(f64_dx_half_k<1>, dim3(grid), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw); break;
-    case 2: hipLaunchKernelGGL(f64_dx_half_k<2>, dim3(grid), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw); break;
-    case 3: hipLaunchKernelGGL(f64_dx_half_k<3>, dim3(grid), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw); break;
-    default: hipLaunchKernelGGL(f64_dx_half_k<0>, dim3(grid), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw); break;
-  }
+  return (size_t)4 * ((size_t)nd * h.p.Q + 3 * (size_t)E + 64) * sizeof(double);
+}
+
+template <int LOGQ>
+int launch_dx_half_q(const double* x, const double* dP, double* gxw, const HalfP& h, int second, long long w0,
+                     long long nw, hipStream_t st) {
+  const size_t lds = dx_half_lds(h, second);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)f64_dx_half_k<LOGQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(f64_dx_half_k<LOGQ>, dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
+}
+
+int launch_dx_half(const double* x, const double* dP, double* gxw, const HalfP& h, int second, long long w0,
+                   long long nw, hipStream_t st) {
+  switch (ilog2_pow2(h.p.Q)) {
+    case 1: return launch_dx_half_q<1>(x, dP, gxw, h, second, w0, nw, st);
+    case 2: return launch_dx_half_q<2>(x, dP, gxw, h, second, w0, nw, st);
+    case 3: return launch_dx_half_q<3>(x, dP, gxw, h, second, w0, nw, st);
+    default: return launch_dx_half_q<0>(x, dP, gxw, h, second, w0, nw, st);
+  }
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -392,8 +534,8 @@ bool eps_f64_wanted(const EpsP& p, int dtype) {
   if (dtype != DCTN_F64 || p.N < 2) return false;
   if (p.R * p.O < 2048 || p.Wn < 64) return false;
   const HalfP h = make_half(p);
-  if (h.Bn > 4096 || h.A > 4096 || h.NB > (1ll << 24)) return false;   // dps[] in LDS; int-sized GEMM dims
-  if (h.n1 * p.Q > 256 || p.Wn >= (1ll << 31)) return false;
+  if (h.Bn > 1024 || h.A > 1024 || h.NB > (1ll << 24)) return false;   // per-wave LDS tables of the dX kernel; int-sized GEMM dims
+  if (p.Wn >= (1ll << 31)) return false;
   return true;
 }
 
