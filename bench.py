@@ -35,6 +35,7 @@ WORKLOADS = {
     "cfg2": (((3, 4),), 28, 2, torch.bfloat16),
     "cfg2_f32": (((3, 4),), 28, 2, torch.float32),
     "cfg3a": (((4, 4), (3, 6)), 28, 2, torch.float32),
+    "cfg3a_bf16": (((4, 4), (3, 6)), 28, 2, torch.bfloat16),   # bf16 storage, exact-f32 matrix-core arithmetic
     "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
 }
 
@@ -128,6 +129,9 @@ def kernel_roofline(model, x, specs, image_size, steps):
 
     dev = x.device
     core = model.epses[0].detach().contiguous()
+    from dctn_amd.eps import _bf16_through_f32
+    if _bf16_through_f32(core, x):   # bf16 storage, exact-f32 matrix-core arithmetic: time what eps() runs
+        core, x = core.float(), x.float()
     C, B, H, W, Q = x.shape
     K, O = specs[0]
     Ho = H - K + 1

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dctn_profile_main_kernel_only": (None, [c_int]),
     "dctn_strerror": (ctypes.c_char_p, [c_int]),
     "dctn_last_kernel": (ctypes.c_char_p, []),
+    "dctn_eps_family": (c_int, [c_int] * 9),
     "dctn_eps_fwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
     "dctn_eps_fwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
     "dctn_eps_bwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 4),

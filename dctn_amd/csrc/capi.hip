@@ -39,6 +39,16 @@ size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   return (a > b ? a : b) + 256;
 }
 
+int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int precision) {
+  EpsP p;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return -1;
+  if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
+  if (eps_bigcore_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_BIGCORE_F32;
+  if (eps_f64_wanted(p, dtype)) return DCTN_EPS_FAMILY_F64_HALVES;
+  return DCTN_EPS_FAMILY_GENERIC;
+}
+
 int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
                  void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q, int K,
                  int O, int dtype, int precision, void* stream) {

@@ -73,6 +73,10 @@ size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision
 int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
                        size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
 
+// which family the forward of a shape dispatches to (dctn_eps_family)
+bool eps_mfma_covers(const EpsP& p, int dtype, int precision);
+bool eps_bigcore_covers(const EpsP& p, int dtype, int precision);
+
 // float64 two-halves path on v_mfma_f64_16x16x4_f64 — eps_f64.hip
 bool eps_f64_wanted(const EpsP& p, int dtype);
 size_t eps_fwd_f64_workspace(const EpsP& p, int dtype);

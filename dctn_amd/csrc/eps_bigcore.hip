@@ -872,6 +872,12 @@ static bool bigcore_wanted(const EpsP& p) {
   return p.R * p.O >= 1024;
 }
 
+bool eps_bigcore_covers(const EpsP& p, int dtype, int precision) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return false;
+  BigP b;
+  return fill_big(b, p, MODE_FWD);
+}
+
 size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
   BigP b;

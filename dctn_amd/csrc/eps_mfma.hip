@@ -1258,3 +1258,5 @@ int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, cons
   if (p.O == 2) return bwd_head_launch_t<4, 4, 2>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
   return bwd_head_launch_t<4, 4, 4>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
 }
+
+bool eps_mfma_covers(const EpsP& p, int dtype, int precision) { return family_ok(p, dtype, precision); }

@@ -75,7 +75,24 @@ def eps(core: Tensor, input: Tensor) -> Tensor:
     (out_size,) with factor index = window position (row-major) * channels + channel.
     Returns (batch, height-K+1, width-K+1, out_size)."""
     _check_core(core, input)
+    if _bf16_through_f32(core, input):
+        return _EpsFunction.apply(core.float(), input.float()).to(torch.bfloat16)
     return _EpsFunction.apply(core, input)
+
+
+def _bf16_through_f32(core: Tensor, input: Tensor) -> bool:
+    """bf16 tensors whose core is outside the bf16 register family (deeper layers, Q > 2) would land on the
+    generic kernels; the exact-f32 matrix-core family takes them instead: bf16 storage, f32 arithmetic
+    (the casts are three small elementwise kernels next to millisecond GEMMs; autograd casts the gradients
+    back)."""
+    if core.dtype != torch.bfloat16 or not core.is_cuda:
+        return False
+    C, B, H, W, Q = input.shape
+    K = math.isqrt((core.ndim - 1) // C)
+    args = (C, B, H, W, Q, K, core.shape[-1])
+    lib, prec = L.lib(), L.precision()
+    return (lib.dctn_eps_family(*args, L.dtype_code(core), prec) == 0
+            and lib.dctn_eps_family(*args, L._DTYPE_CODE[torch.float32], prec) == 2)
 
 
 def eps_one_by_one(core: Tensor, input: Tensor) -> Tensor:

@@ -64,6 +64,14 @@ const char* dctn_last_kernel(void);
  *   workspace : scratch of dctn_eps_fwd_workspace_bytes() bytes (0 for most shapes; the large-core
  *          family splits its row tiles over the grid and sums the slices in a fixed order)
  * ------------------------------------------------------------------------------------------ */
+/* Which kernel family the forward (and backward) of a shape runs on, for a contiguous input: callers use
+ * it to route bf16 tensors with large cores through float32 (the exact-f32 matrix-core family; bf16
+ * storage, f32 arithmetic) instead of the generic kernels — see dctn_amd/eps.py.  -1 = invalid shape. */
+#define DCTN_EPS_FAMILY_GENERIC 0
+#define DCTN_EPS_FAMILY_Q2REG 1        /* bf16 MFMA, Q = 2, N in {8, 9} */
+#define DCTN_EPS_FAMILY_BIGCORE_F32 2  /* exact f32 MFMA, LDS-streamed core */
+#define DCTN_EPS_FAMILY_F64_HALVES 3   /* f64 MFMA two-halves path */
+int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int precision);
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
                                     int dtype, int precision);
 int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,

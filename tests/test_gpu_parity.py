@@ -404,6 +404,26 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
 
 
 # ------------------------------------------------------------------ linear head (bf16, skinny)
+def test_eps_bf16_large_core_runs_on_the_f32_matrix_core_family():
+    """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer) are routed through
+    the exact-f32 bigcore kernels (bf16 storage, f32 arithmetic) instead of the generic kernels."""
+    torch.manual_seed(31)
+    for (C, B, H, W, Q, K, O) in ((1, 5, 9, 8, 2, 4, 4), (1, 3, 7, 7, 4, 3, 6)):
+        N = K * K * C
+        x = torch.randn(C, B, H, W, Q).to(torch.bfloat16)
+        core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(torch.bfloat16)
+        xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
+        y = eps(cd, xd)
+        assert y.dtype == torch.bfloat16 and dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+        want = R.eps_4step(core.double(), x.double())
+        assert bf16_close(y, want)
+        dy = torch.randn(*want.shape).to(torch.bfloat16)
+        y.backward(dy.to(DEV))
+        assert xd.grad.dtype == torch.bfloat16 and cd.grad.dtype == torch.bfloat16
+        gc, gx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+        assert bf16_close(cd.grad, gc) and bf16_close(xd.grad, gx)
+
+
 @pytest.mark.parametrize("B,F,C", [(1024, 2704, 10), (37, 3176, 10), (5, 64, 3), (130, 200, 16)])
 def test_linear_head_vs_torch_reference(B, F, C):
     """bf16 operands, f32 accumulation; reference = the same op in float64 on the rounded inputs.

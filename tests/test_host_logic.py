@@ -51,6 +51,19 @@ def test_argument_validation_without_gpu():
     assert lib.dctn_logmatmulexp_fwd(8, 8, 8, None, 0, 1, 0, 3, 3, 0, 0, 0, None) == _lib.ERR_BAD_SHAPE
 
 
+def test_eps_family_query_matches_the_dispatch_table():
+    """dctn_eps_family (host-only): which kernel family a shape runs on (BASELINE configs)."""
+    lib = _lib.lib()
+    BF16, F32, F64 = (_lib._DTYPE_CODE[t] for t in (torch.bfloat16, torch.float32, torch.float64))
+    assert lib.dctn_eps_family(1, 1024, 28, 28, 2, 3, 4, BF16, 0) == 1      # cfg2: bf16 register family
+    assert lib.dctn_eps_family(1, 128, 28, 28, 2, 4, 4, F32, 0) == 2        # cfg3a layer 1: exact-f32 bigcore
+    assert lib.dctn_eps_family(1, 128, 25, 25, 4, 3, 6, F32, 0) == 2        # cfg3a layer 2
+    assert lib.dctn_eps_family(1, 64, 28, 28, 2, 4, 2, F64, 0) == 3         # cfg1: f64 matrix cores
+    assert lib.dctn_eps_family(1, 128, 28, 28, 2, 4, 4, BF16, 0) == 0       # bf16 big core: routed through f32 by eps()
+    assert lib.dctn_eps_family(1, 2, 5, 5, 3, 2, 2, F64, 0) == 0            # tiny: generic
+    assert lib.dctn_eps_family(1, 2, 5, 5, 3, 9, 2, F32, 0) == -1           # kernel larger than the image
+
+
 def test_product_path_has_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         eps(torch.randn(2, 2, 2, 2, 3), torch.randn(1, 2, 4, 4, 2))
