@@ -534,7 +534,7 @@ bool eps_f64_wanted(const EpsP& p, int dtype) {
   if (dtype != DCTN_F64 || p.N < 2) return false;
   if (p.R * p.O < 2048 || p.Wn < 64) return false;
   const HalfP h = make_half(p);
-  if (h.Bn > 1024 || h.A > 1024 || h.NB > (1ll << 24)) return false;   // per-wave LDS tables of the dX kernel; int-sized GEMM dims
+  if (h.Bn > 1024 || h.A > 1024 || h.NB > (1ll << 20)) return false;   // per-wave LDS tables of the dX kernel; int-sized GEMM dims
   if (p.Wn >= (1ll << 31)) return false;
   return true;
 }
