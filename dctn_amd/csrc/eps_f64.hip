@@ -129,7 +129,11 @@ struct GemmD {
 };
 
 // WTM MFMA tiles per wave along m (block tile 32 WTM x 64), KC = k chunk
-template <int LA, int LB, int WTM, int KC>
+enum { EPI_STORE = 0, EPI_FWD = 1, EPI_DP1 = 2 };
+// Epilogues for Z = P0 x Core when O is a power of two <= 16 (a tile's 64 columns then hold whole groups of O):
+//   EPI_FWD : partial[tile_n][w][o] = sum over the tile's columns n = (i1, o) of Z[w, n] P1[w, i1]   (Z never stored)
+//   EPI_DP1 : dP1[w, i1] = sum_o dY[w, o] Z[w, (i1, o)]
+template <int LA, int LB, int WTM, int KC, int EPI>
 __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag, const double* __restrict__ Bg,
                                                   double* __restrict__ Cg, GemmD g) {
   constexpr int BM = 32 * WTM, BN = GT;
@@ -302,6 +306,48 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
     __syncthreads();
     mma();
   }
+  if (EPI == EPI_FWD) {
+    __shared__ double red[2 * BM * 16];
+    const int logo = __ffs(g.O) - 1;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 16 * WTM * wm + 16 * i + 4 * v + lk, m = m0 + r;
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + 32 * wn + 16 * j + lr;
+          if (m < g.M && n < g.N) sum += acc[i][j][v] * g.p1[(long long)m * g.Bn + (n >> logo)];
+        }
+        // the 16 lanes of a row hold 16 consecutive columns: o = lr % O; sum the lanes of equal o
+        for (int step = g.O; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
+        if (lr < g.O) red[(wn * BM + r) * 16 + lr] = sum;
+      }
+    __syncthreads();
+    for (int e = tid; e < BM * g.O; e += 256) {
+      const int r = e >> logo, o = e & (g.O - 1), m = m0 + r;
+      if (m < g.M)
+        Cg[((long long)(trem % tiles_n) * g.M + m) * g.O + o] = red[r * 16 + o] + red[(BM + r) * 16 + o];
+    }
+    return;
+  }
+  if (EPI == EPI_DP1) {
+    const int logo = __ffs(g.O) - 1;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = m0 + 16 * WTM * wm + 16 * i + 4 * v + lk, n = n0 + 32 * wn + 16 * j + lr;
+          const bool ok = m < g.M && n < g.N;
+          double sum = ok ? acc[i][j][v] * g.dy[(long long)m * g.O + (n & (g.O - 1))] : 0.0;
+          for (int step = 1; step < g.O; step <<= 1) sum += __shfl_xor(sum, step, 64);
+          if (ok && (n & (g.O - 1)) == 0) Cg[(long long)m * g.Bn + (n >> logo)] = sum;
+        }
+    return;
+  }
   double* C = Cg + (long long)bz * g.cslice;
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
@@ -316,13 +362,16 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
 
 // 64 x 64 tiles, k chunks of 16: 128-row tiles or 32-deep chunks measured the same or slower (cfg1: 348 / 379 /
 // 343 / 405 us forward for <2,16> / <2,32> / <4,16> / <4,32>), so the variant with the most workgroups is kept.
-template <int LA, int LB>
+template <int LA, int LB, int EPI = EPI_STORE>
 void gemm_launch(const double* A, const double* B, double* C, GemmD g, int slices, hipStream_t st) {
   constexpr int WTM = 2, KC = 16;
   g.slices = slices;
   const int total = ((g.N + GT - 1) / GT) * ((g.M + 32 * WTM - 1) / (32 * WTM)) * slices;
-  hipLaunchKernelGGL((f64_gemm_k<LA, LB, WTM, KC>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
+  hipLaunchKernelGGL((f64_gemm_k<LA, LB, WTM, KC, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
+
+// the fused epilogues need a tile's 64 columns to hold whole groups of O
+bool fused_epilogue_ok(int O) { return O >= 1 && O <= 16 && (O & (O - 1)) == 0; }
 
 // --------------------------------------------------------------------- contractions around the GEMMs
 // out[w, o] = sum_i1 Z[w, i1, o] P1[w, i1]: one wave per window
@@ -561,12 +610,22 @@ int eps_fwd_f64(const void* xv, const void* corev, void* outv, void* ws, size_t 
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
     int rc = launch_halves(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
-    GemmD g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, nullptr, h.Bn, p.O};
-    gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g, 1, st);
-    DCTN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(f64_fwd_contract_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, Z, P1, out + w0 * p.O, nw,
-                       h.Bn, p.O);
-    DCTN_CHECK_LAUNCH();
+    GemmD g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, P1, nullptr, h.Bn, p.O};
+    if (fused_epilogue_ok(p.O)) {
+      // Z stays in the accumulators: per column tile partial sums [tile_n][w][o] (in the Z slot), then their sum
+      const int tiles_n = (int)((h.NB + GT - 1) / GT);
+      gemm_launch<A_KFAST, B_NFAST, EPI_FWD>(P0, core, Z, g, 1, st);
+      DCTN_CHECK_LAUNCH();
+      hipLaunchKernelGGL(f64_sum_partials_k, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, Z, out + w0 * p.O,
+                         nw * p.O, tiles_n, 0);
+      DCTN_CHECK_LAUNCH();
+    } else {
+      gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g, 1, st);
+      DCTN_CHECK_LAUNCH();
+      hipLaunchKernelGGL(f64_fwd_contract_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, Z, P1, out + w0 * p.O,
+                         nw, h.Bn, p.O);
+      DCTN_CHECK_LAUNCH();
+    }
   }
   dctn_set_last_kernel("eps_fwd_mfma_f64_halves");
   return DCTN_OK;
@@ -631,11 +690,16 @@ int eps_bwd_f64(const void* xv, const void* corev, const void* dYv, void* dXv, v
       gemm_launch<A_T, B_KFAST>(nullptr, core, dP0, g0, 1, st);
       DCTN_CHECK_LAUNCH();
       // Z[w, (i1 o)] = sum_i0 P0[w, i0] Core[i0, (i1 o)], dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
-      GemmD g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, nullptr, h.Bn, p.O};
-      gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g1, 1, st);
-      DCTN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(f64_dp1_k, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, Z, dyc, dP1, nw, h.Bn, p.O);
-      DCTN_CHECK_LAUNCH();
+      GemmD g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, dyc, h.Bn, p.O};
+      if (fused_epilogue_ok(p.O)) {
+        gemm_launch<A_KFAST, B_NFAST, EPI_DP1>(P0, core, dP1, g1, 1, st);
+        DCTN_CHECK_LAUNCH();
+      } else {
+        gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g1, 1, st);
+        DCTN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(f64_dp1_k, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, Z, dyc, dP1, nw, h.Bn, p.O);
+        DCTN_CHECK_LAUNCH();
+      }
       rc = launch_dx_half(x, dP0, gxw, h, 0, w0, nw, st);
       if (rc != DCTN_OK) return rc;
       rc = launch_dx_half(x, dP1, gxw, h, 1, w0, nw, st);
