@@ -67,31 +67,45 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // ------------------------------------------------------------------ P0 / P1 of a chunk of windows
-// one wave per window (4 per workgroup), the window's N x Q features in the wave's LDS
+// One wave per window (4 per workgroup).  Each half is itself a Kronecker product of two quarter tables
+// (its leading ceil(nd/2) factors x its trailing ones, <= 32 entries each for halves <= 1024): the tables cost
+// nd/2 multiplies per entry, every entry of P0 / P1 then one multiply and two LDS reads.
 template <int LOGQ>
 __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x, double* __restrict__ P0,
                                                     double* __restrict__ P1, HalfP h, long long w0, long long nw) {
   extern __shared__ double sm[];
   const EpsP& p = h.p;
+  const int Q = p.Q;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double* xs = sm + (size_t)wv * p.N * p.Q;   // [N][Q]
+  // quarter tables: half s has nh_s leading and nl_s trailing factors, sizes H_s = Q^nh_s, L_s = Q^nl_s
+  const int nl0 = h.n0 / 2, nh0 = h.n0 - nl0, nl1 = h.n1 / 2, nh1 = h.n1 - nl1;
+  int H0 = 1, L0 = 1, H1 = 1, L1 = 1;
+  for (int d = 0; d < nh0; ++d) H0 *= Q;
+  for (int d = 0; d < nl0; ++d) L0 *= Q;
+  for (int d = 0; d < nh1; ++d) H1 *= Q;
+  for (int d = 0; d < nl1; ++d) L1 *= Q;
+  const int off1 = H0, off2 = H0 + L0, off3 = off2 + H1, ntab = off3 + L1;
+  double* xs = sm + (size_t)wv * (p.N * Q + ntab);   // [N][Q]
+  double* tab = xs + p.N * Q;                        // hi0 | lo0 | hi1 | lo1
   const int hw = p.Ho * p.Wo;
-  const int A = (int)h.A, E2 = (int)(h.A + h.Bn);
+  const int A = (int)h.A, Bn = (int)h.Bn;
   for (long long wl = (long long)blockIdx.x * 4 + wv; wl < nw; wl += (long long)gridDim.x * 4) {
     const long long w = w0 + wl;
     const long long b = w / hw;
     const int rem = (int)(w - b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
     wave_sync_lds();
-    for (int e = lane; e < p.N * p.Q; e += 64) {
-      const int n = e / p.Q, q = e - n * p.Q;
+    for (int e = lane; e < p.N * Q; e += 64) {
+      const int n = e / Q, q = e - n * Q;
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
       xs[e] = x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
     wave_sync_lds();
-    for (int e = lane; e < E2; e += 64) {
-      const bool second = e >= A;
-      int t = second ? e - A : e;
-      const int base = second ? h.n0 : 0, nd = second ? h.n1 : h.n0;
+    for (int e = lane; e < ntab; e += 64) {
+      // table of this entry: hi0 | lo0 | hi1 | lo1 -> its first factor, number of factors, index
+      const bool s1 = e >= off2, low = s1 ? e >= off3 : e >= off1;
+      int t = e - (s1 ? (low ? off3 : off2) : (low ? off1 : 0));
+      const int nd = s1 ? (low ? nl1 : nh1) : (low ? nl0 : nh0);
+      const int base = (s1 ? h.n0 : 0) + (low ? (s1 ? nh1 : nh0) : 0);
       double pr = 1.0;
       for (int d = nd - 1; d >= 0; --d) {
         int digit;
@@ -99,15 +113,35 @@ __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x
           digit = t & ((1 << LOGQ) - 1);
           t >>= LOGQ;
         } else {
-          digit = t % p.Q;
-          t /= p.Q;
+          digit = t % Q;
+          t /= Q;
         }
-        pr *= xs[(base + d) * p.Q + digit];
+        pr *= xs[(base + d) * Q + digit];
       }
-      if (second)
-        P1[wl * h.Bn + (e - A)] = pr;
-      else
-        P0[wl * h.A + e] = pr;
+      tab[e] = pr;
+    }
+    wave_sync_lds();
+    for (int e = lane; e < A; e += 64) {
+      int u, l;
+      if (LOGQ > 0) {
+        u = e >> (LOGQ * nl0);
+        l = e & (L0 - 1);
+      } else {
+        u = e / L0;
+        l = e - u * L0;
+      }
+      P0[wl * h.A + e] = tab[u] * tab[off1 + l];
+    }
+    for (int e = lane; e < Bn; e += 64) {
+      int u, l;
+      if (LOGQ > 0) {
+        u = e >> (LOGQ * nl1);
+        l = e & (L1 - 1);
+      } else {
+        u = e / L1;
+        l = e - u * L1;
+      }
+      P1[wl * h.Bn + e] = tab[off2 + u] * tab[off3 + l];
     }
   }
 }
@@ -534,17 +568,30 @@ unsigned blocks_for(long long n, int per) {
   return (unsigned)b;
 }
 
-int launch_halves(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
-  const size_t lds = (size_t)4 * h.p.N * h.p.Q * sizeof(double);
-  const unsigned grid = blocks_for(nw, 4);
-  switch (ilog2_pow2(h.p.Q)) {
-    case 1: hipLaunchKernelGGL(f64_halves_k<1>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
-    case 2: hipLaunchKernelGGL(f64_halves_k<2>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
-    case 3: hipLaunchKernelGGL(f64_halves_k<3>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
-    default: hipLaunchKernelGGL(f64_halves_k<0>, dim3(grid), dim3(256), lds, st, x, P0, P1, h, w0, nw); break;
+template <int LOGQ>
+int launch_halves_q(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+  // per wave: the window's features + the four quarter tables
+  size_t ntab = 0;
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int nd = s2 ? h.n1 : h.n0, nlo = nd / 2;
+    ntab += (size_t)ipow_ll(h.p.Q, nd - nlo) + (size_t)ipow_ll(h.p.Q, nlo);
   }
+  const size_t lds = (size_t)4 * ((size_t)h.p.N * h.p.Q + ntab) * sizeof(double);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)f64_halves_k<LOGQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(f64_halves_k<LOGQ>, dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, P0, P1, h, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
+}
+
+int launch_halves(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+  switch (ilog2_pow2(h.p.Q)) {
+    case 1: return launch_halves_q<1>(x, P0, P1, h, w0, nw, st);
+    case 2: return launch_halves_q<2>(x, P0, P1, h, w0, nw, st);
+    case 3: return launch_halves_q<3>(x, P0, P1, h, w0, nw, st);
+    default: return launch_halves_q<0>(x, P0, P1, h, w0, nw, st);
+  }
 }
 
 size_t dx_half_lds(const HalfP& h, int second) {
@@ -585,6 +632,9 @@ bool eps_f64_wanted(const EpsP& p, int dtype) {
   const HalfP h = make_half(p);
   if (h.Bn > 1024 || h.A > 1024 || h.NB > (1ll << 20)) return false;   // per-wave LDS tables of the dX kernel; int-sized GEMM dims
   if (p.Wn >= (1ll << 31)) return false;
+  // per-workgroup LDS of the halves kernel (features + quarter tables) and of the dX kernel (3 E per wave)
+  if ((size_t)4 * ((size_t)p.N * p.Q + 2 * (size_t)(h.A + h.Bn)) * 8 > DCTN_LDS_BUDGET) return false;
+  if ((size_t)4 * ((size_t)h.n1 * p.Q + 3 * (size_t)h.Bn + 64) * 8 > DCTN_LDS_BUDGET) return false;
   return true;
 }
 
