@@ -154,3 +154,14 @@ def all_reduce_scalar_sums(*values: Tensor) -> List[Tensor]:
     packed = torch.stack([v.double().reshape(()) for v in values])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     return list(packed.unbind(0))
+
+
+@torch.no_grad()
+def global_biased_std(values: Tensor) -> Tensor:
+    """Biased standard deviation of the union of every rank's ``values`` (the statistic behind the
+    empirical-std initialisation, dctn/eps.py:163-181, when each rank holds a shard of the dataset):
+    count, sum and sum of squares are accumulated in float64 and summed over the ranks."""
+    v = values.double()
+    n, s1, s2 = all_reduce_scalar_sums(torch.tensor(float(v.numel()), device=v.device), v.sum(), (v * v).sum())
+    mean = s1 / n
+    return (s2 / n - mean * mean).clamp_min(0).sqrt()

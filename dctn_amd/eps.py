@@ -163,11 +163,16 @@ def make_eps_unit_theoretical_output_std(
 def make_eps_unit_empirical_output_std(
     kernel_size: int, out_size: int, input: Tensor, device: torch.device, dtype: torch.dtype, batch_size: int
 ) -> Tensor:
-    """randn core rescaled so that its output over ``input`` has unit (biased) std."""
+    """randn core rescaled so that its output over ``input`` has unit (biased) std.  Under
+    ``torch.distributed`` every rank passes its shard of the dataset: the random core is rank 0's and the
+    std is that of all shards together, so all ranks end with the same core a single process would get."""
+    from . import ddp
+
     num_channels, dataset_size, height, width, in_size = input.shape
     core = torch.randn(*(in_size,) * (kernel_size**2 * num_channels), out_size, dtype=dtype).to(device)
+    ddp.broadcast_parameters([core])
     output = transform_in_slices(core, input.to(device, dtype), batch_size)
-    inverse_output_std = output.std(unbiased=False) ** -1
+    inverse_output_std = ddp.global_biased_std(output).to(output.dtype) ** -1
     logger = getLogger(f"{__name__}.make_eps_unit_empirical_output_std")
     logger.info(f"Multiplying the output of randn by {inverse_output_std:.30e}")
     core *= inverse_output_std

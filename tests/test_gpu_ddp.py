@@ -57,7 +57,14 @@ def _worker(rank, world, port, q):
         step(xs, ys)
     torch.cuda.synchronize(dev)
     assert step.g_opt is not None and red._flat_key is not None       # split graphs, in-place all-reduce
-    q.put((rank, [p.detach().float().cpu() for p in model.parameters()]))
+    # empirical-std initialisation on shards of the dataset: one global statistic, identical cores
+    from dctn_amd.epses_composition import make_epses_composition_unit_empirical_output_std
+
+    torch.manual_seed(100 + rank)   # different seeds on purpose: the random core must be rank 0's
+    x32 = x.float()
+    cores = make_epses_composition_unit_empirical_output_std(((2, 3), (2, 4)), ddp.shard_batch(x32, rank, world), dev,
+                                                             torch.float32, batch_size=8)
+    q.put((rank, [p.detach().float().cpu() for p in model.parameters()] + [c.cpu() for c in cores]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +84,15 @@ def test_two_ranks_on_one_gpu_match_the_single_process_iteration():
         assert p.exitcode == 0
     for a, b in zip(got[0], got[1]):
         assert torch.equal(a, b)
+    # the two empirically initialised cores: unit output std over the WHOLE dataset, layer by layer
+    from dctn_amd.eps import eps, transform_in_slices
+
+    xin = _data(torch.bfloat16, torch.device("cuda", 0))[0].float()   # what the workers sharded
+    for core in got[0][-2:]:
+        out = transform_in_slices(core.to(xin.device), xin, 32)
+        assert abs(float(out.std(unbiased=False)) - 1.0) < 1e-4
+        xin = out
+    got = {r: v[:-2] for r, v in got.items()}
     # single process, whole batch: 1 warm-up + 3 iterations, same optimizer
     dev = torch.device("cuda", 0)
     model = _make(torch.bfloat16, dev)
