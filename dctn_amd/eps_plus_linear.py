@@ -262,8 +262,15 @@ class EPSesPlusLinear(nn.Module):
 
     @torch.no_grad()
     def log_intermediate_reps_stats(self, x: Tensor, batch_size: int = 128) -> None:
-        """Logs mean / std of every intermediate representation (as in eval mode)."""
+        """Logs mean / std of every intermediate representation and of the K x K windows in front of every
+        EPS, as rank-one tensors (dctn/eps_plus_linear.py:161-196), as if in eval mode.  The window
+        statistics come from the one-pass ``dctn_window_stats`` kernel instead of K*K stacked copies of the
+        representation; like the reference's ``std_over_batch`` (rank_one_tensor.py:107-110, which drops its
+        ``unbiased`` argument) the window sigma carries Bessel's correction."""
+        from .window_stats import window_mean_var
+
         logger = getLogger(f"{__name__}.EPSesPlusLinear.log_intermediate_reps_stats")
+        logger.info("Logging intermediate reps stats as if self.training == False")
 
         def log_one(t: Tensor, name: str) -> None:
             mu, sigma = t.mean(), t.std(unbiased=False)
@@ -271,6 +278,16 @@ class EPSesPlusLinear(nn.Module):
 
         for n, core in enumerate(self.epses):
             log_one(x, f"x_{n}")
+            kernel_size = math.isqrt(core.ndim - 1)
+            assert kernel_size**2 == core.ndim - 1
+            mu, var = window_mean_var(x, kernel_size)
+            sigma = var**0.5
+            C, B, H, W, Q = x.shape
+            logger.info(
+                f"w_{n}: mu={mu:.7e}, sigma={sigma:.7e}, mu^2+sigma^2={mu**2+sigma**2:.7e}, "
+                f"batch_shape={(B, H - kernel_size + 1, W - kernel_size + 1)}, "
+                f"num_factors={kernel_size**2 * C}, num_coordinates_in_one_factor={Q}"
+            )
             x = eps.transform_in_slices(core, x, batch_size)
         flat = x.reshape(x.shape[1], -1)
         log_one(flat, f"x_{len(self.epses)}")

@@ -631,6 +631,33 @@ def test_window_statistics_kernel_against_reference_fixture_and_oracle():
         window_sums(x, 3)                                        # CPU tensor: no fallback
 
 
+def test_log_intermediate_reps_stats_reports_the_reference_window_statistics(caplog):
+    """EPSesPlusLinear.log_intermediate_reps_stats (dctn/eps_plus_linear.py:161-196): the w_n lines carry the
+    mean / std of the K x K windows as rank-one tensors — here from the one-pass kernel, checked against the
+    RankOneTensorsBatch formulas on the stacked windows."""
+    import logging
+    import re
+
+    from dctn_amd.align import make_windows
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    torch.manual_seed(41)
+    model = EPSesPlusLinear(((2, 3), (2, 4)), UnitTheoreticalOutputStd(), 1.0, DEV, torch.float32, image_size=9)
+    u = torch.rand(1, 6, 9, 9)
+    x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1).to(DEV)
+    with caplog.at_level(logging.INFO):
+        model.log_intermediate_reps_stats(x, batch_size=4)
+    lines = [r.getMessage() for r in caplog.records]
+    names = [ln.split(":")[0] for ln in lines[1:]]
+    assert names == ["x_0", "w_0", "x_1", "w_1", "x_2", "output_of_linear_without_bias", "output_of_linear_with_bias"]
+    w0 = next(ln for ln in lines if ln.startswith("w_0"))
+    mu, sigma = (float(v) for v in re.findall(r"(?:mu|sigma)=([-+0-9.e]+)", w0)[:2])
+    ref = make_windows(x.cpu().double(), 2)
+    assert abs(mu - float(ref.mean_over_batch())) < 1e-6 * abs(mu)
+    assert abs(sigma - float(ref.std_over_batch())) < 1e-6 * sigma
+    assert "batch_shape=(6, 8, 8)" in w0 and "num_factors=4" in w0 and "num_coordinates_in_one_factor=2" in w0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_train_step_end_to_end_loss_goes_down(dtype):
     """The reference's training iteration (dctn/training.py:77-84) on the HIP path: forward, CE loss +
