@@ -5,7 +5,7 @@ import sys
 
 _MODULES = (
     "pos2d", "singleton", "align", "utils", "conv_sbs_spec", "contraction_path_cache", "eps",
-    "epses_composition", "conv_sbs", "eps_plus_linear", "logmatmulexp", "rank_one_tensor", "evaluation",
+    "epses_composition", "conv_sbs", "eps_plus_linear", "logmatmulexp", "rank_one_tensor", "evaluation", "training",
 )
 for _name in _MODULES:
     _mod = importlib.import_module(f"dctn_amd.{_name}")

@@ -4,17 +4,29 @@ The reference's loop (dctn/training.py:62-84) is: forward, ``loss_fn(output, y)`
 term scaled by ``reg_coeff``, ``optimizer.zero_grad()``, backward of the sum, ``optimizer.step()``,
 with callback hooks around it.  Here the same sequence is one function; between backward and the
 optimizer step the parameter gradients are averaged over the ranks (``ddp.FlatGradAllReducer``: in
-place on the fused backward's flat gradient buffer when the model provides one).  The callback /
-logging / checkpoint machinery of the reference is out of scope.
+place on the fused backward's flat gradient buffer when the model provides one).
+
+``train`` and the callbacks below it mirror the reference's loop and hook objects
+(dctn/training.py:23-248: same names, arguments, ``st_x`` / ``st_it`` dictionaries and checkpoint file
+names) for SURVEY 8(f) row f4, made safe for one process per GPU: gradients are averaged over the ranks
+before the ``after_back`` hooks, a stop requested on any rank stops all of them in the same iteration,
+and only rank 0 touches checkpoint files.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+import os
+from collections import deque
+from logging import getLogger
+from typing import Any, Callable, Dict, Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
+import torch.distributed as dist
 from torch import Tensor
 
 from . import ddp
+
+StX = Dict[Any, Any]   # state that lives across iterations
+StIt = Dict[Any, Any]  # state of one iteration
 
 
 def train_step(
@@ -214,3 +226,217 @@ class FlatSGD:
     def reg_value(self) -> Tensor:
         """l2 * sum of squared Frobenius norms of the regularised parameters, as of the last step."""
         return self.sq_sum * self.l2
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's training loop and its hooks (dctn/training.py:14-248), one process per GPU
+# ------------------------------------------------------------------------------------------------
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _is_rank0() -> bool:
+    return _world() == 1 or dist.get_rank() == 0
+
+
+def batches_forever(dl: Iterable) -> Iterator[Any]:
+    """Cycles through ``dl`` again and again (a new pass — a new shuffle — each time it runs out)."""
+    while True:
+        for batch in dl:
+            yield batch
+
+
+def train(dl, model, optimizer, dev, loss_fn, reg_fn, reg_coeff: float, at_iter_start, after_back,
+          after_param_upd) -> Tuple[StX, StIt]:
+    """The loop of dctn/training.py:23-84.  ``dl`` yields ``(x, y, indices)`` (this rank's shard under
+    ``torch.distributed``); ``loss_fn(output, y)`` and ``reg_fn(st_x, st_it)`` return 0-dim tensors; the three
+    hook lists hold callables ``f(st_x, st_it)`` run at the start of an iteration, after ``backward()`` (the
+    gradients they see are already averaged over the ranks) and after ``optimizer.step()``.  A hook stops
+    the loop by setting ``st_it["stop"]``; with several ranks the flag is OR-ed over them so that all
+    leave in the same iteration.  Returns the two state dictionaries of the last iteration."""
+    st_x: StX = dict(model=model.to(dev), optimizer=optimizer, loss_fn=loss_fn, reg_fn=reg_fn, reg_coeff=reg_coeff,
+                     at_iter_start=list(at_iter_start), after_back=list(after_back),
+                     after_param_upd=list(after_param_upd), dev=dev)
+    world = _world()
+    reducer = ddp.FlatGradAllReducer(st_x["model"].parameters(), average=True) if world > 1 else None
+    st_it: StIt = {}
+
+    def run_hooks(key: str) -> None:
+        for hook in tuple(st_x[key]):   # a hook may remove itself
+            hook(st_x, st_it)
+
+    for count, (x, y, indices) in enumerate(batches_forever(dl)):
+        st_it = dict(num_iters_done=count, x=x.to(dev), y=y.to(dev), indices=indices.to(dev), stop=False)
+        run_hooks("at_iter_start")
+        st_x["model"].train()
+        st_it["output"] = st_x["model"](st_it["x"])
+        st_it["loss"] = st_x["loss_fn"](st_it["output"], st_it["y"])
+        st_it["reg_term"] = st_x["reg_fn"](st_x, st_it)
+        st_x["optimizer"].zero_grad()
+        (st_it["loss"] + st_it["reg_term"] * st_x["reg_coeff"]).backward()
+        if reducer is not None:
+            reducer()
+        run_hooks("after_back")
+        st_x["optimizer"].step()
+        run_hooks("after_param_upd")
+        if world > 1:
+            flag = torch.tensor([1.0 if st_it["stop"] else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            st_it["stop"] = bool(flag.item() > 0)
+        if st_it["stop"]:
+            break
+    return st_x, st_it
+
+
+def every_n_iters_intervals(*intervals):
+    """Decorator factory: ``intervals`` are ``(length, period)`` pairs laid end to end from iteration 0; the
+    hook runs when ``num_iters_done`` is a multiple of the period of the interval it falls in.  The last
+    length may be ``None`` (forever); otherwise "every iteration" continues after the last interval."""
+    spans = list(intervals)
+    if spans[-1][0] is not None:
+        spans.append((None, 1))
+    starts, begin = [], 0
+    for length, _ in spans:
+        starts.append(begin)
+        begin = begin + length if length is not None else begin
+    periods = [period for _, period in spans]
+
+    def decorate(func: Callable[[StX, StIt], None]) -> Callable[[StX, StIt], None]:
+        def gated(st_x: StX, st_it: StIt) -> None:
+            n = st_it["num_iters_done"]
+            period = periods[0]
+            for start, candidate in zip(starts, periods):
+                if n >= start:
+                    period = candidate
+            if n % period == 0:
+                func(st_x, st_it)
+
+        return gated
+
+    return decorate
+
+
+def _checkpoint_tag(st_it: StIt) -> str:
+    """The metric part of the reference's checkpoint names (training.py:135-140,161-166)."""
+    return (f"nitd={st_it['num_iters_done']:07}_tracc={st_it['train_acc']:.4f}_vacc={st_it['val_acc']:.4f}_"
+            f"trmce={st_it['train_mean_ce']:.4f}_vmce={st_it['val_mean_ce']:.4f}")
+
+
+class Checkpointer:
+    """Writes ``model.state_dict()`` files into ``dir`` — on rank 0 only; the other ranks hold the same
+    parameters and skip the file system."""
+
+    def __init__(self, dir: str):
+        self.dir = dir
+
+    def save(self, st_x: StX, filename: str) -> None:
+        if _is_rank0():
+            torch.save(st_x["model"].state_dict(), os.path.join(self.dir, filename))
+
+    def remove_file(self, filename: str) -> None:
+        if _is_rank0():
+            os.remove(os.path.join(self.dir, filename))
+
+
+class LastModelsCheckpointer(Checkpointer):
+    """One checkpoint per call, the newest ``n`` are kept."""
+
+    def __init__(self, dir: str, n: int):
+        super().__init__(dir)
+        assert n >= 1
+        self.n = n
+        self.filenames: deque = deque()
+
+    def __call__(self, st_x: StX, st_it: StIt) -> None:
+        name = f"model_{_checkpoint_tag(st_it)}.pth"
+        self.save(st_x, name)
+        self.filenames.appendleft(name)
+        while len(self.filenames) > self.n:
+            self.remove_file(self.filenames.pop())
+
+
+class BestModelCheckpointer(Checkpointer):
+    """Keeps the single checkpoint with the best ``st_it[key]`` seen so far."""
+
+    def __init__(self, dir: str, key: str, low_is_good: bool):
+        super().__init__(dir)
+        self.key, self.low_is_good = key, low_is_good
+        self.best_value = float("inf") if low_is_good else float("-inf")
+        self.filename: Optional[str] = None
+
+    def __call__(self, st_x: StX, st_it: StIt) -> None:
+        value = st_it[self.key]
+        better = value < self.best_value if self.low_is_good else value > self.best_value
+        if not better:
+            return
+        name = f"model_best_{self.key}_{_checkpoint_tag(st_it)}.pth"
+        self.save(st_x, name)
+        self.best_value = value
+        if self.filename is not None:
+            self.remove_file(self.filename)
+        self.filename = name
+
+
+class ValuesNotImprovingEarlyStopper:
+    """Requests a stop once more than ``patience`` consecutive calls brought no improvement of any of the
+    watched ``st_it`` values; ``keys`` holds ``(key, low_is_good)`` pairs."""
+
+    def __init__(self, patience: int, keys: Sequence[Tuple[str, bool]]):
+        self.patience, self.keys = patience, tuple(keys)
+        self.best_values = [float("inf") if low else float("-inf") for _, low in self.keys]
+        self.num_bad_calls = 0
+
+    def __call__(self, st_x: StX, st_it: StIt) -> None:
+        improved = False
+        for slot, (key, low_is_good) in enumerate(self.keys):
+            value, best = st_it[key], self.best_values[slot]
+            if (value < best) if low_is_good else (value > best):
+                self.best_values[slot] = value
+                improved = True
+        self.num_bad_calls = 0 if improved else self.num_bad_calls + 1
+        if self.num_bad_calls > self.patience:
+            st_it["stop"] = True
+            getLogger(__name__).info(f"Early stopping at st_it['num_iters_done']={st_it['num_iters_done']}")
+
+
+def make_stopper_after_n_iters(n: int) -> Callable[[StX, StIt], None]:
+    def maybe_stop(st_x: StX, st_it: StIt) -> None:
+        if st_it["num_iters_done"] >= n:
+            st_it["stop"] = True
+
+    return maybe_stop
+
+
+def make_stopper_on_nan_loss(dir: str, set_breakpoint: bool) -> Callable[[StX, StIt], None]:
+    """Stops on a non-finite loss and leaves the model and the offending batch in ``dir/nan_loss_stop``
+    (written by the rank that saw it, under a per-rank name when there are several)."""
+
+    def stop_on_nan_loss(st_x: StX, st_it: StIt) -> None:
+        if torch.isfinite(st_it["loss"]):
+            return
+        log = getLogger(__name__)
+        log.warning("Stopping because of NaN or Inf loss")
+        st_it["stop"] = True
+        subdir = os.path.join(dir, "nan_loss_stop" if _world() == 1 else f"nan_loss_stop_rank{dist.get_rank()}")
+        if os.path.exists(subdir):
+            log.error(f"subdir={subdir!r} already exists")
+        else:
+            os.mkdir(subdir)
+            torch.save(st_x["model"].state_dict(), os.path.join(
+                subdir, f"model_nitd={st_it['num_iters_done']}_loss={st_it['loss']:.3f}_reg_term={st_it['reg_term']:.3f}.pth"))
+            for key in ("x", "y", "indices", "output"):
+                torch.save(st_it[key], os.path.join(subdir, f"{key}.pth"))
+        if set_breakpoint:
+            breakpoint()
+
+    return stop_on_nan_loss
+
+
+def log_parameters_stats(st_x: StX, st_it: StIt) -> None:
+    """Mean / std / shape of every parameter, one log line each."""
+    log = getLogger(f"{__name__}.log_parameters_stats")
+    log.info(f"After {st_it['num_iters_done']:07} iters:")
+    with torch.no_grad():
+        for name, param in st_x["model"].named_parameters():
+            log.info(f"{name}: mu={param.float().mean():.7e}, sigma={param.float().std(unbiased=False):.7e}, "
+                     f"shape={tuple(param.shape)}")

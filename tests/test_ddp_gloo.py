@@ -120,3 +120,78 @@ def test_single_process_is_a_noop():
     ddp.FlatGradAllReducer(m.parameters())()
     assert torch.equal(m.weight.grad, g)
     assert ddp.shard_batch(torch.zeros(1, 9, 2), 1, 2).shape == (1, 4, 2)
+
+
+# ------------------------------------------------------------------ the reference's training loop, two ranks
+def _loop_data():
+    g = torch.Generator().manual_seed(21)
+    return torch.randn(24, 6, generator=g), torch.randint(0, 3, (24,), generator=g)
+
+
+def _loop_model():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+def _train_worker(rank, world, port, q, ckpt_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddp.init_from_env("gloo")
+    from dctn_amd import training as T
+
+    x, y = _loop_data()
+    # rank r sees samples r, r + world, ... of every batch of 8: batches of 4 per rank
+    batches = [(x[b * 8 + rank : b * 8 + 8 : world], y[b * 8 + rank : b * 8 + 8 : world], torch.arange(4)) for b in range(3)]
+    model = _loop_model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    seen = []
+
+    def metrics(st_x, st_it):       # what the reference's evaluation hook would put there
+        st_it.update(train_acc=0.5, val_acc=0.25 + 0.01 * st_it["num_iters_done"], train_mean_ce=1.0, val_mean_ce=2.0)
+        seen.append(st_it["num_iters_done"])
+
+    def rank1_wants_out(st_x, st_it):
+        if rank == 1 and st_it["num_iters_done"] == 4:
+            st_it["stop"] = True
+
+    keep = T.LastModelsCheckpointer(ckpt_dir, 2)
+    st_x, st_it = T.train(batches, model, opt, torch.device("cpu"), torch.nn.functional.cross_entropy,
+                          lambda sx, si: sum((p ** 2).sum() for p in sx["model"].parameters()), 1e-3,
+                          at_iter_start=[], after_back=[], after_param_upd=[metrics, keep, rank1_wants_out])
+    assert st_it["num_iters_done"] == 4 and st_it["stop"] and seen == [0, 1, 2, 3, 4]   # both ranks left together
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()]))   # by value: the worker may exit first
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_training_loop_two_ranks(tmp_path):
+    from dctn_amd import training as T
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: [torch.from_numpy(a) for a in arrs] for r, arrs in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+    # rank 0 alone wrote the checkpoints: the newest two, under the reference's names
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["model_nitd=0000003_tracc=0.5000_vacc=0.2800_trmce=1.0000_vmce=2.0000.pth",
+                     "model_nitd=0000004_tracc=0.5000_vacc=0.2900_trmce=1.0000_vmce=2.0000.pth"]
+    state = torch.load(os.path.join(tmp_path, names[1]))
+    assert all(torch.equal(state[k], v) for k, v in zip(state, got[0]))
+    # one process on the whole batches takes the same 5 steps (mean of the shard gradients == gradient of the mean loss)
+    x, y = _loop_data()
+    model = _loop_model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    T.train([(x[b * 8 : b * 8 + 8], y[b * 8 : b * 8 + 8], torch.arange(8)) for b in range(3)], model, opt,
+            torch.device("cpu"), torch.nn.functional.cross_entropy,
+            lambda sx, si: sum((p ** 2).sum() for p in sx["model"].parameters()), 1e-3,
+            at_iter_start=[], after_back=[], after_param_upd=[T.make_stopper_after_n_iters(4)])
+    for a, p in zip(got[0], model.parameters()):
+        assert torch.allclose(a, p.detach(), atol=1e-6)

@@ -287,3 +287,67 @@ def test_rank_one_tensors_batch_and_make_windows():
         assert w.array.shape[0] == K * K * x.shape[0] and w.factors_dim == 0 and w.coordinates_dim == 4
         assert np.isclose(float(w.mean_over_batch()), float(g[f"mean_{tag}"]), rtol=1e-12)
         assert np.isclose(float(w.var_over_batch()), float(g[f"var_{tag}"]), rtol=1e-10)
+
+
+def test_training_hooks_mirror_the_reference(tmp_path):  # dctn/training.py:87-248
+    """every_n_iters_intervals gating, the two checkpointers (names, retention), the early stopper, the
+    iteration-count stopper and the NaN stopper — model-agnostic host logic, exercised on a CPU model."""
+    from dctn_amd import training as T
+
+    calls = []
+    gated = T.every_n_iters_intervals((4, 2), (6, 3), (None, 5))(lambda sx, si: calls.append(si["num_iters_done"]))
+    for n in range(21):
+        gated({}, {"num_iters_done": n})
+    assert calls == [0, 2, 6, 9, 10, 15, 20]   # period 2 on [0,4), 3 on [4,10), 5 from 10 on
+    calls.clear()
+    always_after = T.every_n_iters_intervals((3, 2))(lambda sx, si: calls.append(si["num_iters_done"]))
+    for n in range(6):
+        always_after({}, {"num_iters_done": n})
+    assert calls == [0, 2, 3, 4, 5]
+
+    model = torch.nn.Linear(3, 2)
+    st_x = {"model": model}
+
+    def it(n, vacc, vmce):
+        return {"num_iters_done": n, "train_acc": 0.5, "val_acc": vacc, "train_mean_ce": 1.25, "val_mean_ce": vmce}
+
+    last = T.LastModelsCheckpointer(str(tmp_path), 2)
+    best = T.BestModelCheckpointer(str(tmp_path), "val_acc", low_is_good=False)
+    for n, (vacc, vmce) in enumerate([(0.1, 3.0), (0.3, 2.0), (0.2, 2.5), (0.25, 2.6)]):
+        last(st_x, it(n, vacc, vmce))
+        best(st_x, it(n, vacc, vmce))
+    assert sorted(os.listdir(tmp_path)) == [
+        "model_best_val_acc_nitd=0000001_tracc=0.5000_vacc=0.3000_trmce=1.2500_vmce=2.0000.pth",
+        "model_nitd=0000002_tracc=0.5000_vacc=0.2000_trmce=1.2500_vmce=2.5000.pth",
+        "model_nitd=0000003_tracc=0.5000_vacc=0.2500_trmce=1.2500_vmce=2.6000.pth"]
+    state = torch.load(os.path.join(tmp_path, sorted(os.listdir(tmp_path))[0]))
+    assert set(state) == {"weight", "bias"}
+
+    stopper = T.ValuesNotImprovingEarlyStopper(2, (("val_acc", False), ("val_mean_ce", True)))
+    history = [(0.1, 3.0), (0.2, 3.1), (0.2, 3.0), (0.2, 3.0), (0.19, 2.9), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0)]
+    stopped_at = None
+    for n, (vacc, vmce) in enumerate(history):
+        st_it = dict(it(n, vacc, vmce), stop=False)
+        stopper(st_x, st_it)
+        if st_it["stop"]:
+            stopped_at = n
+            break
+    assert stopped_at == 7        # improvements at 0, 1, 4; calls 5, 6, 7 bring none: the third exceeds patience 2
+
+    # the loop itself: hooks in order, stop after n, NaN stop with the dump of the offending batch
+    x, y = torch.randn(6, 3), torch.randint(0, 2, (6,))
+    order = []
+    st_x2, st_it2 = T.train([(x, y, torch.arange(6))], model, torch.optim.SGD(model.parameters(), lr=0.1), torch.device("cpu"),
+                            torch.nn.functional.cross_entropy, lambda sx, si: torch.zeros(()), 0.0,
+                            at_iter_start=[lambda sx, si: order.append("start")],
+                            after_back=[lambda sx, si: order.append("back")],
+                            after_param_upd=[lambda sx, si: order.append("upd"), T.make_stopper_after_n_iters(2)])
+    assert st_it2["num_iters_done"] == 2 and order == ["start", "back", "upd"] * 3
+    assert set(st_it2) >= {"x", "y", "indices", "output", "loss", "reg_term", "stop"} and st_x2["model"] is model
+    nan_dir = tmp_path / "nan"
+    nan_dir.mkdir()
+    _, st_it3 = T.train([(x, y, torch.arange(6))], model, torch.optim.SGD(model.parameters(), lr=0.1), torch.device("cpu"),
+                        lambda out, yy: out.sum() * float("nan"), lambda sx, si: torch.zeros(()), 0.0,
+                        at_iter_start=[], after_back=[T.make_stopper_on_nan_loss(str(nan_dir), False)], after_param_upd=[])
+    assert st_it3["num_iters_done"] == 0 and st_it3["stop"]
+    assert sorted(os.listdir(nan_dir / "nan_loss_stop"))[:3] == ["indices.pth", "model_nitd=0_loss=nan_reg_term=0.000.pth", "output.pth"]
