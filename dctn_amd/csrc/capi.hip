@@ -35,7 +35,7 @@ size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   EpsP p;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
-  const size_t a = eps_fwd_bigcore_workspace(p, dtype, precision), b = eps_fwd_f64_workspace(p, dtype);
+  const size_t a = eps_fwd_bigcore_workspace(p, dtype, precision), b = eps_fwd_halves_workspace(p, dtype);
   return (a > b ? a : b) + 256;
 }
 
@@ -45,7 +45,7 @@ int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, 
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return -1;
   if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
   if (eps_bigcore_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_BIGCORE_F32;
-  if (eps_f64_wanted(p, dtype)) return DCTN_EPS_FAMILY_F64_HALVES;
+  if (eps_halves_wanted(p, dtype)) return DCTN_EPS_FAMILY_HALVES;
   return DCTN_EPS_FAMILY_GENERIC;
 }
 
@@ -62,7 +62,7 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
-  rc = eps_fwd_f64(x, core, out, workspace, workspace_bytes, p, dtype, st);
+  rc = eps_fwd_halves(x, core, out, workspace, workspace_bytes, p, dtype, st);
   if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
   return eps_fwd_generic(x, core, out, p, dtype, st);
 }
@@ -78,7 +78,7 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
   const size_t c = need_dx ? eps_bwd_dfactor_bigcore_workspace(p, dtype, precision) : 0;
   if (c > b) b = c;
-  const size_t d = eps_bwd_f64_workspace(p, dtype, need_dx, need_dcore);
+  const size_t d = eps_bwd_halves_workspace(p, dtype, need_dx, need_dcore);
   if (d > b) b = d;
   return a + b + 256;
 }
@@ -129,10 +129,12 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   }
   if (!dX && !dCore) return DCTN_OK;
   const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
-  // float64: both gradients on the f64 matrix cores
-  rc = eps_bwd_f64(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st);
-  if (rc == DCTN_OK) return rc;
-  if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
+  // float64, and float32 shapes the bigcore family does not take: both gradients on the two-halves GEMM path
+  if (dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision)) {
+    rc = eps_bwd_halves(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st);
+    if (rc == DCTN_OK) return rc;
+    if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
+  }
   if (dCore) {
     rc = eps_bwd_dcore_bigcore(x, dY, dCore, p, dtype, precision, st);
     if (rc == DCTN_OK) {

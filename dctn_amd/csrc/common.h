@@ -77,14 +77,15 @@ int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX
 bool eps_mfma_covers(const EpsP& p, int dtype, int precision);
 bool eps_bigcore_covers(const EpsP& p, int dtype, int precision);
 
-// float64 two-halves path on v_mfma_f64_16x16x4_f64 — eps_f64.hip
-bool eps_f64_wanted(const EpsP& p, int dtype);
-size_t eps_fwd_f64_workspace(const EpsP& p, int dtype);
-int eps_fwd_f64(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
-                hipStream_t st);
-size_t eps_bwd_f64_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore);
-int eps_bwd_f64(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
-                const EpsP& p, int dtype, hipStream_t st);
+// two-halves GEMM path on the 16x16x4 matrix instructions — eps_halves.hip: float64 (v_mfma_f64_16x16x4_f64),
+// and float32 (v_mfma_f32_16x16x4_f32) for shapes the other float32 families leave (odd Q, ...)
+bool eps_halves_wanted(const EpsP& p, int dtype);
+size_t eps_fwd_halves_workspace(const EpsP& p, int dtype);
+int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
+                   hipStream_t st);
+size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore);
+int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
+                   const EpsP& p, int dtype, hipStream_t st);
 
 // MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
 // is outside the family so that the dispatcher can take the generic kernels.

@@ -21,6 +21,26 @@
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) double f64x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// The two 16 x 16 x 4 matrix instructions share the operand layout (A: row = lane % 16, k = lane / 16; B: column =
+// lane % 16, k = lane / 16) and differ in the accumulator rows: f64 register v of lane l is row 4 v + l / 16
+// (measured, tools/mfma64probe.hip), f32 register v is row 4 (l / 16) + v.
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int v, int lk) { return 4 * v + lk; }
+};
+template <> struct Mma<float> {
+  typedef f32x4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int v, int lk) { return 4 * lk + v; }
+};
 
 namespace {
 
@@ -35,7 +55,7 @@ struct HalfP {
   int ksplit;             // grid.z of the dCore product
 };
 
-HalfP make_half(const EpsP& p) {
+HalfP make_half(const EpsP& p, size_t esz) {
   HalfP h;
   h.p = p;
   h.n0 = p.N / 2;
@@ -43,7 +63,7 @@ HalfP make_half(const EpsP& p) {
   h.A = ipow_ll(p.Q, h.n0);
   h.Bn = ipow_ll(p.Q, h.n1);
   h.NB = h.Bn * p.O;
-  const long long per_win = (2 * h.A + 2 * h.Bn + h.NB) * (long long)sizeof(double);
+  const long long per_win = (2 * h.A + 2 * h.Bn + h.NB) * (long long)esz;
   long long wc = (long long)(CHUNK_BYTES / (size_t)per_win);
   wc = wc / 64 * 64;
   if (wc < 64) wc = 64;
@@ -70,10 +90,11 @@ __device__ __forceinline__ void wave_sync_lds() {
 // One wave per window (4 per workgroup).  Each half is itself a Kronecker product of two quarter tables
 // (its leading ceil(nd/2) factors x its trailing ones, <= 32 entries each for halves <= 1024): the tables cost
 // nd/2 multiplies per entry, every entry of P0 / P1 then one multiply and two LDS reads.
-template <int LOGQ>
-__global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x, double* __restrict__ P0,
-                                                    double* __restrict__ P1, HalfP h, long long w0, long long nw) {
-  extern __shared__ double sm[];
+template <int LOGQ, typename T>
+__global__ __launch_bounds__(256) void halves_k(const T* __restrict__ x, T* __restrict__ P0,
+                                                    T* __restrict__ P1, HalfP h, long long w0, long long nw) {
+  extern __shared__ __align__(16) unsigned char sm_raw[];
+  T* sm = reinterpret_cast<T*>(sm_raw);
   const EpsP& p = h.p;
   const int Q = p.Q;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -85,8 +106,8 @@ __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x
   for (int d = 0; d < nh1; ++d) H1 *= Q;
   for (int d = 0; d < nl1; ++d) L1 *= Q;
   const int off1 = H0, off2 = H0 + L0, off3 = off2 + H1, ntab = off3 + L1;
-  double* xs = sm + (size_t)wv * (p.N * Q + ntab);   // [N][Q]
-  double* tab = xs + p.N * Q;                        // hi0 | lo0 | hi1 | lo1
+  T* xs = sm + (size_t)wv * (p.N * Q + ntab);   // [N][Q]
+  T* tab = xs + p.N * Q;                        // hi0 | lo0 | hi1 | lo1
   const int hw = p.Ho * p.Wo;
   const int A = (int)h.A, Bn = (int)h.Bn;
   for (long long wl = (long long)blockIdx.x * 4 + wv; wl < nw; wl += (long long)gridDim.x * 4) {
@@ -106,7 +127,7 @@ __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x
       int t = e - (s1 ? (low ? off3 : off2) : (low ? off1 : 0));
       const int nd = s1 ? (low ? nl1 : nh1) : (low ? nl0 : nh0);
       const int base = (s1 ? h.n0 : 0) + (low ? (s1 ? nh1 : nh0) : 0);
-      double pr = 1.0;
+      T pr = 1.0;
       for (int d = nd - 1; d >= 0; --d) {
         int digit;
         if (LOGQ > 0) {
@@ -150,13 +171,14 @@ __global__ __launch_bounds__(256) void f64_halves_k(const double* __restrict__ x
 enum { A_KFAST = 0, A_MFAST = 1, A_T = 2 };   // A[m][k] k-contiguous / stored [k][m] / T[w, (i1 o)] formed from P1, dY
 enum { B_NFAST = 0, B_KFAST = 1, B_T = 2 };   // B[k][n] n-contiguous / stored [n][k] / T (k = window)
 
+template <typename T>
 struct GemmD {
   int M, N, K;
   long long lda, ldb, ldc;
   long long kslice;       // k range per grid.z slice
   long long cslice;       // elements between the C of two slices
-  const double* p1;       // T operand: P1 (ld Bn) and dY (ld O) of the chunk
-  const double* dy;
+  const T* p1;       // T operand: P1 (ld Bn) and dY (ld O) of the chunk
+  const T* dy;
   long long Bn;
   int O;
   int slices;             // k slices (set by gemm_launch)
@@ -167,15 +189,15 @@ enum { EPI_STORE = 0, EPI_FWD = 1, EPI_DP1 = 2 };
 // Epilogues for Z = P0 x Core when O is a power of two <= 16 (a tile's 64 columns then hold whole groups of O):
 //   EPI_FWD : partial[tile_n][w][o] = sum over the tile's columns n = (i1, o) of Z[w, n] P1[w, i1]   (Z never stored)
 //   EPI_DP1 : dP1[w, i1] = sum_o dY[w, o] Z[w, (i1, o)]
-template <int LA, int LB, int WTM, int KC, int EPI>
-__global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag, const double* __restrict__ Bg,
-                                                  double* __restrict__ Cg, GemmD g) {
+template <int LA, int LB, int WTM, int KC, int EPI, typename T>
+__global__ __launch_bounds__(256) void halves_gemm_k(const T* __restrict__ Ag, const T* __restrict__ Bg,
+                                                  T* __restrict__ Cg, GemmD<T> g) {
   constexpr int BM = 32 * WTM, BN = GT;
   constexpr int APk = KC + 1, BPn = BN + 1;
   constexpr int UA = BM * KC / 256, UB = BN * KC / 256;   // staged elements per thread
   constexpr int LOGK = KC == 16 ? 4 : 5, LOGBM = BM == 64 ? 6 : 7;
-  __shared__ double As[BM * APk];
-  __shared__ double Bs[KC * BPn];
+  __shared__ T As[BM * APk];
+  __shared__ T Bs[KC * BPn];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 15, lk = lane >> 4;
   // XCD-aware tile order: workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2.  XCD x takes
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
   const int axf_x = tid & (BM - 1), axf_k = tid >> LOGBM;                  // k step 256 / BM
   const int bxf_x = tid & (BN - 1), bxf_k = tid >> 6;                      // k step 4
   constexpr int KFS = 256 / KC, AXS = 256 / BM;
-  double ra[UA], rb[UB], ra2[LA == A_T ? UA : 1], rb2[LB == B_T ? UB : 1];
+  T ra[UA], rb[UB], ra2[LA == A_T ? UA : 1], rb2[LB == B_T ? UB : 1];
   // The k-invariant part of every load address is formed once per lane (rows / columns clamped into range:
   // what the clamped rows produce lands in rows / columns of C that are never stored, so nothing is masked
   // outside the last, partial k chunk); inside the loop the wave-uniform k0 term is all that changes.
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
     constexpr bool tail = decltype(tailc)::value;
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
-      double va = LA == A_T ? ra[u] * ra2[LA == A_T ? u : 0] : ra[u];
+      T va = LA == A_T ? ra[u] * ra2[LA == A_T ? u : 0] : ra[u];
       if (AKF) {
         if (tail && !(k0 + kf_k < kend)) va = 0.0;
         As[(kf_x + KFS * u) * APk + kf_k] = va;
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      double vb = LB == B_T ? rb[u] * rb2[LB == B_T ? u : 0] : rb[u];
+      T vb = LB == B_T ? rb[u] * rb2[LB == B_T ? u : 0] : rb[u];
       if (BKF) {
         if (tail && !(k0 + kf_k < kend)) vb = 0.0;
         Bs[kf_k * BPn + kf_x + KFS * u] = vb;
@@ -296,17 +318,18 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
       }
     }
   };
-  f64x4 acc[WTM][2];
+  typedef typename Mma<T>::acc_t acc_t;
+  acc_t acc[WTM][2];
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
   // Full chunks run the mask-free code; only the last, partial chunk of the k range clamps its loads (a clamped
   // k re-reads an element of the same row / column) and zeroes what lies beyond kend.
   auto mma = [&]() {
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
-      double a[WTM], b[2];
+      T a[WTM], b[2];
 #pragma unroll
       for (int i = 0; i < WTM; ++i) a[i] = As[(16 * WTM * wm + 16 * i + lr) * APk + 4 * kk + lk];
 #pragma unroll
@@ -314,7 +337,7 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mfma(a[i], b[j], acc[i][j]);
     }
   };
   const std::integral_constant<bool, false> FULL;
@@ -341,14 +364,14 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
     mma();
   }
   if (EPI == EPI_FWD) {
-    __shared__ double red[2 * BM * 16];
+    __shared__ T red[2 * BM * 16];
     const int logo = __ffs(g.O) - 1;
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int r = 16 * WTM * wm + 16 * i + 4 * v + lk, m = m0 + r;
-        double sum = 0.0;
+        const int r = 16 * WTM * wm + 16 * i + Mma<T>::row(v, lk), m = m0 + r;
+        T sum = 0.0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + 32 * wn + 16 * j + lr;
@@ -374,34 +397,34 @@ __global__ __launch_bounds__(256) void f64_gemm_k(const double* __restrict__ Ag,
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int m = m0 + 16 * WTM * wm + 16 * i + 4 * v + lk, n = n0 + 32 * wn + 16 * j + lr;
+          const int m = m0 + 16 * WTM * wm + 16 * i + Mma<T>::row(v, lk), n = n0 + 32 * wn + 16 * j + lr;
           const bool ok = m < g.M && n < g.N;
-          double sum = ok ? acc[i][j][v] * g.dy[(long long)m * g.O + (n & (g.O - 1))] : 0.0;
+          T sum = ok ? acc[i][j][v] * g.dy[(long long)m * g.O + (n & (g.O - 1))] : 0.0;
           for (int step = 1; step < g.O; step <<= 1) sum += __shfl_xor(sum, step, 64);
           if (ok && (n & (g.O - 1)) == 0) Cg[(long long)m * g.Bn + (n >> logo)] = sum;
         }
     return;
   }
-  double* C = Cg + (long long)bz * g.cslice;
+  T* C = Cg + (long long)bz * g.cslice;
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int m = m0 + 16 * WTM * wm + 16 * i + 4 * v + lk, n = n0 + 32 * wn + 16 * j + lr;
+        const int m = m0 + 16 * WTM * wm + 16 * i + Mma<T>::row(v, lk), n = n0 + 32 * wn + 16 * j + lr;
         if (m < g.M && n < g.N) C[(long long)m * g.ldc + n] = acc[i][j][v];
       }
 }
 
 // 64 x 64 tiles, k chunks of 16: 128-row tiles or 32-deep chunks measured the same or slower (cfg1: 348 / 379 /
 // 343 / 405 us forward for <2,16> / <2,32> / <4,16> / <4,32>), so the variant with the most workgroups is kept.
-template <int LA, int LB, int EPI = EPI_STORE>
-void gemm_launch(const double* A, const double* B, double* C, GemmD g, int slices, hipStream_t st) {
+template <int LA, int LB, int EPI = EPI_STORE, typename T>
+void gemm_launch(const T* A, const T* B, T* C, GemmD<T> g, int slices, hipStream_t st) {
   constexpr int WTM = 2, KC = 16;
   g.slices = slices;
   const int total = ((g.N + GT - 1) / GT) * ((g.M + 32 * WTM - 1) / (32 * WTM)) * slices;
-  hipLaunchKernelGGL((f64_gemm_k<LA, LB, WTM, KC, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
+  hipLaunchKernelGGL((halves_gemm_k<LA, LB, WTM, KC, EPI, T>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
 
 // the fused epilogues need a tile's 64 columns to hold whole groups of O
@@ -409,15 +432,16 @@ bool fused_epilogue_ok(int O) { return O >= 1 && O <= 16 && (O & (O - 1)) == 0; 
 
 // --------------------------------------------------------------------- contractions around the GEMMs
 // out[w, o] = sum_i1 Z[w, i1, o] P1[w, i1]: one wave per window
-__global__ __launch_bounds__(256) void f64_fwd_contract_k(const double* __restrict__ Z, const double* __restrict__ P1,
-                                                          double* __restrict__ out, long long nw, long long Bn, int O) {
+template <typename T>
+__global__ __launch_bounds__(256) void halves_fwd_contract_k(const T* __restrict__ Z, const T* __restrict__ P1,
+                                                          T* __restrict__ out, long long nw, long long Bn, int O) {
   const int lane = threadIdx.x & 63;
   const long long wl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wl >= nw) return;
-  const double* z = Z + wl * Bn * O;
-  const double* p1 = P1 + wl * Bn;
+  const T* z = Z + wl * Bn * O;
+  const T* p1 = P1 + wl * Bn;
   for (int o = 0; o < O; ++o) {
-    double s = 0.0;
+    T s = 0.0;
     for (long long i1 = lane; i1 < Bn; i1 += 64) s += z[i1 * O + o] * p1[i1];
     s = wave_reduce_sum(s);
     if (lane == 0) out[wl * O + o] = s;
@@ -425,14 +449,15 @@ __global__ __launch_bounds__(256) void f64_fwd_contract_k(const double* __restri
 }
 
 // dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
-__global__ __launch_bounds__(256) void f64_dp1_k(const double* __restrict__ Z, const double* __restrict__ dY,
-                                                 double* __restrict__ dP1, long long nw, long long Bn, int O) {
+template <typename T>
+__global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, const T* __restrict__ dY,
+                                                 T* __restrict__ dP1, long long nw, long long Bn, int O) {
   const long long total = nw * Bn;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const long long wl = idx / Bn;
-    const double* z = Z + idx * O;
-    const double* dy = dY + wl * O;
-    double s = 0.0;
+    const T* z = Z + idx * O;
+    const T* dy = dY + wl * O;
+    T s = 0.0;
     for (int o = 0; o < O; ++o) s += dy[o] * z[o];
     dP1[idx] = s;
   }
@@ -445,22 +470,23 @@ __global__ __launch_bounds__(256) void f64_dp1_k(const double* __restrict__ Z, c
 // SUF_f[l] (factors below f): both families of Kronecker prefix / suffix products are built level by level in
 // the wave's LDS (sum over levels < E entries each), so a term costs three LDS reads and two multiplies.
 // Lane -> (pair (f, q), slice of the (u, l) range); slices are summed through LDS.
-template <int LOGQ>
-__global__ __launch_bounds__(256) void f64_dx_half_k(const double* __restrict__ x, const double* __restrict__ dP,
-                                                     double* __restrict__ gxw, HalfP h, int second, long long w0,
+template <int LOGQ, typename T>
+__global__ __launch_bounds__(256) void halves_dx_half_k(const T* __restrict__ x, const T* __restrict__ dP,
+                                                     T* __restrict__ gxw, HalfP h, int second, long long w0,
                                                      long long nw) {
-  extern __shared__ double sm[];
+  extern __shared__ __align__(16) unsigned char sm_raw[];
+  T* sm = reinterpret_cast<T*>(sm_raw);
   const EpsP& p = h.p;
   const int Q = p.Q;
   const int base = second ? h.n0 : 0, nd = second ? h.n1 : h.n0;
   const int E = (int)(second ? h.Bn : h.A);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int per_wave = nd * Q + 3 * E + 64;
-  double* xs = sm + (size_t)wv * per_wave;   // [nd][Q]
-  double* dps = xs + nd * Q;                 // [E]
-  double* pre = dps + E;                     // levels 0 .. nd-1, level f has Q^f entries
-  double* suf = pre + E;                     // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
-  double* red = suf + E;                     // [64]
+  T* xs = sm + (size_t)wv * per_wave;   // [nd][Q]
+  T* dps = xs + nd * Q;                 // [E]
+  T* pre = dps + E;                     // levels 0 .. nd-1, level f has Q^f entries
+  T* suf = pre + E;                     // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
+  T* red = suf + E;                     // [64]
   const int np = nd * Q;
   const int ppl = np < 64 ? np : 64, nsl = 64 / ppl;
   const int hw = p.Ho * p.Wo;
@@ -504,7 +530,7 @@ __global__ __launch_bounds__(256) void f64_dx_half_k(const double* __restrict__ 
     }
     for (int pbase = 0; pbase < np; pbase += ppl) {
       const int pr = pbase + lane % ppl, sl = lane / ppl;
-      double acc = 0.0;
+      T acc = 0.0;
       if (pr < np && sl < nsl) {
         const int fd = pr / Q, fq = pr - fd * Q;
         // stride of factor fd, offsets of its PRE level (fd) and SUF level (nd-1-fd)
@@ -536,7 +562,7 @@ __global__ __launch_bounds__(256) void f64_dx_half_k(const double* __restrict__ 
       red[lane] = acc;
       wave_sync_lds();
       if (lane < ppl && pbase + lane < np) {
-        double s = 0.0;
+        T s = 0.0;
         for (int k = 0; k < nsl; ++k) s += red[k * ppl + lane];
         const int prr = pbase + lane;
         gxw[(long long)(base * Q + prr) * p.Wn + w] = s;
@@ -546,10 +572,11 @@ __global__ __launch_bounds__(256) void f64_dx_half_k(const double* __restrict__ 
 }
 
 // dCore (+)= sum of the split-k partial products
-__global__ __launch_bounds__(256) void f64_sum_partials_k(const double* __restrict__ part, double* __restrict__ dCore,
+template <typename T>
+__global__ __launch_bounds__(256) void halves_sum_partials_k(const T* __restrict__ part, T* __restrict__ dCore,
                                                           long long n, int slices, int accumulate) {
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-    double s = accumulate ? dCore[idx] : 0.0;
+    T s = accumulate ? dCore[idx] : 0.0;
     for (int k = 0; k < slices; ++k) s += part[(long long)k * n + idx];
     dCore[idx] = s;
   }
@@ -568,198 +595,237 @@ unsigned blocks_for(long long n, int per) {
   return (unsigned)b;
 }
 
-template <int LOGQ>
-int launch_halves_q(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+template <int LOGQ, typename T>
+int launch_halves_q(const T* x, T* P0, T* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
   // per wave: the window's features + the four quarter tables
   size_t ntab = 0;
   for (int s2 = 0; s2 < 2; ++s2) {
     const int nd = s2 ? h.n1 : h.n0, nlo = nd / 2;
     ntab += (size_t)ipow_ll(h.p.Q, nd - nlo) + (size_t)ipow_ll(h.p.Q, nlo);
   }
-  const size_t lds = (size_t)4 * ((size_t)h.p.N * h.p.Q + ntab) * sizeof(double);
+  const size_t lds = (size_t)4 * ((size_t)h.p.N * h.p.Q + ntab) * sizeof(T);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)f64_halves_k<LOGQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(f64_halves_k<LOGQ>, dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, P0, P1, h, w0, nw);
+    (void)hipFuncSetAttribute((const void*)halves_k<LOGQ, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((halves_k<LOGQ, T>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, P0, P1, h, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
 
-int launch_halves(const double* x, double* P0, double* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+template <typename T>
+int launch_halves(const T* x, T* P0, T* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
   switch (ilog2_pow2(h.p.Q)) {
-    case 1: return launch_halves_q<1>(x, P0, P1, h, w0, nw, st);
-    case 2: return launch_halves_q<2>(x, P0, P1, h, w0, nw, st);
-    case 3: return launch_halves_q<3>(x, P0, P1, h, w0, nw, st);
-    default: return launch_halves_q<0>(x, P0, P1, h, w0, nw, st);
+    case 1: return launch_halves_q<1, T>(x, P0, P1, h, w0, nw, st);
+    case 2: return launch_halves_q<2, T>(x, P0, P1, h, w0, nw, st);
+    case 3: return launch_halves_q<3, T>(x, P0, P1, h, w0, nw, st);
+    default: return launch_halves_q<0, T>(x, P0, P1, h, w0, nw, st);
   }
 }
 
-size_t dx_half_lds(const HalfP& h, int second) {
+size_t dx_half_lds(const HalfP& h, int second, size_t esz) {
   const int nd = second ? h.n1 : h.n0;
   const long long E = second ? h.Bn : h.A;
-  return (size_t)4 * ((size_t)nd * h.p.Q + 3 * (size_t)E + 64) * sizeof(double);
+  return (size_t)4 * ((size_t)nd * h.p.Q + 3 * (size_t)E + 64) * esz;
 }
 
-template <int LOGQ>
-int launch_dx_half_q(const double* x, const double* dP, double* gxw, const HalfP& h, int second, long long w0,
+template <int LOGQ, typename T>
+int launch_dx_half_q(const T* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
                      long long nw, hipStream_t st) {
-  const size_t lds = dx_half_lds(h, second);
+  const size_t lds = dx_half_lds(h, second, sizeof(T));
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)f64_dx_half_k<LOGQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(f64_dx_half_k<LOGQ>, dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
+    (void)hipFuncSetAttribute((const void*)halves_dx_half_k<LOGQ, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((halves_dx_half_k<LOGQ, T>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
 
-int launch_dx_half(const double* x, const double* dP, double* gxw, const HalfP& h, int second, long long w0,
+template <typename T>
+int launch_dx_half(const T* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
                    long long nw, hipStream_t st) {
   switch (ilog2_pow2(h.p.Q)) {
-    case 1: return launch_dx_half_q<1>(x, dP, gxw, h, second, w0, nw, st);
-    case 2: return launch_dx_half_q<2>(x, dP, gxw, h, second, w0, nw, st);
-    case 3: return launch_dx_half_q<3>(x, dP, gxw, h, second, w0, nw, st);
-    default: return launch_dx_half_q<0>(x, dP, gxw, h, second, w0, nw, st);
+    case 1: return launch_dx_half_q<1, T>(x, dP, gxw, h, second, w0, nw, st);
+    case 2: return launch_dx_half_q<2, T>(x, dP, gxw, h, second, w0, nw, st);
+    case 3: return launch_dx_half_q<3, T>(x, dP, gxw, h, second, w0, nw, st);
+    default: return launch_dx_half_q<0, T>(x, dP, gxw, h, second, w0, nw, st);
   }
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-}  // namespace
-
-// float64, at least two factors, a core worth a GEMM, halves that fit the per-window LDS of the dX kernel
-bool eps_f64_wanted(const EpsP& p, int dtype) {
-  if (dtype != DCTN_F64 || p.N < 2) return false;
+// ---- host side, per element type
+bool halves_shape_ok(const EpsP& p, size_t esz) {
+  if (p.N < 2) return false;
   if (p.R * p.O < 2048 || p.Wn < 64) return false;
-  const HalfP h = make_half(p);
+  const HalfP h = make_half(p, esz);
   if (h.Bn > 1024 || h.A > 1024 || h.NB > (1ll << 20)) return false;   // per-wave LDS tables of the dX kernel; int-sized GEMM dims
   if (p.Wn >= (1ll << 31)) return false;
   // per-workgroup LDS of the halves kernel (features + quarter tables) and of the dX kernel (3 E per wave)
-  if ((size_t)4 * ((size_t)p.N * p.Q + 2 * (size_t)(h.A + h.Bn)) * 8 > DCTN_LDS_BUDGET) return false;
-  if ((size_t)4 * ((size_t)h.n1 * p.Q + 3 * (size_t)h.Bn + 64) * 8 > DCTN_LDS_BUDGET) return false;
+  if ((size_t)4 * ((size_t)p.N * p.Q + 2 * (size_t)(h.A + h.Bn)) * esz > DCTN_LDS_BUDGET) return false;
+  if ((size_t)4 * ((size_t)h.n1 * p.Q + 3 * (size_t)h.Bn + 64) * esz > DCTN_LDS_BUDGET) return false;
   return true;
 }
 
-size_t eps_fwd_f64_workspace(const EpsP& p, int dtype) {
-  if (!eps_f64_wanted(p, dtype)) return 0;
-  const HalfP h = make_half(p);
-  return align_up((size_t)h.wc * h.A * 8) + align_up((size_t)h.wc * h.Bn * 8) + align_up((size_t)h.wc * h.NB * 8) + 256;
+template <typename T>
+size_t fwd_workspace_t(const EpsP& p) {
+  const HalfP h = make_half(p, sizeof(T));
+  return align_up((size_t)h.wc * h.A * sizeof(T)) + align_up((size_t)h.wc * h.Bn * sizeof(T)) +
+         align_up((size_t)h.wc * h.NB * sizeof(T)) + 256;
 }
 
-int eps_fwd_f64(const void* xv, const void* corev, void* outv, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
-                hipStream_t st) {
-  if (!eps_f64_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
-  if (!ws || ws_bytes < eps_fwd_f64_workspace(p, dtype)) return DCTN_ERR_WORKSPACE;
-  const HalfP h = make_half(p);
-  const double* x = (const double*)xv;
-  const double* core = (const double*)corev;
-  double* out = (double*)outv;
+template <typename T>
+int fwd_t(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st) {
+  const HalfP h = make_half(p, sizeof(T));
+  const T* x = (const T*)xv;
+  const T* core = (const T*)corev;
+  T* out = (T*)outv;
   unsigned char* w8 = (unsigned char*)ws;
-  double* P0 = (double*)w8;
-  double* P1 = (double*)(w8 + align_up((size_t)h.wc * h.A * 8));
-  double* Z = (double*)((unsigned char*)P1 + align_up((size_t)h.wc * h.Bn * 8));
+  T* P0 = (T*)w8;
+  T* P1 = (T*)(w8 + align_up((size_t)h.wc * h.A * sizeof(T)));
+  T* Z = (T*)((unsigned char*)P1 + align_up((size_t)h.wc * h.Bn * sizeof(T)));
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
-    int rc = launch_halves(x, P0, P1, h, w0, nw, st);
+    int rc = launch_halves<T>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
-    GemmD g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, P1, nullptr, h.Bn, p.O};
+    GemmD<T> g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, P1, nullptr, h.Bn, p.O};
     if (fused_epilogue_ok(p.O)) {
       // Z stays in the accumulators: per column tile partial sums [tile_n][w][o] (in the Z slot), then their sum
       const int tiles_n = (int)((h.NB + GT - 1) / GT);
-      gemm_launch<A_KFAST, B_NFAST, EPI_FWD>(P0, core, Z, g, 1, st);
+      gemm_launch<A_KFAST, B_NFAST, EPI_FWD, T>(P0, core, Z, g, 1, st);
       DCTN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(f64_sum_partials_k, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, Z, out + w0 * p.O,
-                         nw * p.O, tiles_n, 0);
+      hipLaunchKernelGGL(halves_sum_partials_k<T>, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, (const T*)Z,
+                         out + w0 * p.O, nw * p.O, tiles_n, 0);
       DCTN_CHECK_LAUNCH();
     } else {
-      gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g, 1, st);
+      gemm_launch<A_KFAST, B_NFAST, EPI_STORE, T>(P0, core, Z, g, 1, st);
       DCTN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(f64_fwd_contract_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, Z, P1, out + w0 * p.O,
-                         nw, h.Bn, p.O);
+      hipLaunchKernelGGL(halves_fwd_contract_k<T>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, (const T*)Z,
+                         (const T*)P1, out + w0 * p.O, nw, h.Bn, p.O);
       DCTN_CHECK_LAUNCH();
     }
   }
-  dctn_set_last_kernel("eps_fwd_mfma_f64_halves");
   return DCTN_OK;
 }
 
-size_t eps_bwd_f64_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore) {
-  if (!eps_f64_wanted(p, dtype)) return 0;
-  const HalfP h = make_half(p);
-  size_t s = align_up((size_t)h.wc * h.A * 8) + align_up((size_t)h.wc * h.Bn * 8);
-  if (need_dcore) s += align_up((size_t)h.ksplit * h.A * h.NB * 8);
+template <typename T>
+size_t bwd_workspace_t(const EpsP& p, int need_dx, int need_dcore) {
+  const HalfP h = make_half(p, sizeof(T));
+  const size_t e = sizeof(T);
+  size_t s = align_up((size_t)h.wc * h.A * e) + align_up((size_t)h.wc * h.Bn * e);
+  if (need_dcore) s += align_up((size_t)h.ksplit * h.A * h.NB * e);
   if (need_dx)
-    s += align_up((size_t)h.wc * h.NB * 8) + align_up((size_t)h.wc * h.A * 8) + align_up((size_t)h.wc * h.Bn * 8) +
-         align_up((size_t)p.N * p.Q * p.Wn * 8);
+    s += align_up((size_t)h.wc * h.NB * e) + align_up((size_t)h.wc * h.A * e) + align_up((size_t)h.wc * h.Bn * e) +
+         align_up((size_t)p.N * p.Q * p.Wn * e);
   return s + 256;
 }
 
-int eps_bwd_f64(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, size_t ws_bytes,
-                const EpsP& p, int dtype, hipStream_t st) {
-  if (!eps_f64_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
+template <typename T>
+int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, const EpsP& p,
+          int dtype, hipStream_t st) {
   const int need_dx = dXv != nullptr, need_dcore = dCorev != nullptr;
-  if (!ws || ws_bytes < eps_bwd_f64_workspace(p, dtype, need_dx, need_dcore)) return DCTN_ERR_WORKSPACE;
-  const HalfP h = make_half(p);
-  const double* x = (const double*)xv;
-  const double* core = (const double*)corev;
-  const double* dY = (const double*)dYv;
+  const HalfP h = make_half(p, sizeof(T));
+  const size_t e = sizeof(T);
+  const T* x = (const T*)xv;
+  const T* core = (const T*)corev;
+  const T* dY = (const T*)dYv;
   unsigned char* w8 = (unsigned char*)ws;
   auto take = [&](size_t bytes) {
-    double* ptr = (double*)w8;
+    T* ptr = (T*)w8;
     w8 += align_up(bytes);
     return ptr;
   };
-  double* P0 = take((size_t)h.wc * h.A * 8);
-  double* P1 = take((size_t)h.wc * h.Bn * 8);
-  double* part = need_dcore ? take((size_t)h.ksplit * h.A * h.NB * 8) : nullptr;
-  double *Z = nullptr, *dP0 = nullptr, *dP1 = nullptr, *gxw = nullptr;
+  T* P0 = take((size_t)h.wc * h.A * e);
+  T* P1 = take((size_t)h.wc * h.Bn * e);
+  T* part = need_dcore ? take((size_t)h.ksplit * h.A * h.NB * e) : nullptr;
+  T *Z = nullptr, *dP0 = nullptr, *dP1 = nullptr, *gxw = nullptr;
   if (need_dx) {
-    Z = take((size_t)h.wc * h.NB * 8);
-    dP0 = take((size_t)h.wc * h.A * 8);
-    dP1 = take((size_t)h.wc * h.Bn * 8);
-    gxw = take((size_t)p.N * p.Q * p.Wn * 8);
+    Z = take((size_t)h.wc * h.NB * e);
+    dP0 = take((size_t)h.wc * h.A * e);
+    dP1 = take((size_t)h.wc * h.Bn * e);
+    gxw = take((size_t)p.N * p.Q * p.Wn * e);
   }
   int chunk = 0;
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc, ++chunk) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
-    const double* dyc = dY + w0 * p.O;
-    int rc = launch_halves(x, P0, P1, h, w0, nw, st);
+    const T* dyc = dY + w0 * p.O;
+    int rc = launch_halves<T>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
     if (need_dcore) {
       // dCore[(i0), (i1 o)] = sum_w P0[w, i0] T[w, (i1 o)]: K = windows, split over grid.z
       const long long ksl = ((nw + h.ksplit - 1) / h.ksplit + GK - 1) / GK * GK;
       const int slices = (int)((nw + ksl - 1) / ksl);
-      GemmD g{(int)h.A, (int)h.NB, (int)nw, h.A, 0, h.NB, ksl, h.A * h.NB, P1, dyc, h.Bn, p.O};
-      gemm_launch<A_MFAST, B_T>(P0, nullptr, part, g, slices, st);
+      GemmD<T> g{(int)h.A, (int)h.NB, (int)nw, h.A, 0, h.NB, ksl, h.A * h.NB, P1, dyc, h.Bn, p.O};
+      gemm_launch<A_MFAST, B_T, EPI_STORE, T>(P0, nullptr, part, g, slices, st);
       DCTN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(f64_sum_partials_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, part, (double*)dCorev,
-                         h.A * h.NB, slices, chunk > 0);
+      hipLaunchKernelGGL(halves_sum_partials_k<T>, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, (const T*)part,
+                         (T*)dCorev, h.A * h.NB, slices, chunk > 0);
       DCTN_CHECK_LAUNCH();
     }
     if (need_dx) {
       // dP0[w, i0] = sum_(i1 o) T[w, (i1 o)] Core[i0, (i1 o)]
-      GemmD g0{(int)nw, (int)h.A, (int)h.NB, 0, h.NB, h.A, h.NB, 0, P1, dyc, h.Bn, p.O};
-      gemm_launch<A_T, B_KFAST>(nullptr, core, dP0, g0, 1, st);
+      GemmD<T> g0{(int)nw, (int)h.A, (int)h.NB, 0, h.NB, h.A, h.NB, 0, P1, dyc, h.Bn, p.O};
+      gemm_launch<A_T, B_KFAST, EPI_STORE, T>(nullptr, core, dP0, g0, 1, st);
       DCTN_CHECK_LAUNCH();
       // Z[w, (i1 o)] = sum_i0 P0[w, i0] Core[i0, (i1 o)], dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
-      GemmD g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, dyc, h.Bn, p.O};
+      GemmD<T> g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, dyc, h.Bn, p.O};
       if (fused_epilogue_ok(p.O)) {
-        gemm_launch<A_KFAST, B_NFAST, EPI_DP1>(P0, core, dP1, g1, 1, st);
+        gemm_launch<A_KFAST, B_NFAST, EPI_DP1, T>(P0, core, dP1, g1, 1, st);
         DCTN_CHECK_LAUNCH();
       } else {
-        gemm_launch<A_KFAST, B_NFAST>(P0, core, Z, g1, 1, st);
+        gemm_launch<A_KFAST, B_NFAST, EPI_STORE, T>(P0, core, Z, g1, 1, st);
         DCTN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(f64_dp1_k, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, Z, dyc, dP1, nw, h.Bn, p.O);
+        hipLaunchKernelGGL(halves_dp1_k<T>, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, (const T*)Z, dyc, dP1,
+                           nw, h.Bn, p.O);
         DCTN_CHECK_LAUNCH();
       }
-      rc = launch_dx_half(x, dP0, gxw, h, 0, w0, nw, st);
+      rc = launch_dx_half<T>(x, dP0, gxw, h, 0, w0, nw, st);
       if (rc != DCTN_OK) return rc;
-      rc = launch_dx_half(x, dP1, gxw, h, 1, w0, nw, st);
+      rc = launch_dx_half<T>(x, dP1, gxw, h, 1, w0, nw, st);
       if (rc != DCTN_OK) return rc;
     }
   }
   if (need_dx) {
-    const int rc = eps_gather_dx_launch(gxw, dXv, p, DCTN_F64, st);
+    const int rc = eps_gather_dx_launch(gxw, dXv, p, dtype, st);
     if (rc != DCTN_OK) return rc;
   }
-  dctn_set_last_kernel("eps_bwd_mfma_f64_halves");
   return DCTN_OK;
+}
+
+}  // namespace
+
+// float64 (the dtype of the reference's tests and of BASELINE cfg1) and float32 shapes the other families leave
+// (odd Q, ...; the dispatcher asks the bf16-register and bigcore families first): at least two factors, a core
+// worth a GEMM, halves that fit the per-wave LDS tables.
+bool eps_halves_wanted(const EpsP& p, int dtype) {
+  if (dtype == DCTN_F64) return halves_shape_ok(p, sizeof(double));
+  if (dtype == DCTN_F32) return halves_shape_ok(p, sizeof(float));
+  return false;
+}
+
+size_t eps_fwd_halves_workspace(const EpsP& p, int dtype) {
+  if (!eps_halves_wanted(p, dtype)) return 0;
+  return dtype == DCTN_F64 ? fwd_workspace_t<double>(p) : fwd_workspace_t<float>(p);
+}
+
+int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
+                   hipStream_t st) {
+  if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < eps_fwd_halves_workspace(p, dtype)) return DCTN_ERR_WORKSPACE;
+  const int rc = dtype == DCTN_F64 ? fwd_t<double>(x, core, out, ws, p, st) : fwd_t<float>(x, core, out, ws, p, st);
+  if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_fwd_mfma_f64_halves" : "eps_fwd_mfma_f32_halves");
+  return rc;
+}
+
+size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore) {
+  if (!eps_halves_wanted(p, dtype)) return 0;
+  return dtype == DCTN_F64 ? bwd_workspace_t<double>(p, need_dx, need_dcore) : bwd_workspace_t<float>(p, need_dx, need_dcore);
+}
+
+int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
+                   const EpsP& p, int dtype, hipStream_t st) {
+  if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < eps_bwd_halves_workspace(p, dtype, dX != nullptr, dCore != nullptr)) return DCTN_ERR_WORKSPACE;
+  const int rc = dtype == DCTN_F64 ? bwd_t<double>(x, core, dY, dX, dCore, ws, p, dtype, st)
+                                   : bwd_t<float>(x, core, dY, dX, dCore, ws, p, dtype, st);
+  if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_bwd_mfma_f64_halves" : "eps_bwd_mfma_f32_halves");
+  return rc;
 }

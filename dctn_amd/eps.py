@@ -82,7 +82,7 @@ def eps(core: Tensor, input: Tensor) -> Tensor:
 
 def _bf16_through_f32(core: Tensor, input: Tensor) -> bool:
     """bf16 tensors whose core is outside the bf16 register family (deeper layers, Q > 2) would land on the
-    generic kernels; the exact-f32 matrix-core family takes them instead: bf16 storage, f32 arithmetic
+    generic kernels; the exact-f32 matrix-core families (bigcore, two-halves GEMMs) take them instead: bf16 storage, f32 arithmetic
     (the casts are three small elementwise kernels next to millisecond GEMMs; autograd casts the gradients
     back)."""
     if core.dtype != torch.bfloat16 or not core.is_cuda:
@@ -92,7 +92,7 @@ def _bf16_through_f32(core: Tensor, input: Tensor) -> bool:
     args = (C, B, H, W, Q, K, core.shape[-1])
     lib, prec = L.lib(), L.precision()
     return (lib.dctn_eps_family(*args, L.dtype_code(core), prec) == 0
-            and lib.dctn_eps_family(*args, L._DTYPE_CODE[torch.float32], prec) == 2)
+            and lib.dctn_eps_family(*args, L._DTYPE_CODE[torch.float32], prec) in (2, 3))
 
 
 def eps_one_by_one(core: Tensor, input: Tensor) -> Tensor:

@@ -70,7 +70,7 @@ const char* dctn_last_kernel(void);
 #define DCTN_EPS_FAMILY_GENERIC 0
 #define DCTN_EPS_FAMILY_Q2REG 1        /* bf16 MFMA, Q = 2, N in {8, 9} */
 #define DCTN_EPS_FAMILY_BIGCORE_F32 2  /* exact f32 MFMA, LDS-streamed core */
-#define DCTN_EPS_FAMILY_F64_HALVES 3   /* f64 MFMA two-halves path */
+#define DCTN_EPS_FAMILY_HALVES 3       /* two-halves GEMM path: f64 MFMA, and f32 MFMA for shapes 1 and 2 leave */
 int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int precision);
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
                                     int dtype, int precision);

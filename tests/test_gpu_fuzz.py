@@ -158,6 +158,36 @@ def test_eps_f64_matrix_core_path(case):
     check(c3.grad, dcore, torch.float64, "dCore alone")
 
 
+# float32 shapes the bf16-register and bigcore families leave (odd Q): the two-halves GEMM path on v_mfma_f32_16x16x4_f32
+F32_HALVES_CASES = [(2, 2, 3, 3, 3, 7, 9, True), (1, 2, 5, 4, 4, 8, 8, False), (1, 3, 3, 2, 2, 9, 9, False),
+                    (1, 2, 6, 8, 5, 7, 6, False)]
+
+
+@pytest.mark.parametrize("case", F32_HALVES_CASES, ids=lambda c: "C%dK%dQ%dO%dB%d_%dx%d%s" % (c[:7] + ("_strided" if c[7] else "",)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eps_f32_halves_path_for_odd_q(case, dtype):
+    C, K, Q, O, B, H, W, strided = case
+    torch.manual_seed(sum(case[:7]) + 1)
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q).to(dtype)
+    core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(dtype)
+    xd = x.to(DEV)
+    if strided:
+        xd = xd.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    xd = xd.requires_grad_(True)
+    cd = core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f32_halves" and y.dtype == dtype   # bf16: storage only
+    want = R.eps_4step(core.double(), x.double())
+    check(y, want, dtype, "forward")
+    dy = torch.randn(*want.shape).to(dtype)
+    y.backward(dy.to(DEV))
+    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f32_halves"
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    check(xd.grad, dx, dtype, "dX")
+    check(cd.grad, dcore, dtype, "dCore")
+
+
 @pytest.mark.parametrize("T,Rr,I,dtype", [(1, 1, 1, torch.float64), (7, 3, 5, torch.float32), (33, 65, 17, torch.float64),
                                           (256, 256, 256, torch.float32), (5, 128, 3, torch.float32)])
 def test_logmatmulexp_random(T, Rr, I, dtype):

@@ -159,7 +159,9 @@ def bench_eps(cpu):
              ("cfg3a-L1 K=4 Q=2 O=4 f32 B=128", 1, 128, 28, 2, 4, 4, torch.float32),
              ("cfg3a-L2 K=3 Q=4 O=6 f32 B=128", 1, 128, 25, 4, 3, 6, torch.float32),
              ("cfg3b-L1 K=4 Q=2 O=8 f32 B=128", 1, 128, 28, 2, 4, 8, torch.float32),
-             ("cfg3b-L2 K=2 Q=8 O=8 f32 B=128", 1, 128, 25, 8, 2, 8, torch.float32)]
+             ("cfg3b-L2 K=2 Q=8 O=8 f32 B=128", 1, 128, 25, 8, 2, 8, torch.float32),
+             ("odd Q: C=2 K=2 Q=3 O=8 f32 B=128 (two-halves f32 path)", 2, 128, 28, 3, 2, 8, torch.float32),
+             ("odd Q: C=1 K=3 Q=3 O=6 f32 B=128 (two-halves f32 path)", 1, 128, 28, 3, 3, 6, torch.float32)]
     for name, C, B, HW, Q, K, O, dt in cases:
         N = K * K * C
         x = torch.randn(C, B, HW, HW, Q, device=DEV, dtype=dt, requires_grad=True)
@@ -179,7 +181,7 @@ def bench_eps(cpu):
             eps(core, x).backward(dy)
 
         f, b = time_gpu(fwd, 5), time_gpu(fb, 3)
-        report("eps " + name, windows, f, b, {"fwd_TFLOPs": round(flops / f / 1e12, 2),
+        report("eps " + name, windows, f, b, {"kernel": dctn_amd.last_kernel(), "fwd_TFLOPs": round(flops / f / 1e12, 2),
                                                 "fwd_bwd_TFLOPs": round(3 * flops / b / 1e12, 2)})
 
 
