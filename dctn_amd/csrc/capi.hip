@@ -1,6 +1,8 @@
 // C-ABI entry points (include/dctn_amd.h): argument validation + dispatch to kernel families.
 #include "common.h"
 
+#include <stdlib.h>
+
 static const char* volatile g_last_kernel = "none";  // process-wide: autograd runs backward on its own thread
 void dctn_set_last_kernel(const char* name) { g_last_kernel = name; }
 
@@ -28,6 +30,16 @@ const char* dctn_strerror(int code) {
   return "unknown error";
 }
 
+// measurement aid: DCTN_F32_PREFER_HALVES=1 sends float32 shapes that both families cover to the two-halves path
+static bool f32_prefers_halves(const EpsP& p, int dtype) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DCTN_F32_PREFER_HALVES");
+    v = e ? atoi(e) : 0;
+  }
+  return v != 0 && dtype == DCTN_F32 && eps_halves_wanted(p, dtype);
+}
+
 static bool dtype_ok(int dtype) { return dtype == DCTN_F32 || dtype == DCTN_F64 || dtype == DCTN_BF16; }
 
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
@@ -44,7 +56,7 @@ int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, 
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return -1;
   if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
-  if (eps_bigcore_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_BIGCORE_F32;
+  if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return DCTN_EPS_FAMILY_BIGCORE_F32;
   if (eps_halves_wanted(p, dtype)) return DCTN_EPS_FAMILY_HALVES;
   return DCTN_EPS_FAMILY_GENERIC;
 }
@@ -60,8 +72,10 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   hipStream_t st = (hipStream_t)stream;
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
-  rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st);
-  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  if (!f32_prefers_halves(p, dtype)) {
+    rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
   rc = eps_fwd_halves(x, core, out, workspace, workspace_bytes, p, dtype, st);
   if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
   return eps_fwd_generic(x, core, out, p, dtype, st);
@@ -130,7 +144,7 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   if (!dX && !dCore) return DCTN_OK;
   const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
   // float64, and float32 shapes the bigcore family does not take: both gradients on the two-halves GEMM path
-  if (dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision)) {
+  if (dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision) || f32_prefers_halves(p, dtype)) {
     rc = eps_bwd_halves(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st);
     if (rc == DCTN_OK) return rc;
     if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
