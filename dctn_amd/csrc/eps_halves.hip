@@ -18,6 +18,8 @@
 // tools/mfma64probe.hip): register v of lane l is D[4 v + l / 16][l % 16].
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) double f64x4;
@@ -45,7 +47,7 @@ template <> struct Mma<float> {
 namespace {
 
 constexpr int GT = 64, GK = 16;                 // tile, k chunk
-constexpr size_t CHUNK_BYTES = (size_t)1 << 30; // bound of the per-chunk buffers
+constexpr size_t CHUNK_BYTES = (size_t)1 << 30; // bound of the per-chunk buffers (DCTN_HALVES_CHUNK_BYTES overrides: tests)
 
 struct HalfP {
   EpsP p;
@@ -64,7 +66,12 @@ HalfP make_half(const EpsP& p, size_t esz) {
   h.Bn = ipow_ll(p.Q, h.n1);
   h.NB = h.Bn * p.O;
   const long long per_win = (2 * h.A + 2 * h.Bn + h.NB) * (long long)esz;
-  long long wc = (long long)(CHUNK_BYTES / (size_t)per_win);
+  size_t budget = CHUNK_BYTES;
+  if (const char* e = getenv("DCTN_HALVES_CHUNK_BYTES")) {
+    const long long v = atoll(e);
+    if (v > 0) budget = (size_t)v;
+  }
+  long long wc = (long long)(budget / (size_t)per_win);
   wc = wc / 64 * 64;
   if (wc < 64) wc = 64;
   const long long wn64 = (p.Wn + 63) / 64 * 64;

@@ -158,6 +158,39 @@ def test_eps_f64_matrix_core_path(case):
     check(c3.grad, dcore, torch.float64, "dCore alone")
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_eps_halves_path_in_several_window_chunks(dtype, monkeypatch):
+    """The two-halves path bounds its per-chunk buffers (1 GiB); with the bound lowered to 256 KiB the 1 000
+    windows below run in 16 chunks of 64 windows (dCore accumulated over the chunks, per-chunk columns of the factor
+    gradients) — same numbers as the oracle, and as the single-chunk run."""
+    C, K, Q, O, B, H, W = 1, 3, 3, 2, 10, 12, 12      # N = 9, Q = 3: halves of 81 and 243 entries, 1 000 windows
+    torch.manual_seed(77)
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q, dtype=dtype)
+    core = torch.randn(*(Q,) * N, O, dtype=dtype) * Q ** (-N / 4)
+    dy = torch.randn(B, H - K + 1, W - K + 1, O, dtype=dtype)
+
+    def run():
+        xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
+        y = eps(cd, xd)
+        assert "halves" in dctn_amd.last_kernel()
+        y.backward(dy.to(DEV))
+        return y.detach(), xd.grad, cd.grad
+
+    whole = run()
+    monkeypatch.setenv("DCTN_HALVES_CHUNK_BYTES", str(256 * 1024))
+    chunked = run()
+    want = R.eps_4step(core.double(), x.double())
+    dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+    for got in (whole, chunked):
+        check(got[0], want, dtype, "forward")
+        check(got[1], dx, dtype, "dX")
+        check(got[2], dcore, dtype, "dCore")
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    for a, b in zip(whole, chunked):
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max())
+
+
 # float32 shapes the bf16-register and bigcore families leave (odd Q): the two-halves GEMM path on v_mfma_f32_16x16x4_f32
 F32_HALVES_CASES = [(2, 2, 3, 3, 3, 7, 9, True), (1, 2, 5, 4, 4, 8, 8, False), (1, 3, 3, 2, 2, 9, 9, False),
                     (1, 2, 6, 8, 5, 7, 6, False)]
