@@ -24,6 +24,11 @@ constexpr int HEAD_MAXC = 16;
 // ------------------------------------------------------------------------------------ forward
 constexpr int HF_MAXK = 12;  // k-steps (of 32 features) one wave can hold in flight
 
+// ROWS samples per workgroup (rows of the 16 x 16 tile that carry a sample): 16, or 4 when 16 would leave most of
+// the 256 CUs without a workgroup (B = 1024: 64 -> 256 workgroups; the idle tile rows cost nothing, the kernel
+// is one memory round trip long).  cfg2 step: 39.0 us with 16 rows, 38.4 (8), 37.5 (4), 39.2 (2), 42.1 (1); 16 waves
+// per workgroup instead of 8: no change.
+template <int ROWS>
 __global__ __launch_bounds__(512) void head_fwd_k(const bf16_t* __restrict__ feat,
                                                   const bf16_t* __restrict__ W,
                                                   const bf16_t* __restrict__ bias,
@@ -32,8 +37,8 @@ __global__ __launch_bounds__(512) void head_fwd_k(const bf16_t* __restrict__ fea
   __shared__ float red[8][16 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const long long b = (long long)blockIdx.x * 16 + r;      // sample of this lane's A rows
-  const bool bok = b < B, cok = r < Cout;
+  const long long b = (long long)blockIdx.x * ROWS + r;    // sample of this lane's A rows
+  const bool bok = r < ROWS && b < B, cok = r < Cout;
   const int ksteps = (F + 31) / 32;
   const int per = (ksteps + 7) / 8;                        // k-steps per wave
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -48,10 +53,10 @@ __global__ __launch_bounds__(512) void head_fwd_k(const bf16_t* __restrict__ fea
       const int k0 = s * 32 + 8 * g;
       const bool in = s < (wv + 1) * per && k0 + 8 <= F;   // F % 8 == 0: a chunk is in or out
       const int kc = in ? k0 : 0;
-      av[u] = *reinterpret_cast<const bf16x8*>(fa + kc);
-      bv[u] = *reinterpret_cast<const bf16x8*>(wb + kc);
-      if (!in || !bok) av[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (!in || !cok) bv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      av[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      bv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (in && bok) av[u] = *reinterpret_cast<const bf16x8*>(fa + kc);
+      if (in && cok) bv[u] = *reinterpret_cast<const bf16x8*>(wb + kc);
     }
 #pragma unroll
     for (int u = 0; u < HF_MAXK; ++u)
@@ -66,8 +71,8 @@ __global__ __launch_bounds__(512) void head_fwd_k(const bf16_t* __restrict__ fea
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][tid];
-    const long long bb = (long long)blockIdx.x * 16 + row;
-    if (bb < B && c < Cout) out[bb * Cout + c] = (bf16_t)(s + (float)bias[c]);
+    const long long bb = (long long)blockIdx.x * ROWS + row;
+    if (row < ROWS && bb < B && c < Cout) out[bb * Cout + c] = (bf16_t)(s + (float)bias[c]);
   }
 }
 
@@ -248,9 +253,14 @@ int dctn_linear_head_fwd(const void* feat, const void* weight, const void* bias,
   if (B < 1 || F < 1 || Cout < 1) return DCTN_ERR_BAD_SHAPE;
   if (!head_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (((uintptr_t)feat % 16) || ((uintptr_t)weight % 16)) return DCTN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(head_fwd_k, dim3((unsigned)((B + 15) / 16)), dim3(512), 0, (hipStream_t)stream,
-                     (const bf16_t*)feat, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out,
-                     (long long)B, F, Cout);
+  if ((B + 15) / 16 >= 256)
+    hipLaunchKernelGGL(head_fwd_k<16>, dim3((unsigned)((B + 15) / 16)), dim3(512), 0, (hipStream_t)stream,
+                       (const bf16_t*)feat, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out,
+                       (long long)B, F, Cout);
+  else
+    hipLaunchKernelGGL(head_fwd_k<4>, dim3((unsigned)((B + 3) / 4)), dim3(512), 0, (hipStream_t)stream,
+                       (const bf16_t*)feat, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out,
+                       (long long)B, F, Cout);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("linear_head_fwd_mfma");
   return DCTN_OK;
