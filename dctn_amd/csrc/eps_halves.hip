@@ -97,9 +97,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 // One wave per window (4 per workgroup).  Each half is itself a Kronecker product of two quarter tables
 // (its leading ceil(nd/2) factors x its trailing ones, <= 32 entries each for halves <= 1024): the tables cost
 // nd/2 multiplies per entry, every entry of P0 / P1 then one multiply and two LDS reads.
-template <int LOGQ, typename T>
-__global__ __launch_bounds__(256) void halves_k(const T* __restrict__ x, T* __restrict__ P0,
-                                                    T* __restrict__ P1, HalfP h, long long w0, long long nw) {
+template <int LOGQ, typename T, typename S = T>   // T: arithmetic / LDS type, S: storage type of x, P0, P1
+__global__ __launch_bounds__(256) void halves_k(const S* __restrict__ x, S* __restrict__ P0,
+                                                    S* __restrict__ P1, HalfP h, long long w0, long long nw) {
   extern __shared__ __align__(16) unsigned char sm_raw[];
   T* sm = reinterpret_cast<T*>(sm_raw);
   const EpsP& p = h.p;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void halves_k(const T* __restrict__ x, T* __re
     for (int e = lane; e < p.N * Q; e += 64) {
       const int n = e / Q, q = e - n * Q;
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
-      xs[e] = x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
+      xs[e] = (T)x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
     wave_sync_lds();
     for (int e = lane; e < ntab; e += 64) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void halves_k(const T* __restrict__ x, T* __re
         u = e / L0;
         l = e - u * L0;
       }
-      P0[wl * h.A + e] = tab[u] * tab[off1 + l];
+      P0[wl * h.A + e] = (S)(tab[u] * tab[off1 + l]);
     }
     for (int e = lane; e < Bn; e += 64) {
       int u, l;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void halves_k(const T* __restrict__ x, T* __re
         u = e / L1;
         l = e - u * L1;
       }
-      P1[wl * h.Bn + e] = tab[off2 + u] * tab[off3 + l];
+      P1[wl * h.Bn + e] = (S)(tab[off2 + u] * tab[off3 + l]);
     }
   }
 }
@@ -439,33 +439,33 @@ bool fused_epilogue_ok(int O) { return O >= 1 && O <= 16 && (O & (O - 1)) == 0; 
 
 // --------------------------------------------------------------------- contractions around the GEMMs
 // out[w, o] = sum_i1 Z[w, i1, o] P1[w, i1]: one wave per window
-template <typename T>
-__global__ __launch_bounds__(256) void halves_fwd_contract_k(const T* __restrict__ Z, const T* __restrict__ P1,
-                                                          T* __restrict__ out, long long nw, long long Bn, int O) {
+template <typename T, typename S = T>
+__global__ __launch_bounds__(256) void halves_fwd_contract_k(const T* __restrict__ Z, const S* __restrict__ P1,
+                                                          S* __restrict__ out, long long nw, long long Bn, int O) {
   const int lane = threadIdx.x & 63;
   const long long wl = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wl >= nw) return;
   const T* z = Z + wl * Bn * O;
-  const T* p1 = P1 + wl * Bn;
+  const S* p1 = P1 + wl * Bn;
   for (int o = 0; o < O; ++o) {
     T s = 0.0;
-    for (long long i1 = lane; i1 < Bn; i1 += 64) s += z[i1 * O + o] * p1[i1];
+    for (long long i1 = lane; i1 < Bn; i1 += 64) s += z[i1 * O + o] * (T)p1[i1];
     s = wave_reduce_sum(s);
-    if (lane == 0) out[wl * O + o] = s;
+    if (lane == 0) out[wl * O + o] = (S)s;
   }
 }
 
 // dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
-template <typename T>
-__global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, const T* __restrict__ dY,
+template <typename T, typename S = T>
+__global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, const S* __restrict__ dY,
                                                  T* __restrict__ dP1, long long nw, long long Bn, int O) {
   const long long total = nw * Bn;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const long long wl = idx / Bn;
     const T* z = Z + idx * O;
-    const T* dy = dY + wl * O;
+    const S* dy = dY + wl * O;
     T s = 0.0;
-    for (int o = 0; o < O; ++o) s += dy[o] * z[o];
+    for (int o = 0; o < O; ++o) s += (T)dy[o] * z[o];
     dP1[idx] = s;
   }
 }
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, con
 // SUF_f[l] (factors below f): both families of Kronecker prefix / suffix products are built level by level in
 // the wave's LDS (sum over levels < E entries each), so a term costs three LDS reads and two multiplies.
 // Lane -> (pair (f, q), slice of the (u, l) range); slices are summed through LDS.
-template <int LOGQ, typename T>
-__global__ __launch_bounds__(256) void halves_dx_half_k(const T* __restrict__ x, const T* __restrict__ dP,
+template <int LOGQ, typename T, typename S = T>
+__global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x, const T* __restrict__ dP,
                                                      T* __restrict__ gxw, HalfP h, int second, long long w0,
                                                      long long nw) {
   extern __shared__ __align__(16) unsigned char sm_raw[];
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const T* __restrict__ x,
     for (int e = lane; e < np; e += 64) {
       const int n = base + e / Q, q = e % Q;
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
-      xs[e] = x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
+      xs[e] = (T)x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
     for (int e = lane; e < E; e += 64) dps[e] = dP[wl * E + e];
     if (lane == 0) pre[0] = 1.0, suf[0] = 1.0;   // level 0 of PRE (factor 0), level nd-1 of SUF (last factor)
@@ -579,13 +579,13 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const T* __restrict__ x,
 }
 
 // dCore (+)= sum of the split-k partial products
-template <typename T>
-__global__ __launch_bounds__(256) void halves_sum_partials_k(const T* __restrict__ part, T* __restrict__ dCore,
+template <typename T, typename S = T>
+__global__ __launch_bounds__(256) void halves_sum_partials_k(const T* __restrict__ part, S* __restrict__ dCore,
                                                           long long n, int slices, int accumulate) {
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-    T s = accumulate ? dCore[idx] : 0.0;
+    T s = accumulate ? (T)dCore[idx] : (T)0;
     for (int k = 0; k < slices; ++k) s += part[(long long)k * n + idx];
-    dCore[idx] = s;
+    dCore[idx] = (S)s;
   }
 }
 
@@ -602,8 +602,8 @@ unsigned blocks_for(long long n, int per) {
   return (unsigned)b;
 }
 
-template <int LOGQ, typename T>
-int launch_halves_q(const T* x, T* P0, T* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+template <int LOGQ, typename T, typename S>
+int launch_halves_q(const S* x, S* P0, S* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
   // per wave: the window's features + the four quarter tables
   size_t ntab = 0;
   for (int s2 = 0; s2 < 2; ++s2) {
@@ -613,19 +613,19 @@ int launch_halves_q(const T* x, T* P0, T* P1, const HalfP& h, long long w0, long
   const size_t lds = (size_t)4 * ((size_t)h.p.N * h.p.Q + ntab) * sizeof(T);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)halves_k<LOGQ, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((halves_k<LOGQ, T>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, P0, P1, h, w0, nw);
+    (void)hipFuncSetAttribute((const void*)halves_k<LOGQ, T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((halves_k<LOGQ, T, S>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, P0, P1, h, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
 
-template <typename T>
-int launch_halves(const T* x, T* P0, T* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
+template <typename T, typename S = T>
+int launch_halves(const S* x, S* P0, S* P1, const HalfP& h, long long w0, long long nw, hipStream_t st) {
   switch (ilog2_pow2(h.p.Q)) {
-    case 1: return launch_halves_q<1, T>(x, P0, P1, h, w0, nw, st);
-    case 2: return launch_halves_q<2, T>(x, P0, P1, h, w0, nw, st);
-    case 3: return launch_halves_q<3, T>(x, P0, P1, h, w0, nw, st);
-    default: return launch_halves_q<0, T>(x, P0, P1, h, w0, nw, st);
+    case 1: return launch_halves_q<1, T, S>(x, P0, P1, h, w0, nw, st);
+    case 2: return launch_halves_q<2, T, S>(x, P0, P1, h, w0, nw, st);
+    case 3: return launch_halves_q<3, T, S>(x, P0, P1, h, w0, nw, st);
+    default: return launch_halves_q<0, T, S>(x, P0, P1, h, w0, nw, st);
   }
 }
 
@@ -635,25 +635,25 @@ size_t dx_half_lds(const HalfP& h, int second, size_t esz) {
   return (size_t)4 * ((size_t)nd * h.p.Q + 3 * (size_t)E + 64) * esz;
 }
 
-template <int LOGQ, typename T>
-int launch_dx_half_q(const T* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
+template <int LOGQ, typename T, typename S>
+int launch_dx_half_q(const S* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
                      long long nw, hipStream_t st) {
   const size_t lds = dx_half_lds(h, second, sizeof(T));
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)halves_dx_half_k<LOGQ, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((halves_dx_half_k<LOGQ, T>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
+    (void)hipFuncSetAttribute((const void*)halves_dx_half_k<LOGQ, T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((halves_dx_half_k<LOGQ, T, S>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
 
-template <typename T>
-int launch_dx_half(const T* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
+template <typename T, typename S = T>
+int launch_dx_half(const S* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
                    long long nw, hipStream_t st) {
   switch (ilog2_pow2(h.p.Q)) {
-    case 1: return launch_dx_half_q<1, T>(x, dP, gxw, h, second, w0, nw, st);
-    case 2: return launch_dx_half_q<2, T>(x, dP, gxw, h, second, w0, nw, st);
-    case 3: return launch_dx_half_q<3, T>(x, dP, gxw, h, second, w0, nw, st);
-    default: return launch_dx_half_q<0, T>(x, dP, gxw, h, second, w0, nw, st);
+    case 1: return launch_dx_half_q<1, T, S>(x, dP, gxw, h, second, w0, nw, st);
+    case 2: return launch_dx_half_q<2, T, S>(x, dP, gxw, h, second, w0, nw, st);
+    case 3: return launch_dx_half_q<3, T, S>(x, dP, gxw, h, second, w0, nw, st);
+    default: return launch_dx_half_q<0, T, S>(x, dP, gxw, h, second, w0, nw, st);
   }
 }
 
@@ -670,6 +670,373 @@ bool halves_shape_ok(const EpsP& p, size_t esz) {
   if ((size_t)4 * ((size_t)p.N * p.Q + 2 * (size_t)(h.A + h.Bn)) * esz > DCTN_LDS_BUDGET) return false;
   if ((size_t)4 * ((size_t)h.n1 * p.Q + 3 * (size_t)h.Bn + 64) * esz > DCTN_LDS_BUDGET) return false;
   return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 storage on the bf16 matrix cores: the same products with v_mfma_f32_16x16x32_bf16 (float32 accumulate).
+// The instruction wants 8 consecutive k per lane for BOTH operands, so both LDS tiles are kept [row][k] and every
+// operand is read from memory 8 elements (16 bytes) at a time.  To make that possible for any O the core is
+// re-laid once per call with its output index in front of the half index:
+//     coreP[i0][(o, i1)] = core[i0][(i1, o)]        coreQ[i1][(o, i0)] = core[i0][(i1, o)]
+//   forward : Z' = P0 x coreP, a 64-column tile then holds ONE o and 64 consecutive i1: the epilogue multiplies by
+//             P1[w, i1] and sums the tile's columns -> partial[tile][w]          (Z never stored, any O)
+//   dCore   : dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]  (k = window, split-k; un-permuted at the end)
+//   dP0     : sum_(o, i1) (dY[w, o] P1[w, i1]) coreP[i0][(o, i1)]          dP1 : sum_(o, i0) (dY[w, o] P0[w, i0]) coreQ[i1][(o, i0)]
+// A "scaled" operand is one 16-byte load of the half's row times one scalar of dY, formed in float32 and rounded once.
+// Sources that are contiguous along the row index instead of k (coreP for Z', P0 and the scaled P1 rows for dCore) are
+// transposed while they are staged (eight 2-byte LDS writes).  Accumulator rows as in the float32 instruction.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+
+constexpr int BK = 32;        // k per chunk = one MFMA step
+constexpr int BROW = BK + 4;  // LDS row in bf16 (72 bytes: 8-byte aligned operand reads, rows spread over the banks)
+
+enum { BA_KFAST = 0, BA_MFAST = 1, BA_SCALED = 2 };   // A[m][k] rows / A stored [k][m] / sc[m][o] * V[m][j], k = o KV + j
+enum { BB_NFAST = 0, BB_KFAST = 1, BB_SCALEDX = 2 };  // B stored [k][n] / [n][k] / sc[k][o] * V[k][j], n = o KV + j (k = window)
+enum { BEPI_STORE = 0, BEPI_FWD = 1 };
+
+struct GemmB {
+  int M, N, K;
+  long long lda, ldb;
+  long long kslice, cslice;
+  const bf16_t* vec;   // scaled operand: rows of P0 / P1 (ld ldv) and dY (ld O) of the chunk
+  const bf16_t* sc;
+  long long ldv;
+  int KV, O;
+  const bf16_t* p1;    // forward epilogue: P1 (ld Bn)
+  int Bn;
+  int slices;
+};
+
+__device__ __forceinline__ bf16x8v zero8() { return bf16x8v{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+__device__ __forceinline__ bf16x8v scale8(bf16x8v v, float s) {
+  bf16x8v r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16_t)((float)v[j] * s);
+  return r;
+}
+
+// C[m, n] = sum_k A(m, k) B(k, n), float32 out.  M, N, K of the k-contiguous sources are multiples of 8, KV of 32.
+template <int LA, int LB, int EPI>
+__global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
+                                                   float* __restrict__ Cg, GemmB g) {
+  __shared__ __align__(16) bf16_t smem[2 * 64 * BROW];
+  bf16_t* As = smem;               // [m][k]
+  bf16_t* Bs = smem + 64 * BROW;   // [n][k]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int tiles_n = (g.N + 63) / 64, tiles_m = (g.M + 63) / 64;
+  const int total = tiles_n * tiles_m * g.slices, per = (total + 7) / 8;
+  const int t = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;   // XCD-aware tile order (see halves_gemm_k)
+  if (t >= total) return;
+  const int bz = t / (tiles_n * tiles_m), trem = t - bz * tiles_n * tiles_m;
+  const int m0 = (trem / tiles_n) * 64, n0 = (trem % tiles_n) * 64;
+  const long long kbeg = (long long)bz * g.kslice;
+  const long long kend = kbeg + g.kslice < g.K ? kbeg + g.kslice : g.K;
+  // k-contiguous source: row = tid >> 2, 8 k's from (tid & 3) * 8; row-contiguous source: k = tid >> 3, 8 rows from (tid & 7) * 8
+  const int kf_r = tid >> 2, kf_k8 = (tid & 3) * 8;
+  const int xf_k = tid >> 3, xf_x8 = (tid & 7) * 8;
+  constexpr bool AKF = LA != BA_MFAST, BKF = LB == BB_KFAST;
+  // scaled B operand: this thread's 8 columns n = o KV + j are fixed
+  int sb_o = 0, sb_j = 0;
+  if (LB == BB_SCALEDX) {
+    const int n = min(n0 + xf_x8, g.N - 8);
+    sb_o = n / g.KV;
+    sb_j = n - sb_o * g.KV;
+  }
+  bf16x8v ra, rb;
+  float sa = 1.f, sb = 1.f;
+  auto fetch = [&](long long k0) {
+    if (LA == BA_KFAST) {
+      const long long m = min(m0 + kf_r, g.M - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
+      ra = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
+    } else if (LA == BA_MFAST) {
+      const long long k = min(k0 + xf_k, (long long)g.K - 1), m = min(m0 + xf_x8, g.M - 8);
+      ra = *reinterpret_cast<const bf16x8v*>(Ag + k * g.lda + m);
+    } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide chunk lies inside one o)
+      const long long m = min(m0 + kf_r, g.M - 1);
+      const int k = (int)min(k0 + kf_k8, (long long)g.K - 8);
+      const int o = k / g.KV, j = k - o * g.KV;
+      ra = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
+      sa = (float)g.sc[m * g.O + o];
+    }
+    if (LB == BB_NFAST) {
+      const long long k = min(k0 + xf_k, (long long)g.K - 1), n = min(n0 + xf_x8, g.N - 8);
+      rb = *reinterpret_cast<const bf16x8v*>(Bg + k * g.ldb + n);
+    } else if (LB == BB_KFAST) {
+      const long long n = min(n0 + kf_r, g.N - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
+      rb = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
+    } else {   // sc[k = w][o] * V[w][j .. j+7]
+      const long long k = min(k0 + xf_k, (long long)g.K - 1);
+      rb = *reinterpret_cast<const bf16x8v*>(g.vec + k * g.ldv + sb_j);
+      sb = (float)g.sc[k * g.O + sb_o];
+    }
+  };
+  auto put8 = [&](bf16_t* dst, bf16x8v v) {   // 8-byte aligned destination
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+    reinterpret_cast<bf16x4v*>(dst)[0] = bf16x4v{v[0], v[1], v[2], v[3]};
+    reinterpret_cast<bf16x4v*>(dst)[1] = bf16x4v{v[4], v[5], v[6], v[7]};
+  };
+  auto stage = [&](long long k0) {
+    const bf16x8v va = LA == BA_SCALED ? scale8(ra, sa) : ra;
+    const bf16x8v vb = LB == BB_SCALEDX ? scale8(rb, sb) : rb;
+    if (AKF) {
+      put8(As + kf_r * BROW + kf_k8, k0 + kf_k8 < kend ? va : zero8());
+    } else {
+      const bool in = k0 + xf_k < kend;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) As[(xf_x8 + j) * BROW + xf_k] = in ? va[j] : (bf16_t)0.f;
+    }
+    if (BKF) {
+      put8(Bs + kf_r * BROW + kf_k8, k0 + kf_k8 < kend ? vb : zero8());
+    } else {
+      const bool in = k0 + xf_k < kend;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Bs[(xf_x8 + j) * BROW + xf_k] = in ? vb[j] : (bf16_t)0.f;
+    }
+  };
+  auto get8 = [&](const bf16_t* src) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+    const bf16x4v lo = reinterpret_cast<const bf16x4v*>(src)[0], hi = reinterpret_cast<const bf16x4v*>(src)[1];
+    return bf16x8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (kbeg < kend) fetch(kbeg);
+  for (long long k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+    stage(k0);
+    __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);
+    bf16x8v a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = get8(As + (32 * wm + 16 * i + lr) * BROW + 8 * lk);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = get8(Bs + (32 * wn + 16 * j + lr) * BROW + 8 * lk);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  if (EPI == BEPI_FWD) {
+    // the tile's 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[tile][w] =
+    // sum over the columns of Z'[w, n] P1[w, i1(n)]
+    float* red = reinterpret_cast<float*>(smem);   // [2 (wn)][64 rows]
+    const int i1_0 = n0 % g.Bn;
+    __syncthreads();   // every wave is done reading the tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 32 * wm + 16 * i + 4 * lk + v, m = min(m0 + r, g.M - 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          sum += acc[i][j][v] * (float)g.p1[(long long)m * g.Bn + i1_0 + 32 * wn + 16 * j + lr];
+#pragma unroll
+        for (int step = 1; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
+        if (lr == 0) red[wn * 64 + r] = sum;
+      }
+    __syncthreads();
+    if (tid < 64 && m0 + tid < g.M) Cg[(long long)(trem % tiles_n) * g.M + m0 + tid] = red[tid] + red[64 + tid];
+    return;
+  }
+  float* C = Cg + (long long)bz * g.cslice;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int m = m0 + 32 * wm + 16 * i + 4 * lk + v, n = n0 + 32 * wn + 16 * j + lr;
+        if (m < g.M && n < g.N) C[(long long)m * g.N + n] = acc[i][j][v];
+      }
+}
+
+template <int LA, int LB, int EPI = BEPI_STORE>
+void bf16_gemm_launch(const bf16_t* A, const bf16_t* B, float* C, GemmB g, int slices, hipStream_t st) {
+  g.slices = slices;
+  const int total = ((g.N + 63) / 64) * ((g.M + 63) / 64) * slices;
+  hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
+}
+
+// coreP[i0][o Bn + i1] = core[i0][i1 O + o] (and, with which = 1, coreQ[i1][o A + i0])
+__global__ __launch_bounds__(256) void bf16_core_permute_k(const bf16_t* __restrict__ core, bf16_t* __restrict__ dst,
+                                                           long long A, long long Bn, int O, int which) {
+  const long long total = A * Bn * O;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    // idx runs over the DESTINATION (coalesced writes)
+    if (which == 0) {
+      const long long i0 = idx / (Bn * O), rem = idx - i0 * Bn * O;
+      const long long o = rem / Bn, i1 = rem - o * Bn;
+      dst[idx] = core[(i0 * Bn + i1) * O + o];
+    } else {
+      const long long i1 = idx / (A * O), rem = idx - i1 * A * O;
+      const long long o = rem / A, i0 = rem - o * A;
+      dst[idx] = core[(i0 * Bn + i1) * O + o];
+    }
+  }
+}
+
+// dCore[i0][i1 O + o] = (bf16) dCoreP32[i0][o Bn + i1]
+__global__ __launch_bounds__(256) void bf16_dcore_unpermute_k(const float* __restrict__ src, bf16_t* __restrict__ dCore,
+                                                              long long A, long long Bn, int O) {
+  const long long total = A * Bn * O;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long i0 = idx / (Bn * O), rem = idx - i0 * Bn * O;
+    const long long i1 = rem / O, o = rem - i1 * O;
+    dCore[idx] = (bf16_t)src[(i0 * O + o) * Bn + i1];
+  }
+}
+
+// out[w][o] = sum over the Bn / 64 column tiles of output o of partial[tile][w]
+__global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ part, bf16_t* __restrict__ out,
+                                                      long long nw, int O, int tiles_per_o) {
+  const long long total = nw * O;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long w = idx / O;
+    const int o = (int)(idx - w * O);
+    float s = 0.f;
+    for (int tt = 0; tt < tiles_per_o; ++tt) s += part[(long long)(o * tiles_per_o + tt) * nw + w];
+    out[idx] = (bf16_t)s;
+  }
+}
+
+// bf16 path: every k-contiguous source is read 16 bytes at a time, scaled chunks and forward tiles lie inside one o
+bool bf16_shape_ok(const EpsP& p) {
+  if (!halves_shape_ok(p, sizeof(float))) return false;
+  const HalfP h = make_half(p, sizeof(float));
+  return h.A % 32 == 0 && h.Bn % 64 == 0;
+}
+
+size_t bf16_fwd_workspace(const EpsP& p) {
+  const HalfP h = make_half(p, sizeof(float));
+  return align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2) + align_up((size_t)h.A * h.NB * 2) +
+         align_up((size_t)(h.NB / 64) * h.wc * 4) + 256;
+}
+
+int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st) {
+  const HalfP h = make_half(p, sizeof(float));
+  const bf16_t* x = (const bf16_t*)xv;
+  const bf16_t* core = (const bf16_t*)corev;
+  bf16_t* out = (bf16_t*)outv;
+  unsigned char* w8 = (unsigned char*)ws;
+  auto take = [&](size_t bytes) {
+    void* ptr = w8;
+    w8 += align_up(bytes);
+    return ptr;
+  };
+  bf16_t* P0 = (bf16_t*)take((size_t)h.wc * h.A * 2);
+  bf16_t* P1 = (bf16_t*)take((size_t)h.wc * h.Bn * 2);
+  bf16_t* coreP = (bf16_t*)take((size_t)h.A * h.NB * 2);
+  float* part = (float*)take((size_t)(h.NB / 64) * h.wc * 4);
+  hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreP, h.A, h.Bn,
+                     p.O, 0);
+  DCTN_CHECK_LAUNCH();
+  for (long long w0 = 0; w0 < p.Wn; w0 += h.wc) {
+    const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
+    int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
+    if (rc != DCTN_OK) return rc;
+    GemmB g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.A, 0, nullptr, nullptr, 0, 32, p.O, P1, (int)h.Bn};
+    bf16_gemm_launch<BA_KFAST, BB_NFAST, BEPI_FWD>(P0, coreP, part, g, 1, st);
+    DCTN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bf16_out_sum_k, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, (const float*)part,
+                       out + w0 * p.O, nw, p.O, (int)(h.Bn / 64));
+    DCTN_CHECK_LAUNCH();
+  }
+  return DCTN_OK;
+}
+
+size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
+  const HalfP h = make_half(p, sizeof(float));
+  size_t s = align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2);
+  if (need_dcore) s += align_up((size_t)h.ksplit * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4);
+  if (need_dx)
+    s += 2 * align_up((size_t)h.A * h.NB * 2) + align_up((size_t)h.wc * h.A * 4) + align_up((size_t)h.wc * h.Bn * 4) +
+         align_up((size_t)p.N * p.Q * p.Wn * 4);
+  return s + 256;
+}
+
+int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, const EpsP& p,
+             hipStream_t st) {
+  const int need_dx = dXv != nullptr, need_dcore = dCorev != nullptr;
+  const HalfP h = make_half(p, sizeof(float));
+  const bf16_t* x = (const bf16_t*)xv;
+  const bf16_t* core = (const bf16_t*)corev;
+  const bf16_t* dY = (const bf16_t*)dYv;
+  unsigned char* w8 = (unsigned char*)ws;
+  auto take = [&](size_t bytes) {
+    void* ptr = w8;
+    w8 += align_up(bytes);
+    return ptr;
+  };
+  bf16_t* P0 = (bf16_t*)take((size_t)h.wc * h.A * 2);
+  bf16_t* P1 = (bf16_t*)take((size_t)h.wc * h.Bn * 2);
+  float *part = nullptr, *dcore32 = nullptr, *dP0 = nullptr, *dP1 = nullptr, *gxw = nullptr;
+  bf16_t *coreP = nullptr, *coreQ = nullptr;
+  if (need_dcore) {
+    part = (float*)take((size_t)h.ksplit * h.A * h.NB * 4);
+    dcore32 = (float*)take((size_t)h.A * h.NB * 4);   // float32 running sum over the window chunks, (o, i1) order
+  }
+  if (need_dx) {
+    coreP = (bf16_t*)take((size_t)h.A * h.NB * 2);
+    coreQ = (bf16_t*)take((size_t)h.A * h.NB * 2);
+    dP0 = (float*)take((size_t)h.wc * h.A * 4);
+    dP1 = (float*)take((size_t)h.wc * h.Bn * 4);
+    gxw = (float*)take((size_t)p.N * p.Q * p.Wn * 4);
+    hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreP, h.A, h.Bn,
+                       p.O, 0);
+    DCTN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreQ, h.A, h.Bn,
+                       p.O, 1);
+    DCTN_CHECK_LAUNCH();
+  }
+  int chunk = 0;
+  for (long long w0 = 0; w0 < p.Wn; w0 += h.wc, ++chunk) {
+    const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
+    const bf16_t* dyc = dY + w0 * p.O;
+    int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
+    if (rc != DCTN_OK) return rc;
+    if (need_dcore) {
+      // dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]: k = windows, split over grid.z
+      const long long ksl = ((nw + h.ksplit - 1) / h.ksplit + BK - 1) / BK * BK;
+      const int slices = (int)((nw + ksl - 1) / ksl);
+      GemmB g{(int)h.A, (int)h.NB, (int)nw, h.A, 0, ksl, h.A * h.NB, P1, dyc, h.Bn, (int)h.Bn, p.O, nullptr, (int)h.Bn};
+      bf16_gemm_launch<BA_MFAST, BB_SCALEDX>(P0, nullptr, part, g, slices, st);
+      DCTN_CHECK_LAUNCH();
+      hipLaunchKernelGGL((halves_sum_partials_k<float, float>), dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st,
+                         (const float*)part, dcore32, h.A * h.NB, slices, chunk > 0);
+      DCTN_CHECK_LAUNCH();
+    }
+    if (need_dx) {
+      // dP0[w, i0] = sum_(o, i1) (dY[w, o] P1[w, i1]) coreP[i0][(o, i1)]
+      GemmB g0{(int)nw, (int)h.A, (int)h.NB, 0, h.NB, h.NB, 0, P1, dyc, h.Bn, (int)h.Bn, p.O, nullptr, (int)h.Bn};
+      bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreP, dP0, g0, 1, st);
+      DCTN_CHECK_LAUNCH();
+      // dP1[w, i1] = sum_(o, i0) (dY[w, o] P0[w, i0]) coreQ[i1][(o, i0)]
+      const long long KQ = h.A * p.O;
+      GemmB g1{(int)nw, (int)h.Bn, (int)KQ, 0, KQ, KQ, 0, P0, dyc, h.A, (int)h.A, p.O, nullptr, (int)h.Bn};
+      bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreQ, dP1, g1, 1, st);
+      DCTN_CHECK_LAUNCH();
+      rc = launch_dx_half<float, bf16_t>(x, dP0, gxw, h, 0, w0, nw, st);
+      if (rc != DCTN_OK) return rc;
+      rc = launch_dx_half<float, bf16_t>(x, dP1, gxw, h, 1, w0, nw, st);
+      if (rc != DCTN_OK) return rc;
+    }
+  }
+  if (need_dcore) {
+    hipLaunchKernelGGL(bf16_dcore_unpermute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, (const float*)dcore32,
+                       (bf16_t*)dCorev, h.A, h.Bn, p.O);
+    DCTN_CHECK_LAUNCH();
+  }
+  if (need_dx) {
+    const int rc = eps_gather_dx_launch(gxw, dXv, p, DCTN_BF16, st);
+    if (rc != DCTN_OK) return rc;
+  }
+  return DCTN_OK;
 }
 
 template <typename T>
@@ -805,11 +1172,13 @@ int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* d
 bool eps_halves_wanted(const EpsP& p, int dtype) {
   if (dtype == DCTN_F64) return halves_shape_ok(p, sizeof(double));
   if (dtype == DCTN_F32) return halves_shape_ok(p, sizeof(float));
+  if (dtype == DCTN_BF16) return bf16_shape_ok(p);   // bf16 MFMA; the dispatcher asks the bf16 register family first
   return false;
 }
 
 size_t eps_fwd_halves_workspace(const EpsP& p, int dtype) {
   if (!eps_halves_wanted(p, dtype)) return 0;
+  if (dtype == DCTN_BF16) return bf16_fwd_workspace(p);
   return dtype == DCTN_F64 ? fwd_workspace_t<double>(p) : fwd_workspace_t<float>(p);
 }
 
@@ -817,6 +1186,12 @@ int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t 
                    hipStream_t st) {
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_fwd_halves_workspace(p, dtype)) return DCTN_ERR_WORKSPACE;
+  if (dtype == DCTN_BF16) {
+    if ((uintptr_t)core % 16) return DCTN_ERR_UNSUPPORTED;   // 16-byte vector loads of core rows
+    const int rc = bf16_fwd(x, core, out, ws, p, st);
+    if (rc == DCTN_OK) dctn_set_last_kernel("eps_fwd_mfma_bf16_halves");
+    return rc;
+  }
   const int rc = dtype == DCTN_F64 ? fwd_t<double>(x, core, out, ws, p, st) : fwd_t<float>(x, core, out, ws, p, st);
   if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_fwd_mfma_f64_halves" : "eps_fwd_mfma_f32_halves");
   return rc;
@@ -824,6 +1199,7 @@ int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t 
 
 size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore) {
   if (!eps_halves_wanted(p, dtype)) return 0;
+  if (dtype == DCTN_BF16) return bf16_bwd_workspace(p, need_dx, need_dcore);
   return dtype == DCTN_F64 ? bwd_workspace_t<double>(p, need_dx, need_dcore) : bwd_workspace_t<float>(p, need_dx, need_dcore);
 }
 
@@ -831,6 +1207,12 @@ int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, vo
                    const EpsP& p, int dtype, hipStream_t st) {
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_bwd_halves_workspace(p, dtype, dX != nullptr, dCore != nullptr)) return DCTN_ERR_WORKSPACE;
+  if (dtype == DCTN_BF16) {
+    if ((uintptr_t)core % 16) return DCTN_ERR_UNSUPPORTED;
+    const int rc = bf16_bwd(x, core, dY, dX, dCore, ws, p, st);
+    if (rc == DCTN_OK) dctn_set_last_kernel("eps_bwd_mfma_bf16_halves");
+    return rc;
+  }
   const int rc = dtype == DCTN_F64 ? bwd_t<double>(x, core, dY, dX, dCore, ws, p, dtype, st)
                                    : bwd_t<float>(x, core, dY, dX, dCore, ws, p, dtype, st);
   if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_bwd_mfma_f64_halves" : "eps_bwd_mfma_f32_halves");

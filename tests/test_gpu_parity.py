@@ -404,9 +404,9 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
 
 
 # ------------------------------------------------------------------ linear head (bf16, skinny)
-def test_eps_bf16_large_core_runs_on_the_f32_matrix_core_family():
-    """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer) are routed through
-    the exact-f32 bigcore kernels (bf16 storage, f32 arithmetic) instead of the generic kernels."""
+def test_eps_bf16_large_core_runs_on_the_matrix_cores():
+    """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer): two-halves GEMMs on
+    v_mfma_f32_16x16x32_bf16 (bf16 P0 / P1 / T, float32 accumulate) — not the generic kernels."""
     torch.manual_seed(31)
     for (C, B, H, W, Q, K, O) in ((1, 5, 9, 8, 2, 4, 4), (1, 3, 7, 7, 4, 3, 6)):
         N = K * K * C
@@ -414,11 +414,12 @@ def test_eps_bf16_large_core_runs_on_the_f32_matrix_core_family():
         core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(torch.bfloat16)
         xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
         y = eps(cd, xd)
-        assert y.dtype == torch.bfloat16 and dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+        assert y.dtype == torch.bfloat16 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves"
         want = R.eps_4step(core.double(), x.double())
         assert bf16_close(y, want)
         dy = torch.randn(*want.shape).to(torch.bfloat16)
         y.backward(dy.to(DEV))
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bf16_halves"
         assert xd.grad.dtype == torch.bfloat16 and cd.grad.dtype == torch.bfloat16
         gc, gx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
         assert bf16_close(cd.grad, gc) and bf16_close(xd.grad, gx)

@@ -59,7 +59,8 @@ def test_eps_family_query_matches_the_dispatch_table():
     assert lib.dctn_eps_family(1, 128, 28, 28, 2, 4, 4, F32, 0) == 2        # cfg3a layer 1: exact-f32 bigcore
     assert lib.dctn_eps_family(1, 128, 25, 25, 4, 3, 6, F32, 0) == 2        # cfg3a layer 2
     assert lib.dctn_eps_family(1, 64, 28, 28, 2, 4, 2, F64, 0) == 3         # cfg1: f64 matrix cores
-    assert lib.dctn_eps_family(1, 128, 28, 28, 2, 4, 4, BF16, 0) == 0       # bf16 big core: routed through f32 by eps()
+    assert lib.dctn_eps_family(1, 128, 28, 28, 2, 4, 4, BF16, 0) == 3       # bf16 big core: two-halves GEMMs on the bf16 matrix cores
+    assert lib.dctn_eps_family(2, 3, 7, 9, 3, 2, 3, BF16, 0) == 0           # bf16, odd Q: eps() routes it through float32
     assert lib.dctn_eps_family(1, 2, 5, 5, 3, 2, 2, F64, 0) == 0            # tiny: generic
     assert lib.dctn_eps_family(2, 3, 7, 9, 3, 2, 3, F32, 0) == 3            # odd Q in float32: two-halves GEMMs
     assert lib.dctn_eps_family(1, 2, 5, 5, 3, 9, 2, F32, 0) == -1           # kernel larger than the image

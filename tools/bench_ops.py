@@ -160,6 +160,9 @@ def bench_eps(cpu):
              ("cfg3a-L2 K=3 Q=4 O=6 f32 B=128", 1, 128, 25, 4, 3, 6, torch.float32),
              ("cfg3b-L1 K=4 Q=2 O=8 f32 B=128", 1, 128, 28, 2, 4, 8, torch.float32),
              ("cfg3b-L2 K=2 Q=8 O=8 f32 B=128", 1, 128, 25, 8, 2, 8, torch.float32),
+             ("cfg3a-L1 K=4 Q=2 O=4 bf16 B=128 (two-halves bf16 MFMA path)", 1, 128, 28, 2, 4, 4, torch.bfloat16),
+             ("cfg3a-L2 K=3 Q=4 O=6 bf16 B=128 (two-halves bf16 MFMA path)", 1, 128, 25, 4, 3, 6, torch.bfloat16),
+             ("K=3 Q=4 O=8 bf16 B=128 (two-halves bf16 MFMA path, fused epilogue)", 1, 128, 25, 4, 3, 8, torch.bfloat16),
              ("odd Q: C=2 K=2 Q=3 O=8 f32 B=128 (two-halves f32 path)", 2, 128, 28, 3, 2, 8, torch.float32),
              ("odd Q: C=1 K=3 Q=3 O=6 f32 B=128 (two-halves f32 path)", 1, 128, 28, 3, 3, 6, torch.float32)]
     for name, C, B, HW, Q, K, O, dt in cases:
