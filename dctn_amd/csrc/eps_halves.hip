@@ -687,11 +687,11 @@ bool halves_shape_ok(const EpsP& p, size_t esz) {
 // transposed while they are staged (eight 2-byte LDS writes).  Accumulator rows as in the float32 instruction.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
-constexpr int BK = 32;        // k per chunk = one MFMA step
-constexpr int BROW = BK + 4;  // LDS row in bf16 (72 bytes: 8-byte aligned operand reads, rows spread over the banks)
+constexpr int BK = 64;        // k per chunk (two MFMA steps per barrier pair)
 
 enum { BA_KFAST = 0, BA_MFAST = 1, BA_SCALED = 2 };   // A[m][k] rows / A stored [k][m] / sc[m][o] * V[m][j], k = o KV + j
-enum { BB_NFAST = 0, BB_KFAST = 1, BB_SCALEDX = 2 };  // B stored [k][n] / [n][k] / sc[k][o] * V[k][j], n = o KV + j (k = window)
+enum { BB_NFAST = 0, BB_KFAST = 1, BB_SCALEDX = 2, BB_PROD = 3 };  // B stored [k][n] / [n][k] / sc[k][o] * V[k][j], n = o KV + j
+                                                                   // (k = window) / scT[o][k..] * VT[j][k..] (both k-contiguous)
 enum { BEPI_STORE = 0, BEPI_FWD = 1 };
 
 struct GemmB {
@@ -717,9 +717,10 @@ __device__ __forceinline__ bf16x8v scale8(bf16x8v v, float s) {
 }
 
 // C[m, n] = sum_k A(m, k) B(k, n), float32 out.  M, N, K of the k-contiguous sources are multiples of 8, KV of 32.
-template <int LA, int LB, int EPI>
+template <int LA, int LB, int EPI, int KC>   // KC: k per chunk (32 or 64: one or two MFMA steps per barrier pair)
 __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                    float* __restrict__ Cg, GemmB g) {
+  constexpr int NU = KC / 32, BROW = KC + 4;   // vectors per thread and operand; LDS row in bf16 (8-byte aligned rows)
   __shared__ __align__(16) bf16_t smem[2 * 64 * BROW];
   bf16_t* As = smem;               // [m][k]
   bf16_t* Bs = smem + 64 * BROW;   // [n][k]
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
   // k-contiguous source: row = tid >> 2, 8 k's from (tid & 3) * 8; row-contiguous source: k = tid >> 3, 8 rows from (tid & 7) * 8
   const int kf_r = tid >> 2, kf_k8 = (tid & 3) * 8;
   const int xf_k = tid >> 3, xf_x8 = (tid & 7) * 8;
-  constexpr bool AKF = LA != BA_MFAST, BKF = LB == BB_KFAST;
+  constexpr bool AKF = LA != BA_MFAST, BKF = LB == BB_KFAST || LB == BB_PROD;
   // scaled B operand: this thread's 8 columns n = o KV + j are fixed
   int sb_o = 0, sb_j = 0;
   if (LB == BB_SCALEDX) {
@@ -744,32 +745,44 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
     sb_o = n / g.KV;
     sb_j = n - sb_o * g.KV;
   }
-  bf16x8v ra, rb;
-  float sa = 1.f, sb = 1.f;
-  auto fetch = [&](long long k0) {
-    if (LA == BA_KFAST) {
-      const long long m = min(m0 + kf_r, g.M - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
-      ra = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
-    } else if (LA == BA_MFAST) {
-      const long long k = min(k0 + xf_k, (long long)g.K - 1), m = min(m0 + xf_x8, g.M - 8);
-      ra = *reinterpret_cast<const bf16x8v*>(Ag + k * g.lda + m);
-    } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide chunk lies inside one o)
-      const long long m = min(m0 + kf_r, g.M - 1);
-      const int k = (int)min(k0 + kf_k8, (long long)g.K - 8);
-      const int o = k / g.KV, j = k - o * g.KV;
-      ra = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
-      sa = (float)g.sc[m * g.O + o];
-    }
-    if (LB == BB_NFAST) {
-      const long long k = min(k0 + xf_k, (long long)g.K - 1), n = min(n0 + xf_x8, g.N - 8);
-      rb = *reinterpret_cast<const bf16x8v*>(Bg + k * g.ldb + n);
-    } else if (LB == BB_KFAST) {
-      const long long n = min(n0 + kf_r, g.N - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
-      rb = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
-    } else {   // sc[k = w][o] * V[w][j .. j+7]
-      const long long k = min(k0 + xf_k, (long long)g.K - 1);
-      rb = *reinterpret_cast<const bf16x8v*>(g.vec + k * g.ldv + sb_j);
-      sb = (float)g.sc[k * g.O + sb_o];
+  bf16x8v ra[NU], rb[NU];
+  float sa[NU], sb[NU];
+  auto fetch = [&](long long kc0) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const long long k0 = kc0 + 32 * u;
+      if (LA == BA_KFAST) {
+        const long long m = min(m0 + kf_r, g.M - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
+        ra[u] = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
+      } else if (LA == BA_MFAST) {
+        const long long k = min(k0 + xf_k, (long long)g.K - 1), m = min(m0 + xf_x8, g.M - 8);
+        ra[u] = *reinterpret_cast<const bf16x8v*>(Ag + k * g.lda + m);
+      } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide step lies inside one o)
+        const long long m = min(m0 + kf_r, g.M - 1);
+        const int k = (int)min(k0 + kf_k8, (long long)g.K - 8);
+        const int o = k / g.KV, j = k - o * g.KV;
+        ra[u] = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
+        sa[u] = (float)g.sc[m * g.O + o];
+      }
+      if (LB == BB_NFAST) {
+        const long long k = min(k0 + xf_k, (long long)g.K - 1), n = min(n0 + xf_x8, g.N - 8);
+        rb[u] = *reinterpret_cast<const bf16x8v*>(Bg + k * g.ldb + n);
+      } else if (LB == BB_KFAST) {
+        const long long n = min(n0 + kf_r, g.N - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
+        rb[u] = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
+      } else if (LB == BB_PROD) {   // row n = (o, j): scT[o][k .. k+7] * VT[j][k .. k+7], both stored with ld ldv
+        const int n = min(n0 + kf_r, g.N - 1);
+        const int o = n / g.KV, j = n - o * g.KV;
+        const long long k = min(k0 + kf_k8, (long long)g.K - 8);
+        const bf16x8v v = *reinterpret_cast<const bf16x8v*>(g.vec + (long long)j * g.ldv + k);
+        const bf16x8v c = *reinterpret_cast<const bf16x8v*>(g.sc + (long long)o * g.ldv + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[u][e] = (bf16_t)((float)v[e] * (float)c[e]);
+      } else {   // sc[k = w][o] * V[w][j .. j+7]
+        const long long k = min(k0 + xf_k, (long long)g.K - 1);
+        rb[u] = *reinterpret_cast<const bf16x8v*>(g.vec + k * g.ldv + sb_j);
+        sb[u] = (float)g.sc[k * g.O + sb_o];
+      }
     }
   };
   auto put8 = [&](bf16_t* dst, bf16x8v v) {   // 8-byte aligned destination
@@ -777,22 +790,26 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
     reinterpret_cast<bf16x4v*>(dst)[0] = bf16x4v{v[0], v[1], v[2], v[3]};
     reinterpret_cast<bf16x4v*>(dst)[1] = bf16x4v{v[4], v[5], v[6], v[7]};
   };
-  auto stage = [&](long long k0) {
-    const bf16x8v va = LA == BA_SCALED ? scale8(ra, sa) : ra;
-    const bf16x8v vb = LB == BB_SCALEDX ? scale8(rb, sb) : rb;
-    if (AKF) {
-      put8(As + kf_r * BROW + kf_k8, k0 + kf_k8 < kend ? va : zero8());
-    } else {
-      const bool in = k0 + xf_k < kend;
+  auto stage = [&](long long kc0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) As[(xf_x8 + j) * BROW + xf_k] = in ? va[j] : (bf16_t)0.f;
-    }
-    if (BKF) {
-      put8(Bs + kf_r * BROW + kf_k8, k0 + kf_k8 < kend ? vb : zero8());
-    } else {
-      const bool in = k0 + xf_k < kend;
+    for (int u = 0; u < NU; ++u) {
+      const long long k0 = kc0 + 32 * u;
+      const bf16x8v va = LA == BA_SCALED ? scale8(ra[u], sa[u]) : ra[u];
+      const bf16x8v vb = LB == BB_SCALEDX ? scale8(rb[u], sb[u]) : rb[u];
+      if (AKF) {
+        put8(As + kf_r * BROW + 32 * u + kf_k8, k0 + kf_k8 < kend ? va : zero8());
+      } else {
+        const bool in = k0 + xf_k < kend;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Bs[(xf_x8 + j) * BROW + xf_k] = in ? vb[j] : (bf16_t)0.f;
+        for (int j = 0; j < 8; ++j) As[(xf_x8 + j) * BROW + 32 * u + xf_k] = in ? va[j] : (bf16_t)0.f;
+      }
+      if (BKF) {
+        put8(Bs + kf_r * BROW + 32 * u + kf_k8, k0 + kf_k8 < kend ? vb : zero8());
+      } else {
+        const bool in = k0 + xf_k < kend;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[(xf_x8 + j) * BROW + 32 * u + xf_k] = in ? vb[j] : (bf16_t)0.f;
+      }
     }
   };
   auto get8 = [&](const bf16_t* src) {
@@ -806,20 +823,23 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (kbeg < kend) fetch(kbeg);
-  for (long long k0 = kbeg; k0 < kend; k0 += BK) {
+  for (long long k0 = kbeg; k0 < kend; k0 += KC) {
     __syncthreads();
     stage(k0);
     __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);
-    bf16x8v a[2], b[2];
+    if (k0 + KC < kend) fetch(k0 + KC);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = get8(As + (32 * wm + 16 * i + lr) * BROW + 8 * lk);
+    for (int u = 0; u < NU; ++u) {
+      bf16x8v a[2], b[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = get8(Bs + (32 * wn + 16 * j + lr) * BROW + 8 * lk);
+      for (int i = 0; i < 2; ++i) a[i] = get8(As + (32 * wm + 16 * i + lr) * BROW + 32 * u + 8 * lk);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) b[j] = get8(Bs + (32 * wn + 16 * j + lr) * BROW + 32 * u + 8 * lk);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   }
   if (EPI == BEPI_FWD) {
     // the tile's 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[tile][w] =
@@ -860,7 +880,7 @@ template <int LA, int LB, int EPI = BEPI_STORE>
 void bf16_gemm_launch(const bf16_t* A, const bf16_t* B, float* C, GemmB g, int slices, hipStream_t st) {
   g.slices = slices;
   const int total = ((g.N + 63) / 64) * ((g.M + 63) / 64) * slices;
-  hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
+  hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI, BK>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
 
 // coreP[i0][o Bn + i1] = core[i0][i1 O + o] (and, with which = 1, coreQ[i1][o A + i0])
@@ -873,11 +893,32 @@ __global__ __launch_bounds__(256) void bf16_core_permute_k(const bf16_t* __restr
       const long long i0 = idx / (Bn * O), rem = idx - i0 * Bn * O;
       const long long o = rem / Bn, i1 = rem - o * Bn;
       dst[idx] = core[(i0 * Bn + i1) * O + o];
-    } else {
+    } else if (which == 1) {
       const long long i1 = idx / (A * O), rem = idx - i1 * A * O;
       const long long o = rem / A, i0 = rem - o * A;
       dst[idx] = core[(i0 * Bn + i1) * O + o];
+    } else {   // coreT[(o, i1)][i0]
+      const long long n = idx / A, i0 = idx - n * A;
+      const long long o = n / Bn, i1 = n - o * Bn;
+      dst[idx] = core[(i0 * Bn + i1) * O + o];
     }
+  }
+}
+
+// dst[c][r] = src[r][c] for r < R, zero for R <= r < ldd (ldd: row length of dst, a multiple of 64)
+__global__ __launch_bounds__(256) void bf16_transpose_k(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        long long R, int C, long long ldd) {
+  __shared__ bf16_t tile[64][66];
+  const long long r0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int rr = e >> 6, cc = e & 63;
+    tile[rr][cc] = (r0 + rr < R && c0 + cc < C) ? src[(r0 + rr) * C + c0 + cc] : (bf16_t)0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int cc = e >> 6, rr = e & 63;
+    if (c0 + cc < C && r0 + rr < ldd) dst[(long long)(c0 + cc) * ldd + r0 + rr] = tile[rr][cc];
   }
 }
 
@@ -933,15 +974,16 @@ int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP
   bf16_t* P1 = (bf16_t*)take((size_t)h.wc * h.Bn * 2);
   bf16_t* coreP = (bf16_t*)take((size_t)h.A * h.NB * 2);
   float* part = (float*)take((size_t)(h.NB / 64) * h.wc * 4);
+  // coreT[(o, i1)][i0]: the B operand of Z' with k = i0 contiguous
   hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreP, h.A, h.Bn,
-                     p.O, 0);
+                     p.O, 2);
   DCTN_CHECK_LAUNCH();
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
     int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
-    GemmB g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.A, 0, nullptr, nullptr, 0, 32, p.O, P1, (int)h.Bn};
-    bf16_gemm_launch<BA_KFAST, BB_NFAST, BEPI_FWD>(P0, coreP, part, g, 1, st);
+    GemmB g{(int)nw, (int)h.NB, (int)h.A, h.A, h.A, h.A, 0, nullptr, nullptr, 0, 32, p.O, P1, (int)h.Bn};
+    bf16_gemm_launch<BA_KFAST, BB_KFAST, BEPI_FWD>(P0, coreP, part, g, 1, st);
     DCTN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bf16_out_sum_k, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, (const float*)part,
                        out + w0 * p.O, nw, p.O, (int)(h.Bn / 64));
@@ -953,7 +995,9 @@ int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP
 size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
   const HalfP h = make_half(p, sizeof(float));
   size_t s = align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2);
-  if (need_dcore) s += align_up((size_t)h.ksplit * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4);
+  if (need_dcore)
+    s += align_up((size_t)h.ksplit * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4) +
+         align_up((size_t)(h.A + h.Bn + p.O) * h.wc * 2);
   if (need_dx)
     s += 2 * align_up((size_t)h.A * h.NB * 2) + align_up((size_t)h.wc * h.A * 4) + align_up((size_t)h.wc * h.Bn * 4) +
          align_up((size_t)p.N * p.Q * p.Wn * 4);
@@ -976,10 +1020,11 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
   bf16_t* P0 = (bf16_t*)take((size_t)h.wc * h.A * 2);
   bf16_t* P1 = (bf16_t*)take((size_t)h.wc * h.Bn * 2);
   float *part = nullptr, *dcore32 = nullptr, *dP0 = nullptr, *dP1 = nullptr, *gxw = nullptr;
-  bf16_t *coreP = nullptr, *coreQ = nullptr;
+  bf16_t *coreP = nullptr, *coreQ = nullptr, *halvesT = nullptr;
   if (need_dcore) {
     part = (float*)take((size_t)h.ksplit * h.A * h.NB * 4);
     dcore32 = (float*)take((size_t)h.A * h.NB * 4);   // float32 running sum over the window chunks, (o, i1) order
+    halvesT = (bf16_t*)take((size_t)(h.A + h.Bn + p.O) * h.wc * 2);   // P0^T | P1^T | dY^T, rows of wc windows
   }
   if (need_dx) {
     coreP = (bf16_t*)take((size_t)h.A * h.NB * 2);
@@ -1001,11 +1046,23 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
     int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
     if (need_dcore) {
-      // dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]: k = windows, split over grid.z
-      const long long ksl = ((nw + h.ksplit - 1) / h.ksplit + BK - 1) / BK * BK;
-      const int slices = (int)((nw + ksl - 1) / ksl);
-      GemmB g{(int)h.A, (int)h.NB, (int)nw, h.A, 0, ksl, h.A * h.NB, P1, dyc, h.Bn, (int)h.Bn, p.O, nullptr, (int)h.Bn};
-      bf16_gemm_launch<BA_MFAST, BB_SCALEDX>(P0, nullptr, part, g, slices, st);
+      // dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]: k = windows, split over grid.z.  Both operands are
+      // read along the window index, from transposed copies of the halves and of dY (zero beyond nw)
+      bf16_t* P0T = halvesT;
+      bf16_t* P1T = P0T + h.A * h.wc;
+      bf16_t* dYT = P1T + h.Bn * h.wc;
+      const unsigned rb64 = (unsigned)((nw + 63) / 64);
+      hipLaunchKernelGGL(bf16_transpose_k, dim3(rb64, (unsigned)((h.A + 63) / 64)), dim3(256), 0, st, (const bf16_t*)P0, P0T,
+                         nw, (int)h.A, h.wc);
+      hipLaunchKernelGGL(bf16_transpose_k, dim3(rb64, (unsigned)((h.Bn + 63) / 64)), dim3(256), 0, st, (const bf16_t*)P1,
+                         P1T, nw, (int)h.Bn, h.wc);
+      hipLaunchKernelGGL(bf16_transpose_k, dim3(rb64, 1), dim3(256), 0, st, dyc, dYT, nw, p.O, h.wc);
+      DCTN_CHECK_LAUNCH();
+      const long long K8 = (nw + 7) / 8 * 8;
+      const long long ksl = ((K8 + h.ksplit - 1) / h.ksplit + BK - 1) / BK * BK;
+      const int slices = (int)((K8 + ksl - 1) / ksl);
+      GemmB g{(int)h.A, (int)h.NB, (int)K8, h.wc, 0, ksl, h.A * h.NB, P1T, dYT, h.wc, (int)h.Bn, p.O, nullptr, (int)h.Bn};
+      bf16_gemm_launch<BA_KFAST, BB_PROD>(P0T, nullptr, part, g, slices, st);
       DCTN_CHECK_LAUNCH();
       hipLaunchKernelGGL((halves_sum_partials_k<float, float>), dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st,
                          (const float*)part, dcore32, h.A * h.NB, slices, chunk > 0);
