@@ -683,22 +683,24 @@ bool halves_shape_ok(const EpsP& p, size_t esz) {
 //   dCore   : dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]  (k = window, split-k; un-permuted at the end)
 //   dP0     : sum_(o, i1) (dY[w, o] P1[w, i1]) coreP[i0][(o, i1)]          dP1 : sum_(o, i0) (dY[w, o] P0[w, i0]) coreQ[i1][(o, i0)]
 // A "scaled" operand is one 16-byte load of the half's row times one scalar of dY, formed in float32 and rounded once.
-// Sources that are contiguous along the row index instead of k (coreP for Z', P0 and the scaled P1 rows for dCore) are
-// transposed while they are staged (eight 2-byte LDS writes).  Accumulator rows as in the float32 instruction.
+// Sources whose natural layout is contiguous along the row index instead of k get a k-contiguous copy first (coreT =
+// coreP transposed for Z'; P0^T, P1^T, dY^T per chunk for dCore, whose operand is then the elementwise product of two
+// 16-byte loads) — staging a row-contiguous source through eight 2-byte LDS writes per thread cost 25 % of the forward.
+// Accumulator rows as in the float32 instruction.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
 constexpr int BK = 64;        // k per chunk (two MFMA steps per barrier pair)
+constexpr int BT = 128;       // workgroup tile (2 x 2 waves of 64 x 64 = 4 x 4 MFMA tiles each)
 
-enum { BA_KFAST = 0, BA_MFAST = 1, BA_SCALED = 2 };   // A[m][k] rows / A stored [k][m] / sc[m][o] * V[m][j], k = o KV + j
-enum { BB_NFAST = 0, BB_KFAST = 1, BB_SCALEDX = 2, BB_PROD = 3 };  // B stored [k][n] / [n][k] / sc[k][o] * V[k][j], n = o KV + j
-                                                                   // (k = window) / scT[o][k..] * VT[j][k..] (both k-contiguous)
+enum { BA_KFAST = 0, BA_SCALED = 1 };   // A[m][k] rows / sc[m][o] * V[m][j], k = o KV + j
+enum { BB_KFAST = 0, BB_PROD = 1 };     // B stored [n][k] / scT[o][k..] * VT[j][k..] for row n = (o, j), both k-contiguous
 enum { BEPI_STORE = 0, BEPI_FWD = 1 };
 
 struct GemmB {
   int M, N, K;
   long long lda, ldb;
   long long kslice, cslice;
-  const bf16_t* vec;   // scaled operand: rows of P0 / P1 (ld ldv) and dY (ld O) of the chunk
+  const bf16_t* vec;   // scaled / product operand: rows of P0 / P1 (or their transposes) and dY (or its transpose)
   const bf16_t* sc;
   long long ldv;
   int KV, O;
@@ -716,162 +718,130 @@ __device__ __forceinline__ bf16x8v scale8(bf16x8v v, float s) {
   return r;
 }
 
-// C[m, n] = sum_k A(m, k) B(k, n), float32 out.  M, N, K of the k-contiguous sources are multiples of 8, KV of 32.
-template <int LA, int LB, int EPI, int KC>   // KC: k per chunk (32 or 64: one or two MFMA steps per barrier pair)
+// C[m, n] = sum_k A(m, k) B(n, k), float32 out; both operands k-contiguous, K (and KV) multiples of 32.
+// 128 x 128 tile, 64-deep chunks: per chunk a thread stages 4 vectors of 8 per operand (rows r, r + 64; k steps 0, 32)
+// and a wave issues 2 x 16 MFMAs on 8 + 8 operand vectors read from LDS.
+template <int LA, int LB, int EPI>
 __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                    float* __restrict__ Cg, GemmB g) {
-  constexpr int NU = KC / 32, BROW = KC + 4;   // vectors per thread and operand; LDS row in bf16 (8-byte aligned rows)
-  __shared__ __align__(16) bf16_t smem[2 * 64 * BROW];
+  constexpr int BROW = BK + 4;   // LDS row in bf16: 136 bytes (8-byte aligned operand reads)
+  __shared__ __align__(16) bf16_t smem[2 * BT * BROW];
   bf16_t* As = smem;               // [m][k]
-  bf16_t* Bs = smem + 64 * BROW;   // [n][k]
+  bf16_t* Bs = smem + BT * BROW;   // [n][k]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int tiles_n = (g.N + 63) / 64, tiles_m = (g.M + 63) / 64;
+  const int tiles_n = (g.N + BT - 1) / BT, tiles_m = (g.M + BT - 1) / BT;
   const int total = tiles_n * tiles_m * g.slices, per = (total + 7) / 8;
   const int t = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;   // XCD-aware tile order (see halves_gemm_k)
   if (t >= total) return;
   const int bz = t / (tiles_n * tiles_m), trem = t - bz * tiles_n * tiles_m;
-  const int m0 = (trem / tiles_n) * 64, n0 = (trem % tiles_n) * 64;
+  const int m0 = (trem / tiles_n) * BT, n0 = (trem % tiles_n) * BT;
   const long long kbeg = (long long)bz * g.kslice;
   const long long kend = kbeg + g.kslice < g.K ? kbeg + g.kslice : g.K;
-  // k-contiguous source: row = tid >> 2, 8 k's from (tid & 3) * 8; row-contiguous source: k = tid >> 3, 8 rows from (tid & 7) * 8
-  const int kf_r = tid >> 2, kf_k8 = (tid & 3) * 8;
-  const int xf_k = tid >> 3, xf_x8 = (tid & 7) * 8;
-  constexpr bool AKF = LA != BA_MFAST, BKF = LB == BB_KFAST || LB == BB_PROD;
-  // scaled B operand: this thread's 8 columns n = o KV + j are fixed
-  int sb_o = 0, sb_j = 0;
-  if (LB == BB_SCALEDX) {
-    const int n = min(n0 + xf_x8, g.N - 8);
-    sb_o = n / g.KV;
-    sb_j = n - sb_o * g.KV;
-  }
-  bf16x8v ra[NU], rb[NU];
-  float sa[NU], sb[NU];
+  const int kf_r = tid >> 2, kf_k8 = (tid & 3) * 8;   // row (+64 u), 8 k's (+32 s)
+  bf16x8v ra[2][2], rb[2][2];
+  float sa[2][2];
   auto fetch = [&](long long kc0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const long long k0 = kc0 + 32 * u;
-      if (LA == BA_KFAST) {
-        const long long m = min(m0 + kf_r, g.M - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
-        ra[u] = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
-      } else if (LA == BA_MFAST) {
-        const long long k = min(k0 + xf_k, (long long)g.K - 1), m = min(m0 + xf_x8, g.M - 8);
-        ra[u] = *reinterpret_cast<const bf16x8v*>(Ag + k * g.lda + m);
-      } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide step lies inside one o)
-        const long long m = min(m0 + kf_r, g.M - 1);
-        const int k = (int)min(k0 + kf_k8, (long long)g.K - 8);
-        const int o = k / g.KV, j = k - o * g.KV;
-        ra[u] = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
-        sa[u] = (float)g.sc[m * g.O + o];
-      }
-      if (LB == BB_NFAST) {
-        const long long k = min(k0 + xf_k, (long long)g.K - 1), n = min(n0 + xf_x8, g.N - 8);
-        rb[u] = *reinterpret_cast<const bf16x8v*>(Bg + k * g.ldb + n);
-      } else if (LB == BB_KFAST) {
-        const long long n = min(n0 + kf_r, g.N - 1), k = min(k0 + kf_k8, (long long)g.K - 8);
-        rb[u] = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
-      } else if (LB == BB_PROD) {   // row n = (o, j): scT[o][k .. k+7] * VT[j][k .. k+7], both stored with ld ldv
-        const int n = min(n0 + kf_r, g.N - 1);
-        const int o = n / g.KV, j = n - o * g.KV;
-        const long long k = min(k0 + kf_k8, (long long)g.K - 8);
-        const bf16x8v v = *reinterpret_cast<const bf16x8v*>(g.vec + (long long)j * g.ldv + k);
-        const bf16x8v c = *reinterpret_cast<const bf16x8v*>(g.sc + (long long)o * g.ldv + k);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rb[u][e] = (bf16_t)((float)v[e] * (float)c[e]);
-      } else {   // sc[k = w][o] * V[w][j .. j+7]
-        const long long k = min(k0 + xf_k, (long long)g.K - 1);
-        rb[u] = *reinterpret_cast<const bf16x8v*>(g.vec + k * g.ldv + sb_j);
-        sb[u] = (float)g.sc[k * g.O + sb_o];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const long long k = min(kc0 + 32 * s2 + kf_k8, (long long)g.K - 8);
+        if (LA == BA_KFAST) {
+          const long long m = min(m0 + kf_r + 64 * u, g.M - 1);
+          ra[u][s2] = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
+        } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide step lies inside one o)
+          const long long m = min(m0 + kf_r + 64 * u, g.M - 1);
+          const int o = (int)(k / g.KV), j = (int)(k - (long long)o * g.KV);
+          ra[u][s2] = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
+          sa[u][s2] = (float)g.sc[m * g.O + o];
+        }
+        if (LB == BB_KFAST) {
+          const long long n = min(n0 + kf_r + 64 * u, g.N - 1);
+          rb[u][s2] = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
+        } else {   // row n = (o, j): scT[o][k .. k+7] * VT[j][k .. k+7], both stored with ld ldv
+          const int n = min(n0 + kf_r + 64 * u, g.N - 1);
+          const int o = n / g.KV, j = n - o * g.KV;
+          const bf16x8v v = *reinterpret_cast<const bf16x8v*>(g.vec + (long long)j * g.ldv + k);
+          const bf16x8v c = *reinterpret_cast<const bf16x8v*>(g.sc + (long long)o * g.ldv + k);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rb[u][s2][e] = (bf16_t)((float)v[e] * (float)c[e]);
+        }
       }
-    }
   };
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
   auto put8 = [&](bf16_t* dst, bf16x8v v) {   // 8-byte aligned destination
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
     reinterpret_cast<bf16x4v*>(dst)[0] = bf16x4v{v[0], v[1], v[2], v[3]};
     reinterpret_cast<bf16x4v*>(dst)[1] = bf16x4v{v[4], v[5], v[6], v[7]};
   };
   auto stage = [&](long long kc0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const long long k0 = kc0 + 32 * u;
-      const bf16x8v va = LA == BA_SCALED ? scale8(ra[u], sa[u]) : ra[u];
-      const bf16x8v vb = LB == BB_SCALEDX ? scale8(rb[u], sb[u]) : rb[u];
-      if (AKF) {
-        put8(As + kf_r * BROW + 32 * u + kf_k8, k0 + kf_k8 < kend ? va : zero8());
-      } else {
-        const bool in = k0 + xf_k < kend;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) As[(xf_x8 + j) * BROW + 32 * u + xf_k] = in ? va[j] : (bf16_t)0.f;
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bool in = kc0 + 32 * s2 + kf_k8 < kend;
+        const bf16x8v va = LA == BA_SCALED ? scale8(ra[u][s2], sa[u][s2]) : ra[u][s2];
+        put8(As + (kf_r + 64 * u) * BROW + 32 * s2 + kf_k8, in ? va : zero8());
+        put8(Bs + (kf_r + 64 * u) * BROW + 32 * s2 + kf_k8, in ? rb[u][s2] : zero8());
       }
-      if (BKF) {
-        put8(Bs + kf_r * BROW + 32 * u + kf_k8, k0 + kf_k8 < kend ? vb : zero8());
-      } else {
-        const bool in = k0 + xf_k < kend;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Bs[(xf_x8 + j) * BROW + 32 * u + xf_k] = in ? vb[j] : (bf16_t)0.f;
-      }
-    }
   };
   auto get8 = [&](const bf16_t* src) {
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
     const bf16x4v lo = reinterpret_cast<const bf16x4v*>(src)[0], hi = reinterpret_cast<const bf16x4v*>(src)[1];
     return bf16x8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  f32x4 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (kbeg < kend) fetch(kbeg);
-  for (long long k0 = kbeg; k0 < kend; k0 += KC) {
+  for (long long k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();
     stage(k0);
     __syncthreads();
-    if (k0 + KC < kend) fetch(k0 + KC);
+    if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      bf16x8v a[2], b[2];
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8v a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = get8(As + (32 * wm + 16 * i + lr) * BROW + 32 * u + 8 * lk);
+      for (int i = 0; i < 4; ++i) a[i] = get8(As + (64 * wm + 16 * i + lr) * BROW + 32 * s2 + 8 * lk);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = get8(Bs + (32 * wn + 16 * j + lr) * BROW + 32 * u + 8 * lk);
+      for (int j = 0; j < 4; ++j) b[j] = get8(Bs + (64 * wn + 16 * j + lr) * BROW + 32 * s2 + 8 * lk);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   if (EPI == BEPI_FWD) {
-    // the tile's 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[tile][w] =
-    // sum over the columns of Z'[w, n] P1[w, i1(n)]
-    float* red = reinterpret_cast<float*>(smem);   // [2 (wn)][64 rows]
-    const int i1_0 = n0 % g.Bn;
-    __syncthreads();   // every wave is done reading the tiles
+    // a wave's 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[n / 64][w] = sum over
+    // those columns of Z'[w, n] P1[w, i1(n)] — no other wave shares the (row, column block), so it is written directly
+    const int nb = n0 + 64 * wn;   // first column of this wave
+    if (nb < g.N) {
+      const int i1_0 = nb % g.Bn;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = 32 * wm + 16 * i + 4 * lk + v, m = min(m0 + r, g.M - 1);
-        float sum = 0.f;
+        for (int v = 0; v < 4; ++v) {
+          const int mrow = m0 + 64 * wm + 16 * i + 4 * lk + v, m = min(mrow, g.M - 1);
+          float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          sum += acc[i][j][v] * (float)g.p1[(long long)m * g.Bn + i1_0 + 32 * wn + 16 * j + lr];
+          for (int j = 0; j < 4; ++j) sum += acc[i][j][v] * (float)g.p1[(long long)m * g.Bn + i1_0 + 16 * j + lr];
 #pragma unroll
-        for (int step = 1; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
-        if (lr == 0) red[wn * 64 + r] = sum;
-      }
-    __syncthreads();
-    if (tid < 64 && m0 + tid < g.M) Cg[(long long)(trem % tiles_n) * g.M + m0 + tid] = red[tid] + red[64 + tid];
+          for (int step = 1; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
+          if (lr == 0 && mrow < g.M) Cg[(long long)(nb / 64) * g.M + mrow] = sum;
+        }
+    }
     return;
   }
   float* C = Cg + (long long)bz * g.cslice;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int m = m0 + 32 * wm + 16 * i + 4 * lk + v, n = n0 + 32 * wn + 16 * j + lr;
+        const int m = m0 + 64 * wm + 16 * i + 4 * lk + v, n = n0 + 64 * wn + 16 * j + lr;
         if (m < g.M && n < g.N) C[(long long)m * g.N + n] = acc[i][j][v];
       }
 }
@@ -879,8 +849,8 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
 template <int LA, int LB, int EPI = BEPI_STORE>
 void bf16_gemm_launch(const bf16_t* A, const bf16_t* B, float* C, GemmB g, int slices, hipStream_t st) {
   g.slices = slices;
-  const int total = ((g.N + 63) / 64) * ((g.M + 63) / 64) * slices;
-  hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI, BK>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
+  const int total = ((g.N + BT - 1) / BT) * ((g.M + BT - 1) / BT) * slices;
+  hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
 
 // coreP[i0][o Bn + i1] = core[i0][i1 O + o] (and, with which = 1, coreQ[i1][o A + i0])
@@ -946,6 +916,17 @@ __global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ 
   }
 }
 
+// k slices of the dCore product (128 x 128 tiles): until ~2 workgroups per CU exist, >= 256 windows per slice
+int bf16_ksplit(const HalfP& h) {
+  const long long tiles = ((h.A + BT - 1) / BT) * ((h.NB + BT - 1) / BT);
+  long long ks = (512 + tiles - 1) / tiles;
+  const long long max_ks = (h.wc + 255) / 256;
+  if (ks > max_ks) ks = max_ks;
+  if (ks < 1) ks = 1;
+  if (ks > 64) ks = 64;
+  return (int)ks;
+}
+
 // bf16 path: every k-contiguous source is read 16 bytes at a time, scaled chunks and forward tiles lie inside one o
 bool bf16_shape_ok(const EpsP& p) {
   if (!halves_shape_ok(p, sizeof(float))) return false;
@@ -996,7 +977,7 @@ size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
   const HalfP h = make_half(p, sizeof(float));
   size_t s = align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2);
   if (need_dcore)
-    s += align_up((size_t)h.ksplit * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4) +
+    s += align_up((size_t)bf16_ksplit(h) * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4) +
          align_up((size_t)(h.A + h.Bn + p.O) * h.wc * 2);
   if (need_dx)
     s += 2 * align_up((size_t)h.A * h.NB * 2) + align_up((size_t)h.wc * h.A * 4) + align_up((size_t)h.wc * h.Bn * 4) +
@@ -1022,7 +1003,7 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
   float *part = nullptr, *dcore32 = nullptr, *dP0 = nullptr, *dP1 = nullptr, *gxw = nullptr;
   bf16_t *coreP = nullptr, *coreQ = nullptr, *halvesT = nullptr;
   if (need_dcore) {
-    part = (float*)take((size_t)h.ksplit * h.A * h.NB * 4);
+    part = (float*)take((size_t)bf16_ksplit(h) * h.A * h.NB * 4);
     dcore32 = (float*)take((size_t)h.A * h.NB * 4);   // float32 running sum over the window chunks, (o, i1) order
     halvesT = (bf16_t*)take((size_t)(h.A + h.Bn + p.O) * h.wc * 2);   // P0^T | P1^T | dY^T, rows of wc windows
   }
@@ -1059,7 +1040,8 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
       hipLaunchKernelGGL(bf16_transpose_k, dim3(rb64, 1), dim3(256), 0, st, dyc, dYT, nw, p.O, h.wc);
       DCTN_CHECK_LAUNCH();
       const long long K8 = (nw + 7) / 8 * 8;
-      const long long ksl = ((K8 + h.ksplit - 1) / h.ksplit + BK - 1) / BK * BK;
+      const int ksp = bf16_ksplit(h);
+      const long long ksl = ((K8 + ksp - 1) / ksp + BK - 1) / BK * BK;
       const int slices = (int)((K8 + ksl - 1) / ksl);
       GemmB g{(int)h.A, (int)h.NB, (int)K8, h.wc, 0, ksl, h.A * h.NB, P1T, dYT, h.wc, (int)h.Bn, p.O, nullptr, (int)h.Bn};
       bf16_gemm_launch<BA_KFAST, BB_PROD>(P0T, nullptr, part, g, slices, st);
