@@ -916,6 +916,23 @@ __global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ 
   }
 }
 
+// chunk of windows of the bf16 path: no Z buffer; per window P0, P1 (bf16), their transposes, dP0, dP1 (float32) and the
+// forward partials
+HalfP make_half_bf16(const EpsP& p) {
+  HalfP h = make_half(p, sizeof(float));
+  const long long per_win = (h.A + h.Bn) * 8 + (h.NB / 64) * 4 + p.O * 2;
+  size_t budget = CHUNK_BYTES;
+  if (const char* e = getenv("DCTN_HALVES_CHUNK_BYTES")) {
+    const long long v = atoll(e);
+    if (v > 0) budget = (size_t)v;
+  }
+  long long wc = (long long)(budget / (size_t)per_win) / 64 * 64;
+  if (wc < 64) wc = 64;
+  const long long wn64 = (p.Wn + 63) / 64 * 64;
+  h.wc = wc < wn64 ? wc : wn64;
+  return h;
+}
+
 // k slices of the dCore product (128 x 128 tiles): until ~2 workgroups per CU exist, >= 256 windows per slice
 int bf16_ksplit(const HalfP& h) {
   const long long tiles = ((h.A + BT - 1) / BT) * ((h.NB + BT - 1) / BT);
@@ -935,13 +952,13 @@ bool bf16_shape_ok(const EpsP& p) {
 }
 
 size_t bf16_fwd_workspace(const EpsP& p) {
-  const HalfP h = make_half(p, sizeof(float));
+  const HalfP h = make_half_bf16(p);
   return align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2) + align_up((size_t)h.A * h.NB * 2) +
          align_up((size_t)(h.NB / 64) * h.wc * 4) + 256;
 }
 
 int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st) {
-  const HalfP h = make_half(p, sizeof(float));
+  const HalfP h = make_half_bf16(p);
   const bf16_t* x = (const bf16_t*)xv;
   const bf16_t* core = (const bf16_t*)corev;
   bf16_t* out = (bf16_t*)outv;
@@ -974,7 +991,7 @@ int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP
 }
 
 size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
-  const HalfP h = make_half(p, sizeof(float));
+  const HalfP h = make_half_bf16(p);
   size_t s = align_up((size_t)h.wc * h.A * 2) + align_up((size_t)h.wc * h.Bn * 2);
   if (need_dcore)
     s += align_up((size_t)bf16_ksplit(h) * h.A * h.NB * 4) + align_up((size_t)h.A * h.NB * 4) +
@@ -988,7 +1005,7 @@ size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
 int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, const EpsP& p,
              hipStream_t st) {
   const int need_dx = dXv != nullptr, need_dcore = dCorev != nullptr;
-  const HalfP h = make_half(p, sizeof(float));
+  const HalfP h = make_half_bf16(p);
   const bf16_t* x = (const bf16_t*)xv;
   const bf16_t* core = (const bf16_t*)corev;
   const bf16_t* dY = (const bf16_t*)dYv;

@@ -158,17 +158,19 @@ def test_eps_f64_matrix_core_path(case):
     check(c3.grad, dcore, torch.float64, "dCore alone")
 
 
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.bfloat16])
 def test_eps_halves_path_in_several_window_chunks(dtype, monkeypatch):
     """The two-halves path bounds its per-chunk buffers (1 GiB); with the bound lowered to 256 KiB the 1 000
     windows below run in 16 chunks of 64 windows (dCore accumulated over the chunks, per-chunk columns of the factor
     gradients) — same numbers as the oracle, and as the single-chunk run."""
     C, K, Q, O, B, H, W = 1, 3, 3, 2, 10, 12, 12      # N = 9, Q = 3: halves of 81 and 243 entries, 1 000 windows
+    if dtype == torch.bfloat16:                        # bf16 MFMA instantiation: halves must be multiples of 32 / 64
+        C, K, Q, O, B, H, W = 1, 3, 4, 3, 3, 10, 11   # N = 9, Q = 4: halves of 256 and 1024 entries, 216 windows, odd O
     torch.manual_seed(77)
     N = K * K * C
-    x = torch.randn(C, B, H, W, Q, dtype=dtype)
-    core = torch.randn(*(Q,) * N, O, dtype=dtype) * Q ** (-N / 4)
-    dy = torch.randn(B, H - K + 1, W - K + 1, O, dtype=dtype)
+    x = torch.randn(C, B, H, W, Q).to(dtype)
+    core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(dtype)
+    dy = torch.randn(B, H - K + 1, W - K + 1, O).to(dtype)
 
     def run():
         xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
@@ -186,9 +188,9 @@ def test_eps_halves_path_in_several_window_chunks(dtype, monkeypatch):
         check(got[0], want, dtype, "forward")
         check(got[1], dx, dtype, "dX")
         check(got[2], dcore, dtype, "dCore")
-    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    tol = {torch.float64: 1e-12, torch.float32: 1e-5, torch.bfloat16: 2e-2}[dtype]
     for a, b in zip(whole, chunked):
-        assert float((a - b).abs().max()) <= tol * float(a.abs().max())
+        assert float((a.float() - b.float()).abs().max()) <= tol * float(a.float().abs().max())
 
 
 # float32 shapes the bf16-register and bigcore families leave (odd Q): the two-halves GEMM path on v_mfma_f32_16x16x4_f32
