@@ -37,6 +37,7 @@ WORKLOADS = {
     "cfg3a": (((4, 4), (3, 6)), 28, 2, torch.float32),
     "cfg3a_bf16": (((4, 4), (3, 6)), 28, 2, torch.bfloat16),   # bf16 storage, exact-f32 matrix-core arithmetic
     "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
+    "cfg3b_bf16": (((4, 8), (2, 8)), 28, 2, torch.bfloat16),
 }
 
 

@@ -408,7 +408,8 @@ def test_eps_bf16_large_core_runs_on_the_matrix_cores():
     """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer): two-halves GEMMs on
     v_mfma_f32_16x16x32_bf16 (bf16 P0 / P1 / T, float32 accumulate) — not the generic kernels."""
     torch.manual_seed(31)
-    for (C, B, H, W, Q, K, O) in ((1, 5, 9, 8, 2, 4, 4), (1, 3, 7, 7, 4, 3, 6)):
+    # halves of 256 x 256, 256 x 1024 (odd O) and 64 x 64 (a 128-column tile spans two outputs; 5 outputs)
+    for (C, B, H, W, Q, K, O) in ((1, 5, 9, 8, 2, 4, 4), (1, 3, 7, 7, 4, 3, 6), (1, 7, 9, 10, 8, 2, 5)):
         N = K * K * C
         x = torch.randn(C, B, H, W, Q).to(torch.bfloat16)
         core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(torch.bfloat16)
