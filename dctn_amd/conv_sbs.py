@@ -93,7 +93,15 @@ class _ConvSBSFunction(torch.autograd.Function):
         need_dcores = any(ctx.needs_input_grad[2:])
         g = d_out.contiguous()
         d_x = torch.empty((C, B, H, W, q), dtype=x.dtype, device=dev) if need_dx else None
-        d_cores = [torch.empty_like(c) for c in cores_c] if need_dcores else None
+        d_cores = None
+        if need_dcores:
+            # one flat buffer for the gradients of all cores of the string: the library zero-fills it with a single
+            # launch, and a data-parallel reducer can all-reduce it in place
+            flat = torch.empty(sum(c.numel() for c in cores_c), dtype=cores_c[0].dtype, device=dev)
+            d_cores, off = [], 0
+            for c in cores_c:
+                d_cores.append(flat[off : off + c.numel()].view_as(c))
+                off += c.numel()
         ws = L.workspace(L.lib().dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 1), dev)
         L.check(
             L.lib().dctn_convsbs_bwd(
