@@ -58,8 +58,10 @@ class GraphedTrainStep:
     bound: ~40 kernels of a few microseconds each once loss, regulariser and optimizer are counted).
 
     Single process: one graph holds forward, loss, regulariser, backward and the optimizer step.
-    Data parallel: forward + backward are one graph, the gradient all-reduce runs eagerly on the same
-    stream (RCCL), the optimizer step is a second graph.  Inputs are copied into static buffers, so
+    Data parallel over RCCL: the gradient all-reduce is captured into that same graph (one launch per
+    iteration from the host; ``graph_allreduce=False`` or a capture error falls back to the split form).
+    Data parallel over gloo: forward + backward are one graph, the all-reduce runs eagerly on the same
+    stream, the optimizer step is a second graph.  Inputs are copied into static buffers, so
     every call must use the batch shape of the example; the optimizer must be capturable
     (``torch.optim.SGD``, or ``Adam(..., capturable=True)``).
     """
@@ -67,11 +69,15 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, example_x: Tensor, example_y: Tensor,
                  loss_fn: Callable[[Tensor, Tensor], Tensor], optimizer: torch.optim.Optimizer,
                  reg_fn: Optional[Callable[[torch.nn.Module], Tensor]] = None, reg_coeff: float = 0.0,
-                 reducer: Optional[ddp.FlatGradAllReducer] = None, warmup: int = 3):
+                 reducer: Optional[ddp.FlatGradAllReducer] = None, warmup: int = 3,
+                 graph_allreduce: Optional[bool] = None):
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.x, self.y = example_x.clone(), example_y.clone()
         dev = example_x.device
-        split = reducer is not None and reducer.world > 1
+        reduces = reducer is not None and (reducer.world > 1 or not reducer.skip_single_rank)
+        if graph_allreduce is None:
+            graph_allreduce = reduces and dist.is_initialized() and dist.get_backend() == "nccl"
+        split = reduces
 
         def fwd_bwd():
             model.train()
@@ -93,12 +99,25 @@ class GraphedTrainStep:
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self.g_opt = None
+        self.allreduce_in_graph = False
+        if reduces and graph_allreduce:
+            try:   # the whole iteration, collective included, as one graph
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.out, self.loss, self.reg = fwd_bwd()
+                    reducer()
+                    optimizer.step()
+                self.g_main, self.allreduce_in_graph, split = g, True, False
+                return
+            except Exception as e:   # fall back to the split form below
+                getLogger(__name__).warning(f"capturing the all-reduce into the graph failed ({type(e).__name__}: {e})")
+                torch.cuda.synchronize(dev)
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.out, self.loss, self.reg = fwd_bwd()
             if not split:
                 optimizer.step()
-        self.g_opt = None
         if split:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):

@@ -104,3 +104,51 @@ def test_two_ranks_on_one_gpu_match_the_single_process_iteration():
     for a, p in zip(got[0], model.parameters()):
         ref = p.detach().float().cpu()
         assert float((a - ref).abs().max()) <= 3e-2 * float(ref.abs().max()), "ranks vs single process"
+
+
+def _rccl_single_rank_worker(port, q):
+    """One rank on the real backend (RCCL): the collective is issued although there is nothing to exchange, and the
+    whole iteration — forward, fused backward, all-reduce, optimizer — is ONE captured graph."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+    from dctn_amd.training import FlatSGD, GraphedTrainStep, fused_cross_entropy
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("nccl", single_rank_group=True)
+    model = _make(torch.bfloat16, dev)
+    x, y = _data(torch.bfloat16, dev)
+    opt = FlatSGD(list(model.epses) + [model.linear.weight], [model.linear.bias], lr=0.05, momentum=0.9, l2=1e-3)
+    red = ddp.FlatGradAllReducer(model.parameters(), average=True, skip_single_rank=False)
+    step = GraphedTrainStep(model, x, y, fused_cross_entropy, opt, reducer=red, warmup=1)
+    for _ in range(3):
+        step(x, y)
+    torch.cuda.synchronize(dev)
+    q.put((step.allreduce_in_graph, step.g_opt is None, [p.detach().float().cpu().numpy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_whole_iteration_in_one_graph():
+    from dctn_amd.training import FlatSGD, GraphedTrainStep, fused_cross_entropy
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    proc.start()
+    in_graph, one_graph, params = q.get(timeout=300)
+    proc.join(120)
+    assert proc.exitcode == 0
+    assert in_graph and one_graph
+    dev = torch.device("cuda", 0)
+    model = _make(torch.bfloat16, dev)
+    x, y = _data(torch.bfloat16, dev)
+    opt = FlatSGD(list(model.epses) + [model.linear.weight], [model.linear.bias], lr=0.05, momentum=0.9, l2=1e-3)
+    step = GraphedTrainStep(model, x, y, fused_cross_entropy, opt, warmup=1)
+    for _ in range(3):
+        step(x, y)
+    for a, p in zip(params, model.parameters()):
+        assert torch.equal(torch.from_numpy(a), p.detach().float().cpu())   # averaging over one rank changes nothing
