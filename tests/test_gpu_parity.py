@@ -404,6 +404,33 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
 
 
 # ------------------------------------------------------------------ linear head (bf16, skinny)
+def test_eps_f32_large_core_under_the_bf16_policy():
+    """set_float32_matmul_precision("bf16") lets float32 tensors with a large core use the bf16 matrix cores
+    (operands rounded to bf16, float32 accumulate); the default policy keeps the exact-f32 family."""
+    torch.manual_seed(32)
+    C, B, H, W, Q, K, O = 1, 4, 9, 8, 2, 4, 4
+    N = K * K * C
+    x = torch.randn(C, B, H, W, Q)
+    core = torch.randn(*(Q,) * N, O) * Q ** (-N / 4)
+    want = R.eps_4step(core.double(), x.double())
+    xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
+    y = eps(cd, xd)
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+    dctn_amd.set_float32_matmul_precision("bf16")
+    try:
+        y2 = eps(cd, xd)
+        assert y2.dtype == torch.float32 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves"
+        assert bf16_close(y2, want)
+        dy = torch.randn(*want.shape)
+        y2.backward(dy.to(DEV))
+        assert cd.grad.dtype == torch.float32 and xd.grad.dtype == torch.float32
+        gc, gx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
+        assert bf16_close(cd.grad, gc) and bf16_close(xd.grad, gx)
+    finally:
+        dctn_amd.set_float32_matmul_precision("exact")
+    assert float((y.detach().cpu().double() - want).abs().max()) < 3e-4 * float(want.abs().max())
+
+
 def test_eps_bf16_large_core_runs_on_the_matrix_cores():
     """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer): two-halves GEMMs on
     v_mfma_f32_16x16x32_bf16 (bf16 P0 / P1 / T, float32 accumulate) — not the generic kernels."""
