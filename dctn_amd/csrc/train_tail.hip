@@ -8,15 +8,18 @@
 //   ce_bwd_k   : dLogits = (softmax - onehot) * dLoss / B, in the logits' dtype
 //   sgd_l2_k   : over ONE flat buffer holding all parameters: g += 2 * l2 * w on the regularised
 //                prefix, buf = momentum * buf + g, w -= lr * buf; the regulariser's value
-//                sum w^2 is accumulated on the way (float32 master arithmetic, storage dtype kept)
+//                sum w^2 is left as one partial sum per workgroup (float32 master arithmetic, storage dtype kept)
 #include "common.h"
 
 namespace {
 
-template <typename S>
-__global__ __launch_bounds__(256) void ce_fwd_k(const S* __restrict__ logits, const long long* __restrict__ labels,
-                                                float* __restrict__ loss, long long B, int C) {
-  __shared__ float red[4];
+// SINGLE: the whole batch in one workgroup of 1024 threads — the result is stored, not accumulated, so no fill
+// precedes the kernel (one graph node instead of two; these kernels are launch-latency, not work)
+template <typename S, bool SINGLE>
+__global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restrict__ logits,
+                                                                const long long* __restrict__ labels,
+                                                                float* __restrict__ loss, long long B, int C) {
+  __shared__ float red[16];
   float part = 0.f;
   for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
     const S* row = logits + b * C;
@@ -30,7 +33,14 @@ __global__ __launch_bounds__(256) void ce_fwd_k(const S* __restrict__ logits, co
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, ((red[0] + red[1]) + (red[2] + red[3])) / (float)B);
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += red[k];
+    if (SINGLE)
+      loss[0] = total / (float)B;
+    else
+      atomicAdd(loss, total / (float)B);
+  }
 }
 
 template <typename S>
@@ -73,7 +83,9 @@ __global__ __launch_bounds__(256) void sgd_l2_k(S* __restrict__ w, const S* __re
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0 && sq_sum) atomicAdd(sq_sum, (red[0] + red[1]) + (red[2] + red[3]));
+  // one slot per workgroup, stored (not accumulated): no fill before the kernel, no atomics, a fixed summation order;
+  // the caller adds the dctn_sgd_l2_num_partials(n) slots when it wants the regulariser's value
+  if (threadIdx.x == 0 && sq_sum) sq_sum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 unsigned blocks_for(long long n) {
@@ -90,13 +102,21 @@ int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t
   if (!logits || !labels || !loss) return DCTN_ERR_NULL;
   if (B < 1 || C < 1) return DCTN_ERR_BAD_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype != DCTN_F32 && dtype != DCTN_BF16) return DCTN_ERR_BAD_DTYPE;
+  if (B <= 8192) {   // one workgroup, no fill
+    if (dtype == DCTN_F32)
+      hipLaunchKernelGGL((ce_fwd_k<float, true>), dim3(1), dim3(1024), 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+    else
+      hipLaunchKernelGGL((ce_fwd_k<bf16_t, true>), dim3(1), dim3(1024), 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+    DCTN_CHECK_LAUNCH();
+    return DCTN_OK;
+  }
   if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
   const dim3 g(blocks_for(B)), b(256);
-  switch (dtype) {
-    case DCTN_F32: hipLaunchKernelGGL(ce_fwd_k<float>, g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C); break;
-    case DCTN_BF16: hipLaunchKernelGGL(ce_fwd_k<bf16_t>, g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C); break;
-    default: return DCTN_ERR_BAD_DTYPE;
-  }
+  if (dtype == DCTN_F32)
+    hipLaunchKernelGGL((ce_fwd_k<float, false>), g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+  else
+    hipLaunchKernelGGL((ce_fwd_k<bf16_t, false>), g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
@@ -116,18 +136,19 @@ int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, 
   return DCTN_OK;
 }
 
+int dctn_sgd_l2_num_partials(int64_t n) { return n < 1 ? 0 : (int)blocks_for(n); }
+
 int dctn_sgd_l2_step(void* params, const void* grads, void* momentum_buf, void* sq_sum, int64_t n, int64_t n_reg,
                      float lr, float momentum, float l2, int first_step, int dtype, void* stream) {
   if (!params || !grads || !momentum_buf) return DCTN_ERR_NULL;
   if (n < 1 || n_reg < 0 || n_reg > n) return DCTN_ERR_BAD_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (sq_sum && hipMemsetAsync(sq_sum, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  if (dtype != DCTN_F32 && dtype != DCTN_BF16) return DCTN_ERR_BAD_DTYPE;
   const dim3 g(blocks_for(n)), b(256);
-  switch (dtype) {
-    case DCTN_F32: hipLaunchKernelGGL(sgd_l2_k<float>, g, b, 0, st, (float*)params, (const float*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step); break;
-    case DCTN_BF16: hipLaunchKernelGGL(sgd_l2_k<bf16_t>, g, b, 0, st, (bf16_t*)params, (const bf16_t*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step); break;
-    default: return DCTN_ERR_BAD_DTYPE;
-  }
+  if (dtype == DCTN_F32)
+    hipLaunchKernelGGL(sgd_l2_k<float>, g, b, 0, st, (float*)params, (const float*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step);
+  else
+    hipLaunchKernelGGL(sgd_l2_k<bf16_t>, g, b, 0, st, (bf16_t*)params, (const bf16_t*)grads, (float*)momentum_buf, (float*)sq_sum, (long long)n, (long long)n_reg, lr, momentum, l2, first_step);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }

@@ -44,9 +44,13 @@ def train_step(
     model.train()
     output = model(x)
     loss = loss_fn(output if getattr(loss_fn, "accepts_low_precision", False) else output.float(), y)
-    reg_term = reg_fn(model) if reg_fn is not None else output.new_zeros((), dtype=torch.float32)
     optimizer.zero_grad(set_to_none=True)
-    (loss + reg_term.float() * reg_coeff).backward()
+    if reg_fn is not None:
+        reg_term = reg_fn(model)
+        (loss + reg_term.float() * reg_coeff).backward()
+    else:   # no fill / multiply / add launches for a term that is not there
+        reg_term = output.new_zeros((), dtype=torch.float32)
+        loss.backward()
     if reducer is not None:
         reducer()
     optimizer.step()
@@ -83,11 +87,16 @@ class GraphedTrainStep:
             model.train()
             out = model(self.x)
             loss = loss_fn(out if getattr(loss_fn, "accepts_low_precision", False) else out.float(), self.y)
-            reg = reg_fn(model) if reg_fn is not None else out.new_zeros((), dtype=torch.float32)
             optimizer.zero_grad(set_to_none=True)
-            (loss + reg.float() * reg_coeff).backward()
+            if reg_fn is not None:
+                reg = reg_fn(model)
+                (loss + reg.float() * reg_coeff).backward()
+            else:   # no fill / multiply / add nodes in the graph for a term that is not there
+                reg = no_reg
+                loss.backward()
             return out, loss, reg
 
+        no_reg = torch.zeros((), dtype=torch.float32, device=dev)
         assert warmup >= 1, "capture needs at least one eager iteration first (lazy optimizer state, kernel attributes)"
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -203,7 +212,8 @@ class FlatSGD:
                 p.data = view
                 off += p.numel()
         self.buf = torch.zeros(self.n, dtype=torch.float32, device=ref.device)
-        self.sq_sum = torch.zeros((), dtype=torch.float32, device=ref.device)
+        # one partial sum of squares per workgroup of the kernel; added up only when the value is asked for
+        self.sq_sum = torch.zeros(L.lib().dctn_sgd_l2_num_partials(self.n), dtype=torch.float32, device=ref.device)
         self.flat_grad = torch.zeros(self.n, dtype=ref.dtype, device=ref.device)
         self._steps = 0
 
@@ -244,7 +254,7 @@ class FlatSGD:
 
     def reg_value(self) -> Tensor:
         """l2 * sum of squared Frobenius norms of the regularised parameters, as of the last step."""
-        return self.sq_sum * self.l2
+        return self.sq_sum.sum() * self.l2
 
 
 # ------------------------------------------------------------------------------------------------

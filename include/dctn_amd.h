@@ -213,14 +213,17 @@ int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums,
  *   dctn_ce_loss_bwd : dlogits = (softmax(logits) - onehot(labels)) * dloss[0] / B, dtype of logits
  *   dctn_sgd_l2_step : over one flat parameter buffer (n values; the first n_reg are regularised):
  *                      g = grads + 2*l2*w (regularised prefix), buf = first_step ? g : momentum*buf + g,
- *                      w -= lr*buf; sq_sum[0] (optional, float32, OVERWRITTEN) = sum of w^2 over the
- *                      prefix BEFORE the update, i.e. the regulariser's value / its coefficient.
+ *                      w -= lr*buf; sq_sum (optional, float32 array of dctn_sgd_l2_num_partials(n) slots,
+ *                      OVERWRITTEN): slot b = workgroup b's part of the sum of w^2 over the prefix BEFORE the
+ *                      update; their sum is the regulariser's value / its coefficient (stored, not
+ *                      accumulated: no fill launch and no atomics in the iteration).
  *                      momentum_buf is float32 whatever the parameter dtype.
  * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.
  * ------------------------------------------------------------------------------------------ */
 int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream);
 int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, void* dlogits,
                      int64_t B, int C, int dtype, void* stream);
+int dctn_sgd_l2_num_partials(int64_t n);
 int dctn_sgd_l2_step(void* params, const void* grads, void* momentum_buf, void* sq_sum, int64_t n, int64_t n_reg,
                      float lr, float momentum, float l2, int first_step, int dtype, void* stream);
 
