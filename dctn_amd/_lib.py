@@ -43,6 +43,7 @@ SIGNATURES = {
     "dctn_eps_head_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_size]
                           + [c_int] * 8 + [c_int, c_int, c_void]),
     "dctn_ce_loss_fwd": (c_int, [c_void, c_void, c_void, c_i64, c_int, c_int, c_void]),
+    "dctn_ce_loss_fwd_grad": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_void]),
     "dctn_ce_loss_bwd": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_void]),
     "dctn_sgd_l2_num_partials": (c_int, [c_i64]),
     "dctn_sgd_l2_step": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, ctypes.c_float, ctypes.c_float,

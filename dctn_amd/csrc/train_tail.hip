@@ -18,7 +18,9 @@ namespace {
 template <typename S, bool SINGLE>
 __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restrict__ logits,
                                                                 const long long* __restrict__ labels,
-                                                                float* __restrict__ loss, long long B, int C) {
+                                                                float* __restrict__ loss, S* __restrict__ dunit,
+                                                                long long B, int C) {
+  // dunit (optional): (softmax - onehot) / B, the gradient of the mean loss for an incoming gradient of 1
   __shared__ float red[16];
   float part = 0.f;
   for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
@@ -29,6 +31,11 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restr
     for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
     const long long y = labels[b];
     part += (m + logf(s)) - (float)row[y >= 0 && y < C ? y : 0];
+    if (dunit) {
+      const float inv = 1.f / s, scale = 1.f / (float)B;
+      for (int c = 0; c < C; ++c)
+        dunit[b * C + c] = (S)((expf((float)row[c] - m) * inv - (c == y ? 1.f : 0.f)) * scale);
+    }
   }
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -98,27 +105,37 @@ unsigned blocks_for(long long n) {
 
 extern "C" {
 
-int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream) {
+static int ce_fwd_launch(const void* logits, const void* labels, void* loss, void* dunit, int64_t B, int C, int dtype,
+                         hipStream_t st) {
   if (!logits || !labels || !loss) return DCTN_ERR_NULL;
   if (B < 1 || C < 1) return DCTN_ERR_BAD_SHAPE;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype != DCTN_F32 && dtype != DCTN_BF16) return DCTN_ERR_BAD_DTYPE;
   if (B <= 8192) {   // one workgroup, no fill
     if (dtype == DCTN_F32)
-      hipLaunchKernelGGL((ce_fwd_k<float, true>), dim3(1), dim3(1024), 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+      hipLaunchKernelGGL((ce_fwd_k<float, true>), dim3(1), dim3(1024), 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (float*)dunit, (long long)B, C);
     else
-      hipLaunchKernelGGL((ce_fwd_k<bf16_t, true>), dim3(1), dim3(1024), 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+      hipLaunchKernelGGL((ce_fwd_k<bf16_t, true>), dim3(1), dim3(1024), 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (bf16_t*)dunit, (long long)B, C);
     DCTN_CHECK_LAUNCH();
     return DCTN_OK;
   }
   if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
   const dim3 g(blocks_for(B)), b(256);
   if (dtype == DCTN_F32)
-    hipLaunchKernelGGL((ce_fwd_k<float, false>), g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+    hipLaunchKernelGGL((ce_fwd_k<float, false>), g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (float*)dunit, (long long)B, C);
   else
-    hipLaunchKernelGGL((ce_fwd_k<bf16_t, false>), g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (long long)B, C);
+    hipLaunchKernelGGL((ce_fwd_k<bf16_t, false>), g, b, 0, st, (const bf16_t*)logits, (const long long*)labels, (float*)loss, (bf16_t*)dunit, (long long)B, C);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
+}
+
+int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream) {
+  return ce_fwd_launch(logits, labels, loss, nullptr, B, C, dtype, (hipStream_t)stream);
+}
+
+int dctn_ce_loss_fwd_grad(const void* logits, const void* labels, void* loss, void* dlogits_unit, int64_t B, int C,
+                          int dtype, void* stream) {
+  if (!dlogits_unit) return DCTN_ERR_NULL;
+  return ce_fwd_launch(logits, labels, loss, dlogits_unit, B, C, dtype, (hipStream_t)stream);
 }
 
 int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, void* dlogits, int64_t B, int C,

@@ -90,13 +90,19 @@ class GraphedTrainStep:
             optimizer.zero_grad(set_to_none=True)
             if reg_fn is not None:
                 reg = reg_fn(model)
-                (loss + reg.float() * reg_coeff).backward()
+                total = loss + reg.float() * reg_coeff
             else:   # no fill / multiply / add nodes in the graph for a term that is not there
-                reg = no_reg
-                loss.backward()
+                reg, total = no_reg, loss
+            seed = one.get(total.dtype)   # a ready-made "1": autograd's own root gradient would be a fill node
+            if seed is None:
+                seed = one[total.dtype] = torch.ones((), dtype=total.dtype, device=dev)
+                _UNIT_SEEDS.add(seed.data_ptr())   # (kept alive by this object: the pointer stays ours)
+            total.backward(seed)
             return out, loss, reg
 
         no_reg = torch.zeros((), dtype=torch.float32, device=dev)
+        one: Dict = {}   # filled during the eager warm-up iterations, reused inside the capture
+        self._seeds = one
         assert warmup >= 1, "capture needs at least one eager iteration first (lazy optimizer state, kernel attributes)"
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -146,9 +152,17 @@ class GraphedTrainStep:
 from . import _lib as L  # noqa: E402
 
 
+# data pointers of constant "1" tensors that callers use as the gradient seed of a scalar loss (GraphedTrainStep):
+# a backward that receives one of them knows its incoming gradient is exactly 1 without reading it
+_UNIT_SEEDS = set()
+
+
 class _FusedCrossEntropy(torch.autograd.Function):
-    """``F.cross_entropy(logits, labels)`` (mean reduction) as one forward and one backward HIP kernel
-    (`dctn_ce_loss_fwd/bwd`) instead of cast + log-softmax + nll and their three backward launches."""
+    """``F.cross_entropy(logits, labels)`` (mean reduction) as HIP kernels instead of cast + log-softmax + nll and
+    their three backward launches.  When the logits need a gradient the forward kernel also leaves
+    ``(softmax - onehot) / B`` (`dctn_ce_loss_fwd_grad`); the backward returns it as is when the incoming gradient is
+    a registered constant 1 (the seed GraphedTrainStep passes), otherwise `dctn_ce_loss_bwd` scales by the incoming
+    scalar."""
 
     @staticmethod
     def forward(ctx, logits: Tensor, labels: Tensor) -> Tensor:
@@ -156,14 +170,22 @@ class _FusedCrossEntropy(torch.autograd.Function):
         lg, lb = logits.contiguous(), labels.contiguous().long()
         assert lg.ndim == 2 and lb.shape == (lg.shape[0],)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        L.check(L.lib().dctn_ce_loss_fwd(lg.data_ptr(), lb.data_ptr(), loss.data_ptr(), lg.shape[0], lg.shape[1],
-                                         L.dtype_code(lg), L.stream_ptr(dev)), "cross-entropy forward")
-        ctx.save_for_backward(lg, lb)
+        if ctx.needs_input_grad[0]:
+            unit = torch.empty_like(lg)
+            L.check(L.lib().dctn_ce_loss_fwd_grad(lg.data_ptr(), lb.data_ptr(), loss.data_ptr(), unit.data_ptr(),
+                                                  lg.shape[0], lg.shape[1], L.dtype_code(lg), L.stream_ptr(dev)),
+                    "cross-entropy forward")
+            ctx.save_for_backward(lg, lb, unit)
+        else:
+            L.check(L.lib().dctn_ce_loss_fwd(lg.data_ptr(), lb.data_ptr(), loss.data_ptr(), lg.shape[0], lg.shape[1],
+                                             L.dtype_code(lg), L.stream_ptr(dev)), "cross-entropy forward")
         return loss
 
     @staticmethod
     def backward(ctx, d_loss: Tensor):
-        lg, lb = ctx.saved_tensors
+        lg, lb, unit = ctx.saved_tensors
+        if d_loss.data_ptr() in _UNIT_SEEDS:
+            return unit, None
         dev = lg.device
         g = d_loss.to(torch.float32).contiguous()
         d_logits = torch.empty_like(lg)

@@ -221,6 +221,10 @@ int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums,
  * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.
  * ------------------------------------------------------------------------------------------ */
 int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream);
+/* forward that also leaves dlogits_unit = (softmax - onehot) / B (logits' dtype): the backward for an incoming gradient of 1,
+ * so that a caller who knows its gradient seed is 1 needs no second kernel */
+int dctn_ce_loss_fwd_grad(const void* logits, const void* labels, void* loss, void* dlogits_unit,
+                          int64_t B, int C, int dtype, void* stream);
 int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, void* dlogits,
                      int64_t B, int C, int dtype, void* stream);
 int dctn_sgd_l2_num_partials(int64_t n);
