@@ -139,8 +139,10 @@ class GraphedTrainStep:
                 optimizer.step()
 
     def __call__(self, x: Tensor, y: Tensor) -> Dict[str, Tensor]:
-        self.x.copy_(x, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
+        if x is not self.x:   # a data pipeline may fill the static buffers `step.x` / `step.y` itself and pass them
+            self.x.copy_(x, non_blocking=True)
+        if y is not self.y:
+            self.y.copy_(y, non_blocking=True)
         self.g_main.replay()
         if self.g_opt is not None:
             self.reducer()
