@@ -93,16 +93,12 @@ class GraphedTrainStep:
                 total = loss + reg.float() * reg_coeff
             else:   # no fill / multiply / add nodes in the graph for a term that is not there
                 reg, total = no_reg, loss
-            seed = one.get(total.dtype)   # a ready-made "1": autograd's own root gradient would be a fill node
-            if seed is None:
-                seed = one[total.dtype] = torch.ones((), dtype=total.dtype, device=dev)
-                _UNIT_SEEDS.add(seed.data_ptr())   # (kept alive by this object: the pointer stays ours)
-            total.backward(seed)
+            # a ready-made "1" (created during the eager warm-up, never inside the capture): autograd's own root
+            # gradient would be a fill node
+            total.backward(unit_seed(dev, total.dtype))
             return out, loss, reg
 
         no_reg = torch.zeros((), dtype=torch.float32, device=dev)
-        one: Dict = {}   # filled during the eager warm-up iterations, reused inside the capture
-        self._seeds = one
         assert warmup >= 1, "capture needs at least one eager iteration first (lazy optimizer state, kernel attributes)"
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -154,9 +150,20 @@ class GraphedTrainStep:
 from . import _lib as L  # noqa: E402
 
 
-# data pointers of constant "1" tensors that callers use as the gradient seed of a scalar loss (GraphedTrainStep):
-# a backward that receives one of them knows its incoming gradient is exactly 1 without reading it
+# Constant "1" tensors used as the gradient seed of a scalar loss (GraphedTrainStep), one per (device, dtype), kept alive
+# for the life of the process so that their addresses are never reused: a backward that receives one of them knows
+# its incoming gradient is exactly 1 without reading it.
+_UNIT_SEED_TENSORS: Dict = {}
 _UNIT_SEEDS = set()
+
+
+def unit_seed(device: torch.device, dtype: torch.dtype) -> Tensor:
+    key = (str(device), dtype)
+    seed = _UNIT_SEED_TENSORS.get(key)
+    if seed is None:
+        seed = _UNIT_SEED_TENSORS[key] = torch.ones((), dtype=dtype, device=device)
+        _UNIT_SEEDS.add(seed.data_ptr())
+    return seed
 
 
 class _FusedCrossEntropy(torch.autograd.Function):
