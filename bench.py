@@ -266,8 +266,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch samples per GPU whatever N; strong: --batch is the GLOBAL batch, split over the N GPUs")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
-    ap.add_argument("--graph-allreduce", type=int, default=-1,
-                    help="capture the gradient all-reduce into the step's HIP graph: -1 (default) with RCCL only, 0 never, 1 always")
+    ap.add_argument("--graph-allreduce", type=int, default=0,
+                    help="1: capture the gradient all-reduce into the step's HIP graph as well (opt-in: a capture that "
+                         "fails cannot be recovered from inside the process, see the comment at try_capture)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + "
                     "DCTN_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a single GPU")
@@ -283,7 +284,22 @@ def main():
     # DCTN_BENCH_FORCE_ALLREDUCE=1: create the process group and issue the gradient all-reduce even with
     # one rank (rehearsal of the RCCL calls on a one-GPU machine; not a measurement)
     force_reduce = os.environ.get("DCTN_BENCH_FORCE_ALLREDUCE") == "1"
-    rank, local_rank, world = ddp.init_from_env(args.backend, single_rank_group=force_reduce)
+    # RCCL prints a version banner on stdout when its communicator comes up; stdout must carry the one JSON line
+    # only, so file descriptor 1 points at stderr until the first collective has run
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, local_rank, world = ddp.init_from_env(args.backend, single_rank_group=force_reduce)
+        if dist.is_initialized():
+            dev0 = torch.device("cuda", 0 if os.environ.get("DCTN_BENCH_ONE_DEVICE") == "1" else local_rank)
+            probe = torch.zeros(1, device=dev0)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize(dev0)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", 0 if one_device else local_rank)
@@ -306,49 +322,75 @@ def main():
             p.grad = None
         model(x).backward(out_grad)
 
-    # The step replays from a HIP graph.  With RCCL the gradient all-reduce is captured into the same graph
-    # (one launch per step from the host; measured on one rank: 51.7 -> 42.3 us/step against a graph of
-    # fwd + bwd followed by an eager collective).  The captured step is checked against the eager step before
-    # it is trusted; any failure falls back to "graph of fwd + bwd, eager all-reduce", then to eager.
+    # The step replays from a HIP graph of fwd + bwd; the gradient all-reduce follows it eagerly on the same stream.
+    # --graph-allreduce 1 captures the collective into the same graph (one launch per step from the host; measured
+    # on one rank over RCCL: 51.7 -> 42.3 us/step) and checks the captured step against the eager one before trusting
+    # it.  It is opt-in: when a capture fails (reproduced with gloo, whose collectives cannot be captured) the HIP
+    # runtime stays in a state in which later collectives return "invalid argument" even after ending the capture
+    # and switching streams, so there is no safe in-process fallback for a run that must produce a number.
     def try_capture(with_reduce):
         def body():
             fwd_bwd()
             if with_reduce:
                 reducer()
+        prev = torch.cuda.current_stream(dev)
+        g = None
         try:
             side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
+            side.wait_stream(prev)
             with torch.cuda.stream(side):
                 for _ in range(3):
                     body()
-            torch.cuda.current_stream(dev).wait_stream(side)
+            prev.wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            # a stream of its own for every attempt: torch.cuda.graph's default capture stream is shared, and a failed
+            # capture leaves it invalidated
+            with torch.cuda.graph(g, stream=torch.cuda.Stream(dev), capture_error_mode="thread_local"):
                 body()
             return g
         except Exception as e:  # keep measuring, and say so in the JSON line
             print(f"[bench] HIP graph capture (all-reduce inside: {with_reduce}) failed ({type(e).__name__}: {e})",
                   file=sys.stderr)
-            torch.cuda.synchronize(dev)
+            # A capture that dies inside the `with` leaves the thread on the capture stream, still capturing
+            # (torch.cuda.graph.__exit__ stops at the failing capture_end): end it and give the thread its stream back,
+            # or every later call fails with "operation not permitted when stream is capturing".
+            if g is not None:
+                try:
+                    g.capture_end()
+                except Exception:
+                    pass
+            torch.cuda.set_stream(prev)
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:
+                pass
             return None
 
     graph, reduce_in_graph = None, False
     if args.graph:
-        want_reduce = (reducer is not None and args.graph_allreduce != 0
-                       and (dist.get_backend() == "nccl" or args.graph_allreduce == 1))
+        want_reduce = reducer is not None and args.graph_allreduce == 1
         if want_reduce:
             fwd_bwd()
             reducer()
             torch.cuda.synchronize(dev)
             want = [p.grad.detach().float().clone() for p in model.parameters()]
             graph = try_capture(True)
+
+            def all_ranks(flag: bool) -> bool:   # every rank must take the same branch: the collectives must pair up
+                t = torch.tensor([1.0 if flag else 0.0], device=dev)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item() > 0.5)
+
+            if not all_ranks(graph is not None):
+                graph = None
             if graph is not None:
                 graph.replay()
                 torch.cuda.synchronize(dev)
                 same = all(torch.allclose(p.grad.float(), w, rtol=2e-2, atol=1e-6 + 2e-2 * float(w.abs().max()))
                            for p, w in zip(model.parameters(), want))
-                if same:
+                if all_ranks(same):
                     reduce_in_graph = True
                 else:
                     print("[bench] captured step with all-reduce disagrees with the eager step; not using it", file=sys.stderr)

@@ -62,10 +62,11 @@ class GraphedTrainStep:
     bound: ~40 kernels of a few microseconds each once loss, regulariser and optimizer are counted).
 
     Single process: one graph holds forward, loss, regulariser, backward and the optimizer step.
-    Data parallel over RCCL: the gradient all-reduce is captured into that same graph (one launch per
-    iteration from the host; ``graph_allreduce=False`` or a capture error falls back to the split form).
-    Data parallel over gloo: forward + backward are one graph, the all-reduce runs eagerly on the same
-    stream, the optimizer step is a second graph.  Inputs are copied into static buffers, so
+    Data parallel: forward + backward are one graph, the gradient all-reduce runs eagerly on the same stream,
+    the optimizer step is a second graph.  ``graph_allreduce=True`` (RCCL only) captures the collective into
+    the one graph as well (one launch per iteration from the host); it is opt-in because a capture that fails
+    leaves the HIP runtime unusable for later collectives — there is no safe fallback inside the process.
+    Inputs are copied into static buffers, so
     every call must use the batch shape of the example; the optimizer must be capturable
     (``torch.optim.SGD``, or ``Adam(..., capturable=True)``).
     """
@@ -79,8 +80,7 @@ class GraphedTrainStep:
         self.x, self.y = example_x.clone(), example_y.clone()
         dev = example_x.device
         reduces = reducer is not None and (reducer.world > 1 or not reducer.skip_single_rank)
-        if graph_allreduce is None:
-            graph_allreduce = reduces and dist.is_initialized() and dist.get_backend() == "nccl"
+        graph_allreduce = bool(graph_allreduce) and reduces
         split = reduces
 
         def fwd_bwd():
@@ -121,9 +121,10 @@ class GraphedTrainStep:
                     optimizer.step()
                 self.g_main, self.allreduce_in_graph, split = g, True, False
                 return
-            except Exception as e:   # fall back to the split form below
-                getLogger(__name__).warning(f"capturing the all-reduce into the graph failed ({type(e).__name__}: {e})")
-                torch.cuda.synchronize(dev)
+            except Exception as e:
+                # no fallback: after a failed capture later collectives of this process fail ("invalid argument")
+                raise RuntimeError("capturing the all-reduce into the iteration's graph failed; rerun with "
+                                   "graph_allreduce=False") from e
         self.g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.out, self.loss, self.reg = fwd_bwd()
