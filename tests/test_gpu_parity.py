@@ -790,6 +790,21 @@ def test_fused_training_tail_matches_torch(dtype):
     tol = 1e-6 if dtype == torch.float32 else 2e-2 * float(ref_logits.grad.abs().max())
     assert float((logits.grad.float() - ref_logits.grad).abs().max()) <= tol
 
+    # the registered constant-1 seed (what GraphedTrainStep passes): the forward's unit gradient comes back as is;
+    # and a batch beyond the single-workgroup bound (fill + atomics form of the forward kernel)
+    from dctn_amd.training import unit_seed
+    for rows in (77, 9000):
+        lg = (torch.randn(rows, 10) * 3).to(dtype).to(DEV).requires_grad_(True)
+        lb = torch.randint(0, 10, (rows,), device=DEV)
+        ls = fused_cross_entropy(lg, lb)
+        ls.backward(unit_seed(DEV, torch.float32))
+        rl = lg.detach().float().requires_grad_(True)
+        rf = torch.nn.functional.cross_entropy(rl, lb)
+        rf.backward()
+        assert abs(float(ls.detach()) - float(rf.detach())) < 2e-5 * max(1.0, abs(float(rf.detach())))
+        tol2 = 1e-6 if dtype == torch.float32 else 2e-2 * float(rl.grad.abs().max())
+        assert float((lg.grad.float() - rl.grad).abs().max()) <= tol2
+
     if dtype == torch.bfloat16:
         return   # the optimizer comparison below needs float32 weights on the torch side
     a = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, dtype, image_size=10)
