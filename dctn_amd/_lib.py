@@ -1,7 +1,7 @@
 """ctypes binding of the C-ABI kernel library (include/dctn_amd.h).
 
 The library is the product path.  There is deliberately NO fallback: if the shared object is
-missing, or a tensor is not on an MI355X device, the call raises.
+missing, or no MI355X is visible, the call raises (CPU tensors are staged to the GPU, see `placement`).
 """
 from __future__ import annotations
 
@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libdctn_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, F64, BF16 = 0, 1, 2
-PREC_EXACT, PREC_BF16 = 0, 1
+PREC_EXACT, PREC_BF16, PREC_MASK = 0, 1, 0xFF
+OPT_F32_PREFER_HALVES, OPT_SMALL_CHUNKS, OPT_MAIN_KERNEL_ONLY = 1 << 8, 1 << 9, 1 << 10
 ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_NULL = -1, -2, -3, -4, -5, -6
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16}
@@ -30,7 +31,6 @@ _PtrP = ctypes.POINTER(c_void)
 # name -> (restype, argtypes); mirrors include/dctn_amd.h one to one
 SIGNATURES = {
     "dctn_version": (c_int, []),
-    "dctn_profile_main_kernel_only": (None, [c_int]),
     "dctn_strerror": (ctypes.c_char_p, [c_int]),
     "dctn_last_kernel": (ctypes.c_char_p, []),
     "dctn_eps_family": (c_int, [c_int] * 9),
@@ -109,6 +109,8 @@ def dtype_code(t: torch.Tensor) -> int:
 
 
 def require_device(*tensors: torch.Tensor) -> torch.device:
+    """Device of a kernel-library call: every tensor must already live on the same MI355X device (the
+    autograd Functions are only ever reached through `on_device`, which stages CPU tensors first)."""
     dev = tensors[0].device
     for t in tensors:
         if not t.is_cuda:
@@ -119,6 +121,40 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
         if t.device != dev:
             raise RuntimeError(f"dctn_amd: tensors on different devices ({dev} vs {t.device})")
     return dev
+
+
+def placement(*tensors: torch.Tensor):
+    """(device to compute on, staged?).  "Device follows the tensors" (SURVEY 8b): tensors that all live on
+    one GPU compute there; tensors that all live on the CPU - how the reference's own tests build them
+    (tests/test_eps.py:10-13) - are STAGED to the current GPU, run through the same HIP kernels and the
+    results come back as CPU tensors of the same dtype.  Without a GPU there is nothing to stage to, and
+    no CPU implementation to fall back on: RuntimeError.  Mixed placements raise like torch does."""
+    devs = {t.device for t in tensors}
+    if len(devs) > 1:
+        raise RuntimeError(f"dctn_amd: expected all tensors on one device, got {sorted(str(d) for d in devs)}")
+    dev = tensors[0].device
+    if dev.type == "cuda":
+        return dev, False
+    if dev.type != "cpu":
+        raise RuntimeError(f"dctn_amd: unsupported device '{dev}'")
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "dctn_amd: CPU tensors are staged to an MI355X for the contraction, but no GPU is visible. "
+            "There is deliberately no CPU implementation of this path."
+        )
+    return torch.device("cuda", torch.cuda.current_device()), True
+
+
+def on_device(fn, *tensors: torch.Tensor):
+    """``fn(*tensors)`` with CPU tensors staged to the GPU and the result(s) brought back (see `placement`).
+    The copies are ordinary differentiable ``.to()`` calls, so gradients arrive on the CPU leaves."""
+    dev, staged = placement(*tensors)
+    if not staged:
+        return fn(*tensors)
+    out = fn(*(t.to(dev) for t in tensors))
+    if isinstance(out, torch.Tensor):
+        return out.cpu()
+    return type(out)(o.cpu() for o in out)
 
 
 def check(rc: int, what: str) -> None:
@@ -177,5 +213,28 @@ def set_float32_matmul_precision(mode: str) -> None:
     _precision = {"exact": PREC_EXACT, "highest": PREC_EXACT, "bf16": PREC_BF16}[mode]
 
 
+_options = 0
+
+
 def precision() -> int:
-    return _precision
+    """The `policy` argument of the EPS entry points: precision | option flags (include/dctn_amd.h)."""
+    return _precision | _options
+
+
+class options:
+    """``with L.options(L.OPT_SMALL_CHUNKS): ...`` - DCTN_OPT_* flags OR-ed into the policy of every EPS call inside
+    the block (tests and measurement tools; the flags travel to the library as an explicit argument)."""
+
+    def __init__(self, flags: int):
+        self.flags = int(flags)
+
+    def __enter__(self):
+        global _options
+        self._saved = _options
+        _options |= self.flags
+        return self
+
+    def __exit__(self, *exc):
+        global _options
+        _options = self._saved
+        return False

@@ -239,7 +239,8 @@ class ConvSBS(nn.Module):
         """``input``: a tensor whose first dim is channels, or a tuple of per-channel tensors
         (batch, height, width, q).  Returns (batch, height', width', prod of out sizes)."""
         x = input if isinstance(input, Tensor) else torch.stack(tuple(input))
-        return _ConvSBSFunction.apply(x, self.spec, *self.cores)
+        spec = self.spec
+        return L.on_device(lambda x_, *cores: _ConvSBSFunction.apply(x_, spec, *cores), x, *self.cores)
 
     def multiply_by_scalar(self, scalar: float, /):
         """Multiplies the represented tensor by ``scalar`` in place (spread over the cores)."""
@@ -280,4 +281,10 @@ class ManyConvSBS(nn.Module):
 
     def forward(self, channels: Union[Tensor, Tuple[Tensor, ...]], /) -> Tuple[Tensor, ...]:
         x = channels if isinstance(channels, Tensor) else torch.stack(tuple(channels))
+        dev, staged = L.placement(x, *self.parameters())
+        if staged:   # CPU module and input: the input crosses to the GPU once, not once per string
+            xd = x.to(dev)
+            return tuple(
+                _ConvSBSFunction.apply(xd, s.spec, *(c.to(dev) for c in s.cores)).cpu() for s in self.strings
+            )
         return tuple(string(x) for string in self.strings)

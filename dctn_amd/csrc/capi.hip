@@ -3,19 +3,19 @@
 
 #include <stdlib.h>
 
-static const char* volatile g_last_kernel = "none";  // process-wide: autograd runs backward on its own thread
-void dctn_set_last_kernel(const char* name) { g_last_kernel = name; }
+#include <atomic>
 
-static volatile int g_main_only = 0;
-bool dctn_main_kernel_only() { return g_main_only != 0; }
+// The library's only mutable global: a diagnostic pointer to a string literal naming the kernel family of the last
+// successful call (process-wide, relaxed atomic, last writer wins: autograd runs backward on its own thread, so a
+// thread-local would hide the backward's kernels from the caller).  No entry point reads it to decide anything.
+static std::atomic<const char*> g_last_kernel{"none"};
+void dctn_set_last_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
 
 extern "C" {
 
 int dctn_version(void) { return 100; }
 
-void dctn_profile_main_kernel_only(int on) { g_main_only = on; }
-
-const char* dctn_last_kernel(void) { return g_last_kernel; }
+const char* dctn_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 
 const char* dctn_strerror(int code) {
   switch (code) {
@@ -30,31 +30,28 @@ const char* dctn_strerror(int code) {
   return "unknown error";
 }
 
-// measurement aid: DCTN_F32_PREFER_HALVES=1 sends float32 shapes that both families cover to the two-halves path
+// DCTN_OPT_F32_PREFER_HALVES sends float32 shapes that both exact families cover to the two-halves path
 static bool f32_prefers_halves(const EpsP& p, int dtype) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DCTN_F32_PREFER_HALVES");
-    v = e ? atoi(e) : 0;
-  }
-  return v != 0 && dtype == DCTN_F32 && eps_halves_wanted(p, dtype);
+  return (p.opts & DCTN_OPT_F32_PREFER_HALVES) && dtype == DCTN_F32 && eps_halves_wanted(p, dtype);
 }
 
 static bool dtype_ok(int dtype) { return dtype == DCTN_F32 || dtype == DCTN_F64 || dtype == DCTN_BF16; }
 
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
-                                    int precision) {
+                                    int policy) {
   EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
-  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
   const size_t a = eps_fwd_bigcore_workspace(p, dtype, precision), b = eps_fwd_halves_workspace(p, dtype);
   return (a > b ? a : b) + 256;
 }
 
-int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int precision) {
+int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy) {
   EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
-  if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return -1;
+  if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return -1;
   if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
   if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return DCTN_EPS_FAMILY_BIGCORE_F32;
   if (eps_halves_wanted(p, dtype)) return DCTN_EPS_FAMILY_HALVES;
@@ -63,11 +60,12 @@ int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, 
 
 int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
                  void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q, int K,
-                 int O, int dtype, int precision, void* stream) {
+                 int O, int dtype, int policy, void* stream) {
   if (!x || !core || !out || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   EpsP p;
-  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
+  const int precision = policy & DCTN_PREC_MASK;
+  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
@@ -84,10 +82,11 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
-                                    int precision, int need_dx, int need_dcore) {
+                                    int policy, int need_dx, int need_dcore) {
   EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
-  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
   const size_t a = align256(eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore));
   size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
   const size_t c = need_dx ? eps_bwd_dfactor_bigcore_workspace(p, dtype, precision) : 0;
@@ -98,22 +97,24 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
 }
 
 size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout, int dtype,
-                                         int precision) {
+                                         int policy) {
   EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
-  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O) != DCTN_OK) return 0;
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
   return eps_head_bwd_mfma_workspace(p, Cout, dtype, precision) + 256;
 }
 
 int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features, const void* dLogits,
                       const void* head_weight, void* dCore, void* dWeight, void* dBias, void* workspace,
                       size_t workspace_bytes, int C, int B, int H, int W, int Q, int K, int O, int Cout,
-                      int dtype, int precision, void* stream) {
+                      int dtype, int policy, void* stream) {
   if (!x || !features || !dLogits || !head_weight || !dCore || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   if (Cout < 1) return DCTN_ERR_BAD_SHAPE;
   EpsP p;
-  const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
+  const int precision = policy & DCTN_PREC_MASK;
+  const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
   return eps_head_bwd_mfma(x, features, dLogits, head_weight, dCore, dWeight, dBias, workspace, workspace_bytes, p,
                            Cout, dtype, precision, (hipStream_t)stream);
@@ -121,12 +122,13 @@ int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* fea
 
 int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
                  void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
-                 int H, int W, int Q, int K, int O, int dtype, int precision, void* stream) {
+                 int H, int W, int Q, int K, int O, int dtype, int policy, void* stream) {
   if (!x || !core || !dY || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   if (!dX && !dCore) return DCTN_OK;
   EpsP p;
-  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O);
+  const int precision = policy & DCTN_PREC_MASK;
+  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   // dCore on the MFMA family when it covers the shape; whatever is left goes to the generic kernels

@@ -21,9 +21,6 @@ template <> struct AccOf<double> { typedef double type; };
 // name of the kernel family the last call dispatched to
 void dctn_set_last_kernel(const char* name);
 
-// measurement aid: launch only the dominant kernel of multi-kernel calls (dctn_profile_main_kernel_only)
-bool dctn_main_kernel_only();
-
 static inline long long ipow_ll(long long b, int e) {
   long long r = 1;
   for (int i = 0; i < e; ++i) r *= b;
@@ -50,10 +47,11 @@ struct EpsP {
   int m, LO, NH;   // low split: last m factors, LO = Q^m, NH = N-m high factors
   long long HI;    // Q^NH
   int bits;        // bits per packed digit in the dCore kernel
+  int opts;        // DCTN_OPT_* flags of the call's policy argument (0 from the workspace queries' defaults)
 };
 
 int eps_fill_params(EpsP& p, const int64_t x_strides[5], int C, int B, int H, int W, int Q, int K,
-                    int O);
+                    int O, int policy = 0);
 
 // generic (any shape, f32/f64/bf16-storage) kernels — eps_generic.hip
 int eps_fwd_generic(const void* x, const void* core, void* out, EpsP p, int dtype, hipStream_t st);

@@ -335,7 +335,8 @@ __global__ void convert_k(const A* __restrict__ src, S* __restrict__ dst, long l
 template __global__ void convert_k<bf16_t, float>(const float*, bf16_t*, long long);
 
 // ================================================================================== host side
-int eps_fill_params(EpsP& p, const int64_t xs[5], int C, int B, int H, int W, int Q, int K, int O) {
+int eps_fill_params(EpsP& p, const int64_t xs[5], int C, int B, int H, int W, int Q, int K, int O, int policy) {
+  p.opts = policy & ~DCTN_PREC_MASK;
   if (C < 1 || B < 1 || Q < 1 || K < 1 || O < 1 || H < K || W < K) return DCTN_ERR_BAD_SHAPE;
   p.C = C; p.B = B; p.H = H; p.W = W; p.Q = Q; p.K = K; p.O = O;
   p.N = K * K * C;

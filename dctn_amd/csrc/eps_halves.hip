@@ -47,7 +47,9 @@ template <> struct Mma<float> {
 namespace {
 
 constexpr int GT = 64, GK = 16;                 // tile, k chunk
-constexpr size_t CHUNK_BYTES = (size_t)1 << 30; // bound of the per-chunk buffers (DCTN_HALVES_CHUNK_BYTES overrides: tests)
+constexpr size_t CHUNK_BYTES = (size_t)1 << 30;        // bound of the per-chunk buffers
+constexpr size_t SMALL_CHUNK_BYTES = (size_t)256 << 10;  // ... under DCTN_OPT_SMALL_CHUNKS (tests: many chunks on small inputs)
+static inline size_t chunk_budget(const EpsP& p) { return (p.opts & DCTN_OPT_SMALL_CHUNKS) ? SMALL_CHUNK_BYTES : CHUNK_BYTES; }
 
 struct HalfP {
   EpsP p;
@@ -66,11 +68,7 @@ HalfP make_half(const EpsP& p, size_t esz) {
   h.Bn = ipow_ll(p.Q, h.n1);
   h.NB = h.Bn * p.O;
   const long long per_win = (2 * h.A + 2 * h.Bn + h.NB) * (long long)esz;
-  size_t budget = CHUNK_BYTES;
-  if (const char* e = getenv("DCTN_HALVES_CHUNK_BYTES")) {
-    const long long v = atoll(e);
-    if (v > 0) budget = (size_t)v;
-  }
+  const size_t budget = chunk_budget(p);
   long long wc = (long long)(budget / (size_t)per_win);
   wc = wc / 64 * 64;
   if (wc < 64) wc = 64;
@@ -921,11 +919,7 @@ __global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ 
 HalfP make_half_bf16(const EpsP& p) {
   HalfP h = make_half(p, sizeof(float));
   const long long per_win = (h.A + h.Bn) * 8 + (h.NB / 64) * 4 + p.O * 2;
-  size_t budget = CHUNK_BYTES;
-  if (const char* e = getenv("DCTN_HALVES_CHUNK_BYTES")) {
-    const long long v = atoll(e);
-    if (v > 0) budget = (size_t)v;
-  }
+  const size_t budget = chunk_budget(p);
   long long wc = (long long)(budget / (size_t)per_win) / 64 * 64;
   if (wc < 64) wc = 64;
   const long long wn64 = (p.Wn + 63) / 64 * 64;

@@ -155,6 +155,7 @@ struct MfmaP {
   int Cout;                     // fused-head backward: number of classes (rows of the head weight)
   unsigned hw_rowb, hw_bytes;   //   bytes per row (P * O * 2) and in total
   int ncb;                      //   chunk blocks (8 sample chunks each) of the grouped wave mapping
+  int opts;                     // DCTN_OPT_* flags of the call
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -1005,6 +1006,7 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
   m.vec_ok = p.s[4] == 1 && p.s[0] % 2 == 0 && p.s[1] % 2 == 0 && p.s[2] % 2 == 0 &&
              p.s[3] % 2 == 0 && ((uintptr_t)x % 4) == 0;
   m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0; m.ncb = 0;
+  m.opts = p.opts;
 }
 
 constexpr int FWD_BLOCKS_PER_CU = 4;
@@ -1092,7 +1094,7 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
     DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   DCTN_CHECK_LAUNCH();
-  if (dctn_main_kernel_only()) return DCTN_OK;
+  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_OK;   // measurement option: partial sums only
   hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
                      (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
   DCTN_CHECK_LAUNCH();
@@ -1150,7 +1152,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   }
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
-  if (dctn_main_kernel_only()) return DCTN_OK;
+  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_OK;   // measurement option: partial sums only
   const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
   hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,

@@ -30,9 +30,12 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restr
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
     const long long y = labels[b];
-    part += (m + logf(s)) - (float)row[y >= 0 && y < C ? y : 0];
+    // a label outside [0, C) poisons the loss and its row of the gradient with NaN: F.cross_entropy raises /
+    // device-asserts on such labels (it has no ignore_index here); a plausible-looking number would hide the bug
+    const bool valid = y >= 0 && y < C;
+    part += valid ? (m + logf(s)) - (float)row[y] : __builtin_nanf("");
     if (dunit) {
-      const float inv = 1.f / s, scale = 1.f / (float)B;
+      const float inv = 1.f / s, scale = valid ? 1.f / (float)B : __builtin_nanf("");
       for (int c = 0; c < C; ++c)
         dunit[b * C + c] = (S)((expf((float)row[c] - m) * inv - (c == y ? 1.f : 0.f)) * scale);
     }
@@ -63,9 +66,10 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const S* __restrict__ logits, co
     for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
     const float inv = 1.f / s;
     const long long y = labels[b];
+    const float rs = (y >= 0 && y < C) ? scale : __builtin_nanf("");   // invalid label: NaN row, as in the forward
     for (int c = 0; c < C; ++c) {
       const float p = expf((float)row[c] - m) * inv;
-      dlogits[b * C + c] = (S)((p - (c == y ? 1.f : 0.f)) * scale);
+      dlogits[b * C + c] = (S)((p - (c == y ? 1.f : 0.f)) * rs);
     }
   }
 }

@@ -75,6 +75,10 @@ def eps(core: Tensor, input: Tensor) -> Tensor:
     (out_size,) with factor index = window position (row-major) * channels + channel.
     Returns (batch, height-K+1, width-K+1, out_size)."""
     _check_core(core, input)
+    return L.on_device(_eps_on_device, core, input)
+
+
+def _eps_on_device(core: Tensor, input: Tensor) -> Tensor:
     if _bf16_through_f32(core, input):
         return _EpsFunction.apply(core.float(), input.float()).to(torch.bfloat16)
     if _f32_through_bf16(core, input):
@@ -86,7 +90,7 @@ def _f32_through_bf16(core: Tensor, input: Tensor) -> bool:
     """float32 tensors under ``set_float32_matmul_precision("bf16")`` ("operands rounded to bf16, float32
     accumulate") whose core is too large for the bf16 register family: the two-halves GEMMs on the bf16 matrix
     cores take them (cfg3a: 2.8 ms instead of 10.9 ms per step); with the default 'exact' policy nothing changes."""
-    if core.dtype != torch.float32 or not core.is_cuda or L.precision() != L.PREC_BF16:
+    if core.dtype != torch.float32 or not core.is_cuda or (L.precision() & L.PREC_MASK) != L.PREC_BF16:
         return False
     C, B, H, W, Q = input.shape
     K = math.isqrt((core.ndim - 1) // C)
@@ -115,7 +119,7 @@ def eps_one_by_one(core: Tensor, input: Tensor) -> Tensor:
     """Same contraction.  In the reference this is a second, factor-by-factor evaluation order
     (dctn/eps.py:43-63) used by its tests; on the device both names run the same fused kernel."""
     _check_core(core, input)
-    out = _EpsFunction.apply(core, input)
+    out = L.on_device(_EpsFunction.apply, core, input)
     num_channels, batch_size, height, width, _ = input.shape
     kernel_size = math.isqrt((core.ndim - 1) // num_channels)
     assert out.shape == (batch_size, height - kernel_size + 1, width - kernel_size + 1, core.shape[-1])

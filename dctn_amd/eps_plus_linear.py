@@ -8,7 +8,6 @@ Mirror of the reference's dctn/eps_plus_linear.py:30-196: constructor arguments
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass
 from logging import getLogger
 from typing import Tuple, Union
@@ -42,6 +41,12 @@ class ManuallyChosenInitialization:
 
 Initialization = Union[UnitEmpiricalOutputStd, UnitTheoreticalOutputStd, ManuallyChosenInitialization]
 
+# Host-side routing switches (plain module attributes; tests flip them to compare the paths):
+#   FUSED_HEAD  - last EPS layer + flatten + linear head as one autograd node (`_EpsLinearHeadFunction`)
+#   HEAD_BWD    - backward of the stand-alone linear head: "blas" (library GEMMs, measured faster) or "hip"
+FUSED_HEAD = True
+HEAD_BWD = "blas"
+
 
 class _LinearHeadFunction(torch.autograd.Function):
     """`F.linear(feat, weight, bias)` for a skinny output (<= 16 classes), bf16, on the HIP kernels of
@@ -53,6 +58,9 @@ class _LinearHeadFunction(torch.autograd.Function):
         return (
             feat.is_cuda and bias is not None and feat.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
             and feat.ndim == 2 and weight.shape[0] <= 16 and feat.shape[1] % 8 == 0
+            # the kernels read 16-byte vectors: a parameter re-pointed into a flat buffer (FlatSGD) at an odd
+            # offset, or a sliced feature tensor, takes the library GEMM instead
+            and feat.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
         )
 
     @staticmethod
@@ -71,10 +79,10 @@ class _LinearHeadFunction(torch.autograd.Function):
     def backward(ctx, d_out: Tensor):
         """Measured on MI355X at batch 1024 (profiles/README.md): the HIP backward kernels
         (`dctn_linear_head_bwd`) only tie the library GEMMs (25.8 vs 21.6 us), so the backward
-        stays on rocBLAS; `DCTN_HEAD_BWD=hip` selects the HIP kernels."""
+        stays on rocBLAS; `eps_plus_linear.HEAD_BWD = "hip"` selects the HIP kernels."""
         f, w = ctx.saved_tensors
         need_f, need_w, need_b = ctx.needs_input_grad
-        if os.environ.get("DCTN_HEAD_BWD", "blas") != "hip":
+        if HEAD_BWD != "hip":
             d_f = d_out @ w if need_f else None
             d_w = d_out.t() @ f if need_w else None
             d_b = d_out.sum(0) if need_b else None
@@ -116,7 +124,7 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
             return False
         n, o, cout = core.ndim - 1, core.shape[-1], weight.shape[0]
         return (x.shape[-1] == 2 and n in (8, 9) and o in (2, 4) and cout <= 16 and cout % 2 == 0
-                and weight.shape[1] % 8 == 0 and os.environ.get("DCTN_FUSED_HEAD", "1") == "1")
+                and weight.shape[1] % 8 == 0 and FUSED_HEAD)
 
     @staticmethod
     def forward(ctx, core: Tensor, x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
@@ -233,25 +241,46 @@ class EPSesPlusLinear(nn.Module):
             logger.info(f"Initialized linear.bias from Uniform[{-bias_max:.30e}, {bias_max:.30e}]")
         self.linear.to(device)
         self.register_buffer("p", torch.tensor(p, device=device, dtype=dtype))
+        # Host copy of `p` for the dropout gate (reading the buffer every forward would be a device
+        # synchronisation, impossible under graph capture).  `p` is part of the state_dict, so the copy is
+        # refreshed whenever a checkpoint is loaded.
         self._p_float = float(p)
+        self.register_load_state_dict_post_hook(lambda module, _incompatible: module._refresh_p())
+
+    def _refresh_p(self) -> None:
+        self._p_float = float(self.p)
 
     def forward(self, input: Tensor) -> Tensor:
-        """``input``: (channels, batch, height, width, Q_0) -> logits (batch, 10)."""
-        if self._p_float < 1.0 and self.training:
-            cores = tuple(self.p.expand_as(core).bernoulli() * core / self.p for core in self.epses)
-        else:
-            cores = tuple(self.epses)
+        """``input``: (channels, batch, height, width, Q_0) -> logits (batch, 10).  A model and input that live
+        on the CPU are staged to the GPU once for the whole forward (`_lib.placement`)."""
+        dev, staged = L.placement(input, *self.epses, self.linear.weight, self.linear.bias)
+        if staged:
+            return self._forward_on_device(
+                input.to(dev), tuple(core.to(dev) for core in self.epses), self.linear.weight.to(dev),
+                self.linear.bias.to(dev), self.p.to(dev)).cpu()
+        return self._forward_on_device(input, tuple(self.epses), self.linear.weight, self.linear.bias, self.p)
+
+    def _forward_on_device(self, input: Tensor, cores: Tuple[Tensor, ...], weight: Tensor, bias: Tensor,
+                           p: Tensor) -> Tensor:
+        if self._p_float < 1.0 and self.training:   # component dropout, dctn/eps_plus_linear.py:139-143
+            cores = tuple(self.dropout_mask(core, p) * core / p for core in cores)
         x = input
         for core in cores[:-1]:   # as epses_composition.contract_with_input
             x = eps.eps(core, x).unsqueeze(0)
-        if _EpsLinearHeadFunction.supported(cores[-1], x, self.linear.weight, self.linear.bias):
+        if _EpsLinearHeadFunction.supported(cores[-1], x, weight, bias):
             eps._check_core(cores[-1], x)
-            return _EpsLinearHeadFunction.apply(cores[-1], x, self.linear.weight, self.linear.bias)
+            return _EpsLinearHeadFunction.apply(cores[-1], x, weight, bias)
         features = eps.eps(cores[-1], x)
         flat = features.reshape(features.shape[0], -1)
-        if _LinearHeadFunction.supported(flat, self.linear.weight, self.linear.bias):
-            return _LinearHeadFunction.apply(flat, self.linear.weight, self.linear.bias)
-        return self.linear(flat)
+        if _LinearHeadFunction.supported(flat, weight, bias):
+            return _LinearHeadFunction.apply(flat, weight, bias)
+        return F.linear(flat, weight, bias)
+
+    @staticmethod
+    def dropout_mask(core: Tensor, p: Tensor) -> Tensor:
+        """Bernoulli(p) keep-mask of one core (the reference draws ``self.p.expand_as(core).bernoulli()``); a
+        method of its own so that a test can pin the mask."""
+        return p.expand_as(core).bernoulli()
 
     def epswise_l2_regularizer(self) -> Tensor:
         """||linear.weight||^2 + sum of squared Frobenius norms of the cores (bias excluded)."""

@@ -71,7 +71,7 @@ def logmatmulexp(log_A: Tensor, log_B: Tensor, /) -> Tensor:
     Theta, R = log_A.shape
     I = log_B.shape[1]
     assert log_B.shape == (R, I)
-    return _LME.apply(log_A.unsqueeze(0), log_B.unsqueeze(0)).squeeze(0)
+    return L.on_device(_LME.apply, log_A.unsqueeze(0), log_B.unsqueeze(0)).squeeze(0)
 
 
 def logmatmulexp_lowmem(log_A: Tensor, log_B: Tensor, /) -> Tensor:
@@ -85,7 +85,7 @@ def logmatmulexp_batched(log_A: Tensor, log_B: Tensor, /) -> Tensor:
     broadcasts (its gradient is summed over the batch)."""
     assert log_A.ndim == 3 and log_B.ndim == 3 and log_A.shape[2] == log_B.shape[1]
     assert log_A.shape[0] == log_B.shape[0] or 1 in (log_A.shape[0], log_B.shape[0])
-    return _LME.apply(log_A, log_B)
+    return L.on_device(_LME.apply, log_A, log_B)
 
 
 class _Fold(torch.autograd.Function):
@@ -124,4 +124,4 @@ class _Fold(torch.autograd.Function):
 def logmatmulexp_fold(mats: Tensor, /) -> Tensor:
     """mats (windows, L, D, D): per window ``reduce(logmatmulexp, mats[w])`` -> (windows, D, D)."""
     assert mats.ndim == 4 and mats.shape[2] == mats.shape[3]
-    return _Fold.apply(mats)
+    return L.on_device(_Fold.apply, mats)

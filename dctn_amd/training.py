@@ -69,6 +69,10 @@ class GraphedTrainStep:
     Inputs are copied into static buffers, so
     every call must use the batch shape of the example; the optimizer must be capturable
     (``torch.optim.SGD``, or ``Adam(..., capturable=True)``).
+
+    The dictionary a call returns holds the graph's STATIC output buffers (no copy kernels in the iteration): the
+    next call overwrites them.  A caller that keeps ``loss`` / ``output`` across iterations must ``.clone()`` them
+    (``train_step`` returns fresh tensors).
     """
 
     def __init__(self, model: torch.nn.Module, example_x: Tensor, example_y: Tensor,
@@ -195,7 +199,10 @@ class _FusedCrossEntropy(torch.autograd.Function):
     def backward(ctx, d_loss: Tensor):
         lg, lb, unit = ctx.saved_tensors
         if d_loss.data_ptr() in _UNIT_SEEDS:
-            return unit, None
+            # inside a capture the saved tensor itself is handed on (one node less; the graph owns it).  Eagerly it is
+            # cloned: AccumulateGrad may steal a returned gradient and accumulate into it in place, which would
+            # corrupt the saved tensor for a second backward(retain_graph=True)
+            return (unit if torch.cuda.is_current_stream_capturing() else unit.clone()), None
         dev = lg.device
         g = d_loss.to(torch.float32).contiguous()
         d_logits = torch.empty_like(lg)
@@ -206,7 +213,7 @@ class _FusedCrossEntropy(torch.autograd.Function):
 
 def fused_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """Mean cross-entropy of (batch, classes) logits (float32 or bfloat16) as a float32 scalar."""
-    return _FusedCrossEntropy.apply(logits, labels)
+    return L.on_device(_FusedCrossEntropy.apply, logits, labels)
 
 
 fused_cross_entropy.accepts_low_precision = True   # train_step / GraphedTrainStep skip their float32 cast
@@ -319,7 +326,14 @@ def train(dl, model, optimizer, dev, loss_fn, reg_fn, reg_coeff: float, at_iter_
                      at_iter_start=list(at_iter_start), after_back=list(after_back),
                      after_param_upd=list(after_param_upd), dev=dev)
     world = _world()
-    reducer = ddp.FlatGradAllReducer(st_x["model"].parameters(), average=True) if world > 1 else None
+    reducer = None
+    if world > 1:
+        # the reference is one process with one seed; here every rank drew its own random parameters, and averaged
+        # gradients on different models would diverge silently: everybody starts from rank 0's model
+        ddp.broadcast_parameters(list(st_x["model"].parameters()) + list(st_x["model"].buffers()))
+        if hasattr(st_x["model"], "_refresh_p"):
+            st_x["model"]._refresh_p()
+        reducer = ddp.FlatGradAllReducer(st_x["model"].parameters(), average=True)
     st_it: StIt = {}
 
     def run_hooks(key: str) -> None:
@@ -460,12 +474,18 @@ class ValuesNotImprovingEarlyStopper:
             getLogger(__name__).info(f"Early stopping at st_it['num_iters_done']={st_it['num_iters_done']}")
 
 
-def make_stopper_after_n_iters(n: int) -> Callable[[StX, StIt], None]:
-    def maybe_stop(st_x: StX, st_it: StIt) -> None:
-        if st_it["num_iters_done"] >= n:
-            st_it["stop"] = True
+class _StopAfter:
+    """Hook that raises the stop flag from iteration ``n`` on."""
 
-    return maybe_stop
+    def __init__(self, n: int):
+        self.n = n
+
+    def __call__(self, st_x: StX, st_it: StIt) -> None:
+        st_it["stop"] = st_it["stop"] or st_it["num_iters_done"] >= self.n
+
+
+def make_stopper_after_n_iters(n: int) -> Callable[[StX, StIt], None]:
+    return _StopAfter(n)
 
 
 def make_stopper_on_nan_loss(dir: str, set_breakpoint: bool) -> Callable[[StX, StIt], None]:

@@ -34,6 +34,10 @@ def apply_feature_map(images: Tensor, φ=φ_cos_sin_squared_1) -> Tensor:
 def window_sums(x: Tensor, kernel_size: int) -> Tensor:
     """``x``: (channels, batch, height, width, in_size) on the device.  Returns a float64 tensor
     [sum_w sum(T_w), sum_w ||T_w||^2] over the rank-one tensors T_w of all K x K windows."""
+    return L.on_device(lambda x_: _window_sums_on_device(x_, kernel_size), x)
+
+
+def _window_sums_on_device(x: Tensor, kernel_size: int) -> Tensor:
     dev = L.require_device(x)
     C, B, H, W, Q = x.shape
     assert H >= kernel_size and W >= kernel_size

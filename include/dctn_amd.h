@@ -14,7 +14,8 @@
  *   - return value: 0 on success, negative DCTN_ERR_* otherwise (dctn_strerror()).  The Python
  *     host layer turns shape errors into AssertionError like the reference's `assert`s.
  *   - dtype codes: DCTN_F32 / DCTN_F64 / DCTN_BF16 (bf16 storage, fp32 accumulation).
- *   - re-entrant; no global mutable state.
+ *   - re-entrant.  Nothing a call computes depends on process state: no environment variables are read, there are
+ *     no setters; the one mutable global is the diagnostic name returned by dctn_last_kernel().
  */
 #ifndef DCTN_AMD_H
 #define DCTN_AMD_H
@@ -38,18 +39,27 @@ enum {
   DCTN_ERR_NULL = -6          /* required pointer is NULL */
 };
 
-/* precision policy for float32 tensors on the MFMA paths */
+/* `policy` argument of the EPS entry points: one DCTN_PREC_* value (precision policy for float32 tensors on the
+ * MFMA paths), optionally OR-ed with DCTN_OPT_* flags.  A workspace query and the call it sizes take the same policy. */
 enum {
   DCTN_PREC_EXACT = 0, /* f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32 or VALU fma) */
-  DCTN_PREC_BF16 = 1   /* operands rounded to bf16, f32 accumulate (v_mfma_f32_32x32x16_bf16) */
+  DCTN_PREC_BF16 = 1,  /* operands rounded to bf16, f32 accumulate (v_mfma_f32_32x32x16_bf16) */
+  DCTN_PREC_MASK = 0xFF
+};
+enum {
+  /* float32 shapes that both exact-f32 families cover run on the two-halves GEMM path instead of the LDS-streamed
+   * large-core kernels (cross-check of the two designs; same results to f32 rounding) */
+  DCTN_OPT_F32_PREFER_HALVES = 1 << 8,
+  /* two-halves path: bound its per-chunk buffers to 256 KiB instead of 1 GiB, so that small inputs take many
+   * chunks (tests of the chunk loop; results identical) */
+  DCTN_OPT_SMALL_CHUNKS = 1 << 9,
+  /* measurement only: dctn_eps_bwd / dctn_eps_head_bwd on the register-resident family launch their dominant
+   * kernel (per-workgroup partial sums) and skip the small reduction kernel, so that the kernel can be timed
+   * alone; the gradients are NOT written */
+  DCTN_OPT_MAIN_KERNEL_ONLY = 1 << 10
 };
 
 int dctn_version(void);
-/* Measurement aid (bench.py's roofline leg only): while on, multi-kernel calls launch ONLY their
- * dominant kernel (dctn_eps_bwd on the q2-reg family: the dCore partial-sum kernel without the
- * small slice reduction), so back-to-back launches time that single kernel and can be compared
- * with rocprofv3's per-kernel average.  Results of such calls are incomplete by design. */
-void dctn_profile_main_kernel_only(int on);
 const char* dctn_strerror(int code);
 /* name of the kernel family the last successful call dispatched to
  * (diagnostics / tests: proves which HIP path ran; process-wide, last writer wins) */
@@ -71,13 +81,13 @@ const char* dctn_last_kernel(void);
 #define DCTN_EPS_FAMILY_Q2REG 1        /* bf16 MFMA, Q = 2, N in {8, 9} */
 #define DCTN_EPS_FAMILY_BIGCORE_F32 2  /* exact f32 MFMA, LDS-streamed core */
 #define DCTN_EPS_FAMILY_HALVES 3       /* two-halves GEMM path: f64 MFMA, and f32 MFMA for shapes 1 and 2 leave */
-int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int precision);
+int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy);
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
-                                    int dtype, int precision);
+                                    int dtype, int policy);
 int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
                  void* workspace, size_t workspace_bytes,
                  int C, int B, int H, int W, int Q, int K, int O,
-                 int dtype, int precision, void* stream);
+                 int dtype, int policy, void* stream);
 
 /* Autograd of the above (reference: torch autograd through the 4 path steps, dctn/training.py:81).
  *   dY    : (B, H', W', O) contiguous
@@ -86,11 +96,11 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
  *   Both are OVERWRITTEN (not accumulated).  `workspace` must hold dctn_eps_bwd_workspace_bytes().
  */
 size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
-                                    int dtype, int precision, int need_dx, int need_dcore);
+                                    int dtype, int policy, int need_dx, int need_dcore);
 int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
                  void* dX, void* dCore, void* workspace, size_t workspace_bytes,
                  int C, int B, int H, int W, int Q, int K, int O,
-                 int dtype, int precision, void* stream);
+                 int dtype, int policy, void* stream);
 
 /* Backward of (EPS layer -> "b h w q -> b (h w q)" -> nn.Linear), the tail of
  * EPSesPlusLinear.forward (reference: dctn/eps_plus_linear.py:144-147), in one pass over x: the
@@ -105,12 +115,12 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
  * outside the register-resident MFMA family (the caller then composes dctn_linear_head_bwd or
  * library GEMMs with dctn_eps_bwd; there is no CPU fallback). */
 size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout,
-                                         int dtype, int precision);
+                                         int dtype, int policy);
 int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features,
                       const void* dLogits, const void* head_weight, void* dCore, void* dWeight,
                       void* dBias, void* workspace, size_t workspace_bytes,
                       int C, int B, int H, int W, int Q, int K, int O, int Cout,
-                      int dtype, int precision, void* stream);
+                      int dtype, int policy, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConvSBS — replaces dctn/conv_sbs.py:258-304 `ConvSBS.forward`
@@ -218,7 +228,8 @@ int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums,
  *                      update; their sum is the regulariser's value / its coefficient (stored, not
  *                      accumulated: no fill launch and no atomics in the iteration).
  *                      momentum_buf is float32 whatever the parameter dtype.
- * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.
+ * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.  A label outside [0, C) makes the loss and
+ * that sample's gradient row NaN (F.cross_entropy raises on it; there is no ignore_index here).
  * ------------------------------------------------------------------------------------------ */
 int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream);
 /* forward that also leaves dlogits_unit = (softmax - onehot) / B (logits' dtype): the backward for an incoming gradient of 1,

@@ -98,7 +98,8 @@ def test_cfg2_full_batch_1024_bf16():
     g = (torch.randn(1024, 10, generator=torch.Generator().manual_seed(3)) * 0.1).to(torch.bfloat16).to(DEV)
 
     def grads(xs, gs, fused):
-        os.environ["DCTN_FUSED_HEAD"] = "1" if fused else "0"
+        import dctn_amd.eps_plus_linear as EPL
+        EPL.FUSED_HEAD = fused
         try:
             for prm in model.parameters():
                 prm.grad = None
@@ -106,7 +107,7 @@ def test_cfg2_full_batch_1024_bf16():
             out.backward(gs)
             return out.detach(), [prm.grad.detach().float().cpu() for prm in model.parameters()], dctn_amd.last_kernel()
         finally:
-            os.environ.pop("DCTN_FUSED_HEAD", None)
+            EPL.FUSED_HEAD = True
 
     out_f, gf, kf = grads(x, g, True)
     out_u, gu, ku = grads(x, g, False)

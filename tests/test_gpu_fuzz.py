@@ -179,9 +179,11 @@ def test_eps_halves_path_in_several_window_chunks(dtype, monkeypatch):
         y.backward(dy.to(DEV))
         return y.detach(), xd.grad, cd.grad
 
+    from dctn_amd import _lib as L
+
     whole = run()
-    monkeypatch.setenv("DCTN_HALVES_CHUNK_BYTES", str(256 * 1024))
-    chunked = run()
+    with L.options(L.OPT_SMALL_CHUNKS):   # 256 KiB chunk buffers: the chunk loop runs many times
+        chunked = run()
     want = R.eps_4step(core.double(), x.double())
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
     for got in (whole, chunked):

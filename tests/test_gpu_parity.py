@@ -168,9 +168,31 @@ def test_epses_composition_golden_and_eps_plus_linear():
     assert close(out, want, torch.float32)
     out.logsumexp(1).sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # component dropout (eps_plus_linear.py:139-143) with a PINNED mask: logits and parameter gradients must be those of
+    # the oracle applied to the masked, rescaled cores  core * mask / p
     m.train()
-    m.p.fill_(0.5); m._p_float = 0.5                    # component dropout path (eps_plus_linear.py:139-143)
-    assert m(x).shape == (6, 10)
+    m.load_state_dict({**m.state_dict(), "p": torch.tensor(0.5)})     # the host copy of p follows the state_dict
+    assert m._p_float == 0.5
+    gen = torch.Generator().manual_seed(11)
+    masks = [torch.bernoulli(torch.full(c.shape, 0.5), generator=gen) for c in m.epses]
+    queue = list(masks)
+    m.dropout_mask = lambda core, p: queue.pop(0).to(core)
+    for prm in m.parameters():
+        prm.grad = None
+    out = m(x)
+    assert not queue and out.shape == (6, 10)
+    out.logsumexp(1).sum().backward()
+    cores64 = [c.detach().cpu().double().requires_grad_(True) for c in m.epses]
+    w64 = m.linear.weight.detach().cpu().double()
+    want = R.eps_plus_linear_forward([c * mk.double() / 0.5 for c, mk in zip(cores64, masks)], w64,
+                                     m.linear.bias.detach().cpu().double(), x.cpu().double())
+    assert close(out, want.detach(), torch.float32)
+    want.logsumexp(1).sum().backward()
+    for got, ref, mk in zip(m.epses, cores64, masks):
+        assert close(got.grad, ref.grad, torch.float32)
+        assert bool((got.grad.cpu()[mk == 0] == 0).all())          # dropped components get no gradient
+    del m.dropout_mask
+    assert m(x).shape == (6, 10)                                    # and the random-mask path runs
 
 
 # ------------------------------------------------------------------ ConvSBS
@@ -299,19 +321,32 @@ def test_logmatmulexp_fold_and_batched():
 
 
 # ------------------------------------------------------------------ bf16 MFMA family (q2-reg)
-# bf16 operands (8-bit mantissa), f32 accumulation: every Khatri-Rao product and core entry is
-# rounded to bf16 once -> relative error ~2^-8 per term; tolerance 2e-2 of the output scale.
+# bf16 operands (8-bit mantissa), f32 accumulation: every Khatri-Rao product, core entry and output is rounded to
+# bf16 once (relative error <= 2^-9 each).  Three bounds, all must hold:
+#   * max |err| < 2e-2 of the output scale (catches gross errors),
+#   * rms(err) < 6e-3 * rms(want) (the roundings are independent: small-magnitude outputs are constrained too),
+#   * where the caller supplies mag[e] = sum over the terms of |term| (the same contraction on |operands|):
+#     per element |err| <= 2^-7 * mag + 2^-8 * |want|, i.e. four roundings of slack on the worst case.
 BF16_TOL = 2e-2
+BF16_RMS_TOL = 6e-3
 
 
-def bf16_close(got, want):
+def bf16_close(got, want, mag=None):
     want = want.double()
     got = got.detach().cpu().double()
+    diff = (got - want).abs()
     scale = float(want.abs().max()) or 1.0
-    err = float((got - want).abs().max()) / scale
-    if err >= BF16_TOL:
-        print("bf16 rel err", err)
-    return err < BF16_TOL
+    err = float(diff.max()) / scale
+    rms = float(diff.square().mean().sqrt()) / (float(want.square().mean().sqrt()) or 1.0)
+    ok = err < BF16_TOL and rms < BF16_RMS_TOL
+    if mag is not None:
+        bound = 2.0 ** -7 * mag.double().abs() + 2.0 ** -8 * want.abs() + 1e-300
+        ok = ok and bool((diff <= bound).all())
+        if not bool((diff <= bound).all()):
+            print("bf16 per-element bound exceeded by factor", float((diff / bound).max()))
+    if not ok:
+        print("bf16 rel max err", err, "rel rms err", rms)
+    return ok
 
 
 @pytest.mark.parametrize(
@@ -330,12 +365,13 @@ def test_eps_bf16_mfma_vs_oracle(C, B, H, W, K, O):
     assert dctn_amd.last_kernel() == "eps_fwd_mfma_q2reg"
     assert y.dtype == torch.bfloat16
     want = R.eps_4step(core.double(), x.double())
-    assert bf16_close(y, want)
+    assert bf16_close(y, want, mag=R.eps_4step(core.double().abs(), x.double().abs()))
     dy = torch.randn(*want.shape).bfloat16()
     y.backward(dy.to(DEV))
     assert dctn_amd.last_kernel() == "eps_bwd_mfma_q2reg"
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
-    assert bf16_close(cd.grad, dcore)
+    dcore_mag, _ = R.grads(R.eps_4step, [core.double().abs(), x.double().abs()], dy.double().abs())
+    assert bf16_close(cd.grad, dcore, mag=dcore_mag)
     # with an input gradient too: dCore on the MFMA family, dX on the generic kernels
     xg = xd.clone().requires_grad_(True)
     cd.grad = None
@@ -473,13 +509,14 @@ def test_linear_head_vs_torch_reference(B, F, C):
     g = torch.randn(B, C).bfloat16()
     want.backward(g.double())
     for mode in ("blas", "hip"):  # library-GEMM backward (default) and the HIP backward kernels
-        os.environ["DCTN_HEAD_BWD"] = mode
+        import dctn_amd.eps_plus_linear as EPL
+        EPL.HEAD_BWD = mode
         try:
             for t in (fd, wd, bd):
                 t.grad = None
             _LinearHeadFunction.apply(fd, wd, bd).backward(g.to(DEV))
         finally:
-            os.environ.pop("DCTN_HEAD_BWD", None)
+            EPL.HEAD_BWD = "blas"
         assert bf16_close(fd.grad, f64.grad) and bf16_close(wd.grad, w64.grad) and bf16_close(bd.grad, b64.grad)
 
 
@@ -500,7 +537,8 @@ def test_eps_plus_linear_fused_head_backward(K, O, size, B):
     g = torch.randn(B, 10).to(torch.bfloat16)
 
     def run(fused):
-        os.environ["DCTN_FUSED_HEAD"] = "1" if fused else "0"
+        import dctn_amd.eps_plus_linear as EPL
+        EPL.FUSED_HEAD = fused
         try:
             for prm in m.parameters():
                 prm.grad = None
@@ -508,7 +546,7 @@ def test_eps_plus_linear_fused_head_backward(K, O, size, B):
             out.backward(g.to(DEV))
             return out.detach().cpu(), [prm.grad.detach().cpu().double() for prm in (m.epses[0], m.linear.weight, m.linear.bias)], dctn_amd.last_kernel()
         finally:
-            os.environ.pop("DCTN_FUSED_HEAD", None)
+            EPL.FUSED_HEAD = True
 
     out_f, grads_f, kern_f = run(True)
     out_u, grads_u, kern_u = run(False)
@@ -822,3 +860,21 @@ def test_fused_training_tail_matches_torch(dtype):
         assert abs(float(ra["reg_term"]) * l2 - float(ob.reg_value())) < 1e-4 * max(1.0, float(ra["reg_term"]) * l2)
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=2e-4, atol=2e-6)
+
+
+def test_fused_cross_entropy_invalid_label_poisons_loss_and_gradient():
+    """F.cross_entropy raises (device-asserts) on a label outside [0, C); the fused kernels cannot raise, so they
+    return NaN for the loss and for that sample's gradient row instead of a plausible number."""
+    from dctn_amd.training import fused_cross_entropy
+
+    logits = torch.randn(6, 10, device=DEV, requires_grad=True)
+    labels = torch.tensor([1, 2, 3, 10, 0, 5], device=DEV)
+    loss = fused_cross_entropy(logits, labels)
+    assert torch.isnan(loss)
+    loss.backward()
+    bad = torch.isnan(logits.grad).all(dim=1).cpu()
+    assert bad.tolist() == [False, False, False, True, False, False]
+    # an incoming gradient other than the registered unit seed goes through dctn_ce_loss_bwd: same poisoning
+    logits.grad = None
+    (2.0 * fused_cross_entropy(logits, labels)).backward()
+    assert torch.isnan(logits.grad[3]).all() and torch.isfinite(logits.grad[[0, 1, 2, 4, 5]]).all()

@@ -66,16 +66,29 @@ def test_eps_family_query_matches_the_dispatch_table():
     assert lib.dctn_eps_family(1, 2, 5, 5, 3, 9, 2, F32, 0) == -1           # kernel larger than the image
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="with a GPU, CPU tensors are staged to it (tests/test_gpu_boundary.py)")
 def test_product_path_has_no_cpu_fallback():
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    """CPU tensors are accepted at the boundary by STAGING them to the GPU (`_lib.placement`); on a machine
+    without a GPU there is nothing to stage to and no CPU implementation to fall back on."""
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
         eps(torch.randn(2, 2, 2, 2, 3), torch.randn(1, 2, 4, 4, 2))
     from dctn_amd.logmatmulexp import logmatmulexp
 
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
         logmatmulexp(torch.randn(3, 4), torch.randn(4, 5))
     spec = SBSSpecString((SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 2)), (1, 3), 1, 2)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
         ConvSBS(spec)(torch.randn(1, 2, 3, 3, 2))
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    model = EPSesPlusLinear(((2, 3),), UnitTheoreticalOutputStd(), 1.0, torch.device("cpu"), torch.float32, image_size=5)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        model(torch.rand(1, 2, 5, 5, 2))
+    # the autograd nodes themselves never take CPU tensors
+    from dctn_amd.eps import _EpsFunction
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _EpsFunction.apply(torch.randn(2, 2, 2, 2, 3), torch.randn(1, 2, 4, 4, 2))
 
 
 def test_product_code_never_imports_the_oracle():
