@@ -5,18 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): `EPSesPlusLinear(((3,4),), p=1)` on
+Headline workload (BASELINE.json configs[1]): `EPSesPlusLinear(((3,4),), p=1)` on
 MNIST-shaped synthetic input x (1, B, 28, 28, 2) = (sin^2, cos^2)(pi u / 2), bf16 tensors with f32
 accumulation, B = 1024 per GPU.  A step follows dctn/benchmark.py:40-43: `model(x).backward(out_grad)`
 with a fixed `out_grad = randn_like(out)`; with N > 1 every rank runs its own batch (weak scaling)
 and the step ends with the flat-bucket RCCL all-reduce of the parameter gradients.
 A window = one output site of one sample: 26*26 = 676 windows per sample.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md section 6 for the fields).
+Timing: W warm-up steps, then BLOCKS (5) blocks of EXACTLY K steps, each bracketed by a barrier and a device
+synchronisation; `ms_per_step` / `value` come from the MEDIAN block (max over ranks per block) - one 0.8 ms
+block moved by 20 % from run to run in round 1 - and every block's time is in `config.blocks_ms`.
+
+Prints ONE JSON line on rank 0.  Beside the headline fields it carries `roofline` and `cpu_baseline` for the
+headline workload and, at N = 1, `configs`: one entry per other BASELINE / SURVEY 8(d) configuration (cfg1 f64,
+cfg3a f32, cfg3b f32, cfg4 ConvSBS r = 4 and r = 16, cfg5 logmatmulexp fold), each timed here with the protocol
+of dctn/benchmark.py:14-56 and priced against its own roofline (see README / DESIGN.md section 6).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,18 +35,26 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# MI355X_MICROARCH.md: dense MFMA peaks (no sparsity): bf16 ~2.5 PFLOP/s; exact f32 157.3 TFLOP/s
+# MI355X_MICROARCH.md: dense MFMA peaks (no sparsity): bf16 ~2.5 PFLOP/s; exact f32 157.3 TFLOP/s; f64 78.6
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3, "float64": 78.6}
+DTYPE_NAME = {torch.bfloat16: "bf16", torch.float32: "f32", torch.float64: "f64"}
+BLOCKS = 5
 
 WORKLOADS = {
     # name: (epses_specs, image_size, Q0, dtype)
     "cfg2": (((3, 4),), 28, 2, torch.bfloat16),
     "cfg2_f32": (((3, 4),), 28, 2, torch.float32),
     "cfg3a": (((4, 4), (3, 6)), 28, 2, torch.float32),
-    "cfg3a_bf16": (((4, 4), (3, 6)), 28, 2, torch.bfloat16),   # bf16 storage, exact-f32 matrix-core arithmetic
+    "cfg3a_bf16": (((4, 4), (3, 6)), 28, 2, torch.bfloat16),   # two-halves GEMMs on the bf16 matrix cores
     "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
     "cfg3b_bf16": (((4, 8), (2, 8)), 28, 2, torch.bfloat16),
 }
+EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+SNAKE = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]   # mnist.py:190-199
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def synthetic_input(batch, image_size, q0, dtype, device, seed):
@@ -73,189 +89,525 @@ def usable_cores():
     return cap if cap > 0 else min(n, 64)
 
 
-def cpu_baseline(specs, image_size, q0, target_seconds=12.0):
-    """The oracle's restatement of the reference's 4-step path (oracle/ref_cpu.py), float32, all
-    host cores, same fwd+bwd protocol, on a bounded sample of the workload."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def time_cpu(step, target_seconds, max_iters=200):
+    """(seconds per call, calls) of a CPU callable: one warm-up, one probe, then as many calls as fit the budget."""
+    step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    iters = max(1, min(max_iters, int(target_seconds / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    return (time.perf_counter() - t0) / iters, iters
+
+
+def cpu_baseline_eps_model(specs, image_size, q0, dtype=torch.float32, batch=128, target_seconds=12.0):
+    """The oracle's restatement of the reference's 4-step path (oracle/ref_cpu.py), all host cores, same fwd+bwd
+    protocol, on a bounded sample of the workload."""
     from oracle import ref_cpu as R
 
     cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    batch = 128
-    x = synthetic_input(batch, image_size, q0, torch.float32, "cpu", 0)
+    x = synthetic_input(batch, image_size, q0, dtype, "cpu", 0)
     epses, in_size = [], q0
     for k, o in specs:
-        epses.append((torch.randn(*(in_size,) * (k * k), o) * in_size ** (-k * k / 2)).requires_grad_(True))
+        epses.append((torch.randn(*(in_size,) * (k * k), o, dtype=dtype) * in_size ** (-k * k / 2)).requires_grad_(True))
         in_size = o
     side = image_size - sum(k for k, _ in specs) + len(specs)
-    weight = (torch.randn(10, side * side * in_size) * 0.01).requires_grad_(True)
-    bias = torch.zeros(10, requires_grad=True)
+    weight = (torch.randn(10, side * side * in_size, dtype=dtype) * 0.01).requires_grad_(True)
+    bias = torch.zeros(10, dtype=dtype, requires_grad=True)
+    out_grad = torch.randn(batch, 10, dtype=dtype)
+    # layers after the first get an input gradient through autograd, the first does not (x is the dataset tensor)
 
     def step():
-        out = R.eps_plus_linear_forward(epses, weight, bias, x)
-        out.backward(out_grad)
+        R.eps_plus_linear_forward(epses, weight, bias, x).backward(out_grad)
 
-    out_grad = torch.randn(batch, 10)
-    step()  # warm-up
-    t0 = time.perf_counter()
-    step()
-    one = time.perf_counter() - t0
-    iters = max(1, min(200, int(target_seconds / max(one, 1e-4))))
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
+    dt, iters = time_cpu(step, target_seconds)
     wps = windows_per_sample(specs, image_size) * batch / dt
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
     return {
         "value": wps, "unit": "windows/s", "cores": cores, "kind": "port",
-        "sample": f"oracle 4-step path (torch CPU f32, {cores} threads, {model}), batch {batch}, "
+        "sample": f"oracle 4-step path (torch CPU {DTYPE_NAME[dtype]}, {cores} threads, {cpu_model_name()}), batch {batch}, "
                   f"{iters} fwd+bwd iterations, {dt*1e3:.1f} ms/iteration",
     }
 
 
-def kernel_roofline(model, x, specs, image_size, steps):
-    """Times the EPS kernels of the first layer alone with HIP events on the stream they are
-    launched on (torch's current stream) and prices the dominant one against the compute (MFMA)
-    roofline SURVEY 8(d) assigns to this path; the HBM figures ride along."""
+# ------------------------------------------------------------------------------------------ device timing
+def safe_capture(body, dev, warm=2):
+    """`body` captured into a HIP graph on a stream of its own, or None when the capture fails (the thread is then
+    taken out of capture mode and given its stream back).  Never used for bodies that contain a collective unless
+    a child-process probe has shown that such a capture works (see main)."""
+    prev = torch.cuda.current_stream(dev)
+    g = None
+    try:
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(prev)
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                body()
+        prev.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.Stream(dev), capture_error_mode="thread_local"):
+            body()
+        return g
+    except Exception as e:
+        log(f"HIP graph capture failed ({type(e).__name__}: {e}); timing eager launches")
+        if g is not None:
+            try:
+                g.capture_end()
+            except Exception:
+                pass
+        torch.cuda.set_stream(prev)
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception:
+            pass
+        return None
+
+
+def device_time(fn, dev, iters, graph=True, blocks=3):
+    """Median over `blocks` blocks of (HIP-event time of `iters` back-to-back calls) / iters, in seconds, on the
+    stream the kernels are launched on (torch's current stream).  With `graph` the call is replayed from a HIP
+    graph, so host launch overhead does not count and successive calls stay dependent."""
+    runner = fn
+    if graph:
+        g = safe_capture(fn, dev)
+        if g is not None:
+            runner = g.replay
+    else:
+        for _ in range(2):
+            fn()
+    runner()
+    torch.cuda.synchronize(dev)
+    times = []
+    for _ in range(blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            runner()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        times.append(e0.elapsed_time(e1) / iters * 1e-3)
+    return statistics.median(times)
+
+
+_TRAFFIC = None
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json, produced by
+    tools/pmc_traffic.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script); None when the
+    kernel has not been profiled."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        _TRAFFIC = {}
+        for name in ("pmc_traffic.json", "r02_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                try:
+                    _TRAFFIC.update(json.load(open(path)))
+                except Exception:
+                    pass
+    v = _TRAFFIC.get(key)
+    return int(v) if isinstance(v, (int, float)) else None
+
+
+def roofline_entry(bound, kernel, call, seconds, flops, nbytes, dtype, traffic_key=None, **extra):
+    """One roofline object: `achieved` = algorithmic flops (bound mfma) or bytes (bound hbm) of the call divided by
+    its measured duration."""
+    if bound == "mfma":
+        peak = MFMA_PEAK_TFLOPS[str(dtype).replace("torch.", "")]
+        achieved, unit = flops / seconds / 1e12, "TFLOP/s"
+    else:
+        peak, achieved, unit = HBM_PEAK_GBS, nbytes / seconds / 1e9, "GB/s"
+    entry = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+             "traffic": pmc_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "call": call,
+             "launch_us": seconds * 1e6, "algorithmic_flops": int(flops), "algorithmic_bytes": int(nbytes),
+             "hbm_gbs": nbytes / seconds / 1e9}
+    entry.update(extra)
+    return entry
+
+
+# ------------------------------------------------------------------------------------------ EPS calls
+def eps_call_timers(core, x, need_dx, dev, head=None):
+    """The forward and the backward C-ABI call of ONE EPS layer as closures over preallocated buffers.
+    `head` = (weight, bias) selects the fused EPS + linear-head backward where the model uses it."""
     from dctn_amd import _lib as L
 
-    dev = x.device
-    core = model.epses[0].detach().contiguous()
-    from dctn_amd.eps import _bf16_through_f32
-    if _bf16_through_f32(core, x):   # bf16 storage, exact-f32 matrix-core arithmetic: time what eps() runs
-        core, x = core.float(), x.float()
     C, B, H, W, Q = x.shape
-    K, O = specs[0]
+    N = core.ndim - 1
+    K = int(round((N // C) ** 0.5))
+    O = core.shape[-1]
     Ho = H - K + 1
     out = torch.empty((B, Ho, Ho, O), dtype=x.dtype, device=dev)
     dy = torch.randn((B, Ho, Ho, O), device=dev).to(x.dtype)
     dcore = torch.empty_like(core)
-    code, prec = L.dtype_code(x), L.precision()
-    ws = L.workspace(L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, 0, 1), dev)
-    lib, st = L.lib(), L.stream_ptr(dev)
-    esz = x.element_size()
-
-    wsf = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
+    dx = torch.empty_like(x) if need_dx else None
+    lib, code, pol = L.lib(), L.dtype_code(x), L.precision()
+    wsf = L.workspace(lib.dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, pol), dev)
+    wsb = L.workspace(lib.dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, pol, int(need_dx), 1), dev).clone()
 
     def fwd():
         L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), wsf.data_ptr(),
-                                 wsf.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)), "fwd")
+                                 wsf.numel(), C, B, H, W, Q, K, O, code, pol, L.stream_ptr(dev)), "fwd")
 
-    # The model's own backward for this shape: when the layer feeds the linear head directly and is in
-    # the fused family (bf16 cfg2), that is dctn_eps_head_bwd (dCore + dWeight + dBias, dY formed on the
-    # fly); otherwise the plain dctn_eps_bwd.
-    from dctn_amd.eps_plus_linear import _EpsLinearHeadFunction
+    fused = False
+    if head is not None:
+        from dctn_amd.eps_plus_linear import _EpsLinearHeadFunction
 
-    w_head, b_head = model.linear.weight.detach().contiguous(), model.linear.bias.detach().contiguous()
-    fused = len(specs) == 1 and _EpsLinearHeadFunction.supported(core, x, w_head, b_head)
-    cout = w_head.shape[0]
+        w_head, b_head = head
+        fused = _EpsLinearHeadFunction.supported(core, x, w_head, b_head)
     if fused:
+        cout = w_head.shape[0]
         feat = out.view(B, -1)
         dl = (torch.randn((B, cout), device=dev) * 0.1).to(x.dtype)
         dw, db = torch.empty_like(w_head), torch.empty_like(b_head)
-        wsh = L.workspace(lib.dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, prec), dev)
+        wsh = L.workspace(lib.dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, pol), dev).clone()
 
-        def bwd():
+        def bwd(policy=pol):
             L.check(lib.dctn_eps_head_bwd(x.data_ptr(), L.strides5(x), feat.data_ptr(), dl.data_ptr(), w_head.data_ptr(),
                                           dcore.data_ptr(), dw.data_ptr(), db.data_ptr(), wsh.data_ptr(), wsh.numel(),
-                                          C, B, H, W, Q, K, O, cout, code, prec, L.stream_ptr(dev)), "head bwd")
+                                          C, B, H, W, Q, K, O, cout, code, policy, L.stream_ptr(dev)), "head bwd")
     else:
-        def bwd():
-            L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), None, dcore.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)), "bwd")
+        def bwd(policy=pol):
+            L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(),
+                                     None if dx is None else dx.data_ptr(), dcore.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                                     C, B, H, W, Q, K, O, code, policy, L.stream_ptr(dev)), "bwd")
+    wn = B * Ho * Ho
+    gemm = 2 * (Q ** N) * O   # flops per window of the core GEMM (SURVEY 8d: fwd 2*Q^N*O; + the same per gradient)
+    return {"fwd": fwd, "bwd": bwd, "fused": fused, "windows": wn, "gemm_flops": gemm, "K": K, "O": O, "N": N,
+            "bytes_x": x.numel() * x.element_size(), "bytes_y": wn * O * x.element_size(),
+            "bytes_core": core.numel() * core.element_size(), "keep": (out, dy, dcore, dx, wsf, wsb)}
 
-    # (a) whole C-ABI call, back to back on torch's current stream (the stream the kernels are
-    # launched on): a THROUGHPUT figure, successive launches may overlap head and tail;
-    # (b) the call's dominant KERNEL alone (dctn_profile_main_kernel_only) as a chain of CHAIN dependent
-    # launches captured in a HIP graph and replayed: each launch waits for the previous one to drain, as
-    # it does inside the real step, which is the per-launch duration rocprofv3 reports (plus the
-    # ~1 us boundary between two graph nodes).
-    def timed(fn, n):
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / n * 1e-3
 
+def headline_roofline(model, x, specs, steps):
+    """The dominant KERNEL of the headline step, timed alone: the kernels of the register-resident family
+    (cfg2) as a chain of 20 dependent launches replayed from a HIP graph (each launch drains before the next starts,
+    as inside the real step; the backward's small reduce kernel is left out with DCTN_OPT_MAIN_KERNEL_ONLY - an
+    explicit per-call flag of the C-ABI), which is the per-launch duration rocprofv3 reports."""
+    from dctn_amd import _lib as L
+    from dctn_amd.eps import _bf16_through_f32
+
+    dev = x.device
+    core = model.epses[0].detach().contiguous()
+    if _bf16_through_f32(core, x):
+        core, x = core.float(), x.float()
+    w_head, b_head = model.linear.weight.detach().contiguous(), model.linear.bias.detach().contiguous()
+    t = eps_call_timers(core, x, False, dev, head=(w_head, b_head) if len(specs) == 1 else None)
+    C, B, H, W, Q = x.shape
+    K, O, N, wn = t["K"], t["O"], t["N"], t["windows"]
+    cout = w_head.shape[0]
+    esz = x.element_size()
+    n = max(steps, 100)
     CHAIN = 20
 
-    def timed_chain(fn, n):
-        fn()
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+    def chain(fn):
+        def body():
             for _ in range(CHAIN):
                 fn()
-        reps = max(1, n // CHAIN)
-        return timed(graph.replay, reps) / CHAIN
+        return device_time(body, dev, max(1, n // CHAIN)) / CHAIN
 
-    res, single = {}, {}
-    kernel_symbol = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}
-    n = max(steps, 100)
-    for name, fn in (("eps_fwd", fwd), ("eps_bwd_dcore", bwd)):
-        res[name] = (timed(fn, n), L.last_kernel())
-        if "q2reg" in L.last_kernel():
-            lib.dctn_profile_main_kernel_only(1)
-            try:
-                try:
-                    single[name] = timed_chain(fn, n)
-                except Exception as e:   # capture refused (e.g. another thread's HIP call): throughput figure
-                    print(f"[bench] chain capture failed ({type(e).__name__}: {e}); back-to-back timing", file=sys.stderr)
-                    torch.cuda.synchronize(dev)
-                    single[name] = timed(fn, n)
-            finally:
-                lib.dctn_profile_main_kernel_only(0)
-    wn = B * Ho * Ho
-    n_in = core.numel() // O
+    t["fwd"]()
+    fwd_family = L.last_kernel()
+    q2 = "q2reg" in fwd_family
+    calls = {"eps_fwd": device_time(t["fwd"], dev, n, graph=False), "eps_bwd_dcore": device_time(t["bwd"], dev, n, graph=False)}
+    if q2:
+        main_only = L.precision() | L.OPT_MAIN_KERNEL_ONLY
+        kernels = {"eps_fwd_q2reg_k": chain(t["fwd"]), "eps_bwd_dcore_q2reg_k": chain(lambda: t["bwd"](main_only))}
+    else:
+        kernels = {}
     # SURVEY 8(d): this path is compute bound (MFMA for the core GEMM, VALU for the Khatri-Rao halves);
     # algorithmic flops per window: forward 2*Q^N*O (GEMM) + the two halves and the final dot; dCore the
     # same GEMM size transposed (+ forming dY and dWeight when the head is fused: 4*Cout*O)
-    half = 2 * (Q ** ((K * K * C + 1) // 2) + Q ** ((K * K * C) // 2)) + 2 * Q ** ((K * K * C) // 2) * O
-    flops = {"eps_fwd": wn * (2 * n_in * O + half),
-             "eps_bwd_dcore": wn * (2 * n_in * O + half + (4 * cout * O if fused else 0))}
-    # algorithmic bytes per launch: read x once, write out (fwd) / read dY or the features (bwd) once,
-    # core / dCore once (+ dLogits, head weight and its gradient when fused)
-    bytes_x = C * B * H * W * Q * esz
-    bytes_y = wn * O * esz
-    bytes_core = core.numel() * esz
-    alg = {"eps_fwd": bytes_x + bytes_y + bytes_core,
-           "eps_bwd_dcore": bytes_x + bytes_y + bytes_core + ((B * cout + 2 * w_head.numel() + cout) * esz if fused else 0)}
-    dom = max(single, key=lambda k: single[k]) if single else max(res, key=lambda k: res[k][0])
-    sec = single.get(dom, res[dom][0])
-    kname = kernel_symbol[dom] if dom in single else res[dom][1]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f"{kname}:B{B}")
-        except Exception:
-            traffic = None
-    peak = MFMA_PEAK_TFLOPS[str(x.dtype).replace("torch.", "")]
-    achieved = flops[dom] / sec / 1e12
-    return {
-        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-        "traffic": traffic, "kernel": kname, "launch_us": sec * 1e6, "algorithmic_flops": flops[dom],
-        "flops_per_window": flops[dom] / wn, "algorithmic_bytes": alg[dom], "bytes_per_window": alg[dom] / wn,
-        "hbm_gbs": alg[dom] / sec / 1e9, "hbm_frac": alg[dom] / sec / 1e9 / HBM_PEAK_GBS, "fused_head": bool(fused),
-        "calls_us": {k: v[0] * 1e6 for k, v in res.items()},
-        "kernels_us": {kernel_symbol[k]: v * 1e6 for k, v in single.items()},
-    }
+    half = 2 * (Q ** ((N + 1) // 2) + Q ** (N // 2)) + 2 * Q ** (N // 2) * O
+    flops = {"eps_fwd": wn * (t["gemm_flops"] + half),
+             "eps_bwd_dcore": wn * (t["gemm_flops"] + half + (4 * cout * O if t["fused"] else 0))}
+    alg = {"eps_fwd": t["bytes_x"] + t["bytes_y"] + t["bytes_core"],
+           "eps_bwd_dcore": t["bytes_x"] + t["bytes_y"] + t["bytes_core"]
+                            + ((B * cout + 2 * w_head.numel() + cout) * esz if t["fused"] else 0)}
+    if q2:
+        dom = max(("eps_fwd", "eps_bwd_dcore"), key=lambda k: kernels[{"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[k]])
+        kname = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[dom]
+        sec = kernels[kname]
+    else:
+        dom = max(calls, key=lambda k: calls[k])
+        kname, sec = L.last_kernel() if dom == "eps_bwd_dcore" else fwd_family, calls[dom]
+    return roofline_entry(
+        "mfma", kname, "dctn_eps_fwd" if dom == "eps_fwd" else ("dctn_eps_head_bwd" if t["fused"] else "dctn_eps_bwd"),
+        sec, flops[dom], alg[dom], x.dtype, traffic_key=f"{kname}:B{B}",
+        flops_per_window=flops[dom] / wn, bytes_per_window=alg[dom] / wn, hbm_frac=alg[dom] / sec / 1e9 / HBM_PEAK_GBS,
+        fused_head=bool(t["fused"]), calls_us={k: v * 1e6 for k, v in calls.items()},
+        kernels_us={k: v * 1e6 for k, v in kernels.items()})
 
 
+# ------------------------------------------------------------------------------------------ other configs
+def extra_eps_model(name, dev, iters):
+    """cfg3a / cfg3b: the two-EPS model in the reference's own arithmetic (float32), B = 128: the whole
+    `model(x).backward(out_grad)` step, and each layer's forward / backward call on its own."""
+    from dctn_amd import _lib as L
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    specs, image_size, q0, dtype = WORKLOADS[name]
+    batch = 128
+    torch.manual_seed(0)
+    model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
+    x = synthetic_input(batch, image_size, q0, dtype, dev, seed=1)
+    out_grad = torch.randn(batch, 10, device=dev).to(dtype)
+
+    def fwd():
+        with torch.no_grad():
+            model(x)
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        model(x).backward(out_grad)
+
+    t_f = device_time(fwd, dev, iters)
+    t_fb = device_time(fwd_bwd, dev, iters)
+    # per layer: forward call, backward call (layer 1: dCore only; deeper layers: dX too)
+    layers, xin = [], x
+    for li, (core, (k, o)) in enumerate(zip(model.epses, specs)):
+        c = core.detach().contiguous()
+        t = eps_call_timers(c, xin, li > 0, dev)
+        sf = device_time(t["fwd"], dev, max(3, iters // 2), graph=False)
+        t["fwd"]()
+        kf = L.last_kernel()
+        sb = device_time(t["bwd"], dev, max(3, iters // 2), graph=False)
+        t["bwd"]()
+        kb = L.last_kernel()
+        nb = 2 if li > 0 else 1
+        layers.append({"layer": li + 1, "spec": [k, o], "windows": t["windows"],
+                       "fwd_us": sf * 1e6, "fwd_family": kf, "fwd_tflops": t["windows"] * t["gemm_flops"] / sf / 1e12,
+                       "bwd_us": sb * 1e6, "bwd_family": kb, "bwd_tflops": nb * t["windows"] * t["gemm_flops"] / sb / 1e12,
+                       "_t": t, "_nb": nb})
+        with torch.no_grad():
+            from dctn_amd.eps import eps
+            xin = eps(c, xin).unsqueeze(0)
+    windows = windows_per_sample(specs, image_size) * batch
+    step_flops = sum(l["windows"] * l["_t"]["gemm_flops"] * (1 + l["_nb"]) for l in layers)
+    # dominant call of the step
+    cand = []
+    for l in layers:
+        t = l["_t"]
+        cand.append((l["fwd_us"], f"L{l['layer']} forward", "dctn_eps_fwd", l["fwd_family"], l["windows"] * t["gemm_flops"],
+                     t["bytes_x"] + t["bytes_y"] + t["bytes_core"]))
+        cand.append((l["bwd_us"], f"L{l['layer']} backward", "dctn_eps_bwd", l["bwd_family"],
+                     l["_nb"] * l["windows"] * t["gemm_flops"],
+                     t["bytes_x"] * l["_nb"] + t["bytes_y"] + t["bytes_core"] * 2))
+    us, what, call, fam, fl, by = max(cand)
+    kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k"}.get(fam, fam)
+    roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:{what}",
+                          step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"],
+                          step_algorithmic_flops=int(step_flops))
+    for l in layers:
+        del l["_t"], l["_nb"]
+    return {"workload": f"{name}: EPSesPlusLinear({specs}) f32 on MNIST-shaped 28x28 Q0=2, fwd + bwd(out_grad), batch {batch}",
+            "dtype": DTYPE_NAME[dtype], "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
+            "value": windows / t_fb, "unit": "windows/s", "layers": layers, "roofline": roof,
+            "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, dtype, batch=8, target_seconds=4.0)}
+
+
+def extra_cfg1(dev, iters):
+    """cfg1: the reference's own EPS micro-benchmark (small_experiments/eps2d_benchmark/benchmark.py:45-64):
+    eps(core, x), B = 64, 28x28, K = 4, Q = 2, O = 2, float64, everything randn, core AND input require grad."""
+    from dctn_amd import _lib as L
+    from dctn_amd.eps import eps
+    from oracle import ref_cpu as R
+
+    B, HW, Q, K, O, dt = 64, 28, 2, 4, 2, torch.float64
+    N = K * K
+    torch.manual_seed(0)
+    x = torch.randn(1, B, HW, HW, Q, device=dev, dtype=dt, requires_grad=True)
+    core = torch.randn(*(Q,) * N, O, device=dev, dtype=dt, requires_grad=True)
+    y = eps(core, x)
+    dy = torch.randn_like(y)
+    windows = y.shape[0] * y.shape[1] * y.shape[2]
+
+    def fwd():
+        with torch.no_grad():
+            eps(core, x)
+
+    def fwd_bwd():
+        x.grad = None
+        core.grad = None
+        eps(core, x).backward(dy)
+
+    t_f, t_fb = device_time(fwd, dev, iters), device_time(fwd_bwd, dev, iters)
+    fwd()
+    fam = L.last_kernel()
+    t = eps_call_timers(core.detach(), x.detach(), True, dev)
+    sf = device_time(t["fwd"], dev, iters, graph=False)
+    sb = device_time(t["bwd"], dev, iters, graph=False)
+    gemm = t["gemm_flops"] * windows
+    by_b = 2 * t["bytes_x"] + t["bytes_y"] + 2 * t["bytes_core"]
+    roof = roofline_entry("mfma", "halves_gemm_k<double> (4 GEMMs: Z, dCore, dP0, Z again)", "dctn_eps_bwd", sb, 2 * gemm, by_b, dt,
+                          traffic_key="cfg1:bwd", fwd_call_us=sf * 1e6, fwd_tflops=gemm / sf / 1e12,
+                          step_tflops=3 * gemm / t_fb / 1e12, step_frac=3 * gemm / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float64"],
+                          family=fam)
+    # CPU: the oracle's 4-step path in float64 on a bounded sample (8 of the 64 samples)
+    cores_n = usable_cores()
+    torch.set_num_threads(cores_n)
+    Bc = 8
+    xc = x.detach().cpu()[:, :Bc].clone().requires_grad_(True)
+    cc = core.detach().cpu().clone().requires_grad_(True)
+    dyc = dy.cpu()[:Bc]
+    dtc, it = time_cpu(lambda: R.eps_4step(cc, xc).backward(dyc), 4.0)
+    return {"workload": "cfg1: eps(core, x) B=64 C=1 28x28 K=4 Q=2 O=2 float64, randn core and input, fwd + bwd(dX, dCore)",
+            "dtype": "f64", "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
+            "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
+            "cpu_baseline": {"value": windows * Bc / B / dtc, "unit": "windows/s", "cores": cores_n, "kind": "port",
+                             "sample": f"oracle 4-step path (torch CPU f64, {cores_n} threads, {cpu_model_name()}), batch {Bc} of {B}, "
+                                       f"{it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
+
+
+def extra_cfg4(r, dev, iters):
+    """cfg4: ConvSBS, the 9-core snake of mnist.py:190-199 (outs 1,1,1,1,2,1,1,1,1; open chain, bond r) on the
+    CIFAR colour layout x (1, 128, 32, 32, 3) (dataset_loading.py:192-196), float32, fwd + bwd (dX and dCores)."""
+    import dctn_amd
+    from dctn_amd.conv_sbs import DumbNormalInitialization, ManyConvSBS
+    from dctn_amd.conv_sbs_spec import SBSSpecCore
+    from dctn_amd.pos2d import Pos2D
+    from oracle import ref_cpu as R
+
+    C, q, HW, B = 1, 3, 32, 128
+    spec = (tuple(SBSSpecCore(Pos2D(*p), 2 if i == 4 else 1) for i, p in enumerate(SNAKE)),)
+    torch.manual_seed(r)
+    many = ManyConvSBS(C, q, r, False, spec, (DumbNormalInitialization((q ** C * r) ** -0.5),)).to(dev)
+    x = torch.randn(C, B, HW, HW, q, device=dev, requires_grad=True)
+    (y,) = many(x)
+    dy = torch.randn_like(y)
+    windows = y.shape[0] * y.shape[1] * y.shape[2]
+
+    def fwd():
+        with torch.no_grad():
+            many(x)
+
+    def fwd_bwd():
+        x.grad = None
+        for prm in many.parameters():
+            prm.grad = None
+        many(x)[0].backward(dy)
+
+    t_f, t_fb = device_time(fwd, dev, iters), device_time(fwd_bwd, dev, iters)
+    fwd_bwd()
+    fam = dctn_amd.last_kernel()
+    # algorithmic work per window in the reference's order (SURVEY 8d): step A 2*q^C*sum(o*l*r), then the chain
+    shapes = many.strings[0].spec.shapes
+    step_a = 2 * q ** C * sum(s.out_quantum_dim_size * s.bond_left_size * s.bond_right_size for s in shapes)
+    chain, oacc = 0, shapes[0].out_quantum_dim_size
+    for s in shapes[1:]:
+        chain += 2 * oacc * s.bond_left_size * s.out_quantum_dim_size * s.bond_right_size
+        oacc *= s.out_quantum_dim_size
+    flops_fwd = (step_a + chain) * windows
+    n_par = sum(p.numel() for p in many.parameters())
+    by_fwd = x.numel() * 4 + y.numel() * 4 + n_par * 4
+    by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
+    t_b = max(t_fb - t_f, 1e-9)
+    if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
+        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:bwd", fwd_us=t_f * 1e6,
+                              fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
+                              step_frac=3 * flops_fwd / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"], family=fam)
+    else:         # HBM / launch-latency bound (SURVEY 8d): bytes of the fused ideal against the HBM peak
+        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:bwd", fwd_us=t_f * 1e6,
+                              fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
+                              step_frac=by_fb / t_fb / 1e9 / HBM_PEAK_GBS, family=fam)
+    cores_n = usable_cores()
+    torch.set_num_threads(cores_n)
+    Bc = 16 if r <= 8 else 8
+    cc = [c.detach().cpu().clone().requires_grad_(True) for c in many.strings[0].cores]
+    xc = x.detach().cpu()[:, :Bc].clone().requires_grad_(True)
+    dyc = dy.cpu()[:Bc]
+    dtc, it = time_cpu(lambda: R.convsbs_forward(cc, SNAKE, xc).backward(dyc), 3.0)
+    return {"workload": f"cfg4_r{r}: ConvSBS 9-core snake (mnist.py:190-199), open chain bond {r}, x (1,{B},32,32,3) CIFAR colour "
+                        "layout, float32, fwd + bwd(dX, dCores)",
+            "dtype": "f32", "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
+            "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
+            "cpu_baseline": {"value": windows * Bc / B / dtc, "unit": "windows/s", "cores": cores_n, "kind": "port",
+                             "sample": f"oracle step A + chain (torch CPU f32, {cores_n} threads, {cpu_model_name()}), batch {Bc} of {B}, "
+                                       f"{it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
+
+
+def extra_cfg5(dev, iters):
+    """cfg5: batched logmatmulexp - per window the left fold of 9 log-matrices (16 x 16), float32, 692 224 windows
+    (batch 1024 of 26 x 26 sites), the benchmark loop of small_experiments/logmatmulexp_benchmark/benchmark.py:30."""
+    import dctn_amd
+    from dctn_amd.logmatmulexp import logmatmulexp_fold
+    from oracle import ref_cpu as R
+
+    Wn, Ln, D = 692224, 9, 16
+    torch.manual_seed(0)
+    m = torch.randn(Wn, Ln, D, D, device=dev, requires_grad=True)
+    y = logmatmulexp_fold(m)
+    dy = torch.randn_like(y)
+    del y
+
+    def fwd():
+        with torch.no_grad():
+            logmatmulexp_fold(m)
+
+    def fwd_bwd():
+        m.grad = None
+        logmatmulexp_fold(m).backward(dy)
+
+    t_f = device_time(fwd, dev, iters, graph=False)
+    fwd()
+    fam_f = dctn_amd.last_kernel()
+    t_fb = device_time(fwd_bwd, dev, max(2, iters // 2), graph=False)
+    fam_b = dctn_amd.last_kernel()
+    by_f = Wn * (Ln * D * D * 4 + D * D * 4)                  # read 9 matrices, write one: 10 240 B per window
+    by_b = Wn * (2 * Ln * D * D * 4 + D * D * 4)              # read them again + dOut, write 9 gradients: 19 456 B
+    t_b = max(t_fb - t_f, 1e-9)
+    fl = Wn * (Ln - 1) * 2 * D ** 3
+    roof = roofline_entry("hbm", "lme_fold16_bwd_mfma_k" if "mfma16" in fam_b else fam_b, "dctn_logmatmulexp_fold_bwd", t_b, 2 * fl, by_b,
+                          torch.float32, traffic_key="cfg5:bwd", fwd_kernel="lme_fold16_fwd_mfma_k" if "mfma16" in fam_f else fam_f,
+                          fwd_us=t_f * 1e6, fwd_gbs=by_f / t_f / 1e9, fwd_frac=by_f / t_f / 1e9 / HBM_PEAK_GBS,
+                          step_gbs=(by_f + by_b) / t_fb / 1e9, step_frac=(by_f + by_b) / t_fb / 1e9 / HBM_PEAK_GBS,
+                          bytes_per_window={"fwd": by_f // Wn, "bwd": by_b // Wn}, formulation="factored (exp -> MFMA -> log), exact fallback per step")
+    del m
+    torch.cuda.empty_cache()
+    cores_n = usable_cores()
+    torch.set_num_threads(cores_n)
+    Wc = 4096
+    mc = torch.randn(Wc, Ln, D, D, requires_grad=True)
+    dyc = torch.randn(Wc, D, D)
+    dtc, it = time_cpu(lambda: R.logmatmulexp_fold_batched(mc).backward(dyc), 3.0)
+    return {"workload": f"cfg5: per-window left fold of {Ln} log-matrices ({D}x{D}) (logmatmulexp), float32, {Wn} windows, fwd + bwd",
+            "dtype": "f32", "windows_per_step": Wn, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
+            "value": Wn / t_fb, "unit": "windows/s", "roofline": roof,
+            "cpu_baseline": {"value": Wc / dtc, "unit": "windows/s", "cores": cores_n, "kind": "port",
+                             "sample": f"oracle broadcast-add + logsumexp fold (torch CPU f32, {cores_n} threads, {cpu_model_name()}), "
+                                       f"{Wc} of {Wn} windows, {it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
+
+
+def run_extra(name, dev):
+    if name == "cfg1":
+        return extra_cfg1(dev, 20)
+    if name in ("cfg3a", "cfg3b"):
+        return extra_eps_model(name, dev, 10 if name == "cfg3a" else 20)
+    if name.startswith("cfg4_r"):
+        return extra_cfg4(int(name[6:]), dev, 30)
+    if name == "cfg5":
+        return extra_cfg5(dev, 6)
+    raise SystemExit(f"unknown config {name}")
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,10 +618,18 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch samples per GPU whatever N; strong: --batch is the GLOBAL batch, split over the N GPUs")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
-    ap.add_argument("--graph-allreduce", type=int, default=0,
-                    help="1: capture the gradient all-reduce into the step's HIP graph as well (opt-in: a capture that "
-                         "fails cannot be recovered from inside the process, see the comment at try_capture)")
+    ap.add_argument("--graph-allreduce", default="auto", choices=["auto", "0", "1"],
+                    help="capture the gradient all-reduce into the step's HIP graph.  auto (default): yes over RCCL when a "
+                         "child-process probe shows that the capture works on this machine; 1: the same, and fail if it does "
+                         "not; 0: replay the fwd+bwd graph and launch the collective eagerly")
+    ap.add_argument("--configs", default="all",
+                    help="the other BASELINE configs measured into `configs` at N = 1: all (default), none, or a comma list of "
+                         + ", ".join(EXTRA_CONFIGS))
+    ap.add_argument("--skip-headline", action="store_true", help="profiling aid: run only --configs and print their entries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-proto", default=None, help="sets NCCL_PROTO (LL / LL128 / Simple) before the communicator comes up")
+    ap.add_argument("--rccl-algo", default=None, help="sets NCCL_ALGO (Ring / Tree)")
+    ap.add_argument("--rccl-min-nchannels", default=None, help="sets NCCL_MIN_NCHANNELS")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + "
                     "DCTN_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a single GPU")
     args = ap.parse_args()
@@ -278,12 +638,40 @@ def main():
     from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
     import dctn_amd
 
+    for flag, var in ((args.rccl_proto, "NCCL_PROTO"), (args.rccl_algo, "NCCL_ALGO"), (args.rccl_min_nchannels, "NCCL_MIN_NCHANNELS")):
+        if flag is not None:
+            os.environ[var] = str(flag)
+    rccl_env = {k: os.environ.get(k) for k in ("NCCL_PROTO", "NCCL_ALGO", "NCCL_MIN_NCHANNELS")}
+
+    if args.skip_headline:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
+        out = []
+        for name in names:
+            entry = run_extra(name, dev)
+            if args.no_cpu_baseline:
+                entry.pop("cpu_baseline", None)
+            out.append(entry)
+        print(json.dumps({"configs": out}), flush=True)
+        return
+
     one_device = os.environ.get("DCTN_BENCH_ONE_DEVICE") == "1"
-    if one_device:  # rehearsal only: every rank on cuda:0, collectives through gloo
-        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
     # DCTN_BENCH_FORCE_ALLREDUCE=1: create the process group and issue the gradient all-reduce even with
     # one rank (rehearsal of the RCCL calls on a one-GPU machine; not a measurement)
     force_reduce = os.environ.get("DCTN_BENCH_FORCE_ALLREDUCE") == "1"
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend_name = args.backend or "nccl"
+    will_reduce = env_world > 1 or force_reduce
+
+    # Probe, in child processes and before this process forms its group, whether the collective can be captured
+    # into a HIP graph here (all ranks do this at the same point; the children form a group of their own).
+    probe_ok = None
+    if will_reduce and args.graph and args.graph_allreduce != "0" and backend_name == "nccl":
+        t0 = time.perf_counter()
+        probe_ok = ddp.probe_allreduce_capture()
+        log(f"all-reduce capture probe: {'ok' if probe_ok else 'FAILED'} ({time.perf_counter() - t0:.1f} s)")
+
     # RCCL prints a version banner on stdout when its communicator comes up; stdout must carry the one JSON line
     # only, so file descriptor 1 points at stderr until the first collective has run
     sys.stdout.flush()
@@ -292,7 +680,7 @@ def main():
     try:
         rank, local_rank, world = ddp.init_from_env(args.backend, single_rank_group=force_reduce)
         if dist.is_initialized():
-            dev0 = torch.device("cuda", 0 if os.environ.get("DCTN_BENCH_ONE_DEVICE") == "1" else local_rank)
+            dev0 = torch.device("cuda", 0 if one_device else local_rank)
             probe = torch.zeros(1, device=dev0)
             dist.all_reduce(probe)
             torch.cuda.synchronize(dev0)
@@ -322,81 +710,42 @@ def main():
             p.grad = None
         model(x).backward(out_grad)
 
-    # The step replays from a HIP graph of fwd + bwd; the gradient all-reduce follows it eagerly on the same stream.
-    # --graph-allreduce 1 captures the collective into the same graph (one launch per step from the host; measured
-    # on one rank over RCCL: 51.7 -> 42.3 us/step) and checks the captured step against the eager one before trusting
-    # it.  It is opt-in: when a capture fails (reproduced with gloo, whose collectives cannot be captured) the HIP
-    # runtime stays in a state in which later collectives return "invalid argument" even after ending the capture
-    # and switching streams, so there is no safe in-process fallback for a run that must produce a number.
-    def try_capture(with_reduce):
-        def body():
-            fwd_bwd()
-            if with_reduce:
-                reducer()
-        prev = torch.cuda.current_stream(dev)
-        g = None
-        try:
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(prev)
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    body()
-            prev.wait_stream(side)
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            # a stream of its own for every attempt: torch.cuda.graph's default capture stream is shared, and a failed
-            # capture leaves it invalidated
-            with torch.cuda.graph(g, stream=torch.cuda.Stream(dev), capture_error_mode="thread_local"):
-                body()
-            return g
-        except Exception as e:  # keep measuring, and say so in the JSON line
-            print(f"[bench] HIP graph capture (all-reduce inside: {with_reduce}) failed ({type(e).__name__}: {e})",
-                  file=sys.stderr)
-            # A capture that dies inside the `with` leaves the thread on the capture stream, still capturing
-            # (torch.cuda.graph.__exit__ stops at the failing capture_end): end it and give the thread its stream back,
-            # or every later call fails with "operation not permitted when stream is capturing".
-            if g is not None:
-                try:
-                    g.capture_end()
-                except Exception:
-                    pass
-            torch.cuda.set_stream(prev)
-            try:
-                torch.cuda.synchronize(dev)
-            except Exception:
-                pass
-            return None
+    def fwd_bwd_reduce():
+        fwd_bwd()
+        reducer()
 
+    # Over RCCL the default is ONE graph per step with the collective inside (one host launch per step; the eager
+    # collective made the step host-bound: 51.7 vs 42.3 us on one rank).  It is attempted only when the child-process
+    # probe succeeded on every rank; if the capture then still fails, the run stops with a non-zero exit code instead
+    # of limping on: after a failed capture of a collective, later collectives of this process fail.
     graph, reduce_in_graph = None, False
     if args.graph:
-        want_reduce = reducer is not None and args.graph_allreduce == 1
+        want_reduce = reducer is not None and probe_ok is not None and ddp.all_ranks_agree(bool(probe_ok), dev)
+        if reducer is not None and args.graph_allreduce == "1" and not want_reduce:
+            raise SystemExit("--graph-allreduce 1: the all-reduce capture probe failed (or the backend is not RCCL)")
         if want_reduce:
-            fwd_bwd()
-            reducer()
+            fwd_bwd_reduce()
             torch.cuda.synchronize(dev)
             want = [p.grad.detach().float().clone() for p in model.parameters()]
-            graph = try_capture(True)
-
-            def all_ranks(flag: bool) -> bool:   # every rank must take the same branch: the collectives must pair up
-                t = torch.tensor([1.0 if flag else 0.0], device=dev)
-                if world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item() > 0.5)
-
-            if not all_ranks(graph is not None):
-                graph = None
-            if graph is not None:
-                graph.replay()
-                torch.cuda.synchronize(dev)
-                same = all(torch.allclose(p.grad.float(), w, rtol=2e-2, atol=1e-6 + 2e-2 * float(w.abs().max()))
-                           for p, w in zip(model.parameters(), want))
-                if all_ranks(same):
-                    reduce_in_graph = True
-                else:
-                    print("[bench] captured step with all-reduce disagrees with the eager step; not using it", file=sys.stderr)
-                    graph = None
-        if graph is None:
-            graph = try_capture(False)
+            graph = safe_capture(fwd_bwd_reduce, dev, warm=3)
+            if not ddp.all_ranks_agree(graph is not None, dev):
+                log("capturing the step with the all-reduce inside failed although the probe passed; no safe fallback "
+                    "inside this process - rerun with --graph-allreduce 0")
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(3)
+            graph.replay()
+            torch.cuda.synchronize(dev)
+            same = all(torch.allclose(p.grad.float(), w, rtol=2e-2, atol=1e-6 + 2e-2 * float(w.abs().max()))
+                       for p, w in zip(model.parameters(), want))
+            if not ddp.all_ranks_agree(same, dev):
+                log("the captured step with the all-reduce inside disagrees with the eager step")
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(4)
+            reduce_in_graph = True
+        else:
+            graph = safe_capture(fwd_bwd, dev, warm=3)
 
     def step():
         if graph is not None:
@@ -413,18 +762,48 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_used = dctn_amd.last_kernel()
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    block_s = []
+    for _ in range(BLOCKS):
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t)
+        block_s.append(elapsed)
+    elapsed = statistics.median(block_s)
+
+    # what the collective costs, alone: the same message, replayed from a graph when the step's collective is (device
+    # time of back-to-back dependent all-reduces), else launched eagerly as in the step
+    allreduce_us = step_without_allreduce_us = allreduce_bytes = None
+    if reducer is not None:
+        flat = getattr(reducer, "_flat", None)
+        msg = flat if flat is not None else reducer.bucket
+        allreduce_bytes = int(msg.numel() * msg.element_size())
+        buf = torch.zeros_like(msg)
+
+        def one_reduce():
+            reducer._reduce(buf)
+
+        if reduce_in_graph:
+            def ten():
+                for _ in range(10):
+                    one_reduce()
+            allreduce_us = device_time(ten, dev, 20) / 10 * 1e6
+        else:
+            allreduce_us = device_time(one_reduce, dev, 200, graph=False) * 1e6
+        g2 = safe_capture(fwd_bwd, dev, warm=1) if args.graph else None
+        step_without_allreduce_us = device_time(g2.replay if g2 is not None else fwd_bwd, dev, args.steps, graph=False) * 1e6
+        if world > 1:   # the slowest rank's figures
+            t = torch.tensor([allreduce_us, step_without_allreduce_us], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            allreduce_us, step_without_allreduce_us = float(t[0]), float(t[1])
 
     windows_step = windows_per_sample(specs, image_size) * batch * world
     line = {
@@ -438,7 +817,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": {torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
+        "dtype": DTYPE_NAME[dtype],
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: EPSesPlusLinear({specs}) on MNIST-shaped {image_size}x{image_size} Q0={q0}, "
@@ -447,7 +826,14 @@ def main():
             "per_gpu_batch": batch,
             "parallelism": f"dp{world}",
             "hip_graph": graph is not None,
+            "timing": f"median of {BLOCKS} blocks of {args.steps} steps (each block: barrier + synchronize on both sides, max over ranks)",
+            "blocks_ms": [b * 1e3 for b in block_s],
             "allreduce_in_graph": reduce_in_graph,
+            "allreduce_capture_probe": probe_ok,
+            "allreduce_us": allreduce_us,
+            "allreduce_bytes": allreduce_bytes,
+            "step_without_allreduce_us": step_without_allreduce_us,
+            "rccl_env": rccl_env,
             "last_kernel": kernel_used,
             "grad_allreduce": None if reducer is None else (
                 "in place on the backward's flat gradient buffer (1 launch)" if getattr(reducer, "_flat_key", None)
@@ -455,9 +841,26 @@ def main():
         },
     }
     if rank == 0:
-        line["roofline"] = kernel_roofline(model, x, specs, image_size, args.steps)
+        line["roofline"] = headline_roofline(model, x, specs, args.steps)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(specs, image_size, q0)
+            line["cpu_baseline"] = cpu_baseline_eps_model(specs, image_size, q0)
+            line["config"]["cpu_baseline_note"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
+                                                   f"{DTYPE_NAME[dtype]} at batch {batch}")
+        if world == 1 and args.configs != "none":
+            names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
+            entries = []
+            for name in names:
+                t0 = time.perf_counter()
+                try:
+                    entry = run_extra(name, dev)
+                    if args.no_cpu_baseline:
+                        entry.pop("cpu_baseline", None)
+                except Exception as e:   # a failing side config must not take the headline number with it
+                    entry = {"workload": name, "error": f"{type(e).__name__}: {e}"}
+                entry["bench_seconds"] = round(time.perf_counter() - t0, 1)
+                entries.append(entry)
+                torch.cuda.empty_cache()
+            line["configs"] = entries
         print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():

@@ -37,6 +37,51 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
     return rank, local_rank, world
 
 
+def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: torch.dtype = torch.bfloat16,
+                            port_offset: int = 53) -> bool:
+    """Whether an RCCL all-reduce can be captured into a HIP graph on this machine with this world size, found
+    out in CHILD processes (`dctn_amd._probe_allreduce_capture`): every rank calls this at the same point, each
+    starts one child on its own GPU, the children form a process group of their own on MASTER_PORT + port_offset,
+    capture + replay one all-reduce and report through their exit code.  A failed capture cannot be recovered
+    from inside a process (later collectives fail), so the attempt is made where it is free.  Returns this
+    rank's verdict; combine the ranks' verdicts with `all_ranks_agree` once the parent group exists."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + port_offset)
+    env.setdefault("RANK", "0")
+    env.setdefault("LOCAL_RANK", "0")
+    env.setdefault("WORLD_SIZE", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DCTN_PROBE_NUMEL"] = str(int(numel))
+    env["DCTN_PROBE_DTYPE"] = str(dtype).replace("torch.", "")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    try:
+        child = subprocess.Popen([sys.executable, "-m", "dctn_amd._probe_allreduce_capture"], cwd=root, env=env,
+                                 stdout=sys.stderr, stderr=sys.stderr)
+    except OSError:
+        return False
+    try:
+        return child.wait(timeout=timeout) == 0
+    except subprocess.TimeoutExpired:
+        child.kill()   # this exact child, by handle
+        child.wait()
+        return False
+
+
+def all_ranks_agree(flag: bool, device: Optional[torch.device] = None) -> bool:
+    """True iff `flag` is true on every rank (every rank must then take the same branch, or collectives stop
+    pairing up)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def shard_batch(x: Tensor, rank: int, world: int, dim: int = 1) -> Tensor:
     """Even split of the batch dim (dim 1 of the (C,B,H,W,Q) layout); a remainder is dropped
     like the reference's DataLoader(drop_last=True) (dataset_loading.py:325)."""

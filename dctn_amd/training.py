@@ -62,10 +62,13 @@ class GraphedTrainStep:
     bound: ~40 kernels of a few microseconds each once loss, regulariser and optimizer are counted).
 
     Single process: one graph holds forward, loss, regulariser, backward and the optimizer step.
-    Data parallel: forward + backward are one graph, the gradient all-reduce runs eagerly on the same stream,
-    the optimizer step is a second graph.  ``graph_allreduce=True`` (RCCL only) captures the collective into
-    the one graph as well (one launch per iteration from the host); it is opt-in because a capture that fails
-    leaves the HIP runtime unusable for later collectives — there is no safe fallback inside the process.
+    Data parallel over RCCL (``graph_allreduce=None``, the default): the collective is captured into the one graph
+    as well (one launch per iteration from the host) when a child-process probe (`ddp.probe_allreduce_capture`,
+    every rank at the same point) shows that such a capture works on this machine - a capture that fails cannot be
+    recovered from inside a process (later collectives fail), so it is tried where a failure is free; when the
+    probe fails, or with another backend, or with ``graph_allreduce=False``: forward + backward are one graph,
+    the gradient all-reduce runs eagerly on the same stream, the optimizer step is a second graph.
+    ``graph_allreduce=True`` skips the probe and insists.
     Inputs are copied into static buffers, so
     every call must use the batch shape of the example; the optimizer must be capturable
     (``torch.optim.SGD``, or ``Adam(..., capturable=True)``).
@@ -84,6 +87,13 @@ class GraphedTrainStep:
         self.x, self.y = example_x.clone(), example_y.clone()
         dev = example_x.device
         reduces = reducer is not None and (reducer.world > 1 or not reducer.skip_single_rank)
+        if reduces and graph_allreduce is None:
+            graph_allreduce = False
+            if dist.is_initialized() and dist.get_backend() == "nccl":
+                some = next(p for p in model.parameters() if p.requires_grad)
+                ok = ddp.probe_allreduce_capture(numel=sum(p.numel() for p in model.parameters() if p.requires_grad),
+                                                 dtype=some.dtype)
+                graph_allreduce = ddp.all_ranks_agree(ok, dev)
         graph_allreduce = bool(graph_allreduce) and reduces
         split = reduces
 

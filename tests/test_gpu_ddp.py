@@ -123,7 +123,8 @@ def _rccl_single_rank_worker(port, q):
     x, y = _data(torch.bfloat16, dev)
     opt = FlatSGD(list(model.epses) + [model.linear.weight], [model.linear.bias], lr=0.05, momentum=0.9, l2=1e-3)
     red = ddp.FlatGradAllReducer(model.parameters(), average=True, skip_single_rank=False)
-    step = GraphedTrainStep(model, x, y, fused_cross_entropy, opt, reducer=red, warmup=1, graph_allreduce=True)
+    # graph_allreduce left at its default: a child-process probe decides, and over RCCL it must say yes
+    step = GraphedTrainStep(model, x, y, fused_cross_entropy, opt, reducer=red, warmup=1)
     for _ in range(3):
         step(x, y)
     torch.cuda.synchronize(dev)

@@ -366,3 +366,13 @@ def test_training_hooks_mirror_the_reference(tmp_path):  # dctn/training.py:87-2
                         at_iter_start=[], after_back=[T.make_stopper_on_nan_loss(str(nan_dir), False)], after_param_upd=[])
     assert st_it3["num_iters_done"] == 0 and st_it3["stop"]
     assert sorted(os.listdir(nan_dir / "nan_loss_stop"))[:3] == ["indices.pth", "model_nitd=0_loss=nan_reg_term=0.000.pth", "output.pth"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="on a GPU box the probe is exercised by tests/test_gpu_ddp.py")
+def test_allreduce_capture_probe_says_no_without_a_gpu():
+    """The probe child cannot come up without a GPU: the parent must get a plain False (and survive), which sends
+    the data-parallel step down the eager-collective path."""
+    from dctn_amd import ddp
+
+    assert ddp.probe_allreduce_capture(timeout=120.0) is False
+    assert ddp.all_ranks_agree(True) is True and ddp.all_ranks_agree(False) is False
