@@ -353,6 +353,42 @@ def headline_roofline(model, x, specs, steps):
         kernels_us={k: v * 1e6 for k, v in kernels.items()})
 
 
+def convsbs_call_timers(string, x, dy, dev):
+    """Forward and backward C-ABI calls of one ConvSBS string over preallocated buffers (no allocation or autograd
+    bookkeeping inside the timed region: the r = 4 forward kernel is shorter than a Python-side launch)."""
+    from dctn_amd import _lib as L
+
+    spec = string.spec
+    C, B, H, W, q = x.shape
+    n, shapes = len(spec), spec.shapes
+    cores = [c.detach().contiguous() for c in string.cores]
+    outs = L.int_array([s_.out_quantum_dim_size for s_ in shapes])
+    bonds = L.int_array(spec.bond_sizes)
+    ph, pw = L.int_array([p.h for p in spec.positions]), L.int_array([p.w for p in spec.positions])
+    out = torch.empty((B, H - spec.max_height_pos, W - spec.max_width_pos, spec.out_total_quantum_dim_size), dtype=x.dtype, device=dev)
+    lib, code = L.lib(), L.dtype_code(x)
+    wsf = torch.empty(max(256, lib.dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 0)), dtype=torch.uint8, device=dev)
+    wsb = torch.empty(max(256, lib.dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 1)), dtype=torch.uint8, device=dev)
+    dx = torch.empty_like(x)
+    flat = torch.empty(sum(c.numel() for c in cores), dtype=x.dtype, device=dev)
+    dcores, off = [], 0
+    for c in cores:
+        dcores.append(flat[off:off + c.numel()].view_as(c))
+        off += c.numel()
+    cp, dcp = L.ptr_array(cores), L.ptr_array(dcores)
+    xs = L.strides5(x)
+
+    def fwd():
+        L.check(lib.dctn_convsbs_fwd(x.data_ptr(), xs, cp, out.data_ptr(), n, outs, bonds, ph, pw, C, B, H, W, q,
+                                     wsf.data_ptr(), wsf.numel(), code, L.stream_ptr(dev)), "convsbs fwd")
+
+    def bwd():
+        L.check(lib.dctn_convsbs_bwd(x.data_ptr(), xs, cp, dy.data_ptr(), dx.data_ptr(), dcp, n, outs, bonds, ph, pw,
+                                     C, B, H, W, q, wsb.data_ptr(), wsb.numel(), code, L.stream_ptr(dev)), "convsbs bwd")
+
+    return fwd, bwd, (cores, out, wsf, wsb, dx, flat, dcores)
+
+
 # ------------------------------------------------------------------------------------------ other configs
 def extra_eps_model(name, dev, iters):
     """cfg3a / cfg3b: the two-EPS model in the reference's own arithmetic (float32), B = 128: the whole
@@ -376,8 +412,8 @@ def extra_eps_model(name, dev, iters):
             p.grad = None
         model(x).backward(out_grad)
 
-    t_f = device_time(fwd, dev, iters)
-    t_fb = device_time(fwd_bwd, dev, iters)
+    t_f = device_time(fwd, dev, iters, graph=False)
+    t_fb = device_time(fwd_bwd, dev, iters, graph=False)
     # per layer: forward call, backward call (layer 1: dCore only; deeper layers: dX too)
     layers, xin = [], x
     for li, (core, (k, o)) in enumerate(zip(model.epses, specs)):
@@ -446,7 +482,7 @@ def extra_cfg1(dev, iters):
         core.grad = None
         eps(core, x).backward(dy)
 
-    t_f, t_fb = device_time(fwd, dev, iters), device_time(fwd_bwd, dev, iters)
+    t_f, t_fb = device_time(fwd, dev, iters, graph=False), device_time(fwd_bwd, dev, iters, graph=False)
     fwd()
     fam = L.last_kernel()
     t = eps_call_timers(core.detach(), x.detach(), True, dev)
@@ -502,9 +538,14 @@ def extra_cfg4(r, dev, iters):
             prm.grad = None
         many(x)[0].backward(dy)
 
-    t_f, t_fb = device_time(fwd, dev, iters), device_time(fwd_bwd, dev, iters)
+    # whole step through the module (autograd bookkeeping included), and the two C-ABI calls on their own
+    t_f_mod, t_fb = device_time(fwd, dev, iters, graph=False), device_time(fwd_bwd, dev, iters, graph=False)
     fwd_bwd()
     fam = dctn_amd.last_kernel()
+    c_fwd, c_bwd, _keep = convsbs_call_timers(many.strings[0], x.detach(), dy, dev)
+    t_f = device_time(c_fwd, dev, 5 * iters, graph=False)
+    t_b = device_time(c_bwd, dev, 2 * iters, graph=False)
+    t_fb = min(t_fb, t_f + t_b)   # the module's step is host-bound at r = 4: the two calls back to back are the device time
     # algorithmic work per window in the reference's order: step A 2*q^C*sum(o*l*r), then the chain
     shapes = many.strings[0].spec.shapes
     step_a = 2 * q ** C * sum(s.out_quantum_dim_size * s.bond_left_size * s.bond_right_size for s in shapes)
@@ -516,7 +557,6 @@ def extra_cfg4(r, dev, iters):
     n_par = sum(p.numel() for p in many.parameters())
     by_fwd = x.numel() * 4 + y.numel() * 4 + n_par * 4
     by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
-    t_b = max(t_fb - t_f, 1e-9)
     if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
         roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
                               by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:bwd", fwd_us=t_f * 1e6,
@@ -537,7 +577,7 @@ def extra_cfg4(r, dev, iters):
     return {"workload": f"cfg4_r{r}: ConvSBS 9-core snake (mnist.py:190-199), open chain bond {r}, x (1,{B},32,32,3) CIFAR colour "
                         "layout, float32, fwd + bwd(dX, dCores)",
             "dtype": "f32", "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
-            "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
+            "module_fwd_ms": t_f_mod * 1e3, "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
             "cpu_baseline": {"value": windows * Bc / B / dtc, "unit": "windows/s", "cores": cores_n, "kind": "port",
                              "sample": f"oracle step A + chain (torch CPU f32, {cores_n} threads, {cpu_model_name()}), batch {Bc} of {B}, "
                                        f"{it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
@@ -605,6 +645,24 @@ def run_extra(name, dev):
     if name == "cfg5":
         return extra_cfg5(dev, 6)
     raise SystemExit(f"unknown config {name}")
+
+
+def run_extra_in_child(name, no_cpu_baseline, timeout=420.0):
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--skip-headline", "--configs", name]
+    if no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    try:
+        res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, timeout=timeout, text=True)
+    except subprocess.TimeoutExpired:
+        return {"workload": name, "error": f"timed out after {timeout:.0f} s"}
+    if res.returncode != 0:
+        return {"workload": name, "error": f"child exited with code {res.returncode}"}
+    try:
+        return json.loads(res.stdout.strip().splitlines()[-1])["configs"][0]
+    except Exception as e:   # noqa: BLE001
+        return {"workload": name, "error": f"unparsable child output ({type(e).__name__}: {e})"}
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -841,8 +899,10 @@ def main():
         },
     }
     if rank == 0:
+        log(f"headline: {line['ms_per_step']*1e3:.1f} us/step; timing its kernels")
         line["roofline"] = headline_roofline(model, x, specs, args.steps)
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline of the headline workload")
             line["cpu_baseline"] = cpu_baseline_eps_model(specs, image_size, q0)
             line["config"]["cpu_baseline_note"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
                                                    f"{DTYPE_NAME[dtype]} at batch {batch}")
@@ -850,16 +910,12 @@ def main():
             names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
             entries = []
             for name in names:
+                # one child process per configuration: a crash or an out-of-memory kill in a side configuration must not
+                # take the headline number with it (the child only runs --skip-headline, it never re-executes this process)
                 t0 = time.perf_counter()
-                try:
-                    entry = run_extra(name, dev)
-                    if args.no_cpu_baseline:
-                        entry.pop("cpu_baseline", None)
-                except Exception as e:   # a failing side config must not take the headline number with it
-                    entry = {"workload": name, "error": f"{type(e).__name__}: {e}"}
-                entry["bench_seconds"] = round(time.perf_counter() - t0, 1)
-                entries.append(entry)
-                torch.cuda.empty_cache()
+                log(f"config {name}")
+                entries.append(run_extra_in_child(name, args.no_cpu_baseline))
+                entries[-1]["bench_seconds"] = round(time.perf_counter() - t0, 1)
             line["configs"] = entries
         print(json.dumps(line), flush=True)
     barrier()
