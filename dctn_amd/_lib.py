@@ -36,6 +36,8 @@ SIGNATURES = {
     "dctn_eps_family": (c_int, [c_int] * 9),
     "dctn_eps_fwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
     "dctn_eps_fwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_eps_fwd_stats_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
+    "dctn_eps_fwd_stats": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
     "dctn_eps_bwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 4),
     "dctn_eps_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_size]
                      + [c_int] * 7 + [c_int, c_int, c_void]),
@@ -62,6 +64,9 @@ SIGNATURES = {
     "dctn_linear_head_fwd": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_int, c_int, c_int, c_void]),
     "dctn_linear_head_bwd_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int]),
     "dctn_linear_head_bwd": (c_int, [c_void] * 7 + [c_size, c_i64, c_int, c_int, c_int, c_void]),
+    "dctn_mode_product": (c_int, [c_void, c_void, c_void, c_i64, c_int, c_int, c_i64, c_int, c_void]),
+    "dctn_fiber_gram_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_i64, c_int]),
+    "dctn_fiber_gram": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_i64, c_int, c_void]),
     "dctn_logmatmulexp_fold_bwd": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_int, c_void]),
 }
 

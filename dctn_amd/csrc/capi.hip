@@ -81,6 +81,39 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+size_t dctn_eps_fwd_stats_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy) {
+  EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
+  if (eps_mfma_covers(p, dtype, precision)) return 256;   // in-kernel epilogue: no scratch
+  return align256((size_t)p.Wn * O * dtype_size(dtype)) + dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, dtype, policy) + 256;
+}
+
+int dctn_eps_fwd_stats(const void* x, const int64_t x_strides[5], const void* core, void* stats, void* workspace,
+                       size_t workspace_bytes, int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy,
+                       void* stream) {
+  if (!x || !core || !stats || !x_strides) return DCTN_ERR_NULL;
+  if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
+  EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
+  int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
+  if (rc != DCTN_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // register-resident family: the statistics are an epilogue of the forward kernel, nothing is stored
+  rc = eps_fwd_mfma(x, core, nullptr, p, dtype, precision, st, (double*)stats);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  // other families: the slice's output goes to scratch (cache resident for the slice sizes of eps.py:126-137) and one
+  // reduction pass folds it into the running sums
+  const size_t out_bytes = align256((size_t)p.Wn * O * dtype_size(dtype));
+  if (!workspace || workspace_bytes < out_bytes) return DCTN_ERR_WORKSPACE;
+  unsigned char* ws = (unsigned char*)workspace;
+  rc = dctn_eps_fwd(x, x_strides, core, ws, ws + out_bytes, workspace_bytes - out_bytes, C, B, H, W, Q, K, O, dtype, policy,
+                    stream);
+  if (rc != DCTN_OK) return rc;
+  return eps_out_stats(ws, p.Wn * O, dtype, (double*)stats, st);
+}
+
 size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype,
                                     int policy, int need_dx, int need_dcore) {
   EpsP p;

@@ -87,8 +87,11 @@ int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, vo
 
 // MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
 // is outside the family so that the dispatcher can take the generic kernels.
+// stats (optional): float64 {sum y, sum y^2}, accumulated; out may then be NULL (nothing stored)
 int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int dtype,
-                 int precision, hipStream_t st);
+                 int precision, hipStream_t st, double* stats = nullptr);
+// {sum y, sum y^2} of n stored values, accumulated into float64 stats[2] — window_stats.hip
+int eps_out_stats(const void* y, long long n, int dtype, double* stats, hipStream_t st);
 size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx, int need_dcore);
 int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
                  size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);

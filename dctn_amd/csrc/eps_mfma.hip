@@ -409,7 +409,9 @@ __device__ __forceinline__ void build_p0(const float (*xv)[2], bf16x8 (&X)[(1 <<
 template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4 : 2))) void eps_fwd_q2reg_k(const S* __restrict__ x,
                                                        const S* __restrict__ core,
-                                                       S* __restrict__ out, MfmaP p) {
+                                                       S* __restrict__ out, double* __restrict__ stats, MfmaP p) {
+  // stats (optional): {sum y, sum y^2} over every output value, ACCUMULATED in float64 (the statistic behind the
+  // empirical-output-std initialisation, dctn/eps.py:163-181); with out == nullptr nothing is stored at all
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int LOGO = ilog2(OP);
   static_assert(MT >= 1 && KS >= 1, "tile too small");
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
+  float st1 = 0.f, st2 = 0.f;   // this lane's part of the statistics (a wave covers only a few samples)
   for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, xv);
@@ -515,7 +518,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
       swap_halves(a0, a1);
       res[o] = a0 + a1;
     }
-    store_row<S, OP, OVEC>(rs_o, job.voff_o, (unsigned)b * p.o_s1b, p.O, res);  // no position: out of range
+    if (stats) {   // wave-uniform; the values as the output tensor holds them (rounded to the storage type)
+#pragma unroll
+      for (int o = 0; o < OP; ++o) {
+        const float r = to_f32((S)res[o]);
+        const float keep = (o < p.O && job.valid) ? r : 0.f;
+        st1 += keep;
+        st2 = __builtin_fmaf(keep, keep, st2);
+      }
+    }
+    if (out) store_row<S, OP, OVEC>(rs_o, job.voff_o, (unsigned)b * p.o_s1b, p.O, res);  // no position: out of range
+  }
+  if (stats) {
+    double d1 = wave_reduce_sum((double)st1), d2 = wave_reduce_sum((double)st2);
+    if (lane == 0) {
+      atomicAdd(&stats[0], d1);
+      atomicAdd(&stats[1], d2);
+    }
   }
 }
 
@@ -1046,25 +1065,25 @@ bool row_vec_ok(const MfmaP& m, int OP, const void* ptr) {
 }
 
 template <typename S, int N0, int N1, int OP>
-int fwd_launch_t(const void* x, const void* core, void* out, const MfmaP& m_in, hipStream_t st) {
+int fwd_launch_t(const void* x, const void* core, void* out, double* stats, const MfmaP& m_in, hipStream_t st) {
   MfmaP m = m_in;
   const int blocks = plan_waves(m, 4, (long long)FWD_BLOCKS_PER_CU * NUM_CU * 4);
-  const bool ovec = row_vec_ok<S>(m, OP, out);
+  const bool ovec = out == nullptr || row_vec_ok<S>(m, OP, out);
   const dim3 g((unsigned)blocks), b(256);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;   // K*C window rows: 3x3 single channel, 2x2 two channels
   if (m.rowvec_ok && m.vec_ok && ovec && sizeof(S) == 2)
     hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true, RW>), g, b, 0, st, (const S*)x,
-                       (const S*)core, (S*)out, m);
+                       (const S*)core, (S*)out, stats, m);
   else if (m.vec_ok && ovec)
     hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, true, 0>), g, b, 0, st, (const S*)x,
-                       (const S*)core, (S*)out, m);
+                       (const S*)core, (S*)out, stats, m);
   else if (m.vec_ok)
     hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, true, false, 0>), g, b, 0, st, (const S*)x,
-                       (const S*)core, (S*)out, m);
+                       (const S*)core, (S*)out, stats, m);
   else
     hipLaunchKernelGGL((eps_fwd_q2reg_k<S, N0, N1, OP, false, false, 0>), g, b, 0, st, (const S*)x,
-                       (const S*)core, (S*)out, m);
+                       (const S*)core, (S*)out, stats, m);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_fwd_mfma_q2reg");
   return DCTN_OK;
@@ -1172,10 +1191,10 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   return DCTN_ERR_UNSUPPORTED;
 
 template <typename S>
-int fwd_dispatch(const void* x, const void* core, void* out, const MfmaP& m, int N, int op,
+int fwd_dispatch(const void* x, const void* core, void* out, double* stats, const MfmaP& m, int N, int op,
                  hipStream_t st) {
-  if (N == 9) { DISPATCH_OP(fwd_launch_t, S, 5, 4, op, x, core, out, m, st) }
-  DISPATCH_OP(fwd_launch_t, S, 4, 4, op, x, core, out, m, st)
+  if (N == 9) { DISPATCH_OP(fwd_launch_t, S, 5, 4, op, x, core, out, stats, m, st) }
+  DISPATCH_OP(fwd_launch_t, S, 4, 4, op, x, core, out, stats, m, st)
 }
 
 template <typename S>
@@ -1188,13 +1207,14 @@ int bwd_dispatch(const void* x, const void* dY, void* dCore, void* ws, const Mfm
 }  // namespace
 
 int eps_fwd_mfma(const void* x, const void* core, void* out, const EpsP& p, int dtype,
-                 int precision, hipStream_t st) {
+                 int precision, hipStream_t st, double* stats) {
   if (!family_ok(p, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  if (!out && !stats) return DCTN_ERR_NULL;
   MfmaP m;
   fill_mp(m, p, x, dtype);
   const int op = next_pow2(p.O) < 2 ? 2 : next_pow2(p.O);
-  if (dtype == DCTN_BF16) return fwd_dispatch<bf16_t>(x, core, out, m, p.N, op, st);
-  return fwd_dispatch<float>(x, core, out, m, p.N, op, st);
+  if (dtype == DCTN_BF16) return fwd_dispatch<bf16_t>(x, core, out, stats, m, p.N, op, st);
+  return fwd_dispatch<float>(x, core, out, stats, m, p.N, op, st);
 }
 
 size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx,

@@ -96,6 +96,62 @@ __global__ __launch_bounds__(256) void window_stats_k<double>(const double* __re
 
 }  // namespace
 
+// {sum y, sum y^2} of n stored values, float64, accumulated into stats[2]: the reduction behind the
+// empirical-output-std initialisation (dctn/eps.py:172-175 `output.std(unbiased=False)`) for the kernel families
+// that have no in-kernel epilogue: the forward writes one slice into a scratch buffer that stays in the caches and
+// this pass folds it into the two running sums, so the output of the whole data set never exists.
+template <typename S>
+__global__ __launch_bounds__(256) void eps_out_stats_k(const S* __restrict__ y, long long n, double* __restrict__ stats) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = (double)(float)y[i];
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_reduce_sum(s1);
+  s2 = wave_reduce_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&stats[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+template <>
+__global__ __launch_bounds__(256) void eps_out_stats_k<double>(const double* __restrict__ y, long long n, double* __restrict__ stats) {
+  __shared__ double red[2][4];
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double v = y[i];
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_reduce_sum(s1);
+  s2 = wave_reduce_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&stats[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+int eps_out_stats(const void* y, long long n, int dtype, double* stats, hipStream_t st) {
+  long long blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  const dim3 g((unsigned)blocks), b(256);
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(eps_out_stats_k<float>, g, b, 0, st, (const float*)y, n, stats); break;
+    case DCTN_F64: hipLaunchKernelGGL(eps_out_stats_k<double>, g, b, 0, st, (const double*)y, n, stats); break;
+    case DCTN_BF16: hipLaunchKernelGGL(eps_out_stats_k<bf16_t>, g, b, 0, st, (const bf16_t*)y, n, stats); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
 extern "C" int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums, int C, int B, int H, int W,
                                  int Q, int K, int dtype, void* stream) {
   if (!x || !x_strides || !sums) return DCTN_ERR_NULL;

@@ -202,6 +202,15 @@ def all_reduce_scalar_sums(*values: Tensor) -> List[Tensor]:
 
 
 @torch.no_grad()
+def global_biased_std_from_sums(count: int, sums: Tensor) -> Tensor:
+    """The same statistic from ``(count, [sum, sum of squares])`` of this rank's shard (what `dctn_eps_fwd_stats`
+    leaves): one all-reduce of three float64 numbers."""
+    n, s1, s2 = all_reduce_scalar_sums(torch.tensor(float(count), device=sums.device), sums[0], sums[1])
+    mean = s1 / n
+    return (s2 / n - mean * mean).clamp_min(0).sqrt()
+
+
+@torch.no_grad()
 def global_biased_std(values: Tensor) -> Tensor:
     """Biased standard deviation of the union of every rank's ``values`` (the statistic behind the
     empirical-std initialisation, dctn/eps.py:163-181, when each rank holds a shard of the dataset):

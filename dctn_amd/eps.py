@@ -148,16 +148,22 @@ def matrix_shape(eps_core: Tensor) -> Tuple[int, int]:
 
 
 def contract_on_input_dims(a: Tensor, b: Tensor) -> Tensor:
-    """(out dim of a, out dim of b): both cores contracted over all their input dims."""
+    """(out dim of a, out dim of b): both cores contracted over all their input dims (`dctn_fiber_gram`)."""
+    from . import tn_inner
+
     assert is_eps(a)
     assert is_eps(b)
-    return a.reshape(-1, a.shape[-1]).T @ b.reshape(-1, b.shape[-1])
+    if a.dtype == b.dtype and tn_inner.covers(a.shape[-1], b.shape[-1]):
+        return tn_inner.gram_over_input_dims(a, b)
+    return a.reshape(-1, a.shape[-1]).T @ b.reshape(-1, b.shape[-1])   # out sizes beyond the kernels' 32: library GEMM
 
 
 def inner_product(a: Tensor, b: Tensor) -> Tensor:
+    from . import tn_inner
+
     assert a.shape == b.shape
     assert is_eps(a)
-    return torch.dot(a.reshape(-1), b.reshape(-1))
+    return tn_inner.dot(a, b)
 
 
 @torch.no_grad()
@@ -166,6 +172,34 @@ def transform_in_slices(eps_core: Tensor, x: Tensor, batch_size: int) -> Tensor:
     dataset dim, without autograd; returns (1, dataset_size, H', W', out_size)."""
     assert is_eps(eps_core)
     return torch.cat([eps(eps_core, part) for part in x.split(batch_size, dim=1)]).unsqueeze(0)
+
+
+@torch.no_grad()
+def output_sums_in_slices(eps_core: Tensor, x: Tensor, batch_size: int) -> Tuple[int, Tensor]:
+    """(count, float64 tensor [sum y, sum y^2]) over every value of ``eps(eps_core, x)``, slice by slice along the
+    data-set dim like `transform_in_slices` - but through `dctn_eps_fwd_stats`: the sums are an epilogue of the
+    forward (in-kernel for the register-resident family, one reduction pass over a cache-resident slice for the
+    others), the (dataset_size, H', W', out) output is never materialised."""
+    assert is_eps(eps_core)
+    _check_core(eps_core, x)
+    dev, staged = L.placement(eps_core, x)
+    core = eps_core.to(dev).contiguous()
+    C, _, H, W, Q = x.shape
+    K = math.isqrt((core.ndim - 1) // C)
+    O = core.shape[-1]
+    lib, code, pol = L.lib(), L.dtype_code(core), L.precision()
+    stats = torch.zeros(2, dtype=torch.float64, device=dev)
+    count = 0
+    for part in x.split(batch_size, dim=1):
+        part = part.to(dev)
+        if part.dtype != core.dtype:
+            raise TypeError(f"eps: core is {core.dtype} but input is {part.dtype}")
+        B = part.shape[1]
+        ws = L.workspace(lib.dctn_eps_fwd_stats_workspace_bytes(C, B, H, W, Q, K, O, code, pol), dev)
+        L.check(lib.dctn_eps_fwd_stats(part.data_ptr(), L.strides5(part), core.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), C, B, H, W, Q, K, O, code, pol, L.stream_ptr(dev)), "eps forward statistics")
+        count += B * (H - K + 1) * (W - K + 1) * O
+    return count, (stats.cpu() if staged else stats)
 
 
 def make_eps_unit_theoretical_output_std(
@@ -191,8 +225,10 @@ def make_eps_unit_empirical_output_std(
     num_channels, dataset_size, height, width, in_size = input.shape
     core = torch.randn(*(in_size,) * (kernel_size**2 * num_channels), out_size, dtype=dtype).to(device)
     ddp.broadcast_parameters([core])
-    output = transform_in_slices(core, input.to(device, dtype), batch_size)
-    inverse_output_std = ddp.global_biased_std(output).to(output.dtype) ** -1
+    # the output over the data set is only needed for its std: count, sum and sum of squares come out of the
+    # forward's epilogue (`dctn_eps_fwd_stats`), the (dataset, H', W', out) tensor of eps.py:172 never exists
+    count, sums = output_sums_in_slices(core, input.to(device, dtype), batch_size)
+    inverse_output_std = ddp.global_biased_std_from_sums(count, sums.to(core.device)).to(core.dtype) ** -1
     logger = getLogger(f"{__name__}.make_eps_unit_empirical_output_std")
     logger.info(f"Multiplying the output of randn by {inverse_output_std:.30e}")
     core *= inverse_output_std

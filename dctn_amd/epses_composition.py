@@ -7,7 +7,7 @@ from typing import Dict, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from . import eps
+from . import eps, tn_inner
 from .contraction_path_cache import contract
 from .utils import (
     FromFileInitialization,
@@ -31,7 +31,9 @@ def contract_with_input(epses: Sequence[Tensor], input: Tensor) -> Tensor:
 def inner_product(epses1: Sequence[Tensor], epses2: Sequence[Tensor]) -> Tensor:
     """Inner product of the two linear maps the stacks represent.  The first pair is contracted
     over its inputs into an (out x out) matrix, which is then absorbed into every input leg of
-    the next core of stack 1; recurse on the shortened stacks."""
+    the next core of stack 1; recurse on the shortened stacks.  On the device: `dctn_fiber_gram` for the Gram
+    matrix and the closing dot product, `dctn_mode_product` per absorbed leg (dctn_amd/tn_inner.py), forward and
+    backward."""
     epses1, epses2 = tuple(epses1), tuple(epses2)
     assert len(epses1) == len(epses2)
     for a, b in zip(epses1, epses2):
@@ -41,19 +43,23 @@ def inner_product(epses1: Sequence[Tensor], epses2: Sequence[Tensor]) -> Tensor:
         return eps.inner_product(epses1[0], epses2[0])
     gram = eps.contract_on_input_dims(epses1[0], epses2[0])  # (out of stack1[0], out of stack2[0])
     nxt = epses1[1]
-    n_in = nxt.ndim - 1
-    args = [nxt, tuple(f"in{i}" for i in range(n_in)) + ("out",)]
-    for i in range(n_in):
-        args += [gram, (f"in{i}", f"newin{i}")]
-    args.append(tuple(f"newin{i}" for i in range(n_in)) + ("out",))
-    absorbed = contract(*args)
+    if gram.dtype == nxt.dtype and tn_inner.covers(*gram.shape):
+        absorbed = tn_inner.absorb_into_input_legs(nxt, gram)   # N mode products on the device
+    else:   # sizes beyond the kernels' 32: the planner + library einsums
+        n_in = nxt.ndim - 1
+        args = [nxt, tuple(f"in{i}" for i in range(n_in)) + ("out",)]
+        for i in range(n_in):
+            args += [gram, (f"in{i}", f"newin{i}")]
+        args.append(tuple(f"newin{i}" for i in range(n_in)) + ("out",))
+        absorbed = contract(*args)
     assert eps.is_eps(absorbed)
     return inner_product((absorbed,) + epses1[2:], epses2[1:])
 
 
 def epswise_squared_fro_norm(epses: Sequence[Tensor]) -> Tensor:
+    """Sum of the squared Frobenius norms of the cores: one `dctn_fiber_gram` (a dot product) per core."""
     assert all(eps.is_eps(core) for core in epses)
-    return sum(core.norm(p="fro") ** 2 for core in epses)
+    return sum(tn_inner.dot(core, core) for core in epses)
 
 
 def specs_to_full_specs(epses_specs: Tuple[Tuple[int, int], ...], initial_in_size: int) -> Tuple[Dict[str, int], ...]:

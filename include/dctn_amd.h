@@ -89,6 +89,21 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
                  int C, int B, int H, int W, int Q, int K, int O,
                  int dtype, int policy, void* stream);
 
+/* Forward whose output is only needed for its statistics - replaces the `transform_in_slices(...)` +
+ * `output.std(unbiased=False)` of dctn/eps.py:163-181 `make_eps_unit_empirical_output_std` (and the statistics of
+ * dctn/eps_plus_linear.py:161-196): stats[0] += sum y, stats[1] += sum y^2 over every value of eps(core, x), in
+ * float64, values as the output tensor would hold them (rounded to the storage dtype).  `stats`: two float64 on the
+ * device, ACCUMULATED (the caller zeroes them once and feeds slice after slice; count = B*H'*W'*O per call).
+ * The register-resident family folds the sums into the forward kernel's epilogue and stores nothing; the other
+ * families write the slice into `workspace` (dctn_eps_fwd_stats_workspace_bytes) and reduce it in a second pass -
+ * the output of the whole data set is never materialised either way. */
+size_t dctn_eps_fwd_stats_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
+                                          int dtype, int policy);
+int dctn_eps_fwd_stats(const void* x, const int64_t x_strides[5], const void* core, void* stats,
+                       void* workspace, size_t workspace_bytes,
+                       int C, int B, int H, int W, int Q, int K, int O,
+                       int dtype, int policy, void* stream);
+
 /* Autograd of the above (reference: torch autograd through the 4 path steps, dctn/training.py:81).
  *   dY    : (B, H', W', O) contiguous
  *   dX    : (C, B, H, W, Q) contiguous, or NULL when the input needs no gradient
@@ -241,6 +256,25 @@ int dctn_ce_loss_bwd(const void* logits, const void* labels, const void* dloss, 
 int dctn_sgd_l2_num_partials(int64_t n);
 int dctn_sgd_l2_step(void* params, const void* grads, void* momentum_buf, void* sq_sum, int64_t n, int64_t n_reg,
                      float lr, float momentum, float l2, int first_step, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tensor-network inner product of two stacks of EPS cores - replaces the contractions of
+ * dctn/epses_composition.py:21-58 `inner_product` (Gram of the first pair of cores over their input legs:
+ * dctn/eps.py:106-112 `contract_on_input_dims`; that matrix absorbed into every input leg of the next core:
+ * the N-operand einsum at :46-56; the closing dot product: dctn/eps.py:120-123), which the reference evaluates
+ * every training iteration (dctn/eps_plus_linear.py:156-159).  Forward and backward are compositions of two
+ * primitives over a contiguous tensor viewed as (pre, q, post):
+ *   dctn_mode_product : out[pre, j, post] = sum_i in[pre, i, post] * M[i, j]      M: (q, q2) contiguous
+ *   dctn_fiber_gram   : out[i, j] = sum_(pre, post) A[pre, i, post] * B[pre, j, post]     out: (qa, qb)
+ * (Gram of two (rows, O) matrices: post = 1; dot product: qa = qb = 1.)  q, q2, qa, qb <= 32.  Outputs are
+ * OVERWRITTEN, in the tensors' dtype (f32 / f64 / bf16 storage with f32 accumulation); sums are combined in a
+ * fixed order (no atomics).  `out` must not alias `in`.
+ * ------------------------------------------------------------------------------------------ */
+int dctn_mode_product(const void* in, const void* M, void* out, int64_t pre, int q, int q2, int64_t post,
+                      int dtype, void* stream);
+size_t dctn_fiber_gram_workspace_bytes(int64_t pre, int qa, int qb, int64_t post, int dtype);
+int dctn_fiber_gram(const void* A, const void* B, void* out, void* workspace, size_t workspace_bytes,
+                    int64_t pre, int qa, int qb, int64_t post, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

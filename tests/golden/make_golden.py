@@ -326,9 +326,63 @@ def window_stats_fixture():
     npz("window_stats", **out)
 
 
+def regulariser_and_init_fixture():
+    """the reference's own `epses_composition.inner_product` (value and, through autograd, its
+    gradients - the regulariser is differentiated every iteration) on seeded random stacks, and the cores its
+    empirical-output-std initialisers return for a fixed seed and data set (the random core is drawn from torch's
+    global generator: the same seed gives the same draw in the build's mirror)."""
+    assert os.path.isdir(REF)
+    _install_sequencers()
+    sys.path.insert(0, REF)
+    from dctn import eps as r_eps
+    from dctn import epses_composition as r_comp
+
+    f64 = torch.float64
+    out = {}
+    torch.manual_seed(zlib.crc32(b"inner_product"))
+    stacks = {
+        "s2": [(2,) * 4 + (3,), (3,) * 4 + (5,)],                   # two layers, K=2
+        "s3": [(2,) * 9 + (4,), (4,) * 4 + (3,), (3,) * 4 + (2,)],  # three layers, first one K=3
+        "s1": [(3,) * 4 + (6,)],                                    # one layer: plain dot product
+    }
+    for tag, shapes in stacks.items():
+        e1 = [(torch.randn(*sh, dtype=f64) * 0.7).requires_grad_(True) for sh in shapes]
+        e2 = [(torch.randn(*sh, dtype=f64) * 0.7).requires_grad_(True) for sh in shapes]
+        val = r_comp.inner_product(e1, e2)
+        g = torch.autograd.grad(val, e1 + e2)
+        self_val = r_comp.inner_product(e1, e1)
+        self_g = torch.autograd.grad(self_val, e1)
+        out[f"{tag}_n"] = len(shapes)
+        out[f"{tag}_value"], out[f"{tag}_self_value"] = val, self_val
+        for i in range(len(shapes)):
+            out[f"{tag}_a{i}"], out[f"{tag}_b{i}"] = e1[i], e2[i]
+            out[f"{tag}_da{i}"], out[f"{tag}_db{i}"] = g[i], g[len(shapes) + i]
+            out[f"{tag}_self_da{i}"] = self_g[i]
+        out[f"{tag}_sqfro"] = r_comp.epswise_squared_fro_norm(e1)
+    npz("inner_product", **out)
+
+    out = {}
+    x = phi(torch.rand(1, 20, 8, 8, dtype=f64, generator=torch.Generator().manual_seed(5)))   # (1, 20, 8, 8, 2)
+    out["x"] = x
+    seed, batch = 20261004, 7                                        # 20 samples in slices of 7, 7, 6
+    torch.manual_seed(seed)
+    one = r_eps.make_eps_unit_empirical_output_std(3, 4, x, torch.device("cpu"), f64, batch)
+    torch.manual_seed(seed)
+    raw = torch.randn(*(2,) * 9, 4, dtype=f64)                      # the draw the function starts from
+    out.update(seed=seed, batch_size=batch, one_core=one, one_inverse_output_std=(one.reshape(-1)[0] / raw.reshape(-1)[0]))
+    torch.manual_seed(seed)
+    cores = r_comp.make_epses_composition_unit_empirical_output_std(((3, 3), (2, 4)), x, torch.device("cpu"), f64, batch)
+    out.update(stack_core0=cores[0], stack_core1=cores[1])
+    out["stack_output_std"] = r_eps.transform_in_slices(cores[1], r_eps.transform_in_slices(cores[0], x, batch), batch).std(unbiased=False)
+    npz("empirical_std_init", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "window_stats":
         window_stats_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "regulariser_init":
+        regulariser_and_init_fixture()
     else:
         main()
         window_stats_fixture()
+        regulariser_and_init_fixture()

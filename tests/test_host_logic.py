@@ -15,8 +15,9 @@ from dctn_amd.align import align, align_with_positions
 from dctn_amd.contraction_path_cache import ContractionPathCache, contract
 from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization, KhrulkovNormalInitialization, ManyConvSBS
 from dctn_amd.conv_sbs_spec import SBSCoreShape, SBSSpecCore, SBSSpecString
-from dctn_amd.eps import EPS, contract_on_input_dims, eps, is_eps, matrix_shape
-from dctn_amd.epses_composition import inner_product, specs_to_full_specs
+from dctn_amd.eps import EPS, eps, is_eps, matrix_shape
+from oracle import ref_cpu as R
+from dctn_amd.epses_composition import specs_to_full_specs
 from dctn_amd.pos2d import Pos2D, index_to_pos, pos_to_index
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -187,16 +188,19 @@ def test_contraction_path_cache_formats_bit_identical():  # reference test: test
 
 
 # ------------------------------------------------------------------ parameter-only contractions
-def test_contract_on_inner_dims():  # reference test: tests/test_eps.py:64-73
+# (the product functions of these run on the device: tests/test_gpu_regulariser_init.py; here the ORACLE's restatement
+# is pinned by the reference's closed forms and by the reference's own numbers)
+def test_oracle_contract_on_inner_dims():  # reference test: tests/test_eps.py:64-73
     a = torch.einsum("oi,j->ijo", torch.eye(3), 2.0 * torch.ones(3))
-    assert torch.allclose(contract_on_input_dims(a, a), 12.0 * torch.eye(3))
+    assert torch.allclose(R.contract_on_input_dims(a, a), 12.0 * torch.eye(3))
     a = torch.einsum("oi,j->ijo", 2.0 * torch.eye(4), torch.tensor([1.0, 2.0, 3.0, 4.0]))
     b = torch.einsum("pj,i->ijp", 3.0 * torch.eye(4), torch.ones(4))
-    assert torch.allclose(contract_on_input_dims(a, b),
+    assert torch.allclose(R.contract_on_input_dims(a, b),
                           torch.einsum("o,p->op", 2.0 * torch.ones(4), torch.tensor([3.0, 6.0, 9.0, 12.0])))
 
 
-def test_epses_inner_product_closed_forms():  # reference test: tests/test_epses_composition.py:7-41
+def test_oracle_epses_inner_product_closed_forms():  # reference test: tests/test_epses_composition.py:7-41
+    inner_product = R.epses_inner_product
     a = torch.einsum("oi,j->ijo", torch.eye(3), torch.ones(3))
     assert torch.allclose(inner_product((a,), (a,)), torch.tensor(9.0))
     assert torch.allclose(inner_product((a, a), (a, a)), torch.tensor(3.0**4))
@@ -206,6 +210,28 @@ def test_epses_inner_product_closed_forms():  # reference test: tests/test_epses
     orange = torch.einsum("oi,j->ijo", torch.eye(6)[:4], torch.ones(6))
     red = torch.einsum("oi,j->ijo", torch.eye(4)[1:], torch.tensor([1.0, 0.0, 0.0, 1.0]))
     assert torch.allclose(inner_product((green, black), (orange, red)), torch.tensor((2 + 3 + 4) * 5 * 1.5))
+
+
+def test_oracle_inner_product_and_init_match_the_reference_fixtures():
+    g = load("inner_product")
+    for tag in ("s1", "s2", "s3"):
+        n = int(g[f"{tag}_n"])
+        a = [torch.from_numpy(g[f"{tag}_a{i}"]).requires_grad_(True) for i in range(n)]
+        b = [torch.from_numpy(g[f"{tag}_b{i}"]).requires_grad_(True) for i in range(n)]
+        val = R.epses_inner_product(a, b)
+        assert torch.allclose(val, torch.from_numpy(g[f"{tag}_value"]), rtol=1e-12)
+        grads = torch.autograd.grad(val, a + b)
+        for i in range(n):
+            assert torch.allclose(grads[i], torch.from_numpy(g[f"{tag}_da{i}"]), rtol=1e-10, atol=1e-13)
+            assert torch.allclose(grads[n + i], torch.from_numpy(g[f"{tag}_db{i}"]), rtol=1e-10, atol=1e-13)
+        assert torch.allclose(R.epses_inner_product(a, a), torch.from_numpy(g[f"{tag}_self_value"]), rtol=1e-12)
+    g = load("empirical_std_init")
+    x, batch = torch.from_numpy(g["x"]), int(g["batch_size"])
+    torch.manual_seed(int(g["seed"]))
+    raw = torch.randn(*(2,) * 9, 4, dtype=torch.float64)
+    scale = R.unit_empirical_output_std_scale(raw, x, batch)
+    assert torch.allclose(scale, torch.from_numpy(g["one_inverse_output_std"]), rtol=1e-12)
+    assert torch.allclose(raw * scale, torch.from_numpy(g["one_core"]), rtol=1e-12)
 
 
 @pytest.mark.parametrize("name", ["sbs_2x2_ring_perm0", "sbs_2x2_ring_perm1"])
