@@ -45,6 +45,7 @@ class _ModeProduct(torch.autograd.Function):
         xc, Mc = x.contiguous().reshape(-1), M.contiguous()
         ctx.save_for_backward(xc, Mc)
         ctx.dims = (pre, q, q2, post)
+        ctx.x_shape = x.shape
         return _mode_product(xc, Mc, pre, q, q2, post)
 
     @staticmethod
@@ -52,7 +53,8 @@ class _ModeProduct(torch.autograd.Function):
         xc, Mc = ctx.saved_tensors
         pre, q, q2, post = ctx.dims
         g = d_out.contiguous().reshape(-1)
-        d_x = _mode_product(g, Mc.t().contiguous(), pre, q2, q, post) if ctx.needs_input_grad[0] else None
+        d_x = (_mode_product(g, Mc.t().contiguous(), pre, q2, q, post).reshape(ctx.x_shape)
+               if ctx.needs_input_grad[0] else None)
         d_M = _fiber_gram(xc, g, pre, q, q2, post) if ctx.needs_input_grad[1] else None
         return d_x, d_M, None, None
 
@@ -64,6 +66,7 @@ class _FiberGram(torch.autograd.Function):
         ac, bc = a.contiguous().reshape(-1), b.contiguous().reshape(-1)
         ctx.save_for_backward(ac, bc)
         ctx.dims = (pre, qa, qb, post)
+        ctx.shapes = (a.shape, b.shape)
         return _fiber_gram(ac, bc, pre, qa, qb, post)
 
     @staticmethod
@@ -72,8 +75,9 @@ class _FiberGram(torch.autograd.Function):
         pre, qa, qb, post = ctx.dims
         g = d_out.contiguous()
         # d a[pre, i, post] = sum_j b[pre, j, post] g[i, j]  ->  mode product of b with g^T (qb x qa)
-        d_a = _mode_product(bc, g.t().contiguous(), pre, qb, qa, post) if ctx.needs_input_grad[0] else None
-        d_b = _mode_product(ac, g, pre, qa, qb, post) if ctx.needs_input_grad[1] else None
+        d_a = (_mode_product(bc, g.t().contiguous(), pre, qb, qa, post).reshape(ctx.shapes[0])
+               if ctx.needs_input_grad[0] else None)
+        d_b = _mode_product(ac, g, pre, qa, qb, post).reshape(ctx.shapes[1]) if ctx.needs_input_grad[1] else None
         return d_a, d_b, None, None, None, None
 
 

@@ -77,6 +77,8 @@ def test_inner_product_value_and_gradients_match_the_reference(tag, dtype):
     for i in range(n):
         assert close(a[i].grad, g[f"{tag}_da{i}"]) and close(b[i].grad, g[f"{tag}_db{i}"])
     # the regulariser's own use: a stack with itself (both uses of every core collect gradient)
+    if dtype == torch.float32 and abs(float(g[f"{tag}_self_value"])) > 1e30:
+        return   # the three-layer fixture's self inner product (1.6e48) does not fit float32
     for t in a:
         t.grad = None
     self_val = inner_product(a, a)
