@@ -181,3 +181,32 @@ def test_forward_statistics_epilogue_equals_the_materialised_output(dtype, K, Q,
     code = L.dtype_code(x)
     ws = L.lib().dctn_eps_fwd_stats_workspace_bytes(1, 16, 12, 11, Q, K, O, code, 0)
     assert (ws <= 512) == (family == "q2reg")
+
+
+def test_composition_regulariser_inside_the_graphed_training_iteration():
+    """f1 wired into the iteration: `GraphedTrainStep` with reg_fn = epses_composition_l2_regularizer (Gram, the mode
+    products, the dot and all their backward launches captured in the one HIP graph) follows the eager loop."""
+    import copy
+
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    from dctn_amd.training import GraphedTrainStep, train_step
+
+    torch.manual_seed(9)
+    a = EPSesPlusLinear(((2, 3), (2, 4)), UnitTheoreticalOutputStd(), 1.0, DEV, torch.float32, image_size=8)
+    b = copy.deepcopy(a)
+    xs = [torch.rand(1, 16, 8, 8, 2, device=DEV) for _ in range(4)]
+    ys = [torch.randint(0, 10, (16,), device=DEV) for _ in range(4)]
+    reg = lambda m: m.epses_composition_l2_regularizer()
+    ce = torch.nn.functional.cross_entropy
+    oa = torch.optim.SGD(a.parameters(), lr=0.05, momentum=0.9)
+    ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9)
+    graphed = GraphedTrainStep(b, xs[0], ys[0], ce, ob, reg_fn=reg, reg_coeff=1e-2, warmup=2)
+    for _ in range(2):
+        train_step(a, xs[0], ys[0], ce, oa, reg_fn=reg, reg_coeff=1e-2)
+    for x, y in zip(xs, ys):
+        ra = train_step(a, x, y, ce, oa, reg_fn=reg, reg_coeff=1e-2)
+        rb = graphed(x, y)
+        assert torch.allclose(ra["loss"], rb["loss"], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ra["reg_term"], rb["reg_term"].float(), rtol=1e-5, atol=1e-6)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6)
