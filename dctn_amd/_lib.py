@@ -41,6 +41,7 @@ SIGNATURES = {
     "dctn_eps_bwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 4),
     "dctn_eps_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_size]
                      + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_eps_head_fwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_int, c_int, c_void]),
     "dctn_eps_head_bwd_workspace_bytes": (c_size, [c_int] * 8 + [c_int, c_int]),
     "dctn_eps_head_bwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_size]
                           + [c_int] * 8 + [c_int, c_int, c_void]),

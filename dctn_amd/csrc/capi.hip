@@ -129,6 +129,19 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   return a + b + 256;
 }
 
+int dctn_eps_head_fwd(const void* x, const int64_t x_strides[5], const void* core, const void* head_weight,
+                      const void* head_bias, void* features, void* logits, int C, int B, int H, int W, int Q, int K, int O,
+                      int Cout, int dtype, int policy, void* stream) {
+  if (!x || !core || !head_weight || !head_bias || !features || !logits || !x_strides) return DCTN_ERR_NULL;
+  if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
+  if (Cout < 1) return DCTN_ERR_BAD_SHAPE;
+  EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
+  const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
+  if (rc != DCTN_OK) return rc;
+  return eps_head_fwd_mfma(x, core, head_weight, head_bias, features, logits, p, Cout, dtype, precision, (hipStream_t)stream);
+}
+
 size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout, int dtype,
                                          int policy) {
   EpsP p;

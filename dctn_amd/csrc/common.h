@@ -95,6 +95,8 @@ int eps_out_stats(const void* y, long long n, int dtype, double* stats, hipStrea
 size_t eps_bwd_mfma_workspace(const EpsP& p, int dtype, int precision, int need_dx, int need_dcore);
 int eps_bwd_mfma(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws,
                  size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
+int eps_head_fwd_mfma(const void* x, const void* core, const void* head_w, const void* bias, void* feat, void* logits,
+                      const EpsP& p, int Cout, int dtype, int precision, hipStream_t st);
 size_t eps_head_bwd_mfma_workspace(const EpsP& p, int Cout, int dtype, int precision);
 int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, const void* head_w, void* dCore,
                       void* dW, void* dBias, void* ws, size_t ws_bytes, const EpsP& p, int Cout, int dtype,

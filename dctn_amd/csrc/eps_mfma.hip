@@ -156,7 +156,26 @@ struct MfmaP {
   unsigned hw_rowb, hw_bytes;   //   bytes per row (P * O * 2) and in total
   int ncb;                      //   chunk blocks (8 sample chunks each) of the grouped wave mapping
   int opts;                     // DCTN_OPT_* flags of the call
+#ifdef DCTN_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (tools/stamp_cfg2.hip): per-workgroup phase time stamps
+#endif
 };
+
+#ifdef DCTN_STAMPS
+// 100 MHz wall clock, comparable across workgroups; written by wave 0 / lane 0 to memory nothing else reads
+#define DCTN_STAMP(P, SLOT)                                                                      \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    if ((P).stamps && threadIdx.x == 0) (P).stamps[(long long)blockIdx.x * 8 + (SLOT)] = t_;     \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+static unsigned long long* g_stamps = nullptr;
+void dctn_stamps_set(unsigned long long* p) { g_stamps = p; }
+#else
+#define DCTN_STAMP(P, SLOT) do { } while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -422,6 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
   static_assert(TOT % 256 == 0, "core staging assumes a multiple of 256 elements");
   __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
   const int tid = threadIdx.x, lane = tid & 63;
+  DCTN_STAMP(p, 0);
   // the first sample's window loads go out before the core is staged: both memory round trips overlap
   const WaveJob job = wave_job(p, 4, (int)sizeof(S));
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
@@ -450,6 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
 #pragma unroll
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
+  DCTN_STAMP(p, 1);
 
   float st1 = 0.f, st2 = 0.f;   // this lane's part of the statistics (a wave covers only a few samples)
   for (int b = job.b0; b < job.b1; ++b) {
@@ -528,12 +549,230 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
       }
     }
     if (out) store_row<S, OP, OVEC>(rs_o, job.voff_o, (unsigned)b * p.o_s1b, p.O, res);  // no position: out of range
+    if (b == job.b0) DCTN_STAMP(p, 2);
   }
+  DCTN_STAMP(p, 3);
   if (stats) {
     double d1 = wave_reduce_sum((double)st1), d2 = wave_reduce_sum((double)st2);
     if (lane == 0) {
       atomicAdd(&stats[0], d1);
       atomicAdd(&stats[1], d2);
+    }
+  }
+}
+
+// --------------------------------------------------------------------- forward with the linear head fused
+// EPSesPlusLinear's tail (dctn/eps_plus_linear.py:144-147): features = eps(core, x), logits = Linear(flatten(features)).
+// As separate kernels the head costs a launch, a kernel boundary and a re-read of the features (14.6 of the 38 us of a
+// BASELINE cfg2 step).  Here a workgroup is ALL position groups (one wave each) of a few samples, so a sample's logits
+//   logits[b, c] = bias[c] + sum_(pos, o) W[c, pos, o] * features[b, pos, o]
+// meet inside the workgroup: the lane (= position) multiplies its bf16-rounded outputs - exactly what it stores -
+// with its slice of the head weight (v_dot2c_f32_bf16: bf16 products, f32 sums, the numerics of the stand-alone head
+// kernel), the wave sums its 64 lanes with a halving butterfly (v_permlane32_swap, v_permlane16_swap, DPP row
+// rotations: HEADC values cost ~3*HEADC instructions instead of 6*HEADC), lane 0 of each 16-lane row drops the
+// wave's sums into LDS and after every group of HS samples the workgroup adds the position groups and the bias.
+constexpr int HEAD_FWD_MAXPG = 12;   // waves per workgroup (launch bound 768 threads: 3-4 waves per SIMD)
+constexpr int HEAD_FWD_HS = 4;       // samples per LDS flush
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a row, result in every lane of the row
+__device__ __forceinline__ float row_sum16(float v) {
+  v = dpp_add<0x128>(v);   // row_ror:8
+  v = dpp_add<0x124>(v);   // row_ror:4
+  v = dpp_add<0x122>(v);   // row_ror:2
+  v = dpp_add<0x121>(v);   // row_ror:1
+  return v;
+}
+// Sums NV per-lane values over the wave.  Afterwards lane (h = lane >> 5, p = (lane >> 4) & 1) holds, in w[i],
+// the total of value c = i + H2 * p + H1 * h  (H1 = ceil(NV / 2), H2 = ceil(H1 / 2); slots with i + H2 * p >= H1
+// or c >= NV hold garbage).
+template <int NV>
+struct WaveSums {
+  static constexpr int H1 = (NV + 1) / 2, H2 = (H1 + 1) / 2;
+  float w[H2];
+  __device__ __forceinline__ void reduce(const float (&v)[NV]) {
+    float u[H1];
+#pragma unroll
+    for (int i = 0; i < H1; ++i) {
+      float a = v[i], b = (i + H1 < NV) ? v[i + H1] : 0.f;
+      swap_halves(a, b);          // a = [v_i lo | v_(i+H1) lo], b = [v_i hi | v_(i+H1) hi]
+      u[i] = a + b;
+    }
+#pragma unroll
+    for (int i = 0; i < H2; ++i) {
+      const float a = u[i], b = (i + H2 < H1) ? u[i + H2] : 0.f;
+      // odd rows of a <-> even rows of b: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
+      const int2v r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+      w[i] = row_sum16(__int_as_float(r[0]) + __int_as_float(r[1]));
+    }
+  }
+};
+
+template <int N0, int N1, int OP, int ROWS, int HEADC>
+__global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(const bf16_t* __restrict__ x,
+                                                                           const bf16_t* __restrict__ core,
+                                                                           const bf16_t* __restrict__ hw,
+                                                                           const bf16_t* __restrict__ bias,
+                                                                           bf16_t* __restrict__ out,
+                                                                           bf16_t* __restrict__ logits, MfmaP p) {
+  typedef bf16_t S;
+  constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
+  constexpr int LOGO = ilog2(OP);
+  constexpr int TOT = A * BN * OP;
+  static_assert(OP % 2 == 0, "outputs are handled as bf16 pairs");
+  __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
+  __shared__ float hsum[2][HEAD_FWD_HS][HEADC][HEAD_FWD_MAXPG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
+  const int b0 = (int)blockIdx.x * p.spc, b1 = b0 + p.spc < p.B ? b0 + p.spc : p.B;
+  const int pos = wv * 64 + lane;
+  const bool valid = pos < p.P;
+  const unsigned pu = valid ? (unsigned)pos : 0u;
+  const unsigned ho = fdiv(pu, p.div_wo), wo = pu - ho * (unsigned)p.Wo;
+  const unsigned voff_x = valid ? ho * p.s2b + wo * p.s3b : p.x_bytes;
+  const unsigned voff_o = valid ? pu * (unsigned)(OP * 2) : p.o_bytes;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
+  RawWindow<S, N, true, ROWS> raw;
+  if (b0 < b1) issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)b0 * p.s1b, p, raw);
+  // the lane's slice of the head weight, kept as packed bf16 pairs: W[c, pos, 0..OP)
+  RawRow<S, OP> wr[HEADC];
+  {
+    const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
+    const unsigned voff_hw = valid ? (unsigned)pos * (unsigned)(OP * 2) : p.hw_bytes;
+#pragma unroll
+    for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
+      issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, wr[c]);
+  }
+  // core -> LDS in fragment order (as eps_fwd_q2reg_k), by however many threads the workgroup has: batches of 4
+  // elements per thread, the 4 loads of a batch in flight together
+  for (int e0 = 0; e0 < TOT; e0 += 4 * (int)blockDim.x) {
+    S tmp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP;
+      tmp[i] = e < TOT ? core[(long long)ab * p.O + (o < p.O ? o : 0)] : (S)0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP, bb = ab % BN, aa = ab / BN;
+      const int code = ((bb >> 1) << LOGO) | o;
+      const int row = (((code >> 2) & 3) << 3) | ((bb & 1) << 2) | (code & 3);
+      const int dst = ((((code >> 4) * KS + (aa >> 4)) * 64 + ((aa >> 3) & 1) * 32 + row) << 3) | (aa & 7);
+      if (e < TOT) cs[dst] = o < p.O ? tmp[i] : (bf16_t)0.f;
+    }
+  }
+  __syncthreads();
+  bf16x8 cf[MT][KS];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
+
+  const int h = lane >> 5, rp = (lane >> 4) & 1;
+  for (int g0 = b0, grp = 0; g0 < b1; g0 += HEAD_FWD_HS, ++grp) {
+    const int g1 = g0 + HEAD_FWD_HS < b1 ? g0 + HEAD_FWD_HS : b1;
+    for (int b = g0; b < g1; ++b) {
+      float xv[N][2];
+      unpack_window<S, N, true, ROWS>(raw, xv);
+      {  // prefetch the next sample (the last iteration re-reads its own)
+        const int bn = b + 1 < b1 ? b + 1 : b;
+        issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)bn * p.s1b, p, raw);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 pf0[KS], pf1[KS];
+      build_p0<N0>(xv, pf0, pf1);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) swap_halves(pf0[s], pf1[s]);
+      float m0[BN / 2], m1[BN / 2];
+      {
+        float ph[BN / 2];
+        ph[0] = xv[N - 2][0];
+        ph[1] = xv[N - 2][1];
+#pragma unroll
+        for (int u = 2; u < N1; ++u)
+#pragma unroll
+          for (int bh = (1 << (u - 1)) - 1; bh >= 0; --bh) {
+            const float lo = ph[bh];
+            ph[bh | (1 << (u - 1))] = lo * xv[N - 1 - u][1];
+            ph[bh] = lo * xv[N - 1 - u][0];
+          }
+#pragma unroll
+        for (int bh = 0; bh < BN / 2; ++bh) {
+          m0[bh] = ph[bh] * xv[N - 1][0];
+          m1[bh] = ph[bh] * xv[N - 1][1];
+          swap_halves(m0[bh], m1[bh]);
+        }
+      }
+      float res0[OP], res1[OP];
+#pragma unroll
+      for (int o = 0; o < OP; ++o) { res0[o] = 0.f; res1[o] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+          f32x16 acc;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], set ? pf1[s] : pf0[s], acc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
+            const float mm = set ? m1[code >> LOGO] : m0[code >> LOGO];
+            float& dst = set ? res1[code & (OP - 1)] : res0[code & (OP - 1)];
+            dst = __builtin_fmaf(acc[v], mm, dst);
+          }
+        }
+      }
+      // the lane's OP outputs as the bf16 pairs that go to memory ...
+      unsigned pk[OP / 2];
+#pragma unroll
+      for (int i = 0; i < OP / 2; ++i) {
+        float a0 = res0[2 * i], a1 = res1[2 * i], c0 = res0[2 * i + 1], c1 = res1[2 * i + 1];
+        swap_halves(a0, a1);
+        swap_halves(c0, c1);
+        pk[i] = pack_bf16(a0 + a1, c0 + c1);
+      }
+      if constexpr (OP == 2) {
+        __builtin_amdgcn_raw_buffer_store_b32(pk[0], rs_o, voff_o, (unsigned)b * p.o_s1b, 0);
+      } else if constexpr (OP == 4) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rs_o, voff_o, (unsigned)b * p.o_s1b, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < OP / 8; ++i)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]}, rs_o, voff_o,
+                                                 (unsigned)b * p.o_s1b + 16u * i, 0);
+      }
+      // ... and their products with the head weight of this position (lanes without a position: all zeros)
+      float part[HEADC];
+#pragma unroll
+      for (int c = 0; c < HEADC; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < OP / 2; ++i)
+          a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wr[c].d[i]), __builtin_bit_cast(bf16x2, pk[i]), a, false);
+        part[c] = a;
+      }
+      WaveSums<HEADC> ws;
+      ws.reduce(part);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < WaveSums<HEADC>::H2; ++i) {
+          const int j = i + WaveSums<HEADC>::H2 * rp, c = j + WaveSums<HEADC>::H1 * h;
+          if (j < WaveSums<HEADC>::H1 && c < HEADC) hsum[grp & 1][b - g0][c][wv] = ws.w[i];
+        }
+      }
+    }
+    __syncthreads();   // one barrier per group: the buffers alternate, a buffer is rewritten two groups later
+    for (int e = tid; e < (g1 - g0) * p.Cout; e += (int)blockDim.x) {
+      const int sl = e / p.Cout, c = e - sl * p.Cout;
+      float t = (float)bias[c];
+      for (int w = 0; w < nwv; ++w) t += hsum[grp & 1][sl][c][w];
+      logits[(long long)(g0 + sl) * p.Cout + c] = (bf16_t)t;
     }
   }
 }
@@ -568,6 +807,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   __shared__ float red[BWD_WAVES][32 * 32];
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wv = tid >> 6;
+  DCTN_STAMP(p, 0);
   short* tiles = reinterpret_cast<short*>(dsm) + wv * ((1 + MT) * 64 * LROW);
   const TrLane trl = tr_lane(lane);
 
@@ -625,9 +865,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
 #pragma unroll
     for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
   }
+  DCTN_STAMP(p, 1);
   for (int b = job.b0; b < job.b1; ++b) {
     float xv[N][2];
     unpack_window<S, N, XVEC, ROWS>(raw, xv);
+    if (b == job.b0) DCTN_STAMP(p, 2);
     float dy[OP];
     if constexpr (HEADC > 0) {
       float ft[OP];   // forward output of the window (zeros for lanes without a position)
@@ -779,6 +1021,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     }
   }
 
+  DCTN_STAMP(p, 3);
   // workgroup reduction of the per-wave partial dCoreT tiles, then one coalesced store per block
   float* dst = partial + (long long)blockIdx.x * (MT * 32) * (AT * 32);
 #pragma unroll
@@ -801,6 +1044,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       }
     }
 
+  DCTN_STAMP(p, 4);
   if constexpr (HEADC > 0) {
     // head-weight gradient: sum the 8 waves (same positions, different sample chunks) in LDS, a few
     // classes per round (the 32 KiB tile buffer holds 8 x 1024 floats), and store the workgroup's
@@ -835,6 +1079,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       }
     }
   }
+  DCTN_STAMP(p, 5);
 }
 
 // dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a].  One workgroup per 32 consecutive
@@ -1026,6 +1271,9 @@ void fill_mp(MfmaP& m, const EpsP& p, const void* x, int dtype) {
              p.s[3] % 2 == 0 && ((uintptr_t)x % 4) == 0;
   m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0; m.ncb = 0;
   m.opts = p.opts;
+#ifdef DCTN_STAMPS
+  m.stamps = g_stamps;
+#endif
 }
 
 constexpr int FWD_BLOCKS_PER_CU = 4;
@@ -1181,6 +1429,32 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   return DCTN_OK;
 }
 
+// forward of (EPS layer -> flatten -> linear head) as one kernel (bf16, fast input layout only)
+template <int N0, int N1, int OP>
+int fwd_head_launch_t(const void* x, const void* core, const void* hw, const void* bias, void* out, void* logits,
+                      const MfmaP& m_in, hipStream_t st) {
+  typedef bf16_t S;
+  MfmaP m = m_in;
+  if (m.O != OP || !(m.rowvec_ok && m.vec_ok) || m.npg > HEAD_FWD_MAXPG) return DCTN_ERR_UNSUPPORTED;
+  if (((uintptr_t)hw % (OP * 2)) != 0 || ((uintptr_t)out % (OP * 2)) != 0 || ((uintptr_t)logits % 2) != 0 ||
+      m.hw_rowb % (OP * 2) != 0)
+    return DCTN_ERR_UNSUPPORTED;
+  int nwg = m.B < NUM_CU ? m.B : NUM_CU;
+  m.spc = (m.B + nwg - 1) / nwg;
+  nwg = (m.B + m.spc - 1) / m.spc;
+  const dim3 g((unsigned)nwg), b((unsigned)(64 * m.npg));
+  constexpr int RW = (N0 + N1) == 9 ? 3 : 4;
+  if (m.Cout <= 10)
+    hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW, 10>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
+                       (const S*)bias, (S*)out, (S*)logits, m);
+  else
+    hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW, 16>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
+                       (const S*)bias, (S*)out, (S*)logits, m);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("eps_head_fwd_mfma_q2reg");
+  return DCTN_OK;
+}
+
 #define DISPATCH_OP(FN, S, N0, N1, OPV, ...)                         \
   switch (OPV) {                                                     \
     case 2: return FN<S, N0, N1, 2>(__VA_ARGS__);                    \
@@ -1279,6 +1553,24 @@ int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, cons
   }
   if (p.O == 2) return bwd_head_launch_t<4, 4, 2>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
   return bwd_head_launch_t<4, 4, 4>(x, dLogits, head_w, feat, dCore, dW, dBias, ws, core_ws, m, st);
+}
+
+// Forward of the same tail: features (stored, the backward needs them) and logits from one kernel.
+int eps_head_fwd_mfma(const void* x, const void* core, const void* head_w, const void* bias, void* feat, void* logits,
+                      const EpsP& p, int Cout, int dtype, int precision, hipStream_t st) {
+  if (!head_family_ok(p, Cout, dtype, precision)) return DCTN_ERR_UNSUPPORTED;
+  MfmaP m;
+  fill_mp(m, p, x, dtype);
+  m.Cout = Cout;
+  const long long rowb = (long long)m.P * p.O * 2;
+  m.hw_rowb = (unsigned)rowb;
+  m.hw_bytes = (unsigned)(rowb * Cout);
+  if (p.N == 9) {
+    if (p.O == 2) return fwd_head_launch_t<5, 4, 2>(x, core, head_w, bias, feat, logits, m, st);
+    return fwd_head_launch_t<5, 4, 4>(x, core, head_w, bias, feat, logits, m, st);
+  }
+  if (p.O == 2) return fwd_head_launch_t<4, 4, 2>(x, core, head_w, bias, feat, logits, m, st);
+  return fwd_head_launch_t<4, 4, 4>(x, core, head_w, bias, feat, logits, m, st);
 }
 
 bool eps_mfma_covers(const EpsP& p, int dtype, int precision) { return family_ok(p, dtype, precision); }

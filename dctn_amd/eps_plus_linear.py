@@ -44,7 +44,9 @@ Initialization = Union[UnitEmpiricalOutputStd, UnitTheoreticalOutputStd, Manuall
 # Host-side routing switches (plain module attributes; tests flip them to compare the paths):
 #   FUSED_HEAD  - last EPS layer + flatten + linear head as one autograd node (`_EpsLinearHeadFunction`)
 #   HEAD_BWD    - backward of the stand-alone linear head: "blas" (library GEMMs, measured faster) or "hip"
+#   FUSED_HEAD_FWD - inside that node: forward of layer + head as one kernel (`dctn_eps_head_fwd`) or as two
 FUSED_HEAD = True
+FUSED_HEAD_FWD = True
 HEAD_BWD = "blas"
 
 
@@ -135,17 +137,26 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
         core_c, w, b = core.contiguous(), weight.contiguous(), bias.contiguous()
         prec, code = L.precision(), L.dtype_code(x)
         feat = torch.empty((B, (H - K + 1) * (W - K + 1) * O), dtype=x.dtype, device=dev)
-        ws = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
-        L.check(
-            L.lib().dctn_eps_fwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), feat.data_ptr(), ws.data_ptr(),
-                                 ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
-            "eps forward",
-        )
         assert w.shape[1] == feat.shape[1]
         cout = w.shape[0]
         out = torch.empty((B, cout), dtype=x.dtype, device=dev)
-        L.check(L.lib().dctn_linear_head_fwd(feat.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B,
-                                             feat.shape[1], cout, code, L.stream_ptr(dev)), "linear head forward")
+        # one kernel for the layer and the head (`dctn_eps_head_fwd`); shapes / layouts it does not take run as two
+        rc = L.ERR_UNSUPPORTED
+        if FUSED_HEAD_FWD:
+            rc = L.lib().dctn_eps_head_fwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                           feat.data_ptr(), out.data_ptr(), C, B, H, W, Q, K, O, cout, code, prec,
+                                           L.stream_ptr(dev))
+        if rc == L.ERR_UNSUPPORTED:
+            ws = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
+            L.check(
+                L.lib().dctn_eps_fwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), feat.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
+                "eps forward",
+            )
+            L.check(L.lib().dctn_linear_head_fwd(feat.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B,
+                                                 feat.shape[1], cout, code, L.stream_ptr(dev)), "linear head forward")
+        else:
+            L.check(rc, "eps + linear head forward")
         ctx.save_for_backward(core_c, x, feat, w)
         ctx.dims = (C, B, H, W, Q, K, O, prec)
         return out

@@ -117,6 +117,19 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
                  int C, int B, int H, int W, int Q, int K, int O,
                  int dtype, int policy, void* stream);
 
+/* Forward of (EPS layer -> "b h w q -> b (h w q)" -> nn.Linear), the tail of EPSesPlusLinear.forward (reference:
+ * dctn/eps_plus_linear.py:144-147), as ONE kernel: a workgroup holds all window positions of a few samples, so the
+ * head's sum over (position, output) closes inside the workgroup - no second launch, no re-read of the features.
+ *   features : (B, H'*W'*O) contiguous, OVERWRITTEN (the layer's output; the backward reads it)
+ *   logits   : (B, Cout) contiguous, OVERWRITTEN = features @ head_weight^T + head_bias, products of the stored
+ *              (bf16-rounded) features with the bf16 weight, float32 sums
+ * bfloat16, contiguous x, the register-resident family with O in {2, 4}, Cout <= 16 and at most 768 window positions
+ * per sample; DCTN_ERR_UNSUPPORTED otherwise (the caller then runs dctn_eps_fwd + dctn_linear_head_fwd). */
+int dctn_eps_head_fwd(const void* x, const int64_t x_strides[5], const void* core, const void* head_weight,
+                      const void* head_bias, void* features, void* logits,
+                      int C, int B, int H, int W, int Q, int K, int O, int Cout,
+                      int dtype, int policy, void* stream);
+
 /* Backward of (EPS layer -> "b h w q -> b (h w q)" -> nn.Linear), the tail of
  * EPSesPlusLinear.forward (reference: dctn/eps_plus_linear.py:144-147), in one pass over x: the
  * kernel forms dY[b,h,w,o] = sum_c dLogits[b,c] * head_weight[c, (h*W'+w)*O + o] on the fly, so the

@@ -884,3 +884,43 @@ def test_fused_cross_entropy_invalid_label_poisons_loss_and_gradient():
     logits.grad = None
     (2.0 * fused_cross_entropy(logits, labels)).backward()
     assert torch.isnan(logits.grad[3]).all() and torch.isfinite(logits.grad[[0, 1, 2, 4, 5]]).all()
+
+
+@pytest.mark.parametrize("C,K,O,size,B,cout", [(1, 3, 4, 28, 37, 10), (1, 3, 4, 28, 1024, 10), (1, 3, 2, 12, 9, 16), (2, 2, 4, 9, 5, 6),
+                                               (1, 3, 4, 30, 3, 10), (1, 3, 4, 40, 2, 10)])
+def test_fused_forward_of_layer_and_head_matches_the_two_kernels(C, K, O, size, B, cout):
+    """`dctn_eps_head_fwd` (layer + flatten + linear head in one kernel, a workgroup = all positions of a few samples)
+    against dctn_eps_fwd + dctn_linear_head_fwd: the stored features must be bit-identical (same arithmetic), the
+    logits equal up to the order of the float32 sums; shapes with more than 768 positions fall back (40x40)."""
+    from dctn_amd import _lib as L
+
+    torch.manual_seed(1000 * K + 10 * O + size + B)
+    N = K * K * C
+    u = torch.rand(C, B, size, size)
+    x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1).bfloat16().to(DEV)
+    core = (torch.randn(*(2,) * N, O) * 2 ** (-N / 4)).bfloat16().to(DEV)
+    Ho = size - K + 1
+    F = Ho * Ho * O
+    w = (torch.randn(cout, F) * F ** -0.5).bfloat16().to(DEV)
+    bias = torch.randn(cout).bfloat16().to(DEV)
+    lib, code = L.lib(), L.dtype_code(x)
+    feat_a, feat_b = torch.empty(B, F, dtype=torch.bfloat16, device=DEV), torch.zeros(B, F, dtype=torch.bfloat16, device=DEV)
+    log_a, log_b = torch.empty(B, cout, dtype=torch.bfloat16, device=DEV), torch.zeros(B, cout, dtype=torch.bfloat16, device=DEV)
+    ws = L.workspace(lib.dctn_eps_fwd_workspace_bytes(C, B, size, size, 2, K, O, code, 0), DEV)
+    L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), feat_a.data_ptr(), ws.data_ptr(), ws.numel(),
+                             C, B, size, size, 2, K, O, code, 0, L.stream_ptr(DEV)), "fwd")
+    rc = lib.dctn_eps_head_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), w.data_ptr(), bias.data_ptr(), feat_b.data_ptr(),
+                               log_b.data_ptr(), C, B, size, size, 2, K, O, cout, code, 0, L.stream_ptr(DEV))
+    if Ho * Ho > 768:
+        assert rc == L.ERR_UNSUPPORTED
+        return
+    L.check(rc, "fused forward")
+    assert dctn_amd.last_kernel() == "eps_head_fwd_mfma_q2reg"
+    torch.cuda.synchronize()
+    assert torch.equal(feat_a, feat_b)
+    want = torch.nn.functional.linear(feat_a.double(), w.double(), bias.double())
+    assert bf16_close(log_b, want.cpu())
+    if F % 8 == 0:   # the stand-alone head kernel's own shape constraint
+        L.check(lib.dctn_linear_head_fwd(feat_a.data_ptr(), w.data_ptr(), bias.data_ptr(), log_a.data_ptr(), B, F, cout, code,
+                                         L.stream_ptr(DEV)), "head")
+        assert float((log_a.float() - log_b.float()).abs().max()) <= 2 ** -7 * float(want.abs().max())
