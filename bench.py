@@ -676,6 +676,11 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch samples per GPU whatever N; strong: --batch is the GLOBAL batch, split over the N GPUs")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
+    ap.add_argument("--graph-steps", type=int, default=20,
+                    help="steps captured back to back into ONE HIP graph (default 20; when --steps is not a "
+                         "multiple: the largest divisor of --steps below it is used).  Every step does its full work; what is amortised is the ~6-8 us the GPU's command "
+                         "processor needs between two graph launches (rocprofv3: the gap between the last kernel of one "
+                         "replay and the first of the next), which was a sixth of a 36 us step")
     ap.add_argument("--graph-allreduce", default="auto", choices=["auto", "0", "1"],
                     help="capture the gradient all-reduce into the step's HIP graph.  auto (default): yes over RCCL when a "
                          "child-process probe shows that the capture works on this machine; 1: the same, and fail if it does "
@@ -772,6 +777,16 @@ def main():
         fwd_bwd()
         reducer()
 
+    gsteps = 1
+    if args.graph:   # the largest divisor of --steps that is <= --graph-steps: exactly K timed steps whatever K is
+        gsteps = max(d for d in range(1, max(1, args.graph_steps) + 1) if args.steps % d == 0)
+
+    def several(fn):
+        def body():
+            for _ in range(gsteps):
+                fn()
+        return body
+
     # Over RCCL the default is ONE graph per step with the collective inside (one host launch per step; the eager
     # collective made the step host-bound: 51.7 vs 42.3 us on one rank).  It is attempted only when the child-process
     # probe succeeded on every rank; if the capture then still fails, the run stops with a non-zero exit code instead
@@ -785,7 +800,7 @@ def main():
             fwd_bwd_reduce()
             torch.cuda.synchronize(dev)
             want = [p.grad.detach().float().clone() for p in model.parameters()]
-            graph = safe_capture(fwd_bwd_reduce, dev, warm=3)
+            graph = safe_capture(several(fwd_bwd_reduce), dev, warm=3)
             if not ddp.all_ranks_agree(graph is not None, dev):
                 log("capturing the step with the all-reduce inside failed although the probe passed; no safe fallback "
                     "inside this process - rerun with --graph-allreduce 0")
@@ -803,9 +818,14 @@ def main():
                 os._exit(4)
             reduce_in_graph = True
         else:
-            graph = safe_capture(fwd_bwd, dev, warm=3)
+            if reducer is not None:
+                gsteps = 1   # eager collective after every step: one step per graph
+            graph = safe_capture(several(fwd_bwd), dev, warm=3)
 
-    def step():
+    if graph is None:
+        gsteps = 1
+
+    def step():   # `gsteps` steps of the workload
         if graph is not None:
             graph.replay()
         else:
@@ -817,7 +837,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(-(-args.warmup // gsteps)):   # at least W warm-up steps (rounded up to whole graph launches)
         step()
     kernel_used = dctn_amd.last_kernel()
     block_s = []
@@ -825,7 +845,7 @@ def main():
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // gsteps):
             step()
         torch.cuda.synchronize(dev)
         barrier()
@@ -884,6 +904,7 @@ def main():
             "per_gpu_batch": batch,
             "parallelism": f"dp{world}",
             "hip_graph": graph is not None,
+            "steps_per_graph_launch": gsteps,
             "timing": f"median of {BLOCKS} blocks of {args.steps} steps (each block: barrier + synchronize on both sides, max over ranks)",
             "blocks_ms": [b * 1e3 for b in block_s],
             "allreduce_in_graph": reduce_in_graph,

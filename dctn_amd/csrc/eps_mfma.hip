@@ -566,52 +566,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OP <= 4 ? 4
 // As separate kernels the head costs a launch, a kernel boundary and a re-read of the features (14.6 of the 38 us of a
 // BASELINE cfg2 step).  Here a workgroup is ALL position groups (one wave each) of a few samples, so a sample's logits
 //   logits[b, c] = bias[c] + sum_(pos, o) W[c, pos, o] * features[b, pos, o]
-// meet inside the workgroup: the lane (= position) multiplies its bf16-rounded outputs - exactly what it stores -
-// with its slice of the head weight (v_dot2c_f32_bf16: bf16 products, f32 sums, the numerics of the stand-alone head
-// kernel), the wave sums its 64 lanes with a halving butterfly (v_permlane32_swap, v_permlane16_swap, DPP row
-// rotations: HEADC values cost ~3*HEADC instructions instead of 6*HEADC), lane 0 of each 16-lane row drops the
-// wave's sums into LDS and after every group of HS samples the workgroup adds the position groups and the bias.
+// meet inside the workgroup.  Per wave the sum over its 64 positions x OP outputs is a small GEMM on the matrix core
+// (v_mfma_f32_16x16x32_bf16: rows = classes, columns = the samples of a group, k = (position, output)), which also IS
+// the cross-lane reduction: the lane stores the bf16 pairs it writes to memory into a per-wave LDS tile
+// [sample][position][output] (one ds_write_b64), the B fragments come back as ds_read_b128 (k-contiguous), the A
+// fragments - the wave's slice of the head weight, W[c, 64 pg .. 64 pg + 63, :] - are loaded once per wave straight
+// from memory in fragment layout.  A first version did the products on the vector ALU (v_dot2c) and summed the lanes
+// with a swap/DPP butterfly: 460 cycles per sample and wave, which ate the launch it saved; this costs ~60.
 constexpr int HEAD_FWD_MAXPG = 12;   // waves per workgroup (launch bound 768 threads: 3-4 waves per SIMD)
-constexpr int HEAD_FWD_HS = 4;       // samples per LDS flush
+constexpr int HEAD_FWD_HS = 4;       // samples per group (columns of the head GEMM in use; one LDS flush per group)
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-// sum over the 16 lanes of a row, result in every lane of the row
-__device__ __forceinline__ float row_sum16(float v) {
-  v = dpp_add<0x128>(v);   // row_ror:8
-  v = dpp_add<0x124>(v);   // row_ror:4
-  v = dpp_add<0x122>(v);   // row_ror:2
-  v = dpp_add<0x121>(v);   // row_ror:1
-  return v;
-}
-// Sums NV per-lane values over the wave.  Afterwards lane (h = lane >> 5, p = (lane >> 4) & 1) holds, in w[i],
-// the total of value c = i + H2 * p + H1 * h  (H1 = ceil(NV / 2), H2 = ceil(H1 / 2); slots with i + H2 * p >= H1
-// or c >= NV hold garbage).
-template <int NV>
-struct WaveSums {
-  static constexpr int H1 = (NV + 1) / 2, H2 = (H1 + 1) / 2;
-  float w[H2];
-  __device__ __forceinline__ void reduce(const float (&v)[NV]) {
-    float u[H1];
-#pragma unroll
-    for (int i = 0; i < H1; ++i) {
-      float a = v[i], b = (i + H1 < NV) ? v[i + H1] : 0.f;
-      swap_halves(a, b);          // a = [v_i lo | v_(i+H1) lo], b = [v_i hi | v_(i+H1) hi]
-      u[i] = a + b;
-    }
-#pragma unroll
-    for (int i = 0; i < H2; ++i) {
-      const float a = u[i], b = (i + H2 < H1) ? u[i + H2] : 0.f;
-      // odd rows of a <-> even rows of b: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
-      const int2v r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
-      w[i] = row_sum16(__int_as_float(r[0]) + __int_as_float(r[1]));
-    }
-  }
-};
-
-template <int N0, int N1, int OP, int ROWS, int HEADC>
+template <int N0, int N1, int OP, int ROWS>
 __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(const bf16_t* __restrict__ x,
                                                                            const bf16_t* __restrict__ core,
                                                                            const bf16_t* __restrict__ hw,
@@ -619,13 +584,18 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
                                                                            bf16_t* __restrict__ out,
                                                                            bf16_t* __restrict__ logits, MfmaP p) {
   typedef bf16_t S;
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
   constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
   constexpr int LOGO = ilog2(OP);
   constexpr int TOT = A * BN * OP;
-  static_assert(OP % 2 == 0, "outputs are handled as bf16 pairs");
+  constexpr int HK = 64 * OP / 32;              // k-steps of the head GEMM of one wave (k = (position, output))
+  constexpr int SROW = 64 * OP + 8;             // shorts per sample row of the tile (+16 bytes: the samples' banks differ)
+  static_assert(OP % 2 == 0 && (64 * OP) % 32 == 0, "outputs are handled as bf16 pairs, 32 k per matrix step");
   __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
-  __shared__ float hsum[2][HEAD_FWD_HS][HEADC][HEAD_FWD_MAXPG];
+  __shared__ __attribute__((aligned(16))) short ftile[HEAD_FWD_MAXPG][HEAD_FWD_HS * SROW];
+  __shared__ float hsum[2][HEAD_FWD_HS][16][HEAD_FWD_MAXPG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
+  DCTN_STAMP(p, 0);
   const int b0 = (int)blockIdx.x * p.spc, b1 = b0 + p.spc < p.B ? b0 + p.spc : p.B;
   const int pos = wv * 64 + lane;
   const bool valid = pos < p.P;
@@ -634,16 +604,26 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
   const unsigned voff_x = valid ? ho * p.s2b + wo * p.s3b : p.x_bytes;
   const unsigned voff_o = valid ? pu * (unsigned)(OP * 2) : p.o_bytes;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
-  RawWindow<S, N, true, ROWS> raw;
-  if (b0 < b1) issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)b0 * p.s1b, p, raw);
-  // the lane's slice of the head weight, kept as packed bf16 pairs: W[c, pos, 0..OP)
-  RawRow<S, OP> wr[HEADC];
+  // a group's samples are all in flight before the first is used (a sample's rows are fresh lines: ~1.5 us from
+  // HBM / MALL, two to three steps of arithmetic; a one-deep prefetch left the SIMDs waiting), and a slot is re-issued
+  // for the next group as soon as it has been unpacked
+  RawWindow<S, N, true, ROWS> raw[HEAD_FWD_HS];
+#pragma unroll
+  for (int u = 0; u < HEAD_FWD_HS; ++u) {
+    const int bu = b0 + u < b1 ? b0 + u : (b1 > b0 ? b1 - 1 : b0);
+    if (b0 < b1) issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)bu * p.s1b, p, raw[u]);
+  }
+  // A fragments of the head GEMM: lane (c = lane % 16, g = lane / 16) holds W[c, k = 32 ks + 8 g .. + 7] of this wave's
+  // positions; rows c >= Cout and bytes past the end of the weight read zeros (range check).  A position past P
+  // inside a row meets a zero feature (lanes without a position produce zeros), so it needs no mask.
+  bf16x8 wf[HK];
   {
     const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
-    const unsigned voff_hw = valid ? (unsigned)pos * (unsigned)(OP * 2) : p.hw_bytes;
+    const int c = lane & 15, g = lane >> 4;
+    const unsigned base = c < p.Cout ? (unsigned)c * p.hw_rowb + (unsigned)(wv * 64 * OP + 8 * g) * 2u : p.hw_bytes;
 #pragma unroll
-    for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
-      issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, wr[c]);
+    for (int ks = 0; ks < HK; ++ks)
+      wf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hw, base, (unsigned)(ks * 64), 0));
   }
   // core -> LDS in fragment order (as eps_fwd_q2reg_k), by however many threads the workgroup has: batches of 4
   // elements per thread, the 4 loads of a batch in flight together
@@ -671,15 +651,22 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
     for (int s = 0; s < KS; ++s)
       cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
 
-  const int h = lane >> 5, rp = (lane >> 4) & 1;
+  short* tile = &ftile[wv][0];
+  // B fragment reads: lane (column = sample lane % 16, clamped to the group; k group lane / 16)
+  const int bcol = (lane & 15) < HEAD_FWD_HS ? (lane & 15) : HEAD_FWD_HS - 1;
+  const short* brd = tile + bcol * SROW + 8 * (lane >> 4);
+  DCTN_STAMP(p, 1);
   for (int g0 = b0, grp = 0; g0 < b1; g0 += HEAD_FWD_HS, ++grp) {
     const int g1 = g0 + HEAD_FWD_HS < b1 ? g0 + HEAD_FWD_HS : b1;
-    for (int b = g0; b < g1; ++b) {
+#pragma unroll
+    for (int u = 0; u < HEAD_FWD_HS; ++u) {
+      const int b = g0 + u;
+      if (b >= g1) break;   // wave-uniform
       float xv[N][2];
-      unpack_window<S, N, true, ROWS>(raw, xv);
-      {  // prefetch the next sample (the last iteration re-reads its own)
-        const int bn = b + 1 < b1 ? b + 1 : b;
-        issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)bn * p.s1b, p, raw);
+      unpack_window<S, N, true, ROWS>(raw[u], xv);
+      {  // the same slot of the next group (past the end: a harmless re-read of the last sample)
+        const int bn = b + HEAD_FWD_HS < b1 ? b + HEAD_FWD_HS : b1 - 1;
+        issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)bn * p.s1b, p, raw[u]);
         __builtin_amdgcn_sched_barrier(0);
       }
       bf16x8 pf0[KS], pf1[KS];
@@ -728,7 +715,7 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
           }
         }
       }
-      // the lane's OP outputs as the bf16 pairs that go to memory ...
+      // the lane's OP outputs as the bf16 pairs that go to memory (lanes without a position: zeros) ...
       unsigned pk[OP / 2];
 #pragma unroll
       for (int i = 0; i < OP / 2; ++i) {
@@ -739,34 +726,37 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
       }
       if constexpr (OP == 2) {
         __builtin_amdgcn_raw_buffer_store_b32(pk[0], rs_o, voff_o, (unsigned)b * p.o_s1b, 0);
+        *reinterpret_cast<unsigned*>(tile + (b - g0) * SROW + lane * OP) = pk[0];
       } else if constexpr (OP == 4) {
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rs_o, voff_o, (unsigned)b * p.o_s1b, 0);
+        *reinterpret_cast<u32x2*>(tile + (b - g0) * SROW + lane * OP) = u32x2{pk[0], pk[1]};
       } else {
 #pragma unroll
-        for (int i = 0; i < OP / 8; ++i)
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]}, rs_o, voff_o,
-                                                 (unsigned)b * p.o_s1b + 16u * i, 0);
-      }
-      // ... and their products with the head weight of this position (lanes without a position: all zeros)
-      float part[HEADC];
-#pragma unroll
-      for (int c = 0; c < HEADC; ++c) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < OP / 2; ++i)
-          a = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, wr[c].d[i]), __builtin_bit_cast(bf16x2, pk[i]), a, false);
-        part[c] = a;
-      }
-      WaveSums<HEADC> ws;
-      ws.reduce(part);
-      if ((lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < WaveSums<HEADC>::H2; ++i) {
-          const int j = i + WaveSums<HEADC>::H2 * rp, c = j + WaveSums<HEADC>::H1 * h;
-          if (j < WaveSums<HEADC>::H1 && c < HEADC) hsum[grp & 1][b - g0][c][wv] = ws.w[i];
+        for (int i = 0; i < OP / 8; ++i) {
+          const u32x4 q = u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(q, rs_o, voff_o, (unsigned)b * p.o_s1b + 16u * i, 0);
+          *reinterpret_cast<u32x4*>(tile + (b - g0) * SROW + lane * OP + 8 * i) = q;
         }
       }
+      if (b == b0) DCTN_STAMP(p, 2);
     }
+    // ... and the group's head GEMM of this wave: D[c, s] = sum_k W[c, k] * features[s, k]
+    wave_lds_sync();
+    f32x4v hd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks) {
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(brd + 32 * ks);
+      hd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], fb, hd, 0, 0, 0);
+    }
+    wave_lds_sync();   // the tile is free for the next group's rows
+    {  // D: column = lane % 16 (sample of the group), rows 4 (lane / 16) + v (classes)
+      const int sl = lane & 15, cb = 4 * (lane >> 4);
+      if (sl < g1 - g0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) hsum[grp & 1][sl][cb + v][wv] = hd[v];
+      }
+    }
+    DCTN_STAMP(p, 3);
     __syncthreads();   // one barrier per group: the buffers alternate, a buffer is rewritten two groups later
     for (int e = tid; e < (g1 - g0) * p.Cout; e += (int)blockDim.x) {
       const int sl = e / p.Cout, c = e - sl * p.Cout;
@@ -775,6 +765,7 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
       logits[(long long)(g0 + sl) * p.Cout + c] = (bf16_t)t;
     }
   }
+  DCTN_STAMP(p, 4);
 }
 
 // ------------------------------------------------------------------------------ backward: dCore
@@ -1436,20 +1427,15 @@ int fwd_head_launch_t(const void* x, const void* core, const void* hw, const voi
   typedef bf16_t S;
   MfmaP m = m_in;
   if (m.O != OP || !(m.rowvec_ok && m.vec_ok) || m.npg > HEAD_FWD_MAXPG) return DCTN_ERR_UNSUPPORTED;
-  if (((uintptr_t)hw % (OP * 2)) != 0 || ((uintptr_t)out % (OP * 2)) != 0 || ((uintptr_t)logits % 2) != 0 ||
-      m.hw_rowb % (OP * 2) != 0)
-    return DCTN_ERR_UNSUPPORTED;
+  // 16-byte weight fragments, (OP * 2)-byte feature rows
+  if (((uintptr_t)hw % 16) != 0 || m.hw_rowb % 16 != 0 || ((uintptr_t)out % (OP * 2)) != 0) return DCTN_ERR_UNSUPPORTED;
   int nwg = m.B < NUM_CU ? m.B : NUM_CU;
   m.spc = (m.B + nwg - 1) / nwg;
   nwg = (m.B + m.spc - 1) / m.spc;
   const dim3 g((unsigned)nwg), b((unsigned)(64 * m.npg));
   constexpr int RW = (N0 + N1) == 9 ? 3 : 4;
-  if (m.Cout <= 10)
-    hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW, 10>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
-                       (const S*)bias, (S*)out, (S*)logits, m);
-  else
-    hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW, 16>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
-                       (const S*)bias, (S*)out, (S*)logits, m);
+  hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
+                     (const S*)bias, (S*)out, (S*)logits, m);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_head_fwd_mfma_q2reg");
   return DCTN_OK;
