@@ -771,6 +771,8 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
 // ------------------------------------------------------------------------------ backward: dCore
 // feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
 constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LDS reduction per block)
+// dynamic LDS of the dCore kernel's LDST path: per wave one P0 tile and MT Z tiles of [64 windows][32 features] bf16
+constexpr size_t dcore_dyn_lds_bytes(int mt) { return (size_t)BWD_WAVES * (1 + mt) * 64 * 32 * sizeof(short); }
 
 // HEADC > 0: fused classifier-head backward.  dY is not read; instead `dY` points at dLogits
 // (B, Cout) and `hw` at the head weight (Cout, P*O), both bf16, and the wave forms
@@ -1015,33 +1017,58 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   DCTN_STAMP(p, 3);
   // workgroup reduction of the per-wave partial dCoreT tiles, then one coalesced store per block
   float* dst = partial + (long long)blockIdx.x * (MT * 32) * (AT * 32);
+  if constexpr (LDST) {
+    // the transposition tiles (96 KiB) are free once every wave has left the loop: all MT tiles of all waves meet
+    // there in ONE round (two barriers) instead of one round per tile through the 32 KiB static buffer
+    static_assert(AT == 1 && (size_t)BWD_WAVES * MT * 1024 * 4 <= dcore_dyn_lds_bytes(MT), "dCore tiles must fit");
+    float* big = reinterpret_cast<float*>(dsm);
+    __syncthreads();
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int a = 0; a < AT; ++a) {
-      __syncthreads();
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
-        red[wv][row * 32 + r] = acc[t][a][v];
+        big[(wv * MT + t) * 1024 + row * 32 + r] = acc[t][0][v];
       }
-      __syncthreads();
-      for (int e = tid; e < 1024; e += 64 * BWD_WAVES) {
-        float sum = 0.f;
+    __syncthreads();
+    for (int e = tid; e < MT * 1024; e += 64 * BWD_WAVES) {
+      float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < BWD_WAVES; ++k) sum += red[k][e];
-        const int row = e >> 5, col = e & 31;
-        dst[(long long)(t * 32 + row) * (AT * 32) + a * 32 + col] = sum;
-      }
+      for (int k = 0; k < BWD_WAVES; ++k) sum += big[k * MT * 1024 + e];
+      dst[e] = sum;   // [t][row][col] = row-major (MT * 32) x 32
     }
+  } else {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int a = 0; a < AT; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
+          red[wv][row * 32 + r] = acc[t][a][v];
+        }
+        __syncthreads();
+        for (int e = tid; e < 1024; e += 64 * BWD_WAVES) {
+          float sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < BWD_WAVES; ++k) sum += red[k][e];
+          const int row = e >> 5, col = e & 31;
+          dst[(long long)(t * 32 + row) * (AT * 32) + a * 32 + col] = sum;
+        }
+      }
+  }
 
   DCTN_STAMP(p, 4);
   if constexpr (HEADC > 0) {
-    // head-weight gradient: sum the 8 waves (same positions, different sample chunks) in LDS, a few
-    // classes per round (the 32 KiB tile buffer holds 8 x 1024 floats), and store the workgroup's
-    // partial tile; LDS index (cc*64 + lane)*OP + o makes the stores run along the feature index
-    constexpr int CPR = 1024 / (64 * OP);   // classes per round
-    float* red1 = &red[0][0];
+    // head-weight gradient: sum the 8 waves (same positions, different sample chunks) in LDS and store the
+    // workgroup's partial tile; LDS index (cc*64 + lane)*OP + o makes the stores run along the feature index.
+    // LDST shapes: as many classes per round as the 96 KiB of tiles hold (all 10 of cfg2: one round); others: the
+    // 32 KiB static buffer, a few classes per round.
+    constexpr int SLOT = LDST ? (int)(dcore_dyn_lds_bytes(MT) / (BWD_WAVES * 4)) : 1024;   // floats per wave
+    constexpr int CPR_RAW = SLOT / (64 * OP);
+    constexpr int CPR = CPR_RAW > HEADC ? HEADC : CPR_RAW;   // classes per round
+    float* red1 = LDST ? reinterpret_cast<float*>(dsm) : &red[0][0];
     const int nbk = gridDim.x;
     const int vbk = (nbk % 8 == 0) ? (int)(blockIdx.x % 8) * (nbk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int cb = vbk / p.npg, pg = vbk - cb * p.npg;
@@ -1057,13 +1084,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
           float v = 0.f;
 #pragma unroll
           for (int c = 0; c < HEADC; ++c) v = (c == c0 + cc) ? dwacc[c][o] : v;
-          red1[wv * 1024 + (cc * 64 + lane) * OP + o] = v;
+          red1[wv * SLOT + (cc * 64 + lane) * OP + o] = v;
         }
       __syncthreads();
       for (int e = tid; e < CPR * 64 * OP; e += 64 * BWD_WAVES) {
         float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < BWD_WAVES; ++k) sum += red1[k * 1024 + e];
+        for (int k = 0; k < BWD_WAVES; ++k) sum += red1[k * SLOT + e];
         const int cc = e / (64 * OP), rem = e - cc * (64 * OP);   // rem = lane*OP + o
         const int c = c0 + cc, f = pg * 64 * OP + rem;
         if (cb < p.ncb && c < p.Cout && f < F) dwpart[((long long)cb * p.Cout + c) * F + f] = sum;

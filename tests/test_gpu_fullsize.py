@@ -112,7 +112,8 @@ def test_cfg2_full_batch_1024_bf16():
     out_f, gf, kf = grads(x, g, True)
     out_u, gu, ku = grads(x, g, False)
     assert kf == "eps_head_bwd_mfma_q2reg" and ku != kf
-    assert torch.equal(out_f, out_u)
+    # same features; the fused forward sums the head's products in another order than the stand-alone head kernel
+    assert float((out_f.float() - out_u.float()).abs().max()) <= 2 ** -7 * float(out_u.float().abs().max())
     w64, b64 = model.linear.weight.detach().cpu().double(), model.linear.bias.detach().cpu().double()
     want_logits = R.eps_plus_linear_forward([core.cpu().double()], w64, b64, x[:, idx].cpu().double())
     assert rel_err(out_f[idx], want_logits) < 2e-2

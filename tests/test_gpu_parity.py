@@ -555,7 +555,8 @@ def test_eps_plus_linear_fused_head_backward(K, O, size, B):
     out_f, grads_f, kern_f = run(True)
     out_u, grads_u, kern_u = run(False)
     assert kern_f == "eps_head_bwd_mfma_q2reg" and kern_u != kern_f
-    assert torch.equal(out_f, out_u)
+    # same features; the fused forward sums the head's products in another order than the stand-alone head kernel
+    assert float((out_f.float() - out_u.float()).abs().max()) <= 2 ** -7 * float(out_u.float().abs().max())
     core64 = m.epses[0].detach().cpu().double().requires_grad_(True)
     w64 = m.linear.weight.detach().cpu().double().requires_grad_(True)
     b64 = m.linear.bias.detach().cpu().double().requires_grad_(True)
