@@ -28,6 +28,8 @@ struct SbsMP {
   int dacc_off[SBSM_MAXC + 1];  // backward: float offset of core c's dCore accumulator in LDS
   long long st_off[SBSM_MAXC + 1];  // backward: element offsets of the stored forward states
   float* dcore[SBSM_MAXC];    // backward: global dCore (zero-initialised by the caller)
+  int apack2_off[SBSM_MAXC];  // backward (16x16x4 kernel): float offset of core c's adjoint pack
+  int zt_off, vt_off;         // backward (16x16x4 kernel): per-wave transposition tiles
   int first_off, last_off;    // float offsets of the first / last core tables in LDS
   int fs_off;                 // float offset of the per-wave feature slices (4 waves x n*4*32)
   unsigned char digit[4][4];  // digit[qq][ch]: feature index of channel ch in the flat index qq (host-filled)
@@ -72,6 +74,7 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 // All feature products of a window (every core of the string) at once: the pixel loads of up to 8
 // cores are issued back to back (one memory round trip per chunk instead of one per core), the
 // products go to the wave's LDS slice fs[(c*4 + qq)*32 + window] and are read back per core.
+template <int WPG = 32>
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
@@ -99,7 +102,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
             const float xs = dg == 0 ? raw[cc][ch][0] : dg == 1 ? raw[cc][ch][1] : dg == 2 ? raw[cc][ch][2] : raw[cc][ch][3];
             pr *= ch < p.C ? xs : 1.f;
           }
-          fs[((c0 + cc) * 4 + qq) * 32 + (lane & 31)] = pr;   // both lane halves hold the same window
+          fs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = pr;   // WPG = 32: both lane halves hold the same window
         }
       }
     }
@@ -514,6 +517,506 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------- backward, second version
+// The same adjoint sweep on v_mfma_f32_16x16x4_f32 (exact f32, 32 cycles): with R <= 16 the 32-row tiles of the first
+// version were half empty in two of its three products, its two transposes ran ON the matrix core (identity
+// operands: 40 of the 120 MFMAs per core and state) and every tile of dCore went through 32 conflicting ds_add_f32
+// per lane (PMC at r = 16: matrix pipe 26 % busy, LDS array 41 % busy, 537 us for 115 200 windows = 11x the forward).
+// Layout: a lane is (window wl = lane % 16, k group g = lane / 16) of a 16-window tile; a wave carries two tiles.
+//   state v[l, w]           : B-operand layout, register s of lane (wl, g) holds l = 4 s + g
+//   U = core x v            : M = (r', qq) in 16-row tiles (row i <-> r' = 4 mt + (i >> 2), qq = i & 3), K = l; the
+//                             accumulator gives lane (wl, g) the rows r' = 4 mt + g, qq = 0..3: the lane-local sum
+//                             over qq IS the next state register s = mt - the chain stays in registers
+//   adjoint dv              : M = l with rows permuted (row i <-> l = 4 (i & 3) + (i >> 2)) so that the accumulator is
+//                             in state layout again, K = (r', qq) ordered k-step 4 s2 + qq / group kg <-> r' = 4 s2 + kg,
+//                             i.e. the lane multiplies ITS OWN G[s2] by f[qq]; second LDS pack of the cores
+//   dCore += Z^T v          : windows are k: Z = f (x) G and v go through per-wave LDS tiles [window][feature]
+//                             (b128 row writes, conflict-free b32 fragment reads); the 16x16 tiles of a core's
+//                             gradient are added to a workgroup accumulator kept in ACCUMULATOR layout
+//                             [tile][reg][lane] (conflict-free ds_add_f32), re-ordered once at the final flush
+//   first / last core       : their gradients are lane-local sums kept in registers across all window groups
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int CTRL>
+__device__ __forceinline__ float sbs_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sbs_row_sum16(float v) {   // sum over the 16 lanes of a row, in every lane
+  v = sbs_dpp_add<0x128>(v);
+  v = sbs_dpp_add<0x124>(v);
+  v = sbs_dpp_add<0x122>(v);
+  return sbs_dpp_add<0x121>(v);
+}
+__device__ __forceinline__ float sbs_group_sum(float v) {   // sum over the four k groups (lanes wl, wl+16, wl+32, wl+48)
+  const int iv = __float_as_int(v);
+  const int2v r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  return half_sum(__int_as_float(r[0]) + __int_as_float(r[1]));
+}
+
+template <int R>
+__device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid) {
+  constexpr int MT = R / 4, KS = R / 4, KA = R;
+  for (int c = 1; c + 1 < p.n; ++c) {
+    const int oc = p.o[c];
+    for (int e = tid; e < oc * MT * KS * 64; e += 256) {
+      const int ln = e & 63, i = ln & 15, kg = ln >> 4;
+      int t2 = e >> 6;
+      const int s = t2 % KS; t2 /= KS;
+      const int mt = t2 % MT;
+      const int o = t2 / MT;
+      const int l = 4 * s + kg, rp = 4 * mt + (i >> 2), qq = i & 3;
+      lds[p.apack_off[c] + e] = qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+    }
+    for (int e = tid; e < oc * KA * 64; e += 256) {
+      const int ln = e & 63, i = ln & 15, kg = ln >> 4;
+      const int ks = (e >> 6) % KA, o = (e >> 6) / KA;
+      const int l = 4 * (i & 3) + (i >> 2), rp = 4 * (ks >> 2) + kg, qq = ks & 3;
+      lds[p.apack2_off[c] + e] = (l < R && qq < p.qc) ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+    }
+  }
+  for (int e = tid; e < R * 4; e += 256) {
+    const int rr = e >> 2, qq = e & 3;
+    lds[p.first_off + e] = qq < p.qc ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.qc + qq] : 0.f;
+  }
+}
+
+// NC > 0: the number of cores at compile time (the reference's 9-core snakes): the way back is unrolled over the
+// cores and every middle core's gradient tiles are REGISTER accumulators across all window groups of the wave
+// (slot c - 1; the one core that may have two outputs uses slot NC - 2 for its second): PMC showed the per-group
+// ds_add_f32 of the runtime-n form (NC == 0) keeping the LDS array busy 48 % of the kernel (~200 cycles per
+// wave-instruction, 176 of them per window group and wave) with the matrix pipe at 13 %.
+template <int R, int NC, int NT>
+__global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
+                                                            const float* __restrict__ dY,
+                                                            float* __restrict__ states,
+                                                            float* __restrict__ gxw, SbsMP p, int need_dx) {
+  constexpr int SN = R / 4, MT = R / 4, KS = R / 4, KA = R;
+  constexpr int ZROW = 4 * R + 16;   // floats per window row of the Z tile: rows 16 banks apart
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wl = lane & 15, g = lane >> 4, wv = tid >> 6;
+  pack_cores16<R>(lds, p, tid);
+  if constexpr (NC == 0) {   // (NC > 0: the accumulator region lies over the packs and is zeroed after the sweep)
+    const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
+    for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
+  }
+  __syncthreads();
+  constexpr int WPG = 16 * NT;   // windows per wave iteration: NT tiles of 16
+  float* fs = lds + p.fs_off + wv * p.n * 4 * WPG;
+  float* zt = lds + p.zt_off + wv * 16 * ZROW;
+  float* vt = lds + p.vt_off + wv * 256;
+  float dfirst[SN][4], dlast[SN][4];   // gradients of the first / last core: lane-local over all its windows
+#pragma unroll
+  for (int s = 0; s < SN; ++s)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { dfirst[s][qq] = 0.f; dlast[s][qq] = 0.f; }
+  constexpr int NSLOT = NC > 2 ? NC - 1 : 1;
+  f32x4 dreg[NSLOT][MT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) dreg[i][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long wave = (long long)blockIdx.x * 4 + wv;
+  const long long nwaves = (long long)gridDim.x * 4;
+  const int hw = p.Ho * p.Wo;
+  for (long long grp = wave; grp < p.ngroups; grp += nwaves) {
+    // the wave's 16 NT windows: staging uses one lane per window, the sweep's tile t holds windows 16 t + wl
+    long long wt[NT], bt[NT];
+    int hot[NT], wot[NT];
+    bool vt_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wt[t] = grp * WPG + 16 * t + wl;
+      vt_ok[t] = wt[t] < p.Wn;
+      const long long ww = vt_ok[t] ? wt[t] : 0;
+      bt[t] = ww / hw;
+      const int rem = (int)(ww - bt[t] * hw);
+      hot[t] = rem / p.Wo;
+      wot[t] = rem - hot[t] * p.Wo;
+    }
+    {
+      const long long w = grp * WPG + (lane & (WPG - 1));
+      const bool valid = w < p.Wn;
+      const long long ww = valid ? w : 0;
+      const long long b = ww / hw;
+      const int rem = (int)(ww - b * hw);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      stage_features<WPG>(x, p, b, ho, wo, valid, fs, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    float dy[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      dy[0][t] = vt_ok[t] ? dY[wt[t] * p.Otot] : 0.f;
+      dy[1][t] = (vt_ok[t] && p.Otot > 1) ? dY[wt[t] * p.Otot + 1] : 0.f;
+    }
+    float f[4][NT];
+    auto load_f = [&](int c) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) f[qq][t] = fs[(c * 4 + qq) * WPG + 16 * t + wl];
+    };
+    auto write_dx = [&](int c, const float (&df)[4][NT]) {
+      if (!need_dx || g != 0) return;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!vt_ok[t]) continue;
+        if (p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
+#pragma unroll
+          for (int qv = 0; qv < 4; ++qv)
+            if (qv < p.q) gxw[(long long)(c * p.q + qv) * p.Wn + wt[t]] = df[qv][t];
+          continue;
+        }
+        for (int ch = 0; ch < p.C; ++ch)
+          for (int qv = 0; qv < p.q; ++qv) {
+            float gsum = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              if (qq >= p.qc || p.digit[qq][ch] != qv) continue;
+              float pr = 1.f;
+              for (int c2 = 0; c2 < p.C; ++c2)
+                if (c2 != ch)
+                  pr *= x[c2 * p.s[0] + bt[t] * p.s[1] + (long long)(hot[t] + p.ph[c]) * p.s[2] +
+                          (long long)(wot[t] + p.pw[c]) * p.s[3] + p.digit[qq][c2] * p.s[4]];
+              gsum += df[qq][t] * pr;
+            }
+            gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + wt[t]] = gsum;
+          }
+      }
+    };
+    auto store_state = [&](int c, int oacc, const float (&a)[2][SN][NT]) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!vt_ok[t]) continue;
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+          states[(p.st_off[c] + 4 * s + g) * p.Wn + wt[t]] = a[0][s][t];
+          if (oacc > 1) states[(p.st_off[c] + R + 4 * s + g) * p.Wn + wt[t]] = a[1][s][t];
+        }
+      }
+    };
+    // U tiles of core c, output o, applied to state `vin`: D[mt][t] (rows r' = 4 mt + g, qq = register)
+    auto u_tiles = [&](int c, int o, const float (&vin)[SN][NT], f32x4 (&D)[MT][NT]) {
+      const float* ap = lds + p.apack_off[c] + o * MT * KS * 64 + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) D[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const float av = ap[(mt * KS + s) * 64];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) D[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vin[s][t], D[mt][t], 0, 0, 0);
+        }
+      }
+    };
+
+    // ---------------- forward sweep (input state of every core stored for the way back)
+    float v[2][SN][NT];
+    load_f(0);
+#pragma unroll
+    for (int s = 0; s < SN; ++s) {
+      const float* cp = lds + p.first_off + (4 * s + g) * 4;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        v[0][s][t] = cp[0] * f[0][t] + cp[1] * f[1][t] + cp[2] * f[2][t] + cp[3] * f[3][t];
+        v[1][s][t] = 0.f;
+      }
+    }
+    int oacc = 1;
+    for (int c = 1; c + 1 < p.n; ++c) {
+      store_state(c, oacc, v);
+      const int oc = p.o[c];
+      load_f(c);
+      float nv[2][SN][NT];
+#pragma unroll
+      for (int s = 0; s < SN; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { nv[0][s][t] = 0.f; nv[1][s][t] = 0.f; }
+      for (int a = 0; a < oacc; ++a)
+        for (int o = 0; o < oc; ++o) {
+          float vin[SN][NT];   // (a select, not a runtime index: the states stay in registers)
+#pragma unroll
+          for (int s = 0; s < SN; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) vin[s][t] = a == 0 ? v[0][s][t] : v[1][s][t];
+          f32x4 D[MT][NT];
+          u_tiles(c, o, vin, D);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float val = f[0][t] * D[mt][t][0] + f[1][t] * D[mt][t][1] + f[2][t] * D[mt][t][2] + f[3][t] * D[mt][t][3];
+              if (a * oc + o == 0) nv[0][mt][t] = val; else nv[1][mt][t] = val;
+            }
+        }
+#pragma unroll
+      for (int s = 0; s < SN; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { v[0][s][t] = nv[0][s][t]; v[1][s][t] = nv[1][s][t]; }
+      oacc *= oc;
+    }
+
+    // The way back reads the stored input state of core c while core c + 1 is being processed: the loads of the
+    // NEXT core's states are issued one core ahead (a state row is a fresh line; with one wave per SIMD nothing
+    // else hides the ~2 us round trip, 8 of them per window group).
+    float vnext[2][SN][NT];
+    int oacc_pf = oacc;   // number of input states of the core whose states are in flight
+    auto prefetch_state = [&](int c, int nstates) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+          vnext[0][s][t] = vt_ok[t] ? states[(p.st_off[c] + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+          vnext[1][s][t] = (vt_ok[t] && nstates > 1) ? states[(p.st_off[c] + R + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+        }
+    };
+    if (p.n > 2) {
+      oacc_pf = oacc / p.o[p.n - 2];
+      prefetch_state(p.n - 2, oacc_pf);
+    }
+    // ---------------- last core
+    float G[2][SN][NT];
+    {
+      load_f(p.n - 1);
+      float df[4][NT];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = 0.f;
+#pragma unroll
+      for (int s = 0; s < SN; ++s) {
+        const float* cp = lds + p.last_off + (4 * s + g) * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float tl = cp[0] * f[0][t] + cp[1] * f[1][t] + cp[2] * f[2][t] + cp[3] * f[3][t];
+          G[0][s][t] = dy[0][t] * tl;
+          G[1][s][t] = dy[1][t] * tl;
+          const float u = dy[0][t] * v[0][s][t] + dy[1][t] * v[1][s][t];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            df[qq][t] += u * cp[qq];
+            dlast[s][qq] += u * f[qq][t];
+          }
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = sbs_group_sum(df[qq][t]);
+      write_dx(p.n - 1, df);
+    }
+
+    // ---------------- middle cores, right to left
+    int oacc_out = oacc;
+#pragma unroll
+    for (int c = (NC > 0 ? NC : p.n) - 2; c >= 1; --c) {
+      const int oc = p.o[c];
+      const int oacc_in = oacc_out / oc;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < SN; ++s) { v[0][s][t] = vnext[0][s][t]; v[1][s][t] = vnext[1][s][t]; }
+      if (c > 1) prefetch_state(c - 1, oacc_in / p.o[c - 1]);
+      load_f(c);
+      float df[4][NT];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = 0.f;
+      float d[2][SN][NT];
+#pragma unroll
+      for (int s = 0; s < SN; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { d[0][s][t] = 0.f; d[1][s][t] = 0.f; }
+      for (int a = 0; a < oacc_in; ++a)
+        for (int o = 0; o < oc; ++o) {
+          const bool g_first = (a * oc + o) == 0;
+          float Gs[SN][NT], vin[SN][NT];
+#pragma unroll
+          for (int s = 0; s < SN; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              Gs[s][t] = g_first ? G[0][s][t] : G[1][s][t];
+              vin[s][t] = a == 0 ? v[0][s][t] : v[1][s][t];
+            }
+          // (1) d/d(features): df[qq] += sum_r' G[r'] U[(r', qq)]   (U recomputed: storing it would be 4R floats/window)
+          {
+            f32x4 D[MT][NT];
+            u_tiles(c, o, vin, D);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) df[qq][t] += Gs[mt][t] * D[mt][t][qq];
+          }
+          // (2) adjoint: dv[l] += sum_(r', qq) core[o, l, r', qq] f[qq] G[r']
+          {
+            const float* ap2 = lds + p.apack2_off[c] + o * KA * 64 + lane;
+            f32x4 D2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) D2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KA; ++ks) {
+              const float av = ap2[ks * 64];
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                D2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f[ks & 3][t] * Gs[ks >> 2][t], D2[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                if (a == 0) d[0][s][t] += D2[t][s]; else d[1][s][t] += D2[t][s];
+              }
+          }
+          // (3) dCore[o, l, r', qq] += sum_w v[l, w] f[qq, w] G[r', w]: windows on k through the wave's LDS tiles
+          {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();   // the previous tile's fragment reads are done
+#pragma unroll
+              for (int s = 0; s < SN; ++s) {
+                *reinterpret_cast<f32x4*>(zt + wl * ZROW + 16 * s + 4 * g) =
+                    f32x4{f[0][t] * Gs[s][t], f[1][t] * Gs[s][t], f[2][t] * Gs[s][t], f[3][t] * Gs[s][t]};
+                vt[wl * 16 + 4 * s + g] = vin[s][t];
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const float bv = vt[(4 * ks + g) * 16 + wl];                   // V[w = 4 ks + g][l = wl]
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                  const float av = zt[(4 * ks + g) * ZROW + 16 * mt + wl];     // Z[w][feature 16 mt + wl]
+                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
+                }
+              }
+            }
+            if constexpr (NC > 0) {
+              if (o == 0) {   // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dreg[c - 1][mt] += acc[mt];
+              } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dreg[NC - 2][mt] += acc[mt];
+              }
+            } else {
+              float* dc = lds + p.dacc_off[c] + o * MT * 256 + lane;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[(mt * 4 + vv) * 64], acc[mt][vv]);
+            }
+          }
+        }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = sbs_group_sum(df[qq][t]);
+      write_dx(c, df);
+#pragma unroll
+      for (int s = 0; s < SN; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { G[0][s][t] = d[0][s][t]; G[1][s][t] = d[1][s][t]; }
+      oacc_out = oacc_in;
+    }
+
+    // ---------------- first core
+    {
+      load_f(0);
+      float df[4][NT];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = 0.f;
+#pragma unroll
+      for (int s = 0; s < SN; ++s) {
+        const float* cp = lds + p.first_off + (4 * s + g) * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            df[qq][t] += G[0][s][t] * cp[qq];
+            dfirst[s][qq] += G[0][s][t] * f[qq][t];
+          }
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) df[qq][t] = sbs_group_sum(df[qq][t]);
+      write_dx(0, df);
+    }
+  }
+
+  if constexpr (NC > 0) {   // the register accumulators join the workgroup's LDS accumulator once
+    __syncthreads();        // every wave is done with the packs the accumulator region lies over
+    {
+      const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
+      for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 1; c + 1 < NC; ++c) {
+      float* dc = lds + p.dacc_off[c] + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[(mt * 4 + vv) * 64], dreg[c - 1][mt][vv]);
+      if (p.o[c] > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[MT * 256 + (mt * 4 + vv) * 64], dreg[NC - 2][mt][vv]);
+      }
+    }
+  }
+  // ---- first / last core: sum the 16 window lanes of a k group, one lane per group adds to the LDS accumulator
+  {
+    float* d0p = lds + p.dacc_off[0];
+    float* dlp = lds + p.dacc_off[p.n - 1];
+#pragma unroll
+    for (int s = 0; s < SN; ++s)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const float a = sbs_row_sum16(dfirst[s][qq]), b = sbs_row_sum16(dlast[s][qq]);
+        if (wl == 0 && qq < p.qc) {
+          atomicAdd(&d0p[(4 * s + g) * p.qc + qq], a);
+          atomicAdd(&dlp[(4 * s + g) * p.qc + qq], b);
+        }
+      }
+  }
+  // ---- flush the workgroup's accumulators (middle cores: accumulator layout -> the core's own layout)
+  __syncthreads();
+  for (int c = 0; c < p.n; ++c) {
+    const float* src = lds + p.dacc_off[c];
+    if (c == 0 || c == p.n - 1) {
+      const int E = R * p.qc;
+      for (int e = tid; e < E; e += 256) atomicAdd(&p.dcore[c][e], src[e]);
+    } else {
+      const int E = p.o[c] * MT * 256;
+      for (int e = tid; e < E; e += 256) {
+        const int ln = e & 63, l = ln & 15, gg = ln >> 4, vv = (e >> 6) & 3;
+        const int mt = (e >> 8) % MT, o = (e >> 8) / MT;
+        const int rp = 4 * mt + gg;
+        if (l < R && vv < p.qc) atomicAdd(&p.dcore[c][((o * R + l) * R + rp) * p.qc + vv], src[e]);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Family check + parameter block shared by forward and backward; *lds_floats = floats of LDS used
@@ -610,7 +1113,68 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
   if (rcf != DCTN_OK) return rcf;
   if (R > 16 || !dcores || !states) return DCTN_ERR_UNSUPPORTED;
   long long so = 0;
-  int oacc = 1, dacc = off;
+  int oacc = 1;
+  for (int c = 0; c < n; ++c) {
+    p.st_off[c] = so;
+    if (c >= 1) so += (long long)oacc * R;
+    oacc *= p.o[c];
+    p.dcore[c] = dcores[c];
+  }
+  p.st_off[n] = so;
+  {
+    // second version (16x16x4 tiles): its own LDS plan - two packs of every middle core, the accumulators in
+    // accumulator layout, the per-wave feature slices and transposition tiles
+    const int MT = R / 4, KS = R / 4, KA = R, ZROW = 4 * R + 16;
+    int o2 = 0;
+    SbsMP q2 = p;
+    for (int c = 1; c + 1 < n; ++c) { q2.apack_off[c] = o2; o2 += p.o[c] * MT * KS * 64; }
+    for (int c = 1; c + 1 < n; ++c) { q2.apack2_off[c] = o2; o2 += p.o[c] * KA * 64; }
+    q2.first_off = o2; o2 += R * 4;
+    q2.last_off = o2; o2 += R * 4;
+    const int NT16 = 2;   // window tiles per wave iteration (4 was tried for r = 16: 892 bytes of scratch per lane, slower)
+    q2.fs_off = o2; o2 += 4 * n * 4 * 16 * NT16;
+    q2.zt_off = o2; o2 += 4 * 16 * ZROW;
+    q2.vt_off = o2; o2 += 4 * 256;
+    // the workgroup's dCore accumulator: with the register accumulators (n == 9) it is only used by the final flush,
+    // when the packs are dead, and lies over them; otherwise it is a region of its own
+    int o3 = (n == 9) ? 0 : o2;
+    for (int c = 0; c < n; ++c) {
+      q2.dacc_off[c] = o3;
+      o3 += (c == 0 || c == n - 1) ? ((R * p.qc + 3) / 4 * 4) : p.o[c] * MT * 256;
+    }
+    q2.dacc_off[n] = o3;
+    if (o3 > o2) o2 = o3;
+    const size_t lds2 = (size_t)o2 * sizeof(float);
+    p.ngroups = (p.Wn + 16 * NT16 - 1) / (16 * NT16);
+    q2.ngroups = p.ngroups;
+    if (lds2 <= DCTN_LDS_BUDGET) {
+      long long blocks = (p.ngroups + 3) / 4;
+      const long long per_cu2 = (160 * 1024) / (long long)lds2 >= 2 ? 2 : 1;
+      if (blocks > 256 * per_cu2) blocks = 256 * per_cu2;
+#define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
+  do {                                                                                            \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV>,                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);             \
+    hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV>), dim3((unsigned)blocks), dim3(256), lds2, st, \
+                       (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);       \
+  } while (0)
+      switch (R) {   // 9 cores (mnist.py:189-223): the unrolled form; any other length: runtime loops
+        case 4: if (n == 9) SBS_LAUNCH_B16(4, 9, 2); else SBS_LAUNCH_B16(4, 0, 2); break;
+        case 8: if (n == 9) SBS_LAUNCH_B16(8, 9, 2); else SBS_LAUNCH_B16(8, 0, 2); break;
+        case 16: if (n == 9) SBS_LAUNCH_B16(16, 9, 2); else SBS_LAUNCH_B16(16, 0, 2); break;
+        default: return DCTN_ERR_UNSUPPORTED;
+      }
+#undef SBS_LAUNCH_B16
+      DCTN_CHECK_LAUNCH();
+      dctn_set_last_kernel("convsbs_bwd_mfma_f32");
+      return DCTN_OK;
+    }
+  }
+  // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
+  p.ngroups = (p.Wn + 31) / 32;
+  so = 0;
+  oacc = 1;
+  int dacc = off;
   for (int c = 0; c < n; ++c) {
     p.st_off[c] = so;
     if (c >= 1) so += (long long)oacc * R;
