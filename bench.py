@@ -876,8 +876,11 @@ def main():
             allreduce_us = device_time(ten, dev, 20) / 10 * 1e6
         else:
             allreduce_us = device_time(one_reduce, dev, 200, graph=False) * 1e6
-        g2 = safe_capture(fwd_bwd, dev, warm=1) if args.graph else None
-        step_without_allreduce_us = device_time(g2.replay if g2 is not None else fwd_bwd, dev, args.steps, graph=False) * 1e6
+        g2 = safe_capture(several(fwd_bwd), dev, warm=1) if args.graph else None   # same steps per launch as the step itself
+        if g2 is not None:
+            step_without_allreduce_us = device_time(g2.replay, dev, max(1, args.steps // gsteps), graph=False) / gsteps * 1e6
+        else:
+            step_without_allreduce_us = device_time(fwd_bwd, dev, args.steps, graph=False) * 1e6
         if world > 1:   # the slowest rank's figures
             t = torch.tensor([allreduce_us, step_without_allreduce_us], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -48,7 +48,9 @@ def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: t
     import subprocess
     import sys
 
-    env = dict(os.environ)
+    # the children rendezvous among themselves: under torchrun the parent's environment says "use the agent's store"
+    # (TORCHELASTIC_USE_AGENT_STORE), which on another port would wait for a server nobody starts
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + port_offset)
     env.setdefault("RANK", "0")
