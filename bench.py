@@ -221,6 +221,13 @@ def pmc_traffic(key):
                     _TRAFFIC.update(json.load(open(path)))
                 except Exception:
                     pass
+    if ":" in key and key.split(":", 1)[0] in _TRAFFIC and isinstance(_TRAFFIC[key.split(":", 1)[0]], list):
+        # side config: "<cfg>:<kernel substring>" -> the longest-running instantiation of that kernel in the config's profile
+        cfg, sub = key.split(":", 1)
+        hits = [e for e in _TRAFFIC[cfg] if sub in e["kernel"] and e.get("avg_us")]
+        if not hits:
+            return None
+        return int(max(hits, key=lambda e: e["avg_us"])["traffic_bytes"])
     v = _TRAFFIC.get(key)
     return int(v) if isinstance(v, (int, float)) else None
 
@@ -446,7 +453,7 @@ def extra_eps_model(name, dev, iters):
                      t["bytes_x"] * l["_nb"] + t["bytes_y"] + t["bytes_core"] * 2))
     us, what, call, fam, fl, by = max(cand)
     kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k"}.get(fam, fam)
-    roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:{what}",
+    roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:eps_bigcore_k", traffic_scope="longest eps_bigcore_k instantiation of the profiled config (profiles/r02_pmc_traffic.json)",
                           step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"],
                           step_algorithmic_flops=int(step_flops))
     for l in layers:
@@ -491,7 +498,7 @@ def extra_cfg1(dev, iters):
     gemm = t["gemm_flops"] * windows
     by_b = 2 * t["bytes_x"] + t["bytes_y"] + 2 * t["bytes_core"]
     roof = roofline_entry("mfma", "halves_gemm_k<double> (4 GEMMs: Z, dCore, dP0, Z again)", "dctn_eps_bwd", sb, 2 * gemm, by_b, dt,
-                          traffic_key="cfg1:bwd", fwd_call_us=sf * 1e6, fwd_tflops=gemm / sf / 1e12,
+                          traffic_key="cfg1:halves_gemm_k", traffic_scope="longest halves_gemm_k instantiation (one of the four GEMMs of the call)", fwd_call_us=sf * 1e6, fwd_tflops=gemm / sf / 1e12,
                           step_tflops=3 * gemm / t_fb / 1e12, step_frac=3 * gemm / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float64"],
                           family=fam)
     # CPU: the oracle's 4-step path in float64 on a bounded sample (8 of the 64 samples)
@@ -559,12 +566,12 @@ def extra_cfg4(r, dev, iters):
     by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
     if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
         roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:bwd", fwd_us=t_f * 1e6,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
                               fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
                               step_frac=3 * flops_fwd / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"], family=fam)
     else:         # HBM / launch-latency bound: bytes of the fused ideal against the HBM peak
         roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:bwd", fwd_us=t_f * 1e6,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
                               fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
                               step_frac=by_fb / t_fb / 1e9 / HBM_PEAK_GBS, family=fam)
     cores_n = usable_cores()
@@ -615,7 +622,7 @@ def extra_cfg5(dev, iters):
     t_b = max(t_fb - t_f, 1e-9)
     fl = Wn * (Ln - 1) * 2 * D ** 3
     roof = roofline_entry("hbm", "lme_fold16_bwd_mfma_k" if "mfma16" in fam_b else fam_b, "dctn_logmatmulexp_fold_bwd", t_b, 2 * fl, by_b,
-                          torch.float32, traffic_key="cfg5:bwd", fwd_kernel="lme_fold16_fwd_mfma_k" if "mfma16" in fam_f else fam_f,
+                          torch.float32, traffic_key="cfg5:lme_fold16_bwd_mfma_k", fwd_kernel="lme_fold16_fwd_mfma_k" if "mfma16" in fam_f else fam_f,
                           fwd_us=t_f * 1e6, fwd_gbs=by_f / t_f / 1e9, fwd_frac=by_f / t_f / 1e9 / HBM_PEAK_GBS,
                           step_gbs=(by_f + by_b) / t_fb / 1e9, step_frac=(by_f + by_b) / t_fb / 1e9 / HBM_PEAK_GBS,
                           bytes_per_window={"fwd": by_f // Wn, "bwd": by_b // Wn}, formulation="factored (exp -> MFMA -> log), exact fallback per step")
