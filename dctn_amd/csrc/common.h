@@ -109,4 +109,6 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
 int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
                      float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
-                     int q, int dtype, hipStream_t st);
+                     int q, int dtype, hipStream_t st, float* partials = nullptr, size_t partial_bytes = 0);
+// room for the per-workgroup partial-gradient records of the MFMA backward (deterministic dCore)
+constexpr int SBS_MAX_PARTIAL_RECORDS = 2048;

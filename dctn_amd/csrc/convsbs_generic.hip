@@ -368,6 +368,11 @@ size_t bwd_ws(const SbsP& p, int dtype) {
   total += align256((size_t)p.n * p.C * p.q * p.Wn * asz);           // per-window d/d(pixel features)
   if (dtype == DCTN_BF16)
     for (int c = 0; c < p.n; ++c) total += align256((size_t)core_elems(p, c) * asz);
+  if (dtype == DCTN_F32) {   // per-workgroup partial gradients of the MFMA backward (fixed-order reduce instead of atomics)
+    size_t ce = 0;
+    for (int c = 0; c < p.n; ++c) ce += (size_t)core_elems(p, c);
+    total += align256((size_t)SBS_MAX_PARTIAL_RECORDS * ce * sizeof(float));
+  }
   return total;
 }
 
@@ -429,8 +434,12 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
       float* dcp[SBS_MAXC];
       const void* cp[SBS_MAXC];
       for (int c = 0; c < p.n; ++c) { outs[c] = p.o[c]; bonds[c] = p.bl[c]; dcp[c] = (float*)p.dcore[c]; cp[c] = p.core[c]; }
+      size_t ce = 0;
+      for (int c = 0; c < p.n; ++c) ce += (size_t)core_elems(p, c);
+      const size_t pbytes = (size_t)SBS_MAX_PARTIAL_RECORDS * ce * sizeof(float);
+      float* partials = ((size_t)((unsigned char*)ws + ws_bytes - wsp) >= pbytes) ? (float*)wsp : nullptr;
       const int rcm = convsbs_bwd_mfma(x, (const int64_t*)p.s, cp, dY, (float*)states, dX ? (float*)gxw : nullptr, dcp, p.n, outs,
-                                       bonds, p.ph, p.pw, p.C, p.B, p.H, p.W, p.q, dtype, st);
+                                       bonds, p.ph, p.pw, p.C, p.B, p.H, p.W, p.q, dtype, st, partials, pbytes);
       if (rcm == DCTN_OK) {
         if (dX) {
           const long long total = (long long)p.C * p.B * p.H * p.W * p.q;

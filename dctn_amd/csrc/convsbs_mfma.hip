@@ -29,6 +29,8 @@ struct SbsMP {
   long long st_off[SBSM_MAXC + 1];  // backward: element offsets of the stored forward states
   float* dcore[SBSM_MAXC];    // backward: global dCore (zero-initialised by the caller)
   int apack2_off[SBSM_MAXC];  // backward (16x16x4 kernel): float offset of core c's adjoint pack
+  int core_off[SBSM_MAXC + 1];  // backward: float offset of core c inside one workgroup's partial-gradient record
+  float* partials;            // backward: [workgroup][core_off[n]] partial gradients (NULL: global float atomics)
   int zt_off, vt_off;         // backward (16x16x4 kernel): per-wave transposition tiles
   int first_off, last_off;    // float offsets of the first / last core tables in LDS
   int fs_off;                 // float offset of the per-wave feature slices (4 waves x n*4*32)
@@ -581,11 +583,13 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
   }
 }
 
-// NC > 0: the number of cores at compile time (the reference's 9-core snakes): the way back is unrolled over the
-// cores and every middle core's gradient tiles are REGISTER accumulators across all window groups of the wave
-// (slot c - 1; the one core that may have two outputs uses slot NC - 2 for its second): PMC showed the per-group
-// ds_add_f32 of the runtime-n form (NC == 0) keeping the LDS array busy 48 % of the kernel (~200 cycles per
-// wave-instruction, 176 of them per window group and wave) with the matrix pipe at 13 %.
+// NC > 0: strings of at most NC cores (NC = 9: the reference's snakes): every middle core's gradient tiles are REGISTER
+// accumulators across all window groups of the wave (slot c - 1; the one core that may have two outputs uses slot
+// NC - 2 for its second), selected by a switch on the (runtime) core index around the 16 adds only - PMC showed the
+// per-group ds_add_f32 of the NC == 0 form keeping the LDS array busy 48 % of the kernel (~200 cycles per
+// wave-instruction, 176 of them per window group and wave) with the matrix pipe at 13 %.  (Unrolling the whole way
+// back over the cores instead made the kernel 100 KB of code: it streamed through the 64 KB instruction cache once
+// per window group.)
 template <int R, int NC, int NT>
 __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
                                                             const float* __restrict__ dY,
@@ -815,8 +819,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
 
     // ---------------- middle cores, right to left
     int oacc_out = oacc;
-#pragma unroll
-    for (int c = (NC > 0 ? NC : p.n) - 2; c >= 1; --c) {
+    for (int c = p.n - 2; c >= 1; --c) {
       const int oc = p.o[c];
       const int oacc_in = oacc_out / oc;
 #pragma unroll
@@ -906,13 +909,18 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
               }
             }
             if constexpr (NC > 0) {
-              if (o == 0) {   // wave-uniform
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dreg[c - 1][mt] += acc[mt];
-              } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dreg[NC - 2][mt] += acc[mt];
+              const int slot = o == 0 ? c - 1 : NC - 2;   // wave-uniform
+#define SBS_ACC_CASE(I)                                                        \
+  case I:                                                                      \
+    if constexpr (I < NSLOT) {                                                 \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) dreg[I][mt] += acc[mt]; \
+    }                                                                          \
+    break;
+              switch (slot) {
+                SBS_ACC_CASE(0) SBS_ACC_CASE(1) SBS_ACC_CASE(2) SBS_ACC_CASE(3)
+                SBS_ACC_CASE(4) SBS_ACC_CASE(5) SBS_ACC_CASE(6) SBS_ACC_CASE(7)
               }
+#undef SBS_ACC_CASE
             } else {
               float* dc = lds + p.dacc_off[c] + o * MT * 256 + lane;
 #pragma unroll
@@ -970,6 +978,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
     __syncthreads();
 #pragma unroll
     for (int c = 1; c + 1 < NC; ++c) {
+      if (c + 1 >= p.n) continue;   // shorter strings
       float* dc = lds + p.dacc_off[c] + lane;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -998,22 +1007,56 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
         }
       }
   }
-  // ---- flush the workgroup's accumulators (middle cores: accumulator layout -> the core's own layout)
+  // ---- flush the workgroup's accumulators (middle cores: accumulator layout -> the core's own layout): one record of
+  // partial gradients per workgroup, summed in a fixed order by convsbs_dcore_reduce_k (deterministic; 256+ workgroups
+  // adding into the same 34 KB with float atomics ran at the contended atomic rate), or atomics when no room was given
   __syncthreads();
+  float* rec = p.partials ? p.partials + (long long)blockIdx.x * p.core_off[p.n] : nullptr;
   for (int c = 0; c < p.n; ++c) {
     const float* src = lds + p.dacc_off[c];
     if (c == 0 || c == p.n - 1) {
       const int E = R * p.qc;
-      for (int e = tid; e < E; e += 256) atomicAdd(&p.dcore[c][e], src[e]);
+      for (int e = tid; e < E; e += 256) {
+        if (rec) rec[p.core_off[c] + e] = src[e]; else atomicAdd(&p.dcore[c][e], src[e]);
+      }
     } else {
       const int E = p.o[c] * MT * 256;
       for (int e = tid; e < E; e += 256) {
         const int ln = e & 63, l = ln & 15, gg = ln >> 4, vv = (e >> 6) & 3;
         const int mt = (e >> 8) % MT, o = (e >> 8) / MT;
         const int rp = 4 * mt + gg;
-        if (l < R && vv < p.qc) atomicAdd(&p.dcore[c][((o * R + l) * R + rp) * p.qc + vv], src[e]);
+        if (l < R && vv < p.qc) {
+          const int idx = ((o * R + l) * R + rp) * p.qc + vv;
+          if (rec) rec[p.core_off[c] + idx] = src[e]; else atomicAdd(&p.dcore[c][idx], src[e]);
+        }
       }
     }
+  }
+}
+
+// dCore_c[e] = sum over the workgroups' records, fixed order: 64 elements per workgroup, 4 record subsets, LDS join
+__global__ __launch_bounds__(256) void convsbs_dcore_reduce_k(SbsMP p, int nrec) {
+  __shared__ float red[4][64];
+  const int total = p.core_off[p.n];
+  const int e = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < total) {
+    int r = sub;
+    for (; r + 12 < nrec; r += 16) {
+      a0 += p.partials[(long long)r * total + e];
+      a1 += p.partials[(long long)(r + 4) * total + e];
+      a2 += p.partials[(long long)(r + 8) * total + e];
+      a3 += p.partials[(long long)(r + 12) * total + e];
+    }
+    for (; r < nrec; r += 4) a0 += p.partials[(long long)r * total + e];
+  }
+  red[sub][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sub == 0 && e < total) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    int c = 0;
+    while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
+    p.dcore[c][e - p.core_off[c]] = v;
   }
 }
 
@@ -1049,6 +1092,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
     p.o[c] = out_sizes[c]; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
     p.core[c] = (const float*)cores[c];
     p.dcore[c] = nullptr;
+    p.partials = nullptr;
     max_h = pos_h[c] > max_h ? pos_h[c] : max_h;
     max_w = pos_w[c] > max_w ? pos_w[c] : max_w;
   }
@@ -1080,7 +1124,10 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
   const size_t lds = (size_t)off * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.ngroups + 3) / 4;
-  if (blocks > 256 * 2) blocks = 256 * 2;   // persistent: the core pack is paid once per workgroup
+  long long fwd_per_cu = lds > 0 ? (160 * 1024) / (long long)lds : 8;   // persistent: the core pack is paid once per workgroup
+  if (fwd_per_cu < 2) fwd_per_cu = 2;
+  if (fwd_per_cu > 8) fwd_per_cu = 8;
+  if (blocks > 256 * fwd_per_cu) blocks = 256 * fwd_per_cu;
 #define SBS_LAUNCH(RR)                                                                            \
   (void)hipFuncSetAttribute((const void*)convsbs_fwd_mfma_k<RR>,                                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
@@ -1106,7 +1153,7 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
 int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
                      float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
-                     int q, int dtype, hipStream_t st) {
+                     int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
@@ -1135,9 +1182,9 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     q2.fs_off = o2; o2 += 4 * n * 4 * 16 * NT16;
     q2.zt_off = o2; o2 += 4 * 16 * ZROW;
     q2.vt_off = o2; o2 += 4 * 256;
-    // the workgroup's dCore accumulator: with the register accumulators (n == 9) it is only used by the final flush,
+    // the workgroup's dCore accumulator: with the register accumulators (n <= 9) it is only used by the final flush,
     // when the packs are dead, and lies over them; otherwise it is a region of its own
-    int o3 = (n == 9) ? 0 : o2;
+    int o3 = (n <= 9) ? 0 : o2;
     for (int c = 0; c < n; ++c) {
       q2.dacc_off[c] = o3;
       o3 += (c == 0 || c == n - 1) ? ((R * p.qc + 3) / 4 * 4) : p.o[c] * MT * 256;
@@ -1147,10 +1194,20 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     const size_t lds2 = (size_t)o2 * sizeof(float);
     p.ngroups = (p.Wn + 16 * NT16 - 1) / (16 * NT16);
     q2.ngroups = p.ngroups;
+    q2.core_off[0] = 0;
+    for (int c = 0; c < n; ++c) {
+      const int L = c == 0 ? 1 : R, Rr = c == n - 1 ? 1 : R;
+      q2.core_off[c + 1] = q2.core_off[c] + p.o[c] * L * Rr * p.qc;
+    }
     if (lds2 <= DCTN_LDS_BUDGET) {
       long long blocks = (p.ngroups + 3) / 4;
-      const long long per_cu2 = (160 * 1024) / (long long)lds2 >= 2 ? 2 : 1;
+      // latency-bound sweeps: as many workgroups as the LDS plan lets a CU hold (the small-bond strings fit several;
+      // 3 600 window groups then run in one round instead of two or four)
+      long long per_cu2 = (160 * 1024) / (long long)lds2;
+      if (per_cu2 < 1) per_cu2 = 1;
+      if (per_cu2 > 8) per_cu2 = 8;
       if (blocks > 256 * per_cu2) blocks = 256 * per_cu2;
+      q2.partials = (partials && partial_bytes >= (size_t)blocks * q2.core_off[n] * sizeof(float)) ? partials : nullptr;
 #define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
   do {                                                                                            \
     (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV>,                    \
@@ -1158,14 +1215,18 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV>), dim3((unsigned)blocks), dim3(256), lds2, st, \
                        (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);       \
   } while (0)
-      switch (R) {   // 9 cores (mnist.py:189-223): the unrolled form; any other length: runtime loops
-        case 4: if (n == 9) SBS_LAUNCH_B16(4, 9, 2); else SBS_LAUNCH_B16(4, 0, 2); break;
-        case 8: if (n == 9) SBS_LAUNCH_B16(8, 9, 2); else SBS_LAUNCH_B16(8, 0, 2); break;
-        case 16: if (n == 9) SBS_LAUNCH_B16(16, 9, 2); else SBS_LAUNCH_B16(16, 0, 2); break;
+      switch (R) {   // up to 9 cores (mnist.py:189-223): register accumulators; longer strings: LDS accumulators
+        case 4: if (n <= 9) SBS_LAUNCH_B16(4, 9, 2); else SBS_LAUNCH_B16(4, 0, 2); break;
+        case 8: if (n <= 9) SBS_LAUNCH_B16(8, 9, 2); else SBS_LAUNCH_B16(8, 0, 2); break;
+        case 16: if (n <= 9) SBS_LAUNCH_B16(16, 9, 2); else SBS_LAUNCH_B16(16, 0, 2); break;
         default: return DCTN_ERR_UNSUPPORTED;
       }
 #undef SBS_LAUNCH_B16
       DCTN_CHECK_LAUNCH();
+      if (q2.partials) {
+        hipLaunchKernelGGL(convsbs_dcore_reduce_k, dim3((unsigned)((q2.core_off[n] + 63) / 64)), dim3(256), 0, st, q2, (int)blocks);
+        DCTN_CHECK_LAUNCH();
+      }
       dctn_set_last_kernel("convsbs_bwd_mfma_f32");
       return DCTN_OK;
     }
