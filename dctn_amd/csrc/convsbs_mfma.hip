@@ -76,24 +76,49 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 // All feature products of a window (every core of the string) at once: the pixel loads of up to 8
 // cores are issued back to back (one memory round trip per chunk instead of one per core), the
 // products go to the wave's LDS slice fs[(c*4 + qq)*32 + window] and are read back per core.
-template <int WPG = 32>
+template <int WPG = 32, int CB = 8>   // CB: cores per batch of loads (one memory round trip per batch)
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
-  for (int c0 = 0; c0 < p.n; c0 += 8) {
-    float raw[8][2][4];
+  if (p.C == 1) {   // one channel: the feature products ARE the pixel's q values (no digit table, half the loads)
+    for (int c0 = 0; c0 < p.n; c0 += CB) {
+      float raw1[CB][4];
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
+      for (int cc = 0; cc < CB; ++cc) {
+        const int c = c0 + cc < p.n ? c0 + cc : p.n - 1;
+        const float* base = win + (long long)p.ph[c] * p.s[2] + (long long)p.pw[c] * p.s[3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) raw1[cc][d] = base[(d < p.q ? d : 0) * p.s[4]];
+      }
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+        if (c0 + cc < p.n) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            fs[((c0 + cc) * 4 + d) * WPG + (lane & (WPG - 1))] = (valid && d < p.q) ? raw1[cc][d] : 0.f;
+        }
+      }
+    }
+    return;
+  }
+  for (int c0 = 0; c0 < p.n; c0 += CB) {
+    float raw[CB][2][4];
+#pragma unroll
+    for (int cc = 0; cc < CB; ++cc) {
       const int c = c0 + cc < p.n ? c0 + cc : p.n - 1;
       const float* base = win + (long long)p.ph[c] * p.s[2] + (long long)p.pw[c] * p.s[3];
+      // clamped index + select instead of a predicated load: no control flow between the loads, they all go out back to
+      // back (the caller passes window 0 for lanes without a window, so every address is valid)
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-          raw[cc][ch][d] = (valid && ch < p.C && d < p.q) ? base[ch * p.s[0] + d * p.s[4]] : 1.f;
+        for (int d = 0; d < 4; ++d) {
+          const float ld = base[(ch < p.C ? ch : 0) * p.s[0] + (d < p.q ? d : 0) * p.s[4]];
+          raw[cc][ch][d] = (valid && ch < p.C && d < p.q) ? ld : 1.f;
+        }
     }
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
+    for (int cc = 0; cc < CB; ++cc) {
       if (c0 + cc < p.n) {
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -529,9 +554,9 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
 //   U = core x v            : M = (r', qq) in 16-row tiles (row i <-> r' = 4 mt + (i >> 2), qq = i & 3), K = l; the
 //                             accumulator gives lane (wl, g) the rows r' = 4 mt + g, qq = 0..3: the lane-local sum
 //                             over qq IS the next state register s = mt - the chain stays in registers
-//   adjoint dv              : M = l with rows permuted (row i <-> l = 4 (i & 3) + (i >> 2)) so that the accumulator is
-//                             in state layout again, K = (r', qq) ordered k-step 4 s2 + qq / group kg <-> r' = 4 s2 + kg,
-//                             i.e. the lane multiplies ITS OWN G[s2] by f[qq]; second LDS pack of the cores
+//   adjoint dv and df       : ONE product W = core^T x G with the bond legs exchanged (rows (l, qq), K = r', B = G from
+//                             its state registers; second LDS pack of the cores): dv[l] = sum_qq f[qq] W[(l, qq)] lands in
+//                             state layout like the forward's epilogue, df[qq] = sum_l v[l] W[(l, qq)]
 //   dCore += Z^T v          : windows are k: Z = f (x) G and v go through per-wave LDS tiles [window][feature]
 //                             (b128 row writes, conflict-free b32 fragment reads); the 16x16 tiles of a core's
 //                             gradient are added to a workgroup accumulator kept in ACCUMULATOR layout
@@ -569,11 +594,15 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
       const int l = 4 * s + kg, rp = 4 * mt + (i >> 2), qq = i & 3;
       lds[p.apack_off[c] + e] = qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
     }
-    for (int e = tid; e < oc * KA * 64; e += 256) {
+    // adjoint pack: the same fragment order with the bond legs exchanged: rows <-> (l, qq), k <-> r'
+    for (int e = tid; e < oc * MT * KS * 64; e += 256) {
       const int ln = e & 63, i = ln & 15, kg = ln >> 4;
-      const int ks = (e >> 6) % KA, o = (e >> 6) / KA;
-      const int l = 4 * (i & 3) + (i >> 2), rp = 4 * (ks >> 2) + kg, qq = ks & 3;
-      lds[p.apack2_off[c] + e] = (l < R && qq < p.qc) ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+      int t2 = e >> 6;
+      const int s = t2 % KS; t2 /= KS;
+      const int mt = t2 % MT;
+      const int o = t2 / MT;
+      const int rp = 4 * s + kg, l = 4 * mt + (i >> 2), qq = i & 3;
+      lds[p.apack2_off[c] + e] = qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
     }
   }
   for (int e = tid; e < R * 4; e += 256) {
@@ -590,6 +619,21 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
 // wave-instruction, 176 of them per window group and wave) with the matrix pipe at 13 %.  (Unrolling the whole way
 // back over the cores instead made the kernel 100 KB of code: it streamed through the 64 KB instruction cache once
 // per window group.)
+#ifdef DCTN_STAMPS
+// diagnostic build only: wall-clock phase stamps of the first window group of every workgroup's wave 0
+__device__ unsigned long long sbs_stamps[2048 * 32];
+#define SBS_STAMP(SLOT)                                                                          \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    if (threadIdx.x == 0 && first_group) sbs_stamps[(long long)blockIdx.x * 32 + (SLOT)] = t_;   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#else
+#define SBS_STAMP(SLOT) do { } while (0)
+#endif
+
 template <int R, int NC, int NT>
 __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
                                                             const float* __restrict__ dY,
@@ -599,6 +643,9 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
   constexpr int ZROW = 4 * R + 16;   // floats per window row of the Z tile: rows 16 banks apart
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wl = lane & 15, g = lane >> 4, wv = tid >> 6;
+  bool first_group = true;
+  (void)first_group;
+  SBS_STAMP(0);
   pack_cores16<R>(lds, p, tid);
   if constexpr (NC == 0) {   // (NC > 0: the accumulator region lies over the packs and is zeroed after the sweep)
     const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
@@ -624,6 +671,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
   const long long wave = (long long)blockIdx.x * 4 + wv;
   const long long nwaves = (long long)gridDim.x * 4;
   const int hw = p.Ho * p.Wo;
+  SBS_STAMP(1);
   for (long long grp = wave; grp < p.ngroups; grp += nwaves) {
     // the wave's 16 NT windows: staging uses one lane per window, the sweep's tile t holds windows 16 t + wl
     long long wt[NT], bt[NT];
@@ -648,11 +696,12 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      stage_features<WPG>(x, p, b, ho, wo, valid, fs, lane);
+      stage_features<WPG, 9>(x, p, b, ho, wo, valid, fs, lane);   // a 9-core string's pixels in one round trip
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    SBS_STAMP(2);
     float dy[2][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -767,6 +816,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       oacc *= oc;
     }
 
+    SBS_STAMP(3);
     // The way back reads the stored input state of core c while core c + 1 is being processed: the loads of the
     // NEXT core's states are issued one core ahead (a state row is a fresh line; with one wave per SIMD nothing
     // else hides the ~2 us round trip, 8 of them per window group).
@@ -817,6 +867,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       write_dx(p.n - 1, df);
     }
 
+    SBS_STAMP(4);
     // ---------------- middle cores, right to left
     int oacc_out = oacc;
     for (int c = p.n - 2; c >= 1; --c) {
@@ -849,36 +900,33 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
               Gs[s][t] = g_first ? G[0][s][t] : G[1][s][t];
               vin[s][t] = a == 0 ? v[0][s][t] : v[1][s][t];
             }
-          // (1) d/d(features): df[qq] += sum_r' G[r'] U[(r', qq)]   (U recomputed: storing it would be 4R floats/window)
+          // (1)+(2) ONE product serves d/d(features) and the adjoint: W[(l, qq), w] = sum_r' core[o, l, r', qq] G[r', w]
+          // (the forward product with the core's bond legs exchanged: rows i <-> l = 4 mt + (i >> 2), qq = i & 3, k = r',
+          // B = G straight from its state registers).  The accumulator gives lane (w, g) the rows l = 4 mt + g, qq = 0..3:
+          //   dv[l]  = sum_qq f[qq] W[(l, qq)]   lane-local, lands in state register s = mt;
+          //   df[qq] = sum_l  v[l]  W[(l, qq)]   lane-local over the lane's l, summed over the k groups after the loop.
+          // (The first version computed U = core x v again for df and a separate K = 4R product for dv: 64 MFMAs, now 32.)
           {
-            f32x4 D[MT][NT];
-            u_tiles(c, o, vin, D);
+            const float* ap2 = lds + p.apack2_off[c] + o * MT * KS * 64 + lane;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+              f32x4 Wt[NT];
 #pragma unroll
-              for (int t = 0; t < NT; ++t)
+              for (int t = 0; t < NT; ++t) Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) df[qq][t] += Gs[mt][t] * D[mt][t][qq];
-          }
-          // (2) adjoint: dv[l] += sum_(r', qq) core[o, l, r', qq] f[qq] G[r']
-          {
-            const float* ap2 = lds + p.apack2_off[c] + o * KA * 64 + lane;
-            f32x4 D2[NT];
+              for (int s = 0; s < KS; ++s) {
+                const float av = ap2[(mt * KS + s) * 64];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) D2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KA; ++ks) {
-              const float av = ap2[ks * 64];
-#pragma unroll
-              for (int t = 0; t < NT; ++t)
-                D2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f[ks & 3][t] * Gs[ks >> 2][t], D2[t], 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < SN; ++s)
+                for (int t = 0; t < NT; ++t) Wt[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Gs[s][t], Wt[t], 0, 0, 0);
+              }
 #pragma unroll
               for (int t = 0; t < NT; ++t) {
-                if (a == 0) d[0][s][t] += D2[t][s]; else d[1][s][t] += D2[t][s];
+                const float dvl = f[0][t] * Wt[t][0] + f[1][t] * Wt[t][1] + f[2][t] * Wt[t][2] + f[3][t] * Wt[t][3];
+                if (a == 0) d[0][mt][t] += dvl; else d[1][mt][t] += dvl;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) df[qq][t] += vin[mt][t] * Wt[t][qq];
               }
+            }
           }
           // (3) dCore[o, l, r', qq] += sum_w v[l, w] f[qq, w] G[r', w]: windows on k through the wave's LDS tiles
           {
@@ -940,6 +988,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
 #pragma unroll
         for (int t = 0; t < NT; ++t) { G[0][s][t] = d[0][s][t]; G[1][s][t] = d[1][s][t]; }
       oacc_out = oacc_in;
+      SBS_STAMP(5 + (p.n - 2 - c));
     }
 
     // ---------------- first core
@@ -967,7 +1016,11 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
         for (int t = 0; t < NT; ++t) df[qq][t] = sbs_group_sum(df[qq][t]);
       write_dx(0, df);
     }
+    SBS_STAMP(20);
+    first_group = false;
   }
+  first_group = true;
+  SBS_STAMP(21);
 
   if constexpr (NC > 0) {   // the register accumulators join the workgroup's LDS accumulator once
     __syncthreads();        // every wave is done with the packs the accumulator region lies over
@@ -1011,6 +1064,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
   // partial gradients per workgroup, summed in a fixed order by convsbs_dcore_reduce_k (deterministic; 256+ workgroups
   // adding into the same 34 KB with float atomics ran at the contended atomic rate), or atomics when no room was given
   __syncthreads();
+  SBS_STAMP(22);
   float* rec = p.partials ? p.partials + (long long)blockIdx.x * p.core_off[p.n] : nullptr;
   for (int c = 0; c < p.n; ++c) {
     const float* src = lds + p.dacc_off[c];
@@ -1032,7 +1086,14 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       }
     }
   }
+  SBS_STAMP(23);
 }
+
+#ifdef DCTN_STAMPS
+extern "C" int dctn_debug_read_sbs_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sbs_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 // dCore_c[e] = sum over the workgroups' records, fixed order: 64 elements per workgroup, 4 record subsets, LDS join
 __global__ __launch_bounds__(256) void convsbs_dcore_reduce_k(SbsMP p, int nrec) {
@@ -1175,7 +1236,7 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     int o2 = 0;
     SbsMP q2 = p;
     for (int c = 1; c + 1 < n; ++c) { q2.apack_off[c] = o2; o2 += p.o[c] * MT * KS * 64; }
-    for (int c = 1; c + 1 < n; ++c) { q2.apack2_off[c] = o2; o2 += p.o[c] * KA * 64; }
+    for (int c = 1; c + 1 < n; ++c) { q2.apack2_off[c] = o2; o2 += p.o[c] * MT * KS * 64; }
     q2.first_off = o2; o2 += R * 4;
     q2.last_off = o2; o2 += R * 4;
     const int NT16 = 2;   // window tiles per wave iteration (4 was tried for r = 16: 892 bytes of scratch per lane, slower)
