@@ -498,29 +498,42 @@ def make_stopper_after_n_iters(n: int) -> Callable[[StX, StIt], None]:
     return _StopAfter(n)
 
 
-def make_stopper_on_nan_loss(dir: str, set_breakpoint: bool) -> Callable[[StX, StIt], None]:
-    """Stops on a non-finite loss and leaves the model and the offending batch in ``dir/nan_loss_stop``
-    (written by the rank that saw it, under a per-rank name when there are several)."""
+class _StopOnNonFiniteLoss:
+    """Hook for the ``after_back`` list: on a NaN / infinite loss it raises the stop flag and leaves what is needed
+    to reproduce the failure - the model's state_dict (named after the iteration, loss and regulariser term) and the
+    batch (``x``, ``y``, ``indices``, ``output``) - in ``dir/nan_loss_stop`` (``nan_loss_stop_rank<r>`` when several
+    ranks run: every rank that saw a non-finite loss writes its own).  Same file names as dctn/training.py:213-237."""
 
-    def stop_on_nan_loss(st_x: StX, st_it: StIt) -> None:
-        if torch.isfinite(st_it["loss"]):
+    DUMPED = ("x", "y", "indices", "output")
+
+    def __init__(self, dir: str, set_breakpoint: bool):
+        self.dir, self.set_breakpoint = dir, set_breakpoint
+
+    def _target(self) -> str:
+        leaf = "nan_loss_stop" if _world() == 1 else f"nan_loss_stop_rank{dist.get_rank()}"
+        return os.path.join(self.dir, leaf)
+
+    def __call__(self, st_x: StX, st_it: StIt) -> None:
+        if bool(torch.isfinite(st_it["loss"])):
             return
         log = getLogger(__name__)
         log.warning("Stopping because of NaN or Inf loss")
         st_it["stop"] = True
-        subdir = os.path.join(dir, "nan_loss_stop" if _world() == 1 else f"nan_loss_stop_rank{dist.get_rank()}")
-        if os.path.exists(subdir):
-            log.error(f"subdir={subdir!r} already exists")
+        target = self._target()
+        if os.path.exists(target):
+            log.error(f"subdir={target!r} already exists")
         else:
-            os.mkdir(subdir)
-            torch.save(st_x["model"].state_dict(), os.path.join(
-                subdir, f"model_nitd={st_it['num_iters_done']}_loss={st_it['loss']:.3f}_reg_term={st_it['reg_term']:.3f}.pth"))
-            for key in ("x", "y", "indices", "output"):
-                torch.save(st_it[key], os.path.join(subdir, f"{key}.pth"))
-        if set_breakpoint:
+            os.mkdir(target)
+            tag = f"nitd={st_it['num_iters_done']}_loss={st_it['loss']:.3f}_reg_term={st_it['reg_term']:.3f}"
+            torch.save(st_x["model"].state_dict(), os.path.join(target, f"model_{tag}.pth"))
+            for key in self.DUMPED:
+                torch.save(st_it[key], os.path.join(target, key + ".pth"))
+        if self.set_breakpoint:
             breakpoint()
 
-    return stop_on_nan_loss
+
+def make_stopper_on_nan_loss(dir: str, set_breakpoint: bool) -> Callable[[StX, StIt], None]:
+    return _StopOnNonFiniteLoss(dir, set_breakpoint)
 
 
 def log_parameters_stats(st_x: StX, st_it: StIt) -> None:
