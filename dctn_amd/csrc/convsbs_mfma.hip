@@ -1095,6 +1095,23 @@ extern "C" int dctn_debug_read_sbs_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+// first stage for many records (small cores, many workgroups): records 32 y .. 32 y + 31 -> record `out0 + y`
+__global__ __launch_bounds__(256) void convsbs_dcore_prereduce_k(float* __restrict__ partials, int total, int nrec, int out0) {
+  const int e = (int)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int r0 = (int)blockIdx.y * 32, r1 = r0 + 32 < nrec ? r0 + 32 : nrec;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += partials[(long long)r * total + e];
+    a1 += partials[(long long)(r + 1) * total + e];
+    a2 += partials[(long long)(r + 2) * total + e];
+    a3 += partials[(long long)(r + 3) * total + e];
+  }
+  for (; r < r1; ++r) a0 += partials[(long long)r * total + e];
+  partials[(long long)(out0 + blockIdx.y) * total + e] = (a0 + a1) + (a2 + a3);
+}
+
 // dCore_c[e] = sum over the workgroups' records, fixed order: 64 elements per workgroup, 4 record subsets, LDS join
 __global__ __launch_bounds__(256) void convsbs_dcore_reduce_k(SbsMP p, int nrec) {
   __shared__ float red[4][64];
@@ -1268,6 +1285,7 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
       if (per_cu2 < 1) per_cu2 = 1;
       if (per_cu2 > 8) per_cu2 = 8;
       if (blocks > 256 * per_cu2) blocks = 256 * per_cu2;
+      if (blocks > SBS_MAX_PARTIAL_RECORDS - 64) blocks = SBS_MAX_PARTIAL_RECORDS - 64;   // room for the second-stage records
       q2.partials = (partials && partial_bytes >= (size_t)blocks * q2.core_off[n] * sizeof(float)) ? partials : nullptr;
 #define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
   do {                                                                                            \
@@ -1285,7 +1303,17 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
 #undef SBS_LAUNCH_B16
       DCTN_CHECK_LAUNCH();
       if (q2.partials) {
-        hipLaunchKernelGGL(convsbs_dcore_reduce_k, dim3((unsigned)((q2.core_off[n] + 63) / 64)), dim3(256), 0, st, q2, (int)blocks);
+        int nrec = (int)blocks;
+        const int total = q2.core_off[n], n2 = (nrec + 31) / 32;
+        // many records of a small core: two stages (the one-stage form ran 13 workgroups over 768 records: 21 us)
+        if (nrec > 64 && partial_bytes >= (size_t)(nrec + n2) * total * sizeof(float)) {
+          hipLaunchKernelGGL(convsbs_dcore_prereduce_k, dim3((unsigned)((total + 255) / 256), (unsigned)n2), dim3(256), 0, st,
+                             q2.partials, total, nrec, nrec);
+          DCTN_CHECK_LAUNCH();
+          q2.partials += (long long)nrec * total;
+          nrec = n2;
+        }
+        hipLaunchKernelGGL(convsbs_dcore_reduce_k, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, q2, nrec);
         DCTN_CHECK_LAUNCH();
       }
       dctn_set_last_kernel("convsbs_bwd_mfma_f32");
