@@ -1028,25 +1028,49 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
       for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
     }
-    __syncthreads();
+    // one wave after the other (plain read-modify-write, a barrier between the waves): the record a workgroup writes is
+    // then the same bits in every run, and with the fixed-order reduce so are the gradients
+    float d0s[SN][4], dls[SN][4];
 #pragma unroll
-    for (int c = 1; c + 1 < NC; ++c) {
-      if (c + 1 >= p.n) continue;   // shorter strings
-      float* dc = lds + p.dacc_off[c] + lane;
+    for (int s = 0; s < SN; ++s)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int qq = 0; qq < 4; ++qq) {
+        d0s[s][qq] = sbs_row_sum16(dfirst[s][qq]);
+        dls[s][qq] = sbs_row_sum16(dlast[s][qq]);
+      }
+    for (int turn = 0; turn < 4; ++turn) {
+      __syncthreads();
+      if (wv != turn) continue;
 #pragma unroll
-        for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[(mt * 4 + vv) * 64], dreg[c - 1][mt][vv]);
-      if (p.o[c] > 1) {
+      for (int c = 1; c + 1 < NC; ++c) {
+        if (c + 1 >= p.n) continue;   // shorter strings
+        float* dc = lds + p.dacc_off[c] + lane;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[MT * 256 + (mt * 4 + vv) * 64], dreg[NC - 2][mt][vv]);
+          for (int vv = 0; vv < 4; ++vv) dc[(mt * 4 + vv) * 64] += dreg[c - 1][mt][vv];
+        if (p.o[c] > 1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) dc[MT * 256 + (mt * 4 + vv) * 64] += dreg[NC - 2][mt][vv];
+        }
+      }
+      if (wl == 0) {   // first / last core: one lane per k group holds the sum over the group's 16 window lanes
+        float* d0p = lds + p.dacc_off[0];
+        float* dlp = lds + p.dacc_off[p.n - 1];
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            if (qq < p.qc) {
+              d0p[(4 * s + g) * p.qc + qq] += d0s[s][qq];
+              dlp[(4 * s + g) * p.qc + qq] += dls[s][qq];
+            }
       }
     }
-  }
-  // ---- first / last core: sum the 16 window lanes of a k group, one lane per group adds to the LDS accumulator
-  {
+  } else {
+    // ---- first / last core: sum the 16 window lanes of a k group, one lane per group adds to the LDS accumulator
     float* d0p = lds + p.dacc_off[0];
     float* dlp = lds + p.dacc_off[p.n - 1];
 #pragma unroll

@@ -343,3 +343,62 @@ def test_logmatmulexp_fold16_all_chain_lengths(Wn, L):
     for w in range(Wn):
         scale = float(g[w].abs().max().clamp_min(1.0))
         assert float((got[w] - g[w]).abs().max()) < 3e-4 * scale, w
+
+
+def sbs_mfma_cases():
+    """Open chains with a uniform bond in {4, 8, 16}: the MFMA sweep family.  String lengths on both sides of the
+    9-core specialisation (register accumulators up to 9 cores, LDS accumulators beyond), the one two-output core at
+    any position or absent, one or two channels, ragged window counts (not a multiple of the 32-window group)."""
+    rng = random.Random(77)
+    cases = []
+    for n, r, C, q in [(3, 16, 1, 3), (4, 8, 2, 2), (5, 4, 1, 2), (6, 16, 2, 2), (9, 8, 1, 4), (9, 16, 1, 2), (9, 4, 2, 2),
+                       (10, 4, 1, 3), (12, 8, 1, 2), (7, 16, 1, 3)]:
+        walk, seen = [(0, 0)], {(0, 0)}
+        while len(walk) < n:   # a self-avoiding walk on a 4 x 4 grid (any order of positions is legal)
+            h, w = walk[-1]
+            opts = [(h + dh, w + dw) for dh, dw in ((0, 1), (1, 0), (0, -1), (-1, 0))
+                    if 0 <= h + dh < 4 and 0 <= w + dw < 4 and (h + dh, w + dw) not in seen]
+            if not opts:
+                opts = [(a, b) for a in range(4) for b in range(4) if (a, b) not in seen]
+            nxt = rng.choice(opts)
+            walk.append(nxt)
+            seen.add(nxt)
+        mh, mw = min(p[0] for p in walk), min(p[1] for p in walk)
+        pos = tuple((h - mh, w - mw) for h, w in walk)
+        outs = [1] * n
+        if rng.random() < 0.8:
+            outs[rng.randrange(1, n - 1)] = 2
+        cases.append((pos, (1,) + (r,) * (n - 1), tuple(outs), C, q))
+    return cases
+
+
+@pytest.mark.parametrize("case", sbs_mfma_cases(), ids=lambda c: "n%d_r%d_o%s_C%dq%d" % (
+    len(c[0]), c[1][1], "".join(map(str, c[2])), c[3], c[4]))
+def test_convsbs_mfma_family_random(case):
+    pos, bonds, outs, C, q = case
+    torch.manual_seed(len(pos) * 10 + bonds[1])
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
+    m = ConvSBS(spec, DumbNormalInitialization((q ** C * bonds[1]) ** -0.5)).to(DEV)
+    B, H, W = 3, spec.max_height_pos + 6, spec.max_width_pos + 7      # 126 windows: three full groups and a ragged one
+    x = torch.randn(C, B, H, W, q, device=DEV, requires_grad=True)
+    y = m(x)
+    assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32"
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, list(pos), x.detach().cpu().double())
+    check(y, want, torch.float32, "forward")
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert dctn_amd.last_kernel() == "convsbs_bwd_mfma_f32"
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
+    check(x.grad, gr[0], torch.float32, "dX")
+    for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
+        check(c.grad, gc, torch.float32, f"dCore{i}")
+    if len(pos) > 9:
+        return   # longer strings accumulate in LDS with float atomics (arrival order)
+    # deterministic: a workgroup's waves join in a fixed order and the per-workgroup records are summed in a fixed order
+    g1 = [c.grad.clone() for c in m.cores]
+    for c in m.cores:
+        c.grad = None
+    x.grad = None
+    m(x).backward(dy)
+    assert all(torch.equal(a, c.grad) for a, c in zip(g1, m.cores))
