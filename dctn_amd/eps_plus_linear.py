@@ -126,7 +126,7 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
             return False
         n, o, cout = core.ndim - 1, core.shape[-1], weight.shape[0]
         return (x.shape[-1] == 2 and n in (8, 9) and o in (2, 4) and cout <= 16 and cout % 2 == 0
-                and weight.shape[1] % 8 == 0 and FUSED_HEAD)
+                and weight.shape[1] % 8 == 0 and weight.data_ptr() % 16 == 0 and FUSED_HEAD)
 
     @staticmethod
     def forward(ctx, core: Tensor, x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:

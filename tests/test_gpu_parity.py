@@ -925,3 +925,34 @@ def test_fused_forward_of_layer_and_head_matches_the_two_kernels(C, K, O, size, 
         L.check(lib.dctn_linear_head_fwd(feat_a.data_ptr(), w.data_ptr(), bias.data_ptr(), log_a.data_ptr(), B, F, cout, code,
                                          L.stream_ptr(DEV)), "head")
         assert float((log_a.float() - log_b.float()).abs().max()) <= 2 ** -7 * float(want.abs().max())
+
+
+def test_flat_sgd_repointed_parameters_at_odd_offsets_still_run():
+    """FlatSGD re-points every parameter into one flat buffer; a core whose byte size is not a multiple of 16 leaves
+    `linear.weight` misaligned for the 16-byte loads of the head kernels: the model must then take the library GEMM
+    (not raise), with the same numbers."""
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+    from dctn_amd.training import FlatSGD
+
+    torch.manual_seed(4)
+    m = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, torch.bfloat16, image_size=10, Q_0=3)
+    x = torch.rand(1, 5, 10, 10, 3, device=DEV).bfloat16()
+    before = m(x).detach().float()
+    FlatSGD(list(m.epses) + [m.linear.weight], [m.linear.bias], lr=0.0)
+    assert m.linear.weight.data_ptr() % 16 != 0        # 3^9 * 4 * 2 bytes = 157 464: the case the review named
+    after = m(x)
+    assert torch.allclose(after.detach().float(), before, rtol=2e-2, atol=1e-3)
+    after.float().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for p in m.parameters())
+    # the cfg2 family (Q_0 = 2) with a misaligned weight: the fused node is skipped, the separate kernels / GEMM run
+    m2 = EPSesPlusLinear(((3, 2),), UnitTheoreticalOutputStd(), 1.0, DEV, torch.bfloat16, image_size=9)
+    x2 = torch.rand(1, 4, 9, 9, 2, device=DEV).bfloat16()
+    ref = m2(x2).detach().float()
+    flat = torch.empty(m2.linear.weight.numel() + 8, dtype=torch.bfloat16, device=DEV)
+    view = flat[1 : 1 + m2.linear.weight.numel()].view_as(m2.linear.weight)
+    view.copy_(m2.linear.weight.data)
+    m2.linear.weight.data = view
+    assert m2.linear.weight.data_ptr() % 16 != 0
+    out = m2(x2)
+    assert torch.allclose(out.detach().float(), ref, rtol=2e-2, atol=1e-3)
+    out.float().sum().backward()
