@@ -580,29 +580,59 @@ __device__ __forceinline__ float sbs_group_sum(float v) {   // sum over the four
   return half_sum(__int_as_float(r[0]) + __int_as_float(r[1]));
 }
 
-template <int R>
+// One fragment element of core c for pack position e (ADJ: the adjoint pack, bond legs exchanged).
+template <int R, bool ADJ>
+__device__ __forceinline__ float pack16_element(const SbsMP& p, int c, int e) {
+  constexpr int MT = R / 4, KS = R / 4;
+  const int ln = e & 63, i = ln & 15, kg = ln >> 4;
+  int t2 = e >> 6;
+  const int s = t2 % KS; t2 /= KS;
+  const int mt = t2 % MT;
+  const int o = t2 / MT;
+  const int l = ADJ ? 4 * mt + (i >> 2) : 4 * s + kg;
+  const int rp = ADJ ? 4 * s + kg : 4 * mt + (i >> 2);
+  const int qq = i & 3;
+  return qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+}
+
+// NMID > 0: at most NMID middle cores with at most two outputs each: every global load of the two packs is issued
+// before the first LDS store (one round trip for the whole string instead of one per core and pack: the packing was
+// 10 us of a 230 us kernel at bond 16).  NMID == 0: any string, core by core.
+template <int R, int NMID>
 __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid) {
-  constexpr int MT = R / 4, KS = R / 4, KA = R;
-  for (int c = 1; c + 1 < p.n; ++c) {
-    const int oc = p.o[c];
-    for (int e = tid; e < oc * MT * KS * 64; e += 256) {
-      const int ln = e & 63, i = ln & 15, kg = ln >> 4;
-      int t2 = e >> 6;
-      const int s = t2 % KS; t2 /= KS;
-      const int mt = t2 % MT;
-      const int o = t2 / MT;
-      const int l = 4 * s + kg, rp = 4 * mt + (i >> 2), qq = i & 3;
-      lds[p.apack_off[c] + e] = qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
-    }
-    // adjoint pack: the same fragment order with the bond legs exchanged: rows <-> (l, qq), k <-> r'
-    for (int e = tid; e < oc * MT * KS * 64; e += 256) {
-      const int ln = e & 63, i = ln & 15, kg = ln >> 4;
-      int t2 = e >> 6;
-      const int s = t2 % KS; t2 /= KS;
-      const int mt = t2 % MT;
-      const int o = t2 / MT;
-      const int rp = 4 * s + kg, l = 4 * mt + (i >> 2), qq = i & 3;
-      lds[p.apack2_off[c] + e] = qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+  constexpr int MT = R / 4, KS = R / 4, PER_O = MT * KS * 64, PER = (PER_O + 255) / 256;
+  if constexpr (NMID > 0) {
+    float va[NMID][2][PER], vb[NMID][2][PER];
+#pragma unroll
+    for (int m = 0; m < NMID; ++m)
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const int c = m + 1, e = tid + 256 * j;
+          const bool live = c + 1 < p.n && o < p.o[c] && e < PER_O;
+          va[m][o][j] = live ? pack16_element<R, false>(p, c, o * PER_O + e) : 0.f;
+          vb[m][o][j] = live ? pack16_element<R, true>(p, c, o * PER_O + e) : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < NMID; ++m)
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+          const int c = m + 1, e = tid + 256 * j;
+          if (c + 1 < p.n && o < p.o[c] && e < PER_O) {
+            lds[p.apack_off[c] + o * PER_O + e] = va[m][o][j];
+            lds[p.apack2_off[c] + o * PER_O + e] = vb[m][o][j];
+          }
+        }
+  } else {
+    for (int c = 1; c + 1 < p.n; ++c) {
+      const int oc = p.o[c];
+      for (int e = tid; e < oc * PER_O; e += 256) {
+        lds[p.apack_off[c] + e] = pack16_element<R, false>(p, c, e);
+        lds[p.apack2_off[c] + e] = pack16_element<R, true>(p, c, e);   // the same fragment order, rows <-> (l, qq), k <-> r'
+      }
     }
   }
   for (int e = tid; e < R * 4; e += 256) {
@@ -641,12 +671,13 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
                                                             float* __restrict__ gxw, SbsMP p, int need_dx) {
   constexpr int SN = R / 4, MT = R / 4, KS = R / 4, KA = R;
   constexpr int ZROW = 4 * R + 16;   // floats per window row of the Z tile: rows 16 banks apart
+  constexpr int VROW = 17;           // floats per window row of the V tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wl = lane & 15, g = lane >> 4, wv = tid >> 6;
   bool first_group = true;
   (void)first_group;
   SBS_STAMP(0);
-  pack_cores16<R>(lds, p, tid);
+  pack_cores16<R, (NC > 2 ? NC - 2 : 0)>(lds, p, tid);
   if constexpr (NC == 0) {   // (NC > 0: the accumulator region lies over the packs and is zeroed after the sweep)
     const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
     for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
@@ -655,7 +686,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
   constexpr int WPG = 16 * NT;   // windows per wave iteration: NT tiles of 16
   float* fs = lds + p.fs_off + wv * p.n * 4 * WPG;
   float* zt = lds + p.zt_off + wv * 16 * ZROW;
-  float* vt = lds + p.vt_off + wv * 256;
+  float* vt = lds + p.vt_off + wv * 16 * VROW;
   float dfirst[SN][4], dlast[SN][4];   // gradients of the first / last core: lane-local over all its windows
 #pragma unroll
   for (int s = 0; s < SN; ++s)
@@ -757,16 +788,19 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
     // U tiles of core c, output o, applied to state `vin`: D[mt][t] (rows r' = 4 mt + g, qq = register)
     auto u_tiles = [&](int c, int o, const float (&vin)[SN][NT], f32x4 (&D)[MT][NT]) {
       const float* ap = lds + p.apack_off[c] + o * MT * KS * 64 + lane;
+      float av[MT][KS];   // the whole A operand first: the LDS round trips overlap instead of one per MFMA pair
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) av[mt][s] = ap[(mt * KS + s) * 64];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) D[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const float av = ap[(mt * KS + s) * 64];
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) D[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vin[s][t], D[mt][t], 0, 0, 0);
-        }
+          for (int t = 0; t < NT; ++t) D[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], vin[s][t], D[mt][t], 0, 0, 0);
       }
     };
 
@@ -908,17 +942,20 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
           // (The first version computed U = core x v again for df and a separate K = 4R product for dv: 64 MFMAs, now 32.)
           {
             const float* ap2 = lds + p.apack2_off[c] + o * MT * KS * 64 + lane;
+            float av[MT][KS];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int s = 0; s < KS; ++s) av[mt][s] = ap2[(mt * KS + s) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               f32x4 Wt[NT];
 #pragma unroll
               for (int t = 0; t < NT; ++t) Wt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int s = 0; s < KS; ++s) {
-                const float av = ap2[(mt * KS + s) * 64];
+              for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) Wt[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Gs[s][t], Wt[t], 0, 0, 0);
-              }
+                for (int t = 0; t < NT; ++t) Wt[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s], Gs[s][t], Wt[t], 0, 0, 0);
 #pragma unroll
               for (int t = 0; t < NT; ++t) {
                 const float dvl = f[0][t] * Wt[t][0] + f[1][t] * Wt[t][1] + f[2][t] * Wt[t][2] + f[3][t] * Wt[t][3];
@@ -939,22 +976,27 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
               __builtin_amdgcn_wave_barrier();   // the previous tile's fragment reads are done
 #pragma unroll
               for (int s = 0; s < SN; ++s) {
-                *reinterpret_cast<f32x4*>(zt + wl * ZROW + 16 * s + 4 * g) =
+                // (the 16-byte slot inside a 16-float block is XORed with bits 1..2 of the row, the V rows are 17 floats
+                // long: without either, the 8 rows of one parity land on the same banks in both stores)
+                *reinterpret_cast<f32x4*>(zt + wl * ZROW + 16 * s + 4 * (g ^ ((wl >> 1) & 3))) =
                     f32x4{f[0][t] * Gs[s][t], f[1][t] * Gs[s][t], f[2][t] * Gs[s][t], f[3][t] * Gs[s][t]};
-                vt[wl * 16 + 4 * s + g] = vin[s][t];
+                vt[wl * VROW + 4 * s + g] = vin[s][t];
               }
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              float bv[4], av[4][MT];   // all fragments of the tile first, then its MFMAs
 #pragma unroll
               for (int ks = 0; ks < 4; ++ks) {
-                const float bv = vt[(4 * ks + g) * 16 + wl];                   // V[w = 4 ks + g][l = wl]
+                bv[ks] = vt[(4 * ks + g) * VROW + wl];                                          // V[w = 4 ks + g][l = wl]
+                const int zc = wl ^ (4 * ((2 * ks + (g >> 1)) & 3));                            // the row's slot swizzle
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                  const float av = zt[(4 * ks + g) * ZROW + 16 * mt + wl];     // Z[w][feature 16 mt + wl]
-                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < MT; ++mt) av[ks][mt] = zt[(4 * ks + g) * ZROW + 16 * mt + zc];   // Z[w][feature 16 mt + wl]
               }
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][mt], bv[ks], acc[mt], 0, 0, 0);
             }
             if constexpr (NC > 0) {
               const int slot = o == 0 ? c - 1 : NC - 2;   // wave-uniform
@@ -1023,13 +1065,9 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
   SBS_STAMP(21);
 
   if constexpr (NC > 0) {   // the register accumulators join the workgroup's LDS accumulator once
-    __syncthreads();        // every wave is done with the packs the accumulator region lies over
-    {
-      const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
-      for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
-    }
-    // one wave after the other (plain read-modify-write, a barrier between the waves): the record a workgroup writes is
-    // then the same bits in every run, and with the fixed-order reduce so are the gradients
+    // one wave after the other (wave 0 stores, the others read-modify-write whole tiles, a barrier between the waves):
+    // the record a workgroup writes is then the same bits in every run, and with the fixed-order reduce so are the
+    // gradients.  (The first barrier also says every wave is done with the packs the accumulator region lies over.)
     float d0s[SN][4], dls[SN][4];
 #pragma unroll
     for (int s = 0; s < SN; ++s)
@@ -1038,6 +1076,17 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
         d0s[s][qq] = sbs_row_sum16(dfirst[s][qq]);
         dls[s][qq] = sbs_row_sum16(dlast[s][qq]);
       }
+    auto join_tiles = [&](float* dc, const f32x4 (&regs)[MT], bool first) {
+      float cur[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) cur[mt][vv] = first ? 0.f : dc[(mt * 4 + vv) * 64];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) dc[(mt * 4 + vv) * 64] = cur[mt][vv] + regs[mt][vv];
+    };
     for (int turn = 0; turn < 4; ++turn) {
       __syncthreads();
       if (wv != turn) continue;
@@ -1045,16 +1094,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       for (int c = 1; c + 1 < NC; ++c) {
         if (c + 1 >= p.n) continue;   // shorter strings
         float* dc = lds + p.dacc_off[c] + lane;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int vv = 0; vv < 4; ++vv) dc[(mt * 4 + vv) * 64] += dreg[c - 1][mt][vv];
-        if (p.o[c] > 1) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int vv = 0; vv < 4; ++vv) dc[MT * 256 + (mt * 4 + vv) * 64] += dreg[NC - 2][mt][vv];
-        }
+        join_tiles(dc, dreg[c - 1], turn == 0);
+        if (p.o[c] > 1) join_tiles(dc + MT * 256, dreg[NC - 2], turn == 0);
       }
       if (wl == 0) {   // first / last core: one lane per k group holds the sum over the group's 16 window lanes
         float* d0p = lds + p.dacc_off[0];
@@ -1064,8 +1105,9 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq)
             if (qq < p.qc) {
-              d0p[(4 * s + g) * p.qc + qq] += d0s[s][qq];
-              dlp[(4 * s + g) * p.qc + qq] += dls[s][qq];
+              const int e = (4 * s + g) * p.qc + qq;
+              d0p[e] = (turn == 0 ? 0.f : d0p[e]) + d0s[s][qq];
+              dlp[e] = (turn == 0 ? 0.f : dlp[e]) + dls[s][qq];
             }
       }
     }
@@ -1283,7 +1325,7 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     const int NT16 = 2;   // window tiles per wave iteration (4 was tried for r = 16: 892 bytes of scratch per lane, slower)
     q2.fs_off = o2; o2 += 4 * n * 4 * 16 * NT16;
     q2.zt_off = o2; o2 += 4 * 16 * ZROW;
-    q2.vt_off = o2; o2 += 4 * 256;
+    q2.vt_off = o2; o2 += 4 * 16 * 17;
     // the workgroup's dCore accumulator: with the register accumulators (n <= 9) it is only used by the final flush,
     // when the packs are dead, and lies over them; otherwise it is a region of its own
     int o3 = (n <= 9) ? 0 : o2;
