@@ -59,10 +59,12 @@ struct HalfP {
   int ksplit;             // grid.z of the dCore product
 };
 
-HalfP make_half(const EpsP& p, size_t esz) {
+// big_first: the larger half is the first one (the bf16 products: K = A of the forward GEMM is then the long
+// dimension and its fused epilogue touches O Bn, not O A, columns per window)
+HalfP make_half(const EpsP& p, size_t esz, bool big_first = false) {
   HalfP h;
   h.p = p;
-  h.n0 = p.N / 2;
+  h.n0 = big_first ? p.N - p.N / 2 : p.N / 2;
   h.n1 = p.N - h.n0;
   h.A = ipow_ll(p.Q, h.n0);
   h.Bn = ipow_ll(p.Q, h.n1);
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
         }
         int lstride = 0;
         if (LOGQ > 0) lstride = LOGQ * (nd - 1 - fd);
-        for (int j = sl; j < EQ; j += nsl) {
+#pragma unroll 4
+        for (int j = sl; j < EQ; j += nsl) {   // (unrolled: the three LDS reads of four terms are in flight together)
           int u, l;
           if (LOGQ > 0) {
             u = j >> lstride;
@@ -666,7 +669,7 @@ bool halves_shape_ok(const EpsP& p, size_t esz) {
   if (p.Wn >= (1ll << 31)) return false;
   // per-workgroup LDS of the halves kernel (features + quarter tables) and of the dX kernel (3 E per wave)
   if ((size_t)4 * ((size_t)p.N * p.Q + 2 * (size_t)(h.A + h.Bn)) * esz > DCTN_LDS_BUDGET) return false;
-  if ((size_t)4 * ((size_t)h.n1 * p.Q + 3 * (size_t)h.Bn + 64) * esz > DCTN_LDS_BUDGET) return false;
+  if ((size_t)4 * ((size_t)(h.n1 > h.n0 ? h.n1 : h.n0) * p.Q + 3 * (size_t)(h.Bn > h.A ? h.Bn : h.A) + 64) * esz > DCTN_LDS_BUDGET) return false;
   return true;
 }
 
@@ -688,7 +691,11 @@ bool halves_shape_ok(const EpsP& p, size_t esz) {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 
 constexpr int BK = 64;        // k per chunk (two MFMA steps per barrier pair)
-constexpr int BT = 128;       // workgroup tile (2 x 2 waves of 64 x 64 = 4 x 4 MFMA tiles each)
+// workgroup tile BM x BN: 2 x 2 waves of (16 TI) x (16 TJ).  128 x 64 per wave: 24 KB of LDS fragment reads per 64
+// MFMAs (64 x 64 per wave read 16 KB per 32, and with 12 resident waves the LDS pipe, not the matrix pipe, was the
+// limit: 0.22-0.30 of the bf16 peak)
+constexpr int TI = 4, TJ = 4;
+constexpr int BM = 32 * TI, BN = 32 * TJ;
 
 enum { BA_KFAST = 0, BA_SCALED = 1 };   // A[m][k] rows / sc[m][o] * V[m][j], k = o KV + j
 enum { BB_KFAST = 0, BB_PROD = 1 };     // B stored [n][k] / scT[o][k..] * VT[j][k..] for row n = (o, j), both k-contiguous
@@ -722,38 +729,45 @@ __device__ __forceinline__ bf16x8v scale8(bf16x8v v, float s) {
 template <int LA, int LB, int EPI>
 __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag, const bf16_t* __restrict__ Bg,
                                                    float* __restrict__ Cg, GemmB g) {
-  constexpr int BROW = BK + 4;   // LDS row in bf16: 136 bytes (8-byte aligned operand reads)
-  __shared__ __align__(16) bf16_t smem[2 * BT * BROW];
+  // LDS rows of 128 bytes (64 k), the 16-byte slot XORed with bits 1..3 of the row: every 16-lane group of a ds_read_b128
+  // (8 rows at slot s, 8 rows at slot s ^ 1: MI355X_MICROARCH.md LDS table) then covers all 64 banks.  Padded rows
+  // (136 bytes: 8-byte accesses only; 144 bytes: 2-way conflicts on exactly those groups, 47 % of the LDS cycles) lost.
+  constexpr int BROW = BK;
+  auto sw = [](int row, int k) { return row * BK + ((((k >> 3) ^ (row >> 1)) & 7) << 3) + (k & 7); };   // element offset
+  constexpr int UA = BM / 64, UB = BN / 64;   // staged row groups per thread
+  __shared__ __align__(16) bf16_t smem[(BM + BN) * BROW];
   bf16_t* As = smem;               // [m][k]
-  bf16_t* Bs = smem + BT * BROW;   // [n][k]
+  bf16_t* Bs = smem + BM * BROW;   // [n][k]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int tiles_n = (g.N + BT - 1) / BT, tiles_m = (g.M + BT - 1) / BT;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int total = tiles_n * tiles_m * g.slices, per = (total + 7) / 8;
   const int t = ((int)blockIdx.x % 8) * per + (int)blockIdx.x / 8;   // XCD-aware tile order (see halves_gemm_k)
   if (t >= total) return;
   const int bz = t / (tiles_n * tiles_m), trem = t - bz * tiles_n * tiles_m;
-  const int m0 = (trem / tiles_n) * BT, n0 = (trem % tiles_n) * BT;
+  const int m0 = (trem / tiles_n) * BM, n0 = (trem % tiles_n) * BN;
   const long long kbeg = (long long)bz * g.kslice;
   const long long kend = kbeg + g.kslice < g.K ? kbeg + g.kslice : g.K;
   const int kf_r = tid >> 2, kf_k8 = (tid & 3) * 8;   // row (+64 u), 8 k's (+32 s)
-  bf16x8v ra[2][2], rb[2][2];
-  float sa[2][2];
+  bf16x8v ra[UA][2], rb[UB][2];
+  float sa[UA][2];
   auto fetch = [&](long long kc0) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const long long k = min(kc0 + 32 * s2 + kf_k8, (long long)g.K - 8);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const long long k = min(kc0 + 32 * s2 + kf_k8, (long long)g.K - 8);
+      for (int u = 0; u < UA; ++u) {
+        const long long m = min(m0 + kf_r + 64 * u, g.M - 1);
         if (LA == BA_KFAST) {
-          const long long m = min(m0 + kf_r + 64 * u, g.M - 1);
           ra[u][s2] = *reinterpret_cast<const bf16x8v*>(Ag + m * g.lda + k);
         } else {   // sc[m][o] * V[m][j .. j+7], k = o KV + j (a 32-wide step lies inside one o)
-          const long long m = min(m0 + kf_r + 64 * u, g.M - 1);
           const int o = (int)(k / g.KV), j = (int)(k - (long long)o * g.KV);
           ra[u][s2] = *reinterpret_cast<const bf16x8v*>(g.vec + m * g.ldv + j);
           sa[u][s2] = (float)g.sc[m * g.O + o];
         }
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
         if (LB == BB_KFAST) {
           const long long n = min(n0 + kf_r + 64 * u, g.N - 1);
           rb[u][s2] = *reinterpret_cast<const bf16x8v*>(Bg + n * g.ldb + k);
@@ -766,32 +780,28 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
           for (int e = 0; e < 8; ++e) rb[u][s2][e] = (bf16_t)((float)v[e] * (float)c[e]);
         }
       }
+    }
   };
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
-  auto put8 = [&](bf16_t* dst, bf16x8v v) {   // 8-byte aligned destination
-    reinterpret_cast<bf16x4v*>(dst)[0] = bf16x4v{v[0], v[1], v[2], v[3]};
-    reinterpret_cast<bf16x4v*>(dst)[1] = bf16x4v{v[4], v[5], v[6], v[7]};
-  };
+  auto put8 = [&](bf16_t* dst, bf16x8v v) { *reinterpret_cast<bf16x8v*>(dst) = v; };   // 16-byte aligned destination
   auto stage = [&](long long kc0) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bool in = kc0 + 32 * s2 + kf_k8 < kend;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bool in = kc0 + 32 * s2 + kf_k8 < kend;
+      for (int u = 0; u < UA; ++u) {
         const bf16x8v va = LA == BA_SCALED ? scale8(ra[u][s2], sa[u][s2]) : ra[u][s2];
-        put8(As + (kf_r + 64 * u) * BROW + 32 * s2 + kf_k8, in ? va : zero8());
-        put8(Bs + (kf_r + 64 * u) * BROW + 32 * s2 + kf_k8, in ? rb[u][s2] : zero8());
+        put8(As + sw(kf_r + 64 * u, 32 * s2 + kf_k8), in ? va : zero8());
       }
-  };
-  auto get8 = [&](const bf16_t* src) {
-    const bf16x4v lo = reinterpret_cast<const bf16x4v*>(src)[0], hi = reinterpret_cast<const bf16x4v*>(src)[1];
-    return bf16x8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  };
-  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+      for (int u = 0; u < UB; ++u) put8(Bs + sw(kf_r + 64 * u, 32 * s2 + kf_k8), in ? rb[u][s2] : zero8());
+    }
+  };
+  auto get8 = [&](const bf16_t* src) { return *reinterpret_cast<const bf16x8v*>(src); };
+  f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (kbeg < kend) fetch(kbeg);
   for (long long k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();
@@ -800,31 +810,32 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
     if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8v a[4], b[4];
+      bf16x8v b[TJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = get8(As + (64 * wm + 16 * i + lr) * BROW + 32 * s2 + 8 * lk);
+      for (int j = 0; j < TJ; ++j) b[j] = get8(Bs + sw(16 * TJ * wn + 16 * j + lr, 32 * s2 + 8 * lk));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = get8(Bs + (64 * wn + 16 * j + lr) * BROW + 32 * s2 + 8 * lk);
+      for (int i = 0; i < TI; ++i) {
+        const bf16x8v a = get8(As + sw(16 * TI * wm + 16 * i + lr, 32 * s2 + 8 * lk));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
   if (EPI == BEPI_FWD) {
-    // a wave's 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[n / 64][w] = sum over
-    // those columns of Z'[w, n] P1[w, i1(n)] — no other wave shares the (row, column block), so it is written directly
+    // a wave's 16 TJ = 64 columns are (o, i1 .. i1 + 63) for ONE o (Bn is a multiple of 64): partial[n / 64][w] = sum over
+    // those columns of Z'[w, n] P1[w, i1(n)] - no other wave shares the (row, column block), so it is written directly
+    static_assert(TJ == 4, "the forward epilogue writes one partial per 64 columns");
     const int nb = n0 + 64 * wn;   // first column of this wave
     if (nb < g.N) {
       const int i1_0 = nb % g.Bn;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int mrow = m0 + 64 * wm + 16 * i + 4 * lk + v, m = min(mrow, g.M - 1);
+          const int mrow = m0 + 16 * TI * wm + 16 * i + 4 * lk + v, m = min(mrow, g.M - 1);
           float sum = 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sum += acc[i][j][v] * (float)g.p1[(long long)m * g.Bn + i1_0 + 16 * j + lr];
+          for (int j = 0; j < TJ; ++j) sum += acc[i][j][v] * (float)g.p1[(long long)m * g.Bn + i1_0 + 16 * j + lr];
 #pragma unroll
           for (int step = 1; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
           if (lr == 0 && mrow < g.M) Cg[(long long)(nb / 64) * g.M + mrow] = sum;
@@ -834,12 +845,12 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
   }
   float* C = Cg + (long long)bz * g.cslice;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int m = m0 + 64 * wm + 16 * i + 4 * lk + v, n = n0 + 64 * wn + 16 * j + lr;
+        const int m = m0 + 16 * TI * wm + 16 * i + 4 * lk + v, n = n0 + 16 * TJ * wn + 16 * j + lr;
         if (m < g.M && n < g.N) C[(long long)m * g.N + n] = acc[i][j][v];
       }
 }
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
 template <int LA, int LB, int EPI = BEPI_STORE>
 void bf16_gemm_launch(const bf16_t* A, const bf16_t* B, float* C, GemmB g, int slices, hipStream_t st) {
   g.slices = slices;
-  const int total = ((g.N + BT - 1) / BT) * ((g.M + BT - 1) / BT) * slices;
+  const int total = ((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) * slices;
   hipLaunchKernelGGL((bf16_gemm_k<LA, LB, EPI>), dim3((total + 7) / 8 * 8), dim3(256), 0, st, A, B, C, g);
 }
 
@@ -917,7 +928,7 @@ __global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ 
 // chunk of windows of the bf16 path: no Z buffer; per window P0, P1 (bf16), their transposes, dP0, dP1 (float32) and the
 // forward partials
 HalfP make_half_bf16(const EpsP& p) {
-  HalfP h = make_half(p, sizeof(float));
+  HalfP h = make_half(p, sizeof(float), true);
   const long long per_win = (h.A + h.Bn) * 8 + (h.NB / 64) * 4 + p.O * 2;
   const size_t budget = chunk_budget(p);
   long long wc = (long long)(budget / (size_t)per_win) / 64 * 64;
@@ -927,10 +938,12 @@ HalfP make_half_bf16(const EpsP& p) {
   return h;
 }
 
-// k slices of the dCore product (128 x 128 tiles): until ~2 workgroups per CU exist, >= 256 windows per slice
+// k slices of the dCore product (128 x 128 tiles): one full round of the 3 workgroups a CU holds (768; 576 workgroups
+// left a quarter of the slots empty: 388 -> 3xx us on the cfg3a layer-2 core), >= 256 windows per slice
 int bf16_ksplit(const HalfP& h) {
-  const long long tiles = ((h.A + BT - 1) / BT) * ((h.NB + BT - 1) / BT);
-  long long ks = (512 + tiles - 1) / tiles;
+  const long long tiles = ((h.A + BM - 1) / BM) * ((h.NB + BN - 1) / BN);
+  long long ks = 768 / tiles;
+  if (ks * tiles < 512) ks = (512 + tiles - 1) / tiles;
   const long long max_ks = (h.wc + 255) / 256;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
@@ -941,7 +954,7 @@ int bf16_ksplit(const HalfP& h) {
 // bf16 path: every k-contiguous source is read 16 bytes at a time, scaled chunks and forward tiles lie inside one o
 bool bf16_shape_ok(const EpsP& p) {
   if (!halves_shape_ok(p, sizeof(float))) return false;
-  const HalfP h = make_half(p, sizeof(float));
+  const HalfP h = make_half(p, sizeof(float), true);
   return h.A % 32 == 0 && h.Bn % 64 == 0;
 }
 
