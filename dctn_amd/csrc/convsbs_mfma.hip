@@ -76,11 +76,12 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 // All feature products of a window (every core of the string) at once: the pixel loads of up to 8
 // cores are issued back to back (one memory round trip per chunk instead of one per core), the
 // products go to the wave's LDS slice fs[(c*4 + qq)*32 + window] and are read back per core.
-template <int WPG = 32, int CB = 8>   // CB: cores per batch of loads (one memory round trip per batch)
+// ONECH: 1 = the caller knows p.C == 1 (only that path is compiled), 0 = decided at run time
+template <int WPG = 32, int CB = 8, int ONECH = 0>   // CB: cores per batch of loads (one memory round trip per batch)
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
-  if (p.C == 1) {   // one channel: the feature products ARE the pixel's q values (no digit table, half the loads)
+  if (ONECH || p.C == 1) {   // one channel: the feature products ARE the pixel's q values (no digit table, half the loads)
     for (int c0 = 0; c0 < p.n; c0 += CB) {
       float raw1[CB][4];
 #pragma unroll
@@ -101,6 +102,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
     }
     return;
   }
+  if constexpr (ONECH) return;
   for (int c0 = 0; c0 < p.n; c0 += CB) {
     float raw[CB][2][4];
 #pragma unroll
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
 //                             [tile][reg][lane] (conflict-free ds_add_f32), re-ordered once at the final flush
 //   first / last core       : their gradients are lane-local sums kept in registers across all window groups
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int V> struct sbs_ic { static constexpr int value = V; };
 
 template <int CTRL>
 __device__ __forceinline__ float sbs_dpp_add(float v) {
@@ -664,7 +667,9 @@ __device__ unsigned long long sbs_stamps[2048 * 32];
 #define SBS_STAMP(SLOT) do { } while (0)
 #endif
 
-template <int R, int NC, int NT>
+// ONECH: one input channel (the multi-channel feature products and their gradients are not compiled: 20 KB of the
+// bond-16 kernel's 77 KB, which no longer fits the 64 KB instruction cache)
+template <int R, int NC, int NT, int ONECH>
 __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
                                                             const float* __restrict__ dY,
                                                             float* __restrict__ states,
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      stage_features<WPG, 9>(x, p, b, ho, wo, valid, fs, lane);   // a 9-core string's pixels in one round trip
+      stage_features<WPG, 9, ONECH>(x, p, b, ho, wo, valid, fs, lane);   // a 9-core string's pixels in one round trip
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -751,12 +756,13 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (!vt_ok[t]) continue;
-        if (p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
+        if (ONECH || p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
 #pragma unroll
           for (int qv = 0; qv < 4; ++qv)
             if (qv < p.q) gxw[(long long)(c * p.q + qv) * p.Wn + wt[t]] = df[qv][t];
           continue;
         }
+        if constexpr (!ONECH)
         for (int ch = 0; ch < p.C; ++ch)
           for (int qv = 0; qv < p.q; ++qv) {
             float gsum = 0.f;
@@ -826,23 +832,20 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       for (int s = 0; s < SN; ++s)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { nv[0][s][t] = 0.f; nv[1][s][t] = 0.f; }
-      for (int a = 0; a < oacc; ++a)
-        for (int o = 0; o < oc; ++o) {
-          float vin[SN][NT];   // (a select, not a runtime index: the states stay in registers)
+      auto forward_pair = [&](auto A_, auto O_) {   // (a, o) as constants, as in the way back
+        constexpr int a = decltype(A_)::value, o = decltype(O_)::value;
+        f32x4 D[MT][NT];
+        u_tiles(c, o, v[a], D);
 #pragma unroll
-          for (int s = 0; s < SN; ++s)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) vin[s][t] = a == 0 ? v[0][s][t] : v[1][s][t];
-          f32x4 D[MT][NT];
-          u_tiles(c, o, vin, D);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              const float val = f[0][t] * D[mt][t][0] + f[1][t] * D[mt][t][1] + f[2][t] * D[mt][t][2] + f[3][t] * D[mt][t][3];
-              if (a * oc + o == 0) nv[0][mt][t] = val; else nv[1][mt][t] = val;
-            }
-        }
+          for (int t = 0; t < NT; ++t)
+            nv[(a == 0 && o == 0) ? 0 : 1][mt][t] =
+                f[0][t] * D[mt][t][0] + f[1][t] * D[mt][t][1] + f[2][t] * D[mt][t][2] + f[3][t] * D[mt][t][3];
+      };
+      forward_pair(sbs_ic<0>{}, sbs_ic<0>{});
+      if (oc > 1) forward_pair(sbs_ic<0>{}, sbs_ic<1>{});
+      if (oacc > 1) forward_pair(sbs_ic<1>{}, sbs_ic<0>{});
 #pragma unroll
       for (int s = 0; s < SN; ++s)
 #pragma unroll
@@ -923,17 +926,14 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
       for (int s = 0; s < SN; ++s)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { d[0][s][t] = 0.f; d[1][s][t] = 0.f; }
-      for (int a = 0; a < oacc_in; ++a)
-        for (int o = 0; o < oc; ++o) {
-          const bool g_first = (a * oc + o) == 0;
-          float Gs[SN][NT], vin[SN][NT];
-#pragma unroll
-          for (int s = 0; s < SN; ++s)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              Gs[s][t] = g_first ? G[0][s][t] : G[1][s][t];
-              vin[s][t] = a == 0 ? v[0][s][t] : v[1][s][t];
-            }
+      // (input state a, output o) -> adjoint state a oc + o; at most two states, so the four (a, o) bodies are written
+      // out with a and o as constants: which state / adjoint register a body touches is then fixed at compile time (the
+      // runtime form picked them with ~50 v_cndmask per body, a third of its vector instructions)
+      auto adjoint_pair = [&](auto A_, auto O_) {
+          constexpr int a = decltype(A_)::value, o = decltype(O_)::value;
+          constexpr int gi = (a == 0 && o == 0) ? 0 : 1;   // a oc + o is 0 only for (0, 0); otherwise 1 (two states at most)
+          const float (&Gs)[SN][NT] = G[gi];
+          const float (&vin)[SN][NT] = v[a];
           // (1)+(2) ONE product serves d/d(features) and the adjoint: W[(l, qq), w] = sum_r' core[o, l, r', qq] G[r', w]
           // (the forward product with the core's bond legs exchanged: rows i <-> l = 4 mt + (i >> 2), qq = i & 3, k = r',
           // B = G straight from its state registers).  The accumulator gives lane (w, g) the rows l = 4 mt + g, qq = 0..3:
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
 #pragma unroll
               for (int t = 0; t < NT; ++t) {
                 const float dvl = f[0][t] * Wt[t][0] + f[1][t] * Wt[t][1] + f[2][t] * Wt[t][2] + f[3][t] * Wt[t][3];
-                if (a == 0) d[0][mt][t] += dvl; else d[1][mt][t] += dvl;
+                d[a][mt][t] += dvl;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) df[qq][t] += vin[mt][t] * Wt[t][qq];
               }
@@ -1019,7 +1019,10 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
                 for (int vv = 0; vv < 4; ++vv) atomicAdd(&dc[(mt * 4 + vv) * 64], acc[mt][vv]);
             }
           }
-        }
+      };
+      adjoint_pair(sbs_ic<0>{}, sbs_ic<0>{});
+      if (oc > 1) adjoint_pair(sbs_ic<0>{}, sbs_ic<1>{});        // (the string has at most two output values in all,
+      if (oacc_in > 1) adjoint_pair(sbs_ic<1>{}, sbs_ic<0>{});   //  so (1, 1) does not occur)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -1355,10 +1358,17 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
       q2.partials = (partials && partial_bytes >= (size_t)blocks * q2.core_off[n] * sizeof(float)) ? partials : nullptr;
 #define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
   do {                                                                                            \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV>,                    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);             \
-    hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV>), dim3((unsigned)blocks), dim3(256), lds2, st, \
-                       (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);       \
+    if (p.C == 1) {                                                                               \
+      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>,               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
+      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>), dim3((unsigned)blocks), dim3(256), lds2, st, \
+                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
+    } else {                                                                                      \
+      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 0>,               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
+      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 0>), dim3((unsigned)blocks), dim3(256), lds2, st, \
+                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
+    }                                                                                             \
   } while (0)
       switch (R) {   // up to 9 cores (mnist.py:189-223): register accumulators; longer strings: LDS accumulators
         case 4: if (n <= 9) SBS_LAUNCH_B16(4, 9, 2); else SBS_LAUNCH_B16(4, 0, 2); break;
