@@ -9,23 +9,31 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r02
 mkdir -p $OUT
+CFGS=${CFGS:-"cfg1 cfg3a cfg3b cfg4_r4 cfg4_r16 cfg5"}   # CFGS="cfg4_r4 cfg4_r16" HEADLINE=0 re-takes only those
+HEADLINE=${HEADLINE:-1}
+if [ "$HEADLINE" = 1 ]; then
 echo "[profile] headline kernel stats"
 rocprofv3 --kernel-trace --stats -d $OUT/headline -o h --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 200 --warmup 20 > $OUT/headline.json 2> $OUT/headline.err || echo "headline stats failed"
-for cfg in cfg1 cfg3a cfg3b cfg4_r4 cfg4_r16 cfg5; do
+fi
+for cfg in $CFGS; do
   echo "[profile] $cfg kernel stats"
   rocprofv3 --kernel-trace --stats -d $OUT/$cfg -o k --output-format csv -- python3 bench.py --skip-headline --configs $cfg --no-cpu-baseline > $OUT/$cfg.json 2> $OUT/$cfg.err || echo "$cfg stats failed"
 done
 echo "[profile] PMC traffic passes"
+if [ "$HEADLINE" = 1 ]; then
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/headline_fetch -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_fetch.err || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/headline_write -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_write.err || echo "write failed"
-for cfg in cfg1 cfg3a cfg3b cfg4_r4 cfg4_r16 cfg5; do
+fi
+for cfg in $CFGS; do
   echo "[profile] $cfg traffic"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${cfg}_fetch -o p --output-format csv -- python3 bench.py --skip-headline --configs $cfg --no-cpu-baseline > /dev/null 2> $OUT/${cfg}_fetch.err || echo "$cfg fetch failed"
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${cfg}_write -o p --output-format csv -- python3 bench.py --skip-headline --configs $cfg --no-cpu-baseline > /dev/null 2> $OUT/${cfg}_write.err || echo "$cfg write failed"
 done
+if [ "$HEADLINE" = 1 ]; then
 echo "[profile] SQ busy counters, cfg2 kernels at B = 1024"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/headline_sq1 -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_sq1.err || echo "sq1 failed"
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_COEXEC_CYCLES --kernel-trace -d $OUT/headline_sq2 -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_sq2.err || echo "sq2 failed"
+fi
 find $OUT -name "*kernel_trace.csv" -size +3M -delete   # keep the merge under the 64 MiB limit
 du -sh $OUT
 echo "[profile] done"
