@@ -21,6 +21,8 @@ typedef __attribute__((ext_vector_type(2))) int int2v;
 
 struct SbsMP {
   int n, C, B, H, W, q, qc, Ho, Wo, Otot;
+  int ostride, obase;         // row length of out / dY and the first output of this launch (many-output strings run in slices)
+  int accum;                  // backward: add to gxw and to the core gradients instead of setting them (slices after the first)
   long long Wn, ngroups;
   long long s[5];
   int o[SBSM_MAXC], ph[SBSM_MAXC], pw[SBSM_MAXC];
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     r0 = half_sum(r0);
     r1 = half_sum(r1);
     if (valid && h == 0) {
-      out[w * p.Otot] = r0;
-      if (p.Otot > 1) out[w * p.Otot + 1] = r1;
+      out[w * p.ostride + p.obase] = r0;
+      if (p.Otot > 1) out[w * p.ostride + p.obase + 1] = r1;
     }
   }
 }
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     const long long b = ww / hw;
     const int rem = (int)(ww - b * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    const float dy0 = valid ? dY[w * p.Otot] : 0.f;
-    const float dy1 = (valid && p.Otot > 1) ? dY[w * p.Otot + 1] : 0.f;
+    const float dy0 = valid ? dY[w * p.ostride + p.obase] : 0.f;
+    const float dy1 = (valid && p.Otot > 1) ? dY[w * p.ostride + p.obase + 1] : 0.f;
     float f[4];
     float* fs = lds + p.fs_off + (tid >> 6) * p.n * 128;
     stage_features(x, p, b, ho, wo, valid, fs, lane);
@@ -741,8 +743,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
     float dy[2][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      dy[0][t] = vt_ok[t] ? dY[wt[t] * p.Otot] : 0.f;
-      dy[1][t] = (vt_ok[t] && p.Otot > 1) ? dY[wt[t] * p.Otot + 1] : 0.f;
+      dy[0][t] = vt_ok[t] ? dY[wt[t] * p.ostride + p.obase] : 0.f;
+      dy[1][t] = (vt_ok[t] && p.Otot > 1) ? dY[wt[t] * p.ostride + p.obase + 1] : 0.f;
     }
     float f[4][NT];
     auto load_f = [&](int c) {
@@ -759,7 +761,10 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
         if (ONECH || p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
 #pragma unroll
           for (int qv = 0; qv < 4; ++qv)
-            if (qv < p.q) gxw[(long long)(c * p.q + qv) * p.Wn + wt[t]] = df[qv][t];
+            if (qv < p.q) {
+              float* gp = gxw + (long long)(c * p.q + qv) * p.Wn + wt[t];
+              *gp = p.accum ? *gp + df[qv][t] : df[qv][t];
+            }
           continue;
         }
         if constexpr (!ONECH)
@@ -776,7 +781,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
                           (long long)(wot[t] + p.pw[c]) * p.s[3] + p.digit[qq][c2] * p.s[4]];
               gsum += df[qq][t] * pr;
             }
-            gxw[(long long)((c * p.C + ch) * p.q + qv) * p.Wn + wt[t]] = gsum;
+            float* gp = gxw + (long long)((c * p.C + ch) * p.q + qv) * p.Wn + wt[t];
+            *gp = p.accum ? *gp + gsum : gsum;
           }
       }
     };
@@ -1203,7 +1209,8 @@ __global__ __launch_bounds__(256) void convsbs_dcore_reduce_k(SbsMP p, int nrec)
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     int c = 0;
     while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
-    p.dcore[c][e - p.core_off[c]] = v;
+    float* dst = p.dcore[c] + (e - p.core_off[c]);
+    *dst = p.accum ? *dst + v : v;   // (slices of a many-output string: one launch after the other on the stream)
   }
 }
 
@@ -1234,6 +1241,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   if (otot > 2 || out_sizes[0] != 1 || out_sizes[n - 1] != 1) return DCTN_ERR_UNSUPPORTED;
   p.n = n; p.C = C; p.B = B; p.H = H; p.W = W; p.q = q; p.qc = (int)qc; p.Otot = (int)otot;
+  p.ostride = (int)otot; p.obase = 0; p.accum = 0;
   int max_h = 0, max_w = 0;
   for (int c = 0; c < n; ++c) {
     p.o[c] = out_sizes[c]; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
@@ -1261,13 +1269,34 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   return DCTN_OK;
 }
 
-int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
-                     const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                     int C, int B, int H, int W, int q, int dtype, hipStream_t st) {
+// Strings with ONE many-valued middle core (the final string of the reference's ConvSBS classifier, mnist.py:214-224:
+// ten labels on core 4) run as slices of at most two output values: slice j takes core m's outputs 2j, 2j + 1 (its
+// [o][l][r][q] layout makes a slice a pointer offset), writes columns 2j.. of out and reads those of dY; the gradients of
+// the other cores and of x add up over the slices.  Returns the index of that core, -1 when the string has none, -2 when
+// the outputs have another shape (the generic sweep takes those).
+static int sbsm_many_output_core(int n, const int* out_sizes) {
+  int m = -1;
+  for (int c = 0; c < n; ++c) {
+    if (out_sizes[c] < 1) return -2;
+    if (out_sizes[c] > 2) {
+      if (m >= 0 || c == 0 || c == n - 1 || out_sizes[c] > 64) return -2;
+      m = c;
+    }
+  }
+  if (m < 0) return -1;
+  for (int c = 0; c < n; ++c)
+    if (c != m && out_sizes[c] != 1) return -2;
+  return m;
+}
+
+static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
+                                const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                int C, int B, int H, int W, int q, int dtype, hipStream_t st, int obase, int ostride) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
+  if (ostride > 0) { p.ostride = ostride; p.obase = obase; }
   const size_t lds = (size_t)off * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.ngroups + 3) / 4;
@@ -1292,20 +1321,47 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
   return DCTN_OK;
 }
 
+int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
+                     const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                     int C, int B, int H, int W, int q, int dtype, hipStream_t st) {
+  if (n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
+  const int m = sbsm_many_output_core(n, out_sizes);
+  if (m == -2) return DCTN_ERR_UNSUPPORTED;
+  if (m < 0)
+    return convsbs_fwd_mfma_one(x, xs, cores, out, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st, 0, 0);
+  if (dtype != DCTN_F32) return DCTN_ERR_UNSUPPORTED;
+  int outs[SBSM_MAXC];
+  const void* cp[SBSM_MAXC];
+  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; cp[c] = cores[c]; }
+  long long qc = 1;
+  for (int c = 0; c < C; ++c) qc *= q;
+  const long long per_o = (long long)bond_sizes[m] * bond_sizes[(m + 1) % n] * qc;   // core m is [o][l][r][q...]
+  const int om = out_sizes[m];
+  for (int o0 = 0; o0 < om; o0 += 2) {
+    outs[m] = om - o0 < 2 ? om - o0 : 2;
+    cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
+    const int rc = convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st, o0, om);
+    if (rc != DCTN_OK) return rc;   // (the first slice decides: every later one has the same or a smaller plan)
+  }
+  return DCTN_OK;
+}
+
 // Backward of the same family (R <= 16).  `states` must hold sum_c oacc_c * R floats per window
 // (the generic kernels' state region is large enough), `gxw` the per-window feature gradients
 // [(c*C + ch)*q + qv][Wn] (may be NULL when dX is not needed), `dcores[c]` zero-initialised float
 // accumulators (may be NULL array when no core gradient is needed... the kernel still runs its
 // dCore part into LDS only).
-int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
-                     float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
-                     const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
-                     int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes) {
+static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
+                                float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
+                                const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                                int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes,
+                                int obase, int ostride, int accum) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
   if (R > 16 || !dcores || !states) return DCTN_ERR_UNSUPPORTED;
+  if (ostride > 0) { p.ostride = ostride; p.obase = obase; p.accum = accum; }
   long long so = 0;
   int oacc = 1;
   for (int c = 0; c < n; ++c) {
@@ -1397,6 +1453,7 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
     }
   }
   // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
+  if (ostride > 0) return DCTN_ERR_UNSUPPORTED;   // (slices of a many-output string: second version only)
   p.ngroups = (p.Wn + 31) / 32;
   so = 0;
   oacc = 1;
@@ -1435,3 +1492,34 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
   dctn_set_last_kernel("convsbs_bwd_mfma_f32");
   return DCTN_OK;
 }
+
+int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
+                     float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
+                     const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                     int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes) {
+  if (n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
+  const int m = sbsm_many_output_core(n, out_sizes);
+  if (m == -2) return DCTN_ERR_UNSUPPORTED;
+  if (m < 0)
+    return convsbs_bwd_mfma_one(x, xs, cores, dY, states, gxw, dcores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                                dtype, st, partials, partial_bytes, 0, 0, 0);
+  if (dtype != DCTN_F32 || !dcores) return DCTN_ERR_UNSUPPORTED;
+  int outs[SBSM_MAXC];
+  const void* cp[SBSM_MAXC];
+  float* dcp[SBSM_MAXC];
+  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; cp[c] = cores[c]; dcp[c] = dcores[c]; }
+  long long qc = 1;
+  for (int c = 0; c < C; ++c) qc *= q;
+  const long long per_o = (long long)bond_sizes[m] * bond_sizes[(m + 1) % n] * qc;
+  const int om = out_sizes[m];
+  for (int o0 = 0; o0 < om; o0 += 2) {   // see convsbs_fwd_mfma: slices of two output values, one launch after the other
+    outs[m] = om - o0 < 2 ? om - o0 : 2;
+    cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
+    dcp[m] = dcores[m] + (long long)o0 * per_o;
+    const int rc = convsbs_bwd_mfma_one(x, xs, cp, dY, states, gxw, dcp, n, outs, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                                        dtype, st, partials, partial_bytes, o0, om, o0 > 0);
+    if (rc != DCTN_OK) return rc;
+  }
+  return DCTN_OK;
+}
+

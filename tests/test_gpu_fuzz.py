@@ -369,6 +369,13 @@ def sbs_mfma_cases():
         if rng.random() < 0.8:
             outs[rng.randrange(1, n - 1)] = 2
         cases.append((pos, (1,) + (r,) * (n - 1), tuple(outs), C, q))
+    # one many-valued middle core (the final string of the reference's ConvSBS classifier, mnist.py:214-224: ten labels on
+    # core 4 of a snake over two channels): slices of two outputs on the same kernels; an odd count leaves a one-output slice
+    snake = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
+    for r, C, q, where, om in [(4, 2, 2, 4, 10), (16, 1, 2, 4, 5), (8, 2, 2, 2, 3)]:
+        outs = [1] * 9
+        outs[where] = om
+        cases.append((snake, (1,) + (r,) * 8, tuple(outs), C, q))
     return cases
 
 
