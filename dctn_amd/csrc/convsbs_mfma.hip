@@ -23,6 +23,8 @@ struct SbsMP {
   int n, C, B, H, W, q, qc, Ho, Wo, Otot;
   int ostride, obase;         // row length of out / dY and the first output of this launch (many-output strings run in slices)
   int accum;                  // backward: add to gxw and to the core gradients instead of setting them (slices after the first)
+  int out_accum;              // forward: add to out (rings: one launch per value of the closing bond)
+  int last_stride;            // elements between the rows of the last core's table (qc; rings: a column of its matrix)
   long long Wn, ngroups;
   long long s[5];
   int o[SBSM_MAXC], ph[SBSM_MAXC], pw[SBSM_MAXC];
@@ -170,7 +172,7 @@ __device__ __forceinline__ void pack_cores(float* lds, const SbsMP& p, int tid) 
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
     lds[p.first_off + e] = qq < p.qc ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -258,8 +260,9 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     r0 = half_sum(r0);
     r1 = half_sum(r1);
     if (valid && h == 0) {
-      out[w * p.ostride + p.obase] = r0;
-      if (p.Otot > 1) out[w * p.ostride + p.obase + 1] = r1;
+      float* op = out + w * p.ostride + p.obase;
+      op[0] = p.out_accum ? op[0] + r0 : r0;
+      if (p.Otot > 1) op[1] = p.out_accum ? op[1] + r1 : r1;
     }
   }
 }
@@ -643,7 +646,7 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
     lds[p.first_off + e] = qq < p.qc ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -1146,7 +1149,8 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restr
     if (c == 0 || c == p.n - 1) {
       const int E = R * p.qc;
       for (int e = tid; e < E; e += 256) {
-        if (rec) rec[p.core_off[c] + e] = src[e]; else atomicAdd(&p.dcore[c][e], src[e]);
+        if (rec) rec[p.core_off[c] + e] = src[e];
+        else atomicAdd(&p.dcore[c][c == 0 ? e : (e / p.qc) * p.last_stride + e % p.qc], src[e]);
       }
     } else {
       const int E = p.o[c] * MT * 256;
@@ -1209,7 +1213,8 @@ __global__ __launch_bounds__(256) void convsbs_dcore_reduce_k(SbsMP p, int nrec)
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     int c = 0;
     while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
-    float* dst = p.dcore[c] + (e - p.core_off[c]);
+    const int el = e - p.core_off[c];
+    float* dst = p.dcore[c] + (c == p.n - 1 ? (el / p.qc) * p.last_stride + el % p.qc : el);
     *dst = p.accum ? *dst + v : v;   // (slices of a many-output string: one launch after the other on the stream)
   }
 }
@@ -1241,7 +1246,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   if (otot > 2 || out_sizes[0] != 1 || out_sizes[n - 1] != 1) return DCTN_ERR_UNSUPPORTED;
   p.n = n; p.C = C; p.B = B; p.H = H; p.W = W; p.q = q; p.qc = (int)qc; p.Otot = (int)otot;
-  p.ostride = (int)otot; p.obase = 0; p.accum = 0;
+  p.ostride = (int)otot; p.obase = 0; p.accum = 0; p.out_accum = 0; p.last_stride = (int)qc;
   int max_h = 0, max_w = 0;
   for (int c = 0; c < n; ++c) {
     p.o[c] = out_sizes[c]; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
@@ -1289,14 +1294,18 @@ static int sbsm_many_output_core(int n, const int* out_sizes) {
   return m;
 }
 
+struct SbsSlice {   // one launch of a string that runs in slices (many-valued core and / or ring); sliced == 0: the whole string
+  int sliced, obase, ostride, accum, out_accum, last_stride;
+};
+
 static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
                                 const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                                int C, int B, int H, int W, int q, int dtype, hipStream_t st, int obase, int ostride) {
+                                int C, int B, int H, int W, int q, int dtype, hipStream_t st, const SbsSlice& sl) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
-  if (ostride > 0) { p.ostride = ostride; p.obase = obase; }
+  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.out_accum = sl.out_accum; p.last_stride = sl.last_stride; }
   const size_t lds = (size_t)off * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.ngroups + 3) / 4;
@@ -1321,29 +1330,58 @@ static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* 
   return DCTN_OK;
 }
 
-int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
-                     const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                     int C, int B, int H, int W, int q, int dtype, hipStream_t st) {
+// The slices of a string: rings (bond_sizes[0] == the inner bond: Tr(prod T_c) = sum over the closing bond value l0 of the
+// open chain whose first core is row l0 of core 0 - contiguous in its [o][l][r][q] layout - and whose last core is column
+// l0 of core n-1 - a strided view) times the two-output slices of a many-valued core.  `visit` gets the slice's core
+// pointers, output sizes and SbsSlice; a non-OK return stops the walk (the first slice decides: all later ones have the
+// same or a smaller LDS plan).
+template <typename F>
+static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes, const int* bond_sizes, int C, int q, F visit) {
   if (n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
   const int m = sbsm_many_output_core(n, out_sizes);
   if (m == -2) return DCTN_ERR_UNSUPPORTED;
-  if (m < 0)
-    return convsbs_fwd_mfma_one(x, xs, cores, out, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st, 0, 0);
-  if (dtype != DCTN_F32) return DCTN_ERR_UNSUPPORTED;
-  int outs[SBSM_MAXC];
+  const int Rb = bond_sizes[1];
+  const bool ring = bond_sizes[0] == Rb && Rb > 1;
+  int outs[SBSM_MAXC], bonds[SBSM_MAXC];
   const void* cp[SBSM_MAXC];
-  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; cp[c] = cores[c]; }
+  long long otot = 1;
+  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; bonds[c] = bond_sizes[c]; cp[c] = cores[c]; otot *= out_sizes[c]; }
+  if (m < 0 && !ring) {
+    const SbsSlice whole{0, 0, 0, 0, 0, 0};
+    return visit(cp, outs, bonds, whole, 0, 0);
+  }
+  if (ring && (out_sizes[0] != 1 || out_sizes[n - 1] != 1)) return DCTN_ERR_UNSUPPORTED;
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
-  const long long per_o = (long long)bond_sizes[m] * bond_sizes[(m + 1) % n] * qc;   // core m is [o][l][r][q...]
-  const int om = out_sizes[m];
-  for (int o0 = 0; o0 < om; o0 += 2) {
-    outs[m] = om - o0 < 2 ? om - o0 : 2;
-    cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
-    const int rc = convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st, o0, om);
-    if (rc != DCTN_OK) return rc;   // (the first slice decides: every later one has the same or a smaller plan)
+  bonds[0] = 1;   // every slice is an open chain
+  const long long per_o = (long long)Rb * Rb * qc;   // a many-valued middle core is [o][l][r][q...]
+  const int om = m >= 0 ? out_sizes[m] : 0;
+  for (int l0 = 0; l0 < (ring ? Rb : 1); ++l0) {
+    if (ring) {
+      cp[0] = (const float*)cores[0] + (long long)l0 * Rb * qc;
+      cp[n - 1] = (const float*)cores[n - 1] + (long long)l0 * qc;
+    }
+    for (int o0 = 0; o0 < (m >= 0 ? om : 1); o0 += 2) {
+      if (m >= 0) {
+        outs[m] = om - o0 < 2 ? om - o0 : 2;
+        cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
+      }
+      const SbsSlice sl{1, m >= 0 ? o0 : 0, (int)otot, l0 > 0 || o0 > 0, l0 > 0, (int)(ring ? Rb * qc : qc)};
+      const int rc = visit(cp, outs, bonds, sl, l0, o0);
+      if (rc != DCTN_OK) return rc;
+    }
   }
   return DCTN_OK;
+}
+
+int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
+                     const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                     int C, int B, int H, int W, int q, int dtype, hipStream_t st) {
+  if (dtype != DCTN_F32) return DCTN_ERR_UNSUPPORTED;
+  return sbsm_for_slices(n, cores, out_sizes, bond_sizes, C, q,
+                         [&](const void* const* cp, const int* outs, const int* bonds, const SbsSlice& sl, int, int) {
+                           return convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bonds, pos_h, pos_w, C, B, H, W, q, dtype, st, sl);
+                         });
 }
 
 // Backward of the same family (R <= 16).  `states` must hold sum_c oacc_c * R floats per window
@@ -1355,13 +1393,13 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
                                 float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                                 const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                                 int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes,
-                                int obase, int ostride, int accum) {
+                                const SbsSlice& sl) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
   if (R > 16 || !dcores || !states) return DCTN_ERR_UNSUPPORTED;
-  if (ostride > 0) { p.ostride = ostride; p.obase = obase; p.accum = accum; }
+  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.accum = sl.accum; p.last_stride = sl.last_stride; }
   long long so = 0;
   int oacc = 1;
   for (int c = 0; c < n; ++c) {
@@ -1453,7 +1491,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     }
   }
   // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
-  if (ostride > 0) return DCTN_ERR_UNSUPPORTED;   // (slices of a many-output string: second version only)
+  if (sl.sliced) return DCTN_ERR_UNSUPPORTED;   // (slices of a many-output string or a ring: second version only)
   p.ngroups = (p.Wn + 31) / 32;
   so = 0;
   oacc = 1;
@@ -1497,29 +1535,22 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                      int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes) {
-  if (n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
-  const int m = sbsm_many_output_core(n, out_sizes);
-  if (m == -2) return DCTN_ERR_UNSUPPORTED;
-  if (m < 0)
-    return convsbs_bwd_mfma_one(x, xs, cores, dY, states, gxw, dcores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
-                                dtype, st, partials, partial_bytes, 0, 0, 0);
   if (dtype != DCTN_F32 || !dcores) return DCTN_ERR_UNSUPPORTED;
-  int outs[SBSM_MAXC];
-  const void* cp[SBSM_MAXC];
-  float* dcp[SBSM_MAXC];
-  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; cp[c] = cores[c]; dcp[c] = dcores[c]; }
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
-  const long long per_o = (long long)bond_sizes[m] * bond_sizes[(m + 1) % n] * qc;
-  const int om = out_sizes[m];
-  for (int o0 = 0; o0 < om; o0 += 2) {   // see convsbs_fwd_mfma: slices of two output values, one launch after the other
-    outs[m] = om - o0 < 2 ? om - o0 : 2;
-    cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
-    dcp[m] = dcores[m] + (long long)o0 * per_o;
-    const int rc = convsbs_bwd_mfma_one(x, xs, cp, dY, states, gxw, dcp, n, outs, bond_sizes, pos_h, pos_w, C, B, H, W, q,
-                                        dtype, st, partials, partial_bytes, o0, om, o0 > 0);
-    if (rc != DCTN_OK) return rc;
-  }
-  return DCTN_OK;
+  const int m = sbsm_many_output_core(n, out_sizes);
+  const int Rb = n > 1 ? bond_sizes[1] : 1;
+  const bool ring = n > 1 && bond_sizes[0] == Rb && Rb > 1;
+  return sbsm_for_slices(n, cores, out_sizes, bond_sizes, C, q,
+                         [&](const void* const* cp, const int* outs, const int* bonds, const SbsSlice& sl, int l0, int o0) {
+                           float* dcp[SBSM_MAXC];   // the gradient views follow the core views
+                           for (int c = 0; c < n; ++c) dcp[c] = dcores[c];
+                           if (sl.sliced && ring) {
+                             dcp[0] = dcores[0] + (long long)l0 * Rb * qc;
+                             dcp[n - 1] = dcores[n - 1] + (long long)l0 * qc;
+                           }
+                           if (sl.sliced && m >= 0) dcp[m] = dcores[m] + (long long)o0 * Rb * Rb * qc;
+                           return convsbs_bwd_mfma_one(x, xs, cp, dY, states, gxw, dcp, n, outs, bonds, pos_h, pos_w, C, B, H,
+                                                       W, q, dtype, st, partials, partial_bytes, sl);
+                         });
 }
-

@@ -376,6 +376,11 @@ def sbs_mfma_cases():
         outs = [1] * 9
         outs[where] = om
         cases.append((snake, (1,) + (r,) * 8, tuple(outs), C, q))
+    # rings (trace_edge=True, mnist.py:229): one open-chain launch per value of the closing bond; with and without a
+    # two-valued / many-valued core
+    for r, C, q, outs in [(4, 1, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1)), (8, 2, 2, (1,) * 9), (4, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1)),
+                          (16, 1, 3, (1, 1, 2, 1, 1))]:
+        cases.append((snake[:len(outs)], (r,) * len(outs), tuple(outs), C, q))
     return cases
 
 
