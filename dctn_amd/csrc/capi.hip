@@ -11,6 +11,44 @@
 static std::atomic<const char*> g_last_kernel{"none"};
 void dctn_set_last_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
 
+namespace {
+__global__ __launch_bounds__(256) void dctn_zero_k(unsigned* __restrict__ p, size_t words) {
+  const size_t n4 = words / 4;
+  uint4* p4 = reinterpret_cast<uint4*>(p);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = uint4{0u, 0u, 0u, 0u};
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void dctn_zero_words_k(unsigned* __restrict__ p, size_t words) {   // 4-byte aligned only
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void dctn_zero_bytes_k(unsigned char* __restrict__ p, size_t bytes) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < bytes; i += stride) p[i] = 0;
+}
+}  // namespace
+
+int dctn_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return DCTN_OK;
+  if (!ptr) return DCTN_ERR_NULL;
+  if ((bytes & 3) || ((uintptr_t)ptr & 3)) {   // odd sizes (bf16 tails): byte by byte
+    size_t bb = (bytes + 255) / 256;
+    if (bb > 2048) bb = 2048;
+    hipLaunchKernelGGL(dctn_zero_bytes_k, dim3((unsigned)bb), dim3(256), 0, st, (unsigned char*)ptr, bytes);
+    return hipGetLastError() == hipSuccess ? DCTN_OK : DCTN_ERR_LAUNCH;
+  }
+  const size_t words = bytes / 4;
+  size_t blocks = (words / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  if (((uintptr_t)ptr & 15) == 0)
+    hipLaunchKernelGGL(dctn_zero_k, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)ptr, words);
+  else
+    hipLaunchKernelGGL(dctn_zero_words_k, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)ptr, words);
+  return hipGetLastError() == hipSuccess ? DCTN_OK : DCTN_ERR_LAUNCH;
+}
+
 extern "C" {
 
 int dctn_version(void) { return 100; }

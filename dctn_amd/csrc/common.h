@@ -21,6 +21,12 @@ template <> struct AccOf<double> { typedef double type; };
 // name of the kernel family the last call dispatched to
 void dctn_set_last_kernel(const char* name);
 
+// Zero `bytes` bytes on the stream with a kernel.  Not hipMemsetAsync: recorded into a
+// torch HIP graph, a memset node zero-filled on the first replay and wrote garbage on the later ones
+// (tools/memset_capture_check.py, ROCm 7.2 + torch 2.10; the same node replays correctly from a plain HIP program,
+// tools/probes/memset_graph.hip) - accumulators that start from zero must not depend on it.
+int dctn_zero_async(void* ptr, size_t bytes, hipStream_t st);
+
 static inline long long ipow_ll(long long b, int e) {
   long long r = 1;
   for (int i = 0; i < e; ++i) r *= b;

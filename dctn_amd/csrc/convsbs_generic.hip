@@ -420,10 +420,10 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
       total += (size_t)core_elems(p, c) * sizeof(A);
     }
     if (flat) {
-      if (hipMemsetAsync(p.dcore[0], 0, total, st) != hipSuccess) return DCTN_ERR_LAUNCH;
+      if (dctn_zero_async(p.dcore[0], total, st) != DCTN_OK) return DCTN_ERR_LAUNCH;
     } else {
       for (int c = 0; c < p.n; ++c)
-        if (hipMemsetAsync(p.dcore[c], 0, (size_t)core_elems(p, c) * sizeof(A), st) != hipSuccess)
+        if (dctn_zero_async(p.dcore[c], (size_t)core_elems(p, c) * sizeof(A), st) != DCTN_OK)
           return DCTN_ERR_LAUNCH;
     }
   }

@@ -1007,7 +1007,7 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   wpb = (wpb + DC_WC - 1) / DC_WC * DC_WC;
   chunks = (p.Wn + wpb - 1) / wpb;
   d.win_per_block = wpb;
-  if (hipMemsetAsync(dCore, 0, (size_t)p.R * p.O * sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  if (dctn_zero_async(dCore, (size_t)p.R * p.O * sizeof(float), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
 #define DC_LAUNCH(PX, PY)                                                                                  \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k<PX, PY>,                                    \

@@ -386,7 +386,7 @@ static int fwd_launch(const void* x, const void* core, void* out, const EpsP& p,
   const long long slices = sizeof(S) == sizeof(A) ? hi_slices(p, grid) : 1;
   const long long hps = (p.HI + slices - 1) / slices;
   const dim3 g2(grid, (unsigned)((p.HI + hps - 1) / hps));
-  if (g2.y > 1 && hipMemsetAsync(out, 0, (size_t)p.Wn * p.O * sizeof(S), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  if (g2.y > 1 && dctn_zero_async(out, (size_t)p.Wn * p.O * sizeof(S), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
   if (p.O <= 4) {
     (void)hipFuncSetAttribute((const void*)eps_fwd_generic_k<S, A, 4>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -437,7 +437,7 @@ static int bwd_launch(const void* x, const void* core, const void* dY, void* dX,
     const long long slices = hi_slices(p, grid);
     const long long hps = (p.HI + slices - 1) / slices;
     const dim3 g3(grid, (unsigned)((p.HI + hps - 1) / hps));
-    if (g3.y > 1 && hipMemsetAsync(gxw, 0, (size_t)p.Wn * p.N * p.Q * sizeof(A), st) != hipSuccess)
+    if (g3.y > 1 && dctn_zero_async(gxw, (size_t)p.Wn * p.N * p.Q * sizeof(A), st) != DCTN_OK)
       return DCTN_ERR_LAUNCH;
     (void)hipFuncSetAttribute((const void*)eps_bwd_dfactor_generic_k<S, A>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -454,7 +454,7 @@ static int bwd_launch(const void* x, const void* core, const void* dY, void* dX,
     const size_t lds = dcore_lds(p, sizeof(A));
     if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
     A* acc = sizeof(S) == sizeof(A) ? (A*)dCore : (A*)wsp;
-    if (hipMemsetAsync(acc, 0, (size_t)p.R * p.O * sizeof(A), st) != hipSuccess)
+    if (dctn_zero_async(acc, (size_t)p.R * p.O * sizeof(A), st) != DCTN_OK)
       return DCTN_ERR_LAUNCH;
     const long long row_blocks = (p.R + DCTN_WAVE - 1) / DCTN_WAVE;
     long long chunks = 4096 / row_blocks;

@@ -122,7 +122,7 @@ static int ce_fwd_launch(const void* logits, const void* labels, void* loss, voi
     DCTN_CHECK_LAUNCH();
     return DCTN_OK;
   }
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  if (dctn_zero_async(loss, sizeof(float), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
   const dim3 g(blocks_for(B)), b(256);
   if (dtype == DCTN_F32)
     hipLaunchKernelGGL((ce_fwd_k<float, false>), g, b, 0, st, (const float*)logits, (const long long*)labels, (float*)loss, (float*)dunit, (long long)B, C);

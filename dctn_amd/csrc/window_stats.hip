@@ -163,7 +163,7 @@ extern "C" int dctn_window_stats(const void* x, const int64_t x_strides[5], void
   p.Wn = (long long)B * p.Ho * p.Wo;
   for (int i = 0; i < 5; ++i) p.s[i] = x_strides[i];
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, 2 * sizeof(double), st) != hipSuccess) return DCTN_ERR_LAUNCH;
+  if (dctn_zero_async(sums, 2 * sizeof(double), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
   long long blocks = (p.Wn + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
   const dim3 g((unsigned)blocks), b(256);

@@ -439,6 +439,64 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
     assert close(cd.grad, dcore, torch.float32)
 
 
+@pytest.mark.parametrize("which", ["eps_bigcore_f32", "eps_generic_q3", "convsbs_generic_bond3", "convsbs_ring_many_bond4"])
+def test_graph_replays_start_their_accumulators_from_zero(which):
+    """Kernels that accumulate into a zero-filled buffer (atomics, slices) must zero it with a kernel of their own: a
+    `hipMemsetAsync` recorded into a torch HIP graph filled with garbage from the second replay on
+    (tools/memset_capture_check.py).  Forward + backward captured once, replayed three times with the gradient
+    buffers dirtied in between, compared with the eager result."""
+    torch.manual_seed(3)
+    if which.startswith("eps"):
+        if which == "eps_bigcore_f32":
+            C, B, H, W, Q, K, O = 1, 3, 6, 7, 4, 3, 6
+        else:
+            C, B, H, W, Q, K, O = 1, 5, 6, 6, 3, 2, 3
+        N = K * K * C
+        x = torch.randn(C, B, H, W, Q, device=DEV, requires_grad=True)
+        params = [(torch.randn(*(Q,) * N, O, device=DEV) * Q ** (-N / 4)).requires_grad_(True)]
+        run = lambda: eps(params[0], x)
+    else:
+        snake = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
+        if which == "convsbs_generic_bond3":
+            bonds, outs = (1,) + (3,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1)
+        else:
+            bonds, outs = (4,) * 9, (1, 1, 1, 1, 5, 1, 1, 1, 1)
+        spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(snake, outs)), bonds, 2, 2)
+        m = ConvSBS(spec, DumbNormalInitialization(0.4)).to(DEV)
+        x = torch.randn(2, 3, 7, 8, 2, device=DEV, requires_grad=True)
+        params = list(m.cores)
+        run = lambda: m(x)
+
+    def fwd_bwd():
+        x.grad = None
+        for p in params:
+            p.grad = None
+        y = run()
+        y.backward(torch.ones_like(y))
+        return y
+
+    y_e = fwd_bwd().detach().clone()
+    want = [x.grad.clone()] + [p.grad.clone() for p in params]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_g = fwd_bwd()
+    for rep in range(3):
+        for t in [x] + params:
+            t.grad.fill_(7.0)
+        y_g.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(y_g, y_e, rtol=1e-5, atol=1e-6 * float(y_e.abs().max())), rep
+        for t, w in zip([x] + params, want):
+            assert torch.allclose(t.grad, w, rtol=1e-4, atol=1e-5 * float(w.abs().max())), (rep, tuple(w.shape))
+
+
 # ------------------------------------------------------------------ linear head (bf16, skinny)
 def test_eps_f32_large_core_under_the_bf16_policy():
     """set_float32_matmul_precision("bf16") lets float32 tensors with a large core use the bf16 matrix cores
@@ -811,6 +869,80 @@ def test_graphed_train_step_matches_eager():
         assert torch.allclose(ra["loss"], rb["loss"], rtol=1e-5, atol=1e-6)
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("bond,ring", [(4, False), (4, True), (2, False)])
+def test_convsbs_classifier_step_eager_and_graphed(bond, ring):
+    """The reference's ConvSBS classifier (mnist.py:170-262: two-string layers, a final string with ten labels on its
+    middle core): on bond 4 every string runs on the MFMA sweep (slices of the many-valued core, ring slices), on
+    bond 2 on the generic sweep; the whole training iteration is capturable (no synchronisation, no host read-back on
+    the path) and the graphed iteration leaves the parameters where the eager one leaves them."""
+    import copy
+
+    from dctn_amd.training import GraphedTrainStep, train_step
+
+    A = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]
+    Bs = [(0, 0), (1, 0), (2, 0), (2, 1), (1, 1), (0, 1), (0, 2), (1, 2), (2, 2)]
+
+    def string(pos, mid):
+        return tuple(SBSSpecCore(Pos2D(*p), mid if i == 4 else 1) for i, p in enumerate(pos))
+
+    class Classifier(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            init = DumbNormalInitialization((2 * bond) ** -0.5 * 1.3)
+            two = (string(A, 2), string(Bs, 2))
+            self.layers = torch.nn.ModuleList([
+                ManyConvSBS(1, 2, bond, ring, two, (init,) * 2),
+                ManyConvSBS(2, 2, bond, ring, two, (init,) * 2),
+                ManyConvSBS(2, 2, bond, ring, (string(A, 10),), (init,)),
+            ])
+
+            self.scales = [1.0, 1.0, 1.0]   # fixed per-layer output scales (calibrated below): 27 cores would underflow
+
+        def forward(self, x):   # x: (1, B, H, W, 2)
+            inter = (x[0],)
+            for layer, scale in zip(self.layers, self.scales):   # (tanh: products of 9 random factors are heavy-tailed)
+                inter = tuple(torch.tanh(o * scale) for o in layer(inter))
+            (out,) = inter
+            return out.reshape(out.shape[0], -1, out.shape[-1]).mean(1)   # (B, 10)
+
+        def calibrate(self, x):
+            with torch.no_grad():
+                inter = (x[0],)
+                for k, layer in enumerate(self.layers):
+                    outs = layer(inter)
+                    # (products of many random factors are heavy-tailed: the median of |o| is the typical size)
+                    self.scales[k] = 1.0 / float(torch.cat([o.reshape(-1) for o in outs]).abs().median())
+                    inter = tuple(torch.tanh(o * self.scales[k]) for o in outs)
+
+    torch.manual_seed(5)
+    a = Classifier().to(DEV)
+    xs = [torch.rand(1, 8, 8, 8, 2, device=DEV) for _ in range(4)]
+    ys = [torch.randint(0, 10, (8,), device=DEV) for _ in range(4)]
+    a.calibrate(xs[0])
+    b = copy.deepcopy(a)
+    y0 = a(xs[0])
+    want_family = "convsbs_fwd_mfma_f32" if bond == 4 else "convsbs_fwd_generic"
+    assert dctn_amd.last_kernel() == want_family and y0.shape == (8, 10)
+    assert 1e-3 < float(y0.detach().abs().median()) < 1e3, float(y0.detach().abs().median())   # a live model
+    # (a small step: the gradients of a 27-core product are large and an unnormalised ring model diverges quickly; the
+    # point here is that both forms of the iteration compute the same thing)
+    oa = torch.optim.SGD(a.parameters(), lr=1e-6)
+    ob = torch.optim.SGD(b.parameters(), lr=1e-6)
+    ce = torch.nn.functional.cross_entropy
+    graphed = GraphedTrainStep(b, xs[0], ys[0], ce, ob, warmup=3)
+    for _ in range(3):
+        train_step(a, xs[0], ys[0], ce, oa)
+    for x, y in zip(xs, ys):
+        ra = train_step(a, x, y, ce, oa)
+        rb = graphed(x, y)
+        assert torch.isfinite(ra["loss"]) and torch.allclose(ra["loss"], rb["loss"], rtol=1e-4, atol=1e-6)
+    moved = 0.0
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.isfinite(pa).all() and torch.allclose(pa, pb, rtol=1e-4, atol=1e-7)
+        moved = max(moved, float(pa.grad.abs().max()))
+    assert moved > 0.0   # the iterations did train something
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
