@@ -49,7 +49,7 @@ WORKLOADS = {
     "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
     "cfg3b_bf16": (((4, 8), (2, 8)), 28, 2, torch.bfloat16),
 }
-EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
 SNAKE = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]   # mnist.py:190-199
 
 
@@ -453,15 +453,20 @@ def extra_eps_model(name, dev, iters):
                      t["bytes_x"] * l["_nb"] + t["bytes_y"] + t["bytes_core"] * 2))
     us, what, call, fam, fl, by = max(cand)
     kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k"}.get(fam, fam)
-    roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:eps_bigcore_k", traffic_scope="longest eps_bigcore_k instantiation of the profiled config (profiles/r02_pmc_traffic.json)",
-                          step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"],
+    roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:eps_bigcore_k",
+                          traffic_scope=("longest eps_bigcore_k instantiation of the profiled config (profiles/r02_pmc_traffic.json)"
+                                         if dtype == torch.float32 else "not collected for this config"),
+                          step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS[str(dtype).replace("torch.", "")],
                           step_algorithmic_flops=int(step_flops))
     for l in layers:
         del l["_t"], l["_nb"]
-    return {"workload": f"{name}: EPSesPlusLinear({specs}) f32 on MNIST-shaped 28x28 Q0=2, fwd + bwd(out_grad), batch {batch}",
+    arith = ("f32" if dtype == torch.float32 else
+             "bf16 storage, bf16 matrix cores with float32 accumulation (not a BASELINE config: the cfg3a model under the bf16 policy)")
+    return {"workload": f"{name}: EPSesPlusLinear({specs}) {arith} on MNIST-shaped 28x28 Q0=2, fwd + bwd(out_grad), batch {batch}",
             "dtype": DTYPE_NAME[dtype], "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
             "value": windows / t_fb, "unit": "windows/s", "layers": layers, "roofline": roof,
-            "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, dtype, batch=8, target_seconds=4.0)}
+            "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, torch.float32 if dtype == torch.bfloat16 else dtype,
+                                                   batch=8, target_seconds=4.0)}
 
 
 def extra_cfg1(dev, iters):
@@ -645,7 +650,7 @@ def extra_cfg5(dev, iters):
 def run_extra(name, dev):
     if name == "cfg1":
         return extra_cfg1(dev, 20)
-    if name in ("cfg3a", "cfg3b"):
+    if name in ("cfg3a", "cfg3b", "cfg3a_bf16", "cfg3b_bf16"):
         return extra_eps_model(name, dev, 10 if name == "cfg3a" else 20)
     if name.startswith("cfg4_r"):
         return extra_cfg4(int(name[6:]), dev, 30)
