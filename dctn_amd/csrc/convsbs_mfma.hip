@@ -675,7 +675,7 @@ __device__ unsigned long long sbs_stamps[2048 * 32];
 // ONECH: one input channel (the multi-channel feature products and their gradients are not compiled: 20 KB of the
 // bond-16 kernel's 77 KB, which no longer fits the 64 KB instruction cache)
 template <int R, int NC, int NT, int ONECH>
-__global__ __launch_bounds__(256) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
+__global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
                                                             const float* __restrict__ dY,
                                                             float* __restrict__ states,
                                                             float* __restrict__ gxw, SbsMP p, int need_dx) {
