@@ -162,6 +162,8 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
   const size_t c = need_dx ? eps_bwd_dfactor_bigcore_workspace(p, dtype, precision) : 0;
   if (c > b) b = c;
+  const size_t c2 = need_dcore ? eps_bwd_dcore_bigcore_workspace(p, dtype, precision) : 0;
+  if (c2 > b) b = c2;
   const size_t d = eps_bwd_halves_workspace(p, dtype, need_dx, need_dcore);
   if (d > b) b = d;
   return a + b + 256;
@@ -236,7 +238,8 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
     if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
   }
   if (dCore) {
-    rc = eps_bwd_dcore_bigcore(x, dY, dCore, p, dtype, precision, st);
+    // (its per-chunk slices use the tail of the workspace before dX does: the sum kernel is done with them by then)
+    rc = eps_bwd_dcore_bigcore(x, dY, dCore, p, dtype, precision, st, ws ? ws + off : nullptr, workspace_bytes - off);
     if (rc == DCTN_OK) {
       dCore = nullptr;
     } else if (rc != DCTN_ERR_UNSUPPORTED) {

@@ -71,8 +71,9 @@ int eps_gather_dx_launch(const void* gxw, void* dX, const EpsP& p, int dtype, hi
 size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision);
 int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t ws_bytes,
                     const EpsP& p, int dtype, int precision, hipStream_t st);
+size_t eps_bwd_dcore_bigcore_workspace(const EpsP& p, int dtype, int precision);
 int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
-                          int precision, hipStream_t st);
+                          int precision, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision);
 int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
                        size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);

@@ -480,6 +480,8 @@ struct DcoreP {
   int nlo0, nhi0, nlo1, nhi1;      // table sizes
   int tstride;                     // floats per window in the table image (odd: conflict-free)
   long long win_per_block;
+  float* part;                     // per window-chunk slices [gridDim.y][A * cols] (plain stores, summed in a fixed order), or
+                                   // NULL: float atomics into the zero-filled dCore
 };
 
 // PERX / PERY: register slots of the chunk prefetch (x features / dY values per thread): NQ <= 4 PERX,
@@ -647,7 +649,11 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int a = (a_tile0 + at) * 32 + (v & 3) + 8 * (v >> 2) + 4 * kk;
-          if (a < p.A) atomicAdd(&dCore[(long long)a * p.cols + col], acc[at][bt][v]);
+          if (a < p.A) {
+            const long long e = (long long)a * p.cols + col;
+            if (p.part) p.part[(long long)blockIdx.y * p.A * p.cols + e] = acc[at][bt][v];
+            else atomicAdd(&dCore[e], acc[at][bt][v]);
+          }
         }
       }
     }
@@ -964,20 +970,19 @@ int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX
   return DCTN_OK;
 }
 
-int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
-                          int precision, hipStream_t st) {
-  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
-  if (p.Q < 2 || (p.Q & (p.Q - 1))) return DCTN_ERR_UNSUPPORTED;
-  DcoreP d;
+// plan of the dCore product: parameters, workgroup tiles, window chunks (grid.y), LDS bytes
+static bool dcore_plan(const EpsP& p, int dtype, int precision, DcoreP& d, long long& tiles, long long& chunks, size_t& lds) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return false;
+  if (p.Q < 2 || (p.Q & (p.Q - 1))) return false;
   d.C = p.C; d.B = p.B; d.H = p.H; d.W = p.W; d.K = p.K; d.O = p.O; d.Q = p.Q; d.N = p.N;
   d.LQ = ilog2i(p.Q);
   d.n0 = (p.N + 1) / 2; d.n1 = p.N - d.n0;
-  if (d.n1 < 1 || d.n0 * d.LQ > 20 || d.n1 * d.LQ > 20) return DCTN_ERR_UNSUPPORTED;
+  if (d.n1 < 1 || d.n0 * d.LQ > 20 || d.n1 * d.LQ > 20) return false;
   d.Ho = p.Ho; d.Wo = p.Wo; d.Wn = p.Wn;
   for (int i = 0; i < 5; ++i) d.s[i] = p.s[i];
   d.OP = 2;
   while (d.OP < p.O) d.OP <<= 1;
-  if (d.OP > 32) return DCTN_ERR_UNSUPPORTED;
+  if (d.OP > 32) return false;
   d.LOGO = ilog2i(d.OP);
   d.A = 1 << (d.n0 * d.LQ); d.BN = 1 << (d.n1 * d.LQ); d.cols = d.BN * p.O;
   // lo tables: as many whole digits as fit in 5 bits (32 entries), at least one digit
@@ -989,16 +994,16 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   };
   d.lb0 = lo_bits(d.n0); d.lb1 = lo_bits(d.n1);
   d.nlo0 = 1 << d.lb0; d.nhi0 = d.A >> d.lb0; d.nlo1 = 1 << d.lb1; d.nhi1 = d.BN >> d.lb1;
-  if (p.N * p.Q > 80 || d.OP > 32) return DCTN_ERR_UNSUPPORTED;   // register staging plan of the kernel
+  if (p.N * p.Q > 80 || d.OP > 32) return false;   // register staging plan of the kernel
   int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP + 1;   // + the always-zero entry
   if (tstride % 2 == 0) ++tstride;
   d.tstride = tstride;
-  const size_t lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
-  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
+  if (lds > DCTN_LDS_BUDGET) return false;
   const int ntile_a = (d.A + DC_WR * DC_AT * 32 - 1) / (DC_WR * DC_AT * 32);
   const int ntile_c = (d.cols + DC_WC2 * DC_BT * 32 - 1) / (DC_WC2 * DC_BT * 32);
-  const long long tiles = (long long)ntile_a * ntile_c;
-  long long chunks = 1024 / tiles;
+  tiles = (long long)ntile_a * ntile_c;
+  chunks = 1024 / tiles;
   if (chunks < 1) chunks = 1;
   const long long max_chunks = (p.Wn + DC_WC - 1) / DC_WC;
   if (chunks > max_chunks) chunks = max_chunks;
@@ -1007,18 +1012,53 @@ int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP
   wpb = (wpb + DC_WC - 1) / DC_WC * DC_WC;
   chunks = (p.Wn + wpb - 1) / wpb;
   d.win_per_block = wpb;
-  if (dctn_zero_async(dCore, (size_t)p.R * p.O * sizeof(float), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
+  d.part = nullptr;
+  return true;
+}
+
+// room for one dCore slice per window chunk: the chunks are then summed in a fixed order (bit-reproducible dCore)
+size_t eps_bwd_dcore_bigcore_workspace(const EpsP& p, int dtype, int precision) {
+  DcoreP d;
+  long long tiles, chunks;
+  size_t lds;
+  if (!dcore_plan(p, dtype, precision, d, tiles, chunks, lds) || chunks < 2) return 0;
+  return (size_t)chunks * p.R * p.O * sizeof(float);
+}
+
+int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
+                          int precision, hipStream_t st, void* ws, size_t ws_bytes) {
+  DcoreP d;
+  long long tiles, chunks;
+  size_t lds;
+  if (!dcore_plan(p, dtype, precision, d, tiles, chunks, lds)) return DCTN_ERR_UNSUPPORTED;
+  const size_t slices = (size_t)chunks * p.R * p.O * sizeof(float);
+  float* target = (float*)dCore;
+  if (chunks < 2) {
+    // one chunk: every element has one writer; (the kernel adds) start from zero
+    if (dctn_zero_async(dCore, (size_t)p.R * p.O * sizeof(float), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
+  } else if (ws && ws_bytes >= slices) {
+    d.part = (float*)ws;
+  } else {
+    // no room for the slices: float atomics in arrival order (the low bits of dCore then differ from run to run)
+    if (dctn_zero_async(dCore, (size_t)p.R * p.O * sizeof(float), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
+  }
 #define DC_LAUNCH(PX, PY)                                                                                  \
   do {                                                                                                     \
     (void)hipFuncSetAttribute((const void*)eps_bigcore_dcore_k<PX, PY>,                                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     hipLaunchKernelGGL((eps_bigcore_dcore_k<PX, PY>), dim3((unsigned)tiles, (unsigned)chunks),            \
-                       dim3(DC_THREADS), lds, st, (const float*)x, (const float*)dY, (float*)dCore, d);   \
+                       dim3(DC_THREADS), lds, st, (const float*)x, (const float*)dY, target, d);          \
   } while (0)
   if (p.N * p.Q <= 40 && d.OP <= 8) DC_LAUNCH(10, 2);
   else DC_LAUNCH(20, 8);
 #undef DC_LAUNCH
   DCTN_CHECK_LAUNCH();
+  if (d.part) {
+    const long long n = (long long)p.R * p.O;
+    const unsigned g = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bigcore_sum_slices_k, dim3(g), dim3(256), 0, st, (const float*)d.part, target, n, (int)chunks);
+    DCTN_CHECK_LAUNCH();
+  }
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
   return DCTN_OK;
 }
