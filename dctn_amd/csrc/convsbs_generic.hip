@@ -362,9 +362,25 @@ int fwd_launch(const void* x, void* out, SbsP& p, hipStream_t st) {
   return DCTN_OK;
 }
 
+// State elements per window of the workspace's first region: the generic sweep's own need, or what a slice of the MFMA
+// sweep stores (at most two states of the PADDED bond per core) when that is more - a padded bond (6 -> 8) or a ring
+// (whose generic states are counted differently) would otherwise let the MFMA states run into the feature-gradient
+// region behind them, which ring / many-output slices accumulate across launches.
+long long state_elems(const SbsP& p) {
+  long long need = p.st_off[p.n];
+  int bmax = 1;
+  for (int c = 0; c < p.n; ++c) bmax = p.bl[c] > bmax ? p.bl[c] : bmax;
+  if (bmax <= 16) {
+    const int rpad = bmax <= 4 ? 4 : bmax <= 8 ? 8 : 16;
+    const long long mfma = (long long)p.n * 2 * rpad;
+    if (mfma > need) need = mfma;
+  }
+  return need;
+}
+
 size_t bwd_ws(const SbsP& p, int dtype) {
   const size_t asz = dtype == DCTN_F64 ? 8 : 4;
-  size_t total = align256((size_t)p.st_off[p.n] * p.Wn * asz);      // forward states
+  size_t total = align256((size_t)state_elems(p) * p.Wn * asz);      // forward states
   total += align256((size_t)p.n * p.C * p.q * p.Wn * asz);           // per-window d/d(pixel features)
   if (dtype == DCTN_BF16)
     for (int c = 0; c < p.n; ++c) total += align256((size_t)core_elems(p, c) * asz);
@@ -397,7 +413,7 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   unsigned char* wsp = (unsigned char*)ws;
   A* states = (A*)wsp;
-  wsp += align256((size_t)p.st_off[p.n] * p.Wn * sizeof(A));
+  wsp += align256((size_t)state_elems(p) * p.Wn * sizeof(A));
   A* gxw = (A*)wsp;
   wsp += align256((size_t)p.n * p.C * p.q * p.Wn * sizeof(A));
   const int need_dcore = dCores != nullptr;

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(2))) int int2v;
 
 struct SbsMP {
   int n, C, B, H, W, q, qc, Ho, Wo, Otot;
+  int Ra;                     // the string's bond (<= the kernels' R: packs, tables and states are zero beyond it)
   int ostride, obase;         // row length of out / dY and the first output of this launch (many-output strings run in slices)
   int accum;                  // backward: add to gxw and to the core gradients instead of setting them (slices after the first)
   int out_accum;              // forward: add to out (rings: one launch per value of the closing bond)
@@ -164,15 +165,16 @@ __device__ __forceinline__ void pack_cores(float* lds, const SbsMP& p, int tid) 
       const int o = t2 / TILES;
       const int l = 2 * s + hh, rp = 8 * t + (i >> 2), qq = i & 3;
       float v = 0.f;
-      if (rp < R && qq < p.qc) v = p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq];
+      if (l < p.Ra && rp < p.Ra && qq < p.qc) v = p.core[c][(long long)((o * p.Ra + l) * p.Ra + rp) * p.qc + qq];
       lds[p.apack_off[c] + e] = v;
     }
   }
   // first core (1, 1, R, qc) as [r'][4]; last core (1, R, 1, qc) as [l][4]
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
-    lds[p.first_off + e] = qq < p.qc ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
+    const bool in = qq < p.qc && rr < p.Ra;
+    lds[p.first_off + e] = in ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = in ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -600,7 +602,7 @@ __device__ __forceinline__ float pack16_element(const SbsMP& p, int c, int e) {
   const int l = ADJ ? 4 * mt + (i >> 2) : 4 * s + kg;
   const int rp = ADJ ? 4 * s + kg : 4 * mt + (i >> 2);
   const int qq = i & 3;
-  return qq < p.qc ? p.core[c][(long long)((o * R + l) * R + rp) * p.qc + qq] : 0.f;
+  return (qq < p.qc && l < p.Ra && rp < p.Ra) ? p.core[c][(long long)((o * p.Ra + l) * p.Ra + rp) * p.qc + qq] : 0.f;
 }
 
 // NMID > 0: at most NMID middle cores with at most two outputs each: every global load of the two packs is issued
@@ -645,8 +647,9 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
   }
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
-    lds[p.first_off + e] = qq < p.qc ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = qq < p.qc ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
+    const bool in = qq < p.qc && rr < p.Ra;
+    lds[p.first_off + e] = in ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = in ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
   for (int c = 0; c < p.n; ++c) {
     const float* src = lds + p.dacc_off[c];
     if (c == 0 || c == p.n - 1) {
-      const int E = R * p.qc;
+      const int E = p.Ra * p.qc;   // [bond index][q]: the rows below the string's bond are a prefix of the padded table
       for (int e = tid; e < E; e += 256) {
         if (rec) rec[p.core_off[c] + e] = src[e];
         else atomicAdd(&p.dcore[c][c == 0 ? e : (e / p.qc) * p.last_stride + e % p.qc], src[e]);
@@ -1158,8 +1161,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
         const int ln = e & 63, l = ln & 15, gg = ln >> 4, vv = (e >> 6) & 3;
         const int mt = (e >> 8) % MT, o = (e >> 8) / MT;
         const int rp = 4 * mt + gg;
-        if (l < R && vv < p.qc) {
-          const int idx = ((o * R + l) * R + rp) * p.qc + vv;
+        if (l < p.Ra && rp < p.Ra && vv < p.qc) {
+          const int idx = ((o * p.Ra + l) * p.Ra + rp) * p.qc + vv;
           if (rec) rec[p.core_off[c] + idx] = src[e]; else atomicAdd(&p.dcore[c][idx], src[e]);
         }
       }
@@ -1227,10 +1230,14 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
                      const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
                      int C, int B, int H, int W, int q, int dtype) {
   if (dtype != DCTN_F32 || n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
-  R = bond_sizes[1];
-  if (bond_sizes[0] != 1 || (R != 4 && R != 8 && R != 16 && R != 32)) return DCTN_ERR_UNSUPPORTED;
+  // any uniform bond 2..32 runs on the next of the kernels' tile sizes {4, 8, 16, 32}: packs and tables are zero beyond
+  // the string's bond, so are the states, and only the real entries of a gradient are written back
+  const int Ra = bond_sizes[1];
+  if (bond_sizes[0] != 1 || Ra < 2 || Ra > 32) return DCTN_ERR_UNSUPPORTED;
   for (int c = 2; c < n; ++c)
-    if (bond_sizes[c] != R) return DCTN_ERR_UNSUPPORTED;
+    if (bond_sizes[c] != Ra) return DCTN_ERR_UNSUPPORTED;
+  R = Ra <= 4 ? 4 : Ra <= 8 ? 8 : Ra <= 16 ? 16 : 32;
+  p.Ra = Ra;
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
   if (qc > 4 || C > 2 || q > 4) return DCTN_ERR_UNSUPPORTED;
@@ -1351,6 +1358,10 @@ static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes
     return visit(cp, outs, bonds, whole, 0, 0);
   }
   if (ring && (out_sizes[0] != 1 || out_sizes[n - 1] != 1)) return DCTN_ERR_UNSUPPORTED;
+  // Slices pay a launch (and a recomputed prefix) each: below bond 4 the generic sweep's single launch is faster
+  // (ten labels, C = 2, 61 952 windows, device time: bond 2 0.49 ms generic / 0.88 ms sliced, bond 3 0.63 / 0.88,
+  // bond 4 1.2 / 0.89).  Unsliced open chains take the matrix-core sweep at every bond (bond 2: 2.6x faster).
+  if (Rb < 4) return DCTN_ERR_UNSUPPORTED;
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
   bonds[0] = 1;   // every slice is an open chain
@@ -1437,7 +1448,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     q2.ngroups = p.ngroups;
     q2.core_off[0] = 0;
     for (int c = 0; c < n; ++c) {
-      const int L = c == 0 ? 1 : R, Rr = c == n - 1 ? 1 : R;
+      const int L = c == 0 ? 1 : p.Ra, Rr = c == n - 1 ? 1 : p.Ra;
       q2.core_off[c + 1] = q2.core_off[c] + p.o[c] * L * Rr * p.qc;
     }
     if (lds2 <= DCTN_LDS_BUDGET) {
@@ -1491,7 +1502,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     }
   }
   // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
-  if (sl.sliced) return DCTN_ERR_UNSUPPORTED;   // (slices of a many-output string or a ring: second version only)
+  if (sl.sliced || p.Ra != R) return DCTN_ERR_UNSUPPORTED;   // (slices and padded bonds: second version only)
   p.ngroups = (p.Wn + 31) / 32;
   so = 0;
   oacc = 1;

@@ -381,6 +381,12 @@ def sbs_mfma_cases():
     for r, C, q, outs in [(4, 1, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1)), (8, 2, 2, (1,) * 9), (4, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1)),
                           (16, 1, 3, (1, 1, 2, 1, 1))]:
         cases.append((snake[:len(outs)], (r,) * len(outs), tuple(outs), C, q))
+    # bonds between the kernels' tile sizes (the reference script's default is 2): zero-padded packs, real entries only
+    # in the gradients; open chains, a ring, a many-valued core
+    for r, C, q, outs, ring in [(2, 1, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), False), (3, 2, 2, (1,) * 9, False),
+                                (6, 1, 3, (1, 1, 1, 1, 2, 1, 1, 1, 1), True), (12, 2, 2, (1, 1, 1, 1, 5, 1, 1, 1, 1), False),
+                                (5, 1, 2, (1, 2, 1, 1), False), (5, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1), True)]:
+        cases.append((snake[:len(outs)], ((r if ring else 1),) + (r,) * (len(outs) - 1), tuple(outs), C, q))
     return cases
 
 

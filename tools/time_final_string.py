@@ -30,4 +30,17 @@ for name, C, specs, size in cases:
     t0 = time.perf_counter()
     for _ in range(10): fb()
     torch.cuda.synchronize()
-    print(f"bond {r} ring={ring} {name}: fwd+bwd {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms   ({L.last_kernel()})")
+    eager_ms = (time.perf_counter() - t0) / 10 * 1e3
+    # the same iteration replayed from a HIP graph: device time without the host's launch overhead
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fb()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fb()
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): g.replay()
+    torch.cuda.synchronize()
+    print(f"bond {r} ring={ring} {name}: fwd+bwd eager {eager_ms:.3f} ms, graph replay {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms   ({L.last_kernel()})")
