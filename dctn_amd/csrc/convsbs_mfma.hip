@@ -81,12 +81,41 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 // All feature products of a window (every core of the string) at once: the pixel loads of up to 8
 // cores are issued back to back (one memory round trip per chunk instead of one per core), the
 // products go to the wave's LDS slice fs[(c*4 + qq)*32 + window] and are read back per core.
-// ONECH: 1 = the caller knows p.C == 1 (only that path is compiled), 0 = decided at run time
+// ONECH: 1 = the caller knows p.C == 1, 2 = it knows C == 2 and q == 2 (the deeper layers of the reference's classifier):
+// only that path is compiled; 0 = decided at run time.  Mode 2 also keeps the pixels' raw values, in a second slice
+// behind the products (xs[(c*4 + ch*2 + d)*WPG + window]): the way back turns d/d(products) into d/d(pixel values) from
+// them instead of re-reading x through runtime channel loops.
 template <int WPG = 32, int CB = 8, int ONECH = 0>   // CB: cores per batch of loads (one memory round trip per batch)
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
-  if (ONECH || p.C == 1) {   // one channel: the feature products ARE the pixel's q values (no digit table, half the loads)
+  if constexpr (ONECH == 2) {
+    float* xs = fs + p.n * 4 * WPG;
+    for (int c0 = 0; c0 < p.n; c0 += CB) {
+      float raw2[CB][2][2];
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+        const int c = c0 + cc < p.n ? c0 + cc : p.n - 1;
+        const float* base = win + (long long)p.ph[c] * p.s[2] + (long long)p.pw[c] * p.s[3];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) raw2[cc][ch][d] = base[ch * p.s[0] + d * p.s[4]];
+      }
+#pragma unroll
+      for (int cc = 0; cc < CB; ++cc) {
+        if (c0 + cc < p.n) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {   // channel 0 is the most significant digit of the product index
+            fs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = valid ? raw2[cc][0][qq >> 1] * raw2[cc][1][qq & 1] : 0.f;
+            xs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = valid ? raw2[cc][qq >> 1][qq & 1] : 0.f;
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (ONECH == 1 || p.C == 1) {   // one channel: the feature products ARE the pixel's q values (no digit table, half the loads)
     for (int c0 = 0; c0 < p.n; c0 += CB) {
       float raw1[CB][4];
 #pragma unroll
@@ -107,7 +136,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
     }
     return;
   }
-  if constexpr (ONECH) return;
+  if constexpr (ONECH != 0) return;
   for (int c0 = 0; c0 < p.n; c0 += CB) {
     float raw[CB][2][4];
 #pragma unroll
@@ -697,7 +726,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
   }
   __syncthreads();
   constexpr int WPG = 16 * NT;   // windows per wave iteration: NT tiles of 16
-  float* fs = lds + p.fs_off + wv * p.n * 4 * WPG;
+  float* fs = lds + p.fs_off + wv * p.n * 4 * WPG * (ONECH == 2 ? 2 : 1);   // (mode 2: products, then raw values)
   float* zt = lds + p.zt_off + wv * 16 * ZROW;
   float* vt = lds + p.vt_off + wv * 16 * VROW;
   float dfirst[SN][4], dlast[SN][4];   // gradients of the first / last core: lane-local over all its windows
@@ -764,7 +793,19 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if (!vt_ok[t]) continue;
-        if (ONECH || p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
+        if constexpr (ONECH == 2) {   // two channels of two values: products index (d, e) = 2 d + e, raw values from LDS
+          const float* xsp = fs + (p.n * 4 + c * 4) * WPG + 16 * t + wl;
+          const float x00 = xsp[0], x01 = xsp[WPG], x10 = xsp[2 * WPG], x11 = xsp[3 * WPG];
+          const float gx[4] = {df[0][t] * x10 + df[1][t] * x11, df[2][t] * x10 + df[3][t] * x11,    // channel 0, d = 0, 1
+                               df[0][t] * x00 + df[2][t] * x01, df[1][t] * x00 + df[3][t] * x01};   // channel 1, e = 0, 1
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float* gp = gxw + (long long)(c * 4 + k) * p.Wn + wt[t];
+            *gp = p.accum ? *gp + gx[k] : gx[k];
+          }
+          continue;
+        }
+        if (ONECH == 1 || p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
 #pragma unroll
           for (int qv = 0; qv < 4; ++qv)
             if (qv < p.q) {
@@ -773,7 +814,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
             }
           continue;
         }
-        if constexpr (!ONECH)
+        if constexpr (ONECH == 0)
         for (int ch = 0; ch < p.C; ++ch)
           for (int qv = 0; qv < p.q; ++qv) {
             float gsum = 0.f;
@@ -1358,10 +1399,9 @@ static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes
     return visit(cp, outs, bonds, whole, 0, 0);
   }
   if (ring && (out_sizes[0] != 1 || out_sizes[n - 1] != 1)) return DCTN_ERR_UNSUPPORTED;
-  // Slices pay a launch (and a recomputed prefix) each: below bond 4 the generic sweep's single launch is faster
-  // (ten labels, C = 2, 61 952 windows, device time: bond 2 0.49 ms generic / 0.88 ms sliced, bond 3 0.63 / 0.88,
-  // bond 4 1.2 / 0.89).  Unsliced open chains take the matrix-core sweep at every bond (bond 2: 2.6x faster).
-  if (Rb < 4) return DCTN_ERR_UNSUPPORTED;
+  // (Slices pay a launch and a recomputed prefix each; with the compiled two-channel mode they beat the generic sweep's
+  // single launch at every bond - ten labels, C = 2, 61 952 windows, device time of fwd + bwd: bond 2 0.49 ms generic /
+  // 0.41 ms sliced, bond 3 0.63 / 0.41, bond 4 1.2 / 0.41; rings bond 2: 0.74 / 0.35, bond 3: 1.29 / 0.48.)
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
   bonds[0] = 1;   // every slice is an open chain
@@ -1431,7 +1471,8 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     q2.first_off = o2; o2 += R * 4;
     q2.last_off = o2; o2 += R * 4;
     const int NT16 = 2;   // window tiles per wave iteration (4 was tried for r = 16: 892 bytes of scratch per lane, slower)
-    q2.fs_off = o2; o2 += 4 * n * 4 * 16 * NT16;
+    const int chmode = p.C == 1 ? 1 : (p.C == 2 && p.q == 2) ? 2 : 0;   // compiled channel handling (ONECH)
+    q2.fs_off = o2; o2 += 4 * n * 4 * 16 * NT16 * (chmode == 2 ? 2 : 1);
     q2.zt_off = o2; o2 += 4 * 16 * ZROW;
     q2.vt_off = o2; o2 += 4 * 16 * 17;
     // the workgroup's dCore accumulator: with the register accumulators (n <= 9) it is only used by the final flush,
@@ -1463,10 +1504,15 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
       q2.partials = (partials && partial_bytes >= (size_t)blocks * q2.core_off[n] * sizeof(float)) ? partials : nullptr;
 #define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
   do {                                                                                            \
-    if (p.C == 1) {                                                                               \
+    if (chmode == 1) {                                                                            \
       (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>,               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
       hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>), dim3((unsigned)blocks), dim3(256), lds2, st, \
+                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
+    } else if (chmode == 2) {                                                                     \
+      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 2>,               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
+      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 2>), dim3((unsigned)blocks), dim3(256), lds2, st, \
                          (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
     } else {                                                                                      \
       (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 0>,               \

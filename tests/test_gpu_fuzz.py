@@ -385,7 +385,7 @@ def sbs_mfma_cases():
     # in the gradients; open chains, a ring, a many-valued core
     for r, C, q, outs, ring in [(2, 1, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), False), (3, 2, 2, (1,) * 9, False),
                                 (6, 1, 3, (1, 1, 1, 1, 2, 1, 1, 1, 1), True), (12, 2, 2, (1, 1, 1, 1, 5, 1, 1, 1, 1), False),
-                                (5, 1, 2, (1, 2, 1, 1), False), (5, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1), True)]:
+                                (5, 1, 2, (1, 2, 1, 1), False), (2, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1), True)]:
         cases.append((snake[:len(outs)], ((r if ring else 1),) + (r,) * (len(outs) - 1), tuple(outs), C, q))
     return cases
 

@@ -881,9 +881,8 @@ def test_graphed_train_step_matches_eager():
 @pytest.mark.parametrize("bond,ring", [(4, False), (4, True), (2, False)])
 def test_convsbs_classifier_step_eager_and_graphed(bond, ring):
     """The reference's ConvSBS classifier (mnist.py:170-262: two-string layers, a final string with ten labels on its
-    middle core): at bond 4 every string runs on the MFMA sweep (slices of the many-valued core, ring slices), at bond 2
-    the two-string layers do (zero-padded to the 4-wide tiles) and the ten-label string takes the generic sweep; the
-    whole training iteration is capturable (no synchronisation, no host read-back on
+    middle core): every string runs on the MFMA sweep (slices of the many-valued core, ring slices, bond 2 zero-padded
+    to the 4-wide tiles); the whole training iteration is capturable (no synchronisation, no host read-back on
     the path) and the graphed iteration leaves the parameters where the eager one leaves them."""
     import copy
 
@@ -931,9 +930,7 @@ def test_convsbs_classifier_step_eager_and_graphed(bond, ring):
     a.calibrate(xs[0])
     b = copy.deepcopy(a)
     y0 = a(xs[0])
-    # bond 2: the two-string layers run zero-padded on the 4-wide tiles, the ten-label string (slices pay below bond 4)
-    # on the generic sweep
-    want_family = "convsbs_fwd_mfma_f32" if bond == 4 else "convsbs_fwd_generic"
+    want_family = "convsbs_fwd_mfma_f32"   # (bond 2: zero-padded to the 4-wide tiles)
     assert dctn_amd.last_kernel() == want_family and y0.shape == (8, 10)
     assert 1e-3 < float(y0.detach().abs().median()) < 1e3, float(y0.detach().abs().median())   # a live model
     # (a small step: the gradients of a 27-core product are large and an unnormalised ring model diverges quickly; the
