@@ -85,7 +85,7 @@ __device__ __forceinline__ void features(const float* __restrict__ x, const SbsM
 // only that path is compiled; 0 = decided at run time.  Mode 2 also keeps the pixels' raw values, in a second slice
 // behind the products (xs[(c*4 + ch*2 + d)*WPG + window]): the way back turns d/d(products) into d/d(pixel values) from
 // them instead of re-reading x through runtime channel loops.
-template <int WPG = 32, int CB = 8, int ONECH = 0>   // CB: cores per batch of loads (one memory round trip per batch)
+template <int WPG = 32, int CB = 8, int ONECH = 0, bool RAW = true>   // CB: cores per batch of loads (one round trip per batch); RAW: mode 2 keeps the raw values
 __device__ __forceinline__ void stage_features(const float* __restrict__ x, const SbsMP& p, long long b, int ho,
                                                int wo, bool valid, float* fs, int lane) {
   const float* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
@@ -108,7 +108,7 @@ __device__ __forceinline__ void stage_features(const float* __restrict__ x, cons
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {   // channel 0 is the most significant digit of the product index
             fs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = valid ? raw2[cc][0][qq >> 1] * raw2[cc][1][qq & 1] : 0.f;
-            xs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = valid ? raw2[cc][qq >> 1][qq & 1] : 0.f;
+            if (RAW) xs[((c0 + cc) * 4 + qq) * WPG + (lane & (WPG - 1))] = valid ? raw2[cc][qq >> 1][qq & 1] : 0.f;
           }
         }
       }
@@ -207,7 +207,7 @@ __device__ __forceinline__ void pack_cores(float* lds, const SbsMP& p, int tid) 
   }
 }
 
-template <int R>
+template <int R, int CH>   // CH: compiled channel handling (stage_features' ONECH)
 __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restrict__ x,
                                                           float* __restrict__ out, SbsMP p) {
   constexpr int KS = R / 2;                  // MFMA k-steps per core (K = l = R)
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     float f[4];
     float* fs = lds + p.fs_off + (tid >> 6) * p.n * 128;
-    stage_features(x, p, b, ho, wo, valid, fs, lane);
+    stage_features<32, 8, CH, false>(x, p, b, ho, wo, valid, fs, lane);
     // ---- first core: v[0][s] = sum_qq core0[r' = 2s + h][qq] * f[qq]
     float v0[SR], v1[SR];
     load_features(fs, 0, lane, f);
@@ -1361,11 +1361,18 @@ static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* 
   if (fwd_per_cu < 2) fwd_per_cu = 2;
   if (fwd_per_cu > 8) fwd_per_cu = 8;
   if (blocks > 256 * fwd_per_cu) blocks = 256 * fwd_per_cu;
+  const int chmode = p.C == 1 ? 1 : (p.C == 2 && p.q == 2) ? 2 : 0;
+#define SBS_LAUNCH_CH(RR, CHV)                                                                    \
+  do {                                                                                            \
+    (void)hipFuncSetAttribute((const void*)convsbs_fwd_mfma_k<RR, CHV>,                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    hipLaunchKernelGGL((convsbs_fwd_mfma_k<RR, CHV>), dim3((unsigned)blocks), dim3(256), lds, st, \
+                       (const float*)x, (float*)out, p);                                          \
+  } while (0)
 #define SBS_LAUNCH(RR)                                                                            \
-  (void)hipFuncSetAttribute((const void*)convsbs_fwd_mfma_k<RR>,                                  \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-  hipLaunchKernelGGL((convsbs_fwd_mfma_k<RR>), dim3((unsigned)blocks), dim3(256), lds, st,        \
-                     (const float*)x, (float*)out, p)
+  do {                                                                                            \
+    if (chmode == 1) SBS_LAUNCH_CH(RR, 1); else if (chmode == 2) SBS_LAUNCH_CH(RR, 2); else SBS_LAUNCH_CH(RR, 0); \
+  } while (0)
   switch (R) {
     case 4: SBS_LAUNCH(4); break;
     case 8: SBS_LAUNCH(8); break;
@@ -1373,6 +1380,7 @@ static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     case 32: SBS_LAUNCH(32); break;
   }
 #undef SBS_LAUNCH
+#undef SBS_LAUNCH_CH
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("convsbs_fwd_mfma_f32");
   return DCTN_OK;
