@@ -51,6 +51,46 @@ Initialization = Union[
 ]
 
 
+class _StringPlan:
+    """What a call needs from a spec, computed once per spec (the frozen dataclass hashes by value): core shapes, the
+    int arrays of the C-ABI, output size.  Rebuilding them on every call was a third of the host time of a small
+    layer's forward."""
+
+    __slots__ = ("n", "shape_tuples", "outs", "bonds", "ph", "pw", "max_h", "max_w", "out_total", "C", "q", "ws")
+
+    def __init__(self, spec: SBSSpecString):
+        shapes = spec.shapes
+        self.n = len(spec)
+        self.shape_tuples = tuple(s.as_tuple() for s in shapes)
+        self.outs = L.int_array([s.out_quantum_dim_size for s in shapes])
+        self.bonds = L.int_array(spec.bond_sizes)
+        self.ph = L.int_array([p.h for p in spec.positions])
+        self.pw = L.int_array([p.w for p in spec.positions])
+        self.max_h, self.max_w = spec.max_height_pos, spec.max_width_pos
+        self.out_total = spec.out_total_quantum_dim_size
+        self.C, self.q = spec.in_num_channels, spec.in_quantum_dim_size
+        self.ws = {}   # (B, H, W, dtype code, backward) -> workspace bytes
+
+
+_PLANS: dict = {}
+
+
+def _plan(spec: SBSSpecString) -> _StringPlan:
+    plan = _PLANS.get(spec)
+    if plan is None:
+        plan = _PLANS[spec] = _StringPlan(spec)
+    return plan
+
+
+def _workspace_bytes(plan: _StringPlan, B: int, H: int, W: int, code: int, backward: int) -> int:
+    key = (B, H, W, code, backward)
+    nbytes = plan.ws.get(key)
+    if nbytes is None:
+        nbytes = plan.ws[key] = L.lib().dctn_convsbs_workspace_bytes(plan.n, plan.outs, plan.bonds, plan.C, B, H, W, plan.q,
+                                                                     plan.ph, plan.pw, code, backward)
+    return nbytes
+
+
 class _ConvSBSFunction(torch.autograd.Function):
     """x: (C, B, H, W, q) any strides; cores in string order."""
 
@@ -58,36 +98,33 @@ class _ConvSBSFunction(torch.autograd.Function):
     def forward(ctx, x: Tensor, spec: SBSSpecString, *cores: Tensor) -> Tensor:
         dev = L.require_device(x, *cores)
         C, B, H, W, q = x.shape
-        n = len(spec)
-        shapes = spec.shapes
-        for core, shape in zip(cores, shapes):
-            assert tuple(core.shape) == shape.as_tuple()
+        plan = _plan(spec)
+        n = plan.n
+        for core, shape in zip(cores, plan.shape_tuples):
+            assert tuple(core.shape) == shape
             if core.dtype != x.dtype:
                 raise TypeError(f"ConvSBS: core is {core.dtype} but input is {x.dtype}")
-        assert C == spec.in_num_channels and q == spec.in_quantum_dim_size
+        assert C == plan.C and q == plan.q
         cores_c = [c.contiguous() for c in cores]
-        outs = L.int_array([s.out_quantum_dim_size for s in shapes])
-        bonds = L.int_array(spec.bond_sizes)
-        ph = L.int_array([p.h for p in spec.positions])
-        pw = L.int_array([p.w for p in spec.positions])
-        Ho, Wo = H - spec.max_height_pos, W - spec.max_width_pos
-        out = torch.empty((B, Ho, Wo, spec.out_total_quantum_dim_size), dtype=x.dtype, device=dev)
+        Ho, Wo = H - plan.max_h, W - plan.max_w
+        out = torch.empty((B, Ho, Wo, plan.out_total), dtype=x.dtype, device=dev)
         code = L.dtype_code(x)
-        ws = L.workspace(L.lib().dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 0), dev)
+        ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 0), dev)
         L.check(
             L.lib().dctn_convsbs_fwd(x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), out.data_ptr(), n,
-                                     outs, bonds, ph, pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
+                                     plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
                                      L.stream_ptr(dev)),
             "ConvSBS forward",
         )
         ctx.save_for_backward(x, *cores_c)
-        ctx.meta = (n, outs, bonds, ph, pw, C, B, H, W, q, code)
+        ctx.meta = (plan, C, B, H, W, q, code)
         return out
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
         x, *cores_c = ctx.saved_tensors
-        n, outs, bonds, ph, pw, C, B, H, W, q, code = ctx.meta
+        plan, C, B, H, W, q, code = ctx.meta
+        n = plan.n
         dev = x.device
         need_dx = ctx.needs_input_grad[0]
         need_dcores = any(ctx.needs_input_grad[2:])
@@ -102,12 +139,13 @@ class _ConvSBSFunction(torch.autograd.Function):
             for c in cores_c:
                 d_cores.append(flat[off : off + c.numel()].view_as(c))
                 off += c.numel()
-        ws = L.workspace(L.lib().dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 1), dev)
+        ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 1), dev)
         L.check(
             L.lib().dctn_convsbs_bwd(
                 x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), g.data_ptr(),
                 None if d_x is None else d_x.data_ptr(), None if d_cores is None else L.ptr_array(d_cores),
-                n, outs, bonds, ph, pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code, L.stream_ptr(dev)),
+                n, plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
+                L.stream_ptr(dev)),
             "ConvSBS backward",
         )
         grads = [None] * n if d_cores is None else [
