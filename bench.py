@@ -374,7 +374,9 @@ def convsbs_call_timers(string, x, dy, dev):
     ph, pw = L.int_array([p.h for p in spec.positions]), L.int_array([p.w for p in spec.positions])
     out = torch.empty((B, H - spec.max_height_pos, W - spec.max_width_pos, spec.out_total_quantum_dim_size), dtype=x.dtype, device=dev)
     lib, code = L.lib(), L.dtype_code(x)
-    wsf = torch.empty(max(256, lib.dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 0)), dtype=torch.uint8, device=dev)
+    # the training forward: its workspace is the buffer the forward states are left in for dctn_convsbs_bwd_saved
+    saved = lib.dctn_convsbs_saved_states_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code)
+    wsf = torch.empty(max(256, saved, lib.dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 0)), dtype=torch.uint8, device=dev)
     wsb = torch.empty(max(256, lib.dctn_convsbs_workspace_bytes(n, outs, bonds, C, B, H, W, q, ph, pw, code, 1)), dtype=torch.uint8, device=dev)
     dx = torch.empty_like(x)
     flat = torch.empty(sum(c.numel() for c in cores), dtype=x.dtype, device=dev)
@@ -389,9 +391,10 @@ def convsbs_call_timers(string, x, dy, dev):
         L.check(lib.dctn_convsbs_fwd(x.data_ptr(), xs, cp, out.data_ptr(), n, outs, bonds, ph, pw, C, B, H, W, q,
                                      wsf.data_ptr(), wsf.numel(), code, L.stream_ptr(dev)), "convsbs fwd")
 
-    def bwd():
-        L.check(lib.dctn_convsbs_bwd(x.data_ptr(), xs, cp, dy.data_ptr(), dx.data_ptr(), dcp, n, outs, bonds, ph, pw,
-                                     C, B, H, W, q, wsb.data_ptr(), wsb.numel(), code, L.stream_ptr(dev)), "convsbs bwd")
+    def bwd():   # (after fwd(): the states it left are taken over; saved == 0: the backward recomputes them)
+        L.check(lib.dctn_convsbs_bwd_saved(x.data_ptr(), xs, cp, dy.data_ptr(), dx.data_ptr(), dcp, n, outs, bonds, ph, pw,
+                                           C, B, H, W, q, wsb.data_ptr(), wsb.numel(), wsf.data_ptr() if saved else None,
+                                           saved, code, L.stream_ptr(dev)), "convsbs bwd")
 
     return fwd, bwd, (cores, out, wsf, wsb, dx, flat, dcores)
 
@@ -570,12 +573,12 @@ def extra_cfg4(r, dev, iters):
     by_fwd = x.numel() * 4 + y.numel() * 4 + n_par * 4
     by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
     if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
-        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
+        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)", t_b, 2 * flops_fwd,
                               by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
                               fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
                               step_frac=3 * flops_fwd / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"], family=fam)
     else:         # HBM / launch-latency bound: bytes of the fused ideal against the HBM peak
-        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd", t_b, 2 * flops_fwd,
+        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)", t_b, 2 * flops_fwd,
                               by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
                               fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
                               step_frac=by_fb / t_fb / 1e9 / HBM_PEAK_GBS, family=fam)

@@ -83,11 +83,18 @@ def _plan(spec: SBSSpecString) -> _StringPlan:
 
 
 def _workspace_bytes(plan: _StringPlan, B: int, H: int, W: int, code: int, backward: int) -> int:
+    """backward: 0 forward scratch, 1 backward scratch, 2 the forward states a training forward leaves for the backward
+    (0 bytes: this string's backward recomputes them)."""
     key = (B, H, W, code, backward)
     nbytes = plan.ws.get(key)
     if nbytes is None:
-        nbytes = plan.ws[key] = L.lib().dctn_convsbs_workspace_bytes(plan.n, plan.outs, plan.bonds, plan.C, B, H, W, plan.q,
-                                                                     plan.ph, plan.pw, code, backward)
+        if backward == 2:
+            nbytes = L.lib().dctn_convsbs_saved_states_bytes(plan.n, plan.outs, plan.bonds, plan.C, B, H, W, plan.q, plan.ph,
+                                                             plan.pw, code)
+        else:
+            nbytes = L.lib().dctn_convsbs_workspace_bytes(plan.n, plan.outs, plan.bonds, plan.C, B, H, W, plan.q,
+                                                          plan.ph, plan.pw, code, backward)
+        plan.ws[key] = nbytes
     return nbytes
 
 
@@ -109,21 +116,35 @@ class _ConvSBSFunction(torch.autograd.Function):
         Ho, Wo = H - plan.max_h, W - plan.max_w
         out = torch.empty((B, Ho, Wo, plan.out_total), dtype=x.dtype, device=dev)
         code = L.dtype_code(x)
-        ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 0), dev)
+        # a forward that will be differentiated leaves its forward states (a buffer of its own, alive until the backward)
+        # instead of having the backward's first quarter recompute them
+        saved_bytes = _workspace_bytes(plan, B, H, W, code, 2) if any(ctx.needs_input_grad) else 0
+        if saved_bytes > 0:
+            states = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            ws = states
+        else:
+            states = None
+            ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 0), dev)
         L.check(
             L.lib().dctn_convsbs_fwd(x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), out.data_ptr(), n,
                                      plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
                                      L.stream_ptr(dev)),
             "ConvSBS forward",
         )
-        ctx.save_for_backward(x, *cores_c)
-        ctx.meta = (plan, C, B, H, W, q, code)
+        if states is None:
+            ctx.save_for_backward(x, *cores_c)
+        else:
+            ctx.save_for_backward(x, *cores_c, states)
+        ctx.meta = (plan, C, B, H, W, q, code, states is not None)
         return out
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
-        x, *cores_c = ctx.saved_tensors
-        plan, C, B, H, W, q, code = ctx.meta
+        plan, C, B, H, W, q, code, has_states = ctx.meta
+        if has_states:
+            x, *cores_c, states = ctx.saved_tensors
+        else:
+            (x, *cores_c), states = ctx.saved_tensors, None
         n = plan.n
         dev = x.device
         need_dx = ctx.needs_input_grad[0]
@@ -141,10 +162,11 @@ class _ConvSBSFunction(torch.autograd.Function):
                 off += c.numel()
         ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 1), dev)
         L.check(
-            L.lib().dctn_convsbs_bwd(
+            L.lib().dctn_convsbs_bwd_saved(
                 x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), g.data_ptr(),
                 None if d_x is None else d_x.data_ptr(), None if d_cores is None else L.ptr_array(d_cores),
-                n, plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
+                n, plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(),
+                None if states is None else states.data_ptr(), 0 if states is None else states.numel(), code,
                 L.stream_ptr(dev)),
             "ConvSBS backward",
         )

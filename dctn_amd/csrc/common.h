@@ -110,12 +110,16 @@ int eps_head_bwd_mfma(const void* x, const void* feat, const void* dLogits, cons
                       int precision, hipStream_t st);
 
 // MFMA ConvSBS sweep (open chain, uniform bond) — convsbs_mfma.hip
+// save_states (optional): room of convsbs_saved_states_bytes(...) for the forward states a following backward takes over
+size_t convsbs_saved_states_bytes(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                  int C, int B, int H, int W, int q, int dtype);
 int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
                      const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                     int C, int B, int H, int W, int q, int dtype, hipStream_t st);
+                     int C, int B, int H, int W, int q, int dtype, hipStream_t st, float* save_states = nullptr);
 int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
                      float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
-                     int q, int dtype, hipStream_t st, float* partials = nullptr, size_t partial_bytes = 0);
+                     int q, int dtype, hipStream_t st, float* partials = nullptr, size_t partial_bytes = 0,
+                     const float* saved_states = nullptr);
 // room for the per-workgroup partial-gradient records of the MFMA backward (deterministic dCore)
 constexpr int SBS_MAX_PARTIAL_RECORDS = 2048;

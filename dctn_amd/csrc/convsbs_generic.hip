@@ -394,7 +394,7 @@ size_t bwd_ws(const SbsP& p, int dtype) {
 
 template <typename S, typename A>
 int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, void* ws,
-               size_t ws_bytes, SbsP& p, int dtype, hipStream_t st) {
+               size_t ws_bytes, SbsP& p, int dtype, hipStream_t st, const void* saved = nullptr) {
   if (!ws || bwd_ws(p, dtype) > ws_bytes) return DCTN_ERR_WORKSPACE;
   p.core_off[0] = 0;
   for (int c = 0; c < p.n; ++c) p.core_off[c + 1] = p.core_off[c] + core_elems(p, c);
@@ -455,7 +455,7 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
       const size_t pbytes = (size_t)SBS_MAX_PARTIAL_RECORDS * ce * sizeof(float);
       float* partials = ((size_t)((unsigned char*)ws + ws_bytes - wsp) >= pbytes) ? (float*)wsp : nullptr;
       const int rcm = convsbs_bwd_mfma(x, (const int64_t*)p.s, cp, dY, (float*)states, dX ? (float*)gxw : nullptr, dcp, p.n, outs,
-                                       bonds, p.ph, p.pw, p.C, p.B, p.H, p.W, p.q, dtype, st, partials, pbytes);
+                                       bonds, p.ph, p.pw, p.C, p.B, p.H, p.W, p.q, dtype, st, partials, pbytes, (const float*)saved);
       if (rcm == DCTN_OK) {
         if (dX) {
           const long long total = (long long)p.C * p.B * p.H * p.W * p.q;
@@ -513,11 +513,16 @@ size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int
   return backward ? bwd_ws(p, dtype) + 256 : 256;
 }
 
+size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B, int H,
+                                       int W, int q, const int* pos_h, const int* pos_w, int dtype) {
+  if (!out_sizes || !bond_sizes || !pos_h || !pos_w) return 0;
+  return convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+}
+
 int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* const* cores,
                      void* out, int n_cores, const int* out_sizes, const int* bond_sizes,
                      const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q,
                      void* workspace, size_t workspace_bytes, int dtype, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (!x || !x_strides || !cores || !out || !out_sizes || !bond_sizes || !pos_h || !pos_w)
     return DCTN_ERR_NULL;
   SbsP p;
@@ -529,8 +534,12 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
     p.dcore[c] = nullptr;
   }
   hipStream_t st = (hipStream_t)stream;
+  // a workspace of dctn_convsbs_saved_states_bytes(...) bytes: the forward leaves its states there for
+  // dctn_convsbs_bwd_saved (a training forward); anything smaller: plain forward
+  const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  float* save = (sb > 0 && workspace && workspace_bytes >= sb) ? (float*)workspace : nullptr;
   rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
-                        dtype, st);
+                        dtype, st, save);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   switch (dtype) {
     case DCTN_F32: return fwd_launch<float, float>(x, out, p, st);
@@ -545,8 +554,22 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
                      const int* out_sizes, const int* bond_sizes, const int* pos_h,
                      const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
                      size_t workspace_bytes, int dtype, void* stream) {
+  return dctn_convsbs_bwd_saved(x, x_strides, cores, dY, dX, dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
+                                W, q, workspace, workspace_bytes, nullptr, 0, dtype, stream);
+}
+
+int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void* const* cores,
+                           const void* dY, void* dX, void* const* dCores, int n_cores,
+                           const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                           const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
+                           size_t workspace_bytes, const void* saved_states, size_t saved_states_bytes, int dtype,
+                           void* stream) {
   if (!x || !x_strides || !cores || !dY || !out_sizes || !bond_sizes || !pos_h || !pos_w)
     return DCTN_ERR_NULL;
+  if (saved_states) {   // only what the forward of this very shape can have written
+    const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+    if (sb == 0 || saved_states_bytes < sb) saved_states = nullptr;
+  }
   if (!dX && !dCores) return DCTN_OK;
   SbsP p;
   int rc = fill(p, x_strides, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q);
@@ -559,7 +582,7 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
     case DCTN_F32:
-      return bwd_launch<float, float>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st);
+      return bwd_launch<float, float>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st, saved_states);
     case DCTN_F64:
       return bwd_launch<double, double>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st);
     case DCTN_BF16:

@@ -25,6 +25,7 @@ struct SbsMP {
   int ostride, obase;         // row length of out / dY and the first output of this launch (many-output strings run in slices)
   int accum;                  // backward: add to gxw and to the core gradients instead of setting them (slices after the first)
   int out_accum;              // forward: add to out (rings: one launch per value of the closing bond)
+  float* save;                // forward: store every core's input state here for a following backward (or NULL)
   int last_stride;            // elements between the rows of the last core's table (qc; rings: a column of its matrix)
   long long Wn, ngroups;
   long long s[5];
@@ -242,9 +243,20 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
       v1[s] = 0.f;
     }
     int oacc = 1;
+    // the input state of core c, for the backward that follows a training forward ([state element][window], the layout
+    // the backward's own forward sweep writes): element l = 2s + h of this lane's window
+    auto save_state = [&](int c) {
+      if (!p.save || !valid) return;
+#pragma unroll
+      for (int s = 0; s < SR; ++s) {
+        p.save[(p.st_off[c] + 2 * s + h) * p.Wn + w] = v0[s];
+        if (oacc > 1) p.save[(p.st_off[c] + R + 2 * s + h) * p.Wn + w] = v1[s];
+      }
+    };
     // ---- middle cores on the matrix pipe
     for (int c = 1; c + 1 < p.n; ++c) {
       const int oc = p.o[c];
+      save_state(c);
       load_features(fs, c, lane, f);
       float n0[SR], n1[SR];
 #pragma unroll
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
       oacc *= oc;
     }
     // ---- last core: out[a] = sum_l v[a][l] * sum_qq coreL[l][qq] f[qq]
+    save_state(p.n - 1);
     load_features(fs, p.n - 1, lane, f);
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
@@ -706,7 +719,9 @@ __device__ unsigned long long sbs_stamps[2048 * 32];
 
 // ONECH: one input channel (the multi-channel feature products and their gradients are not compiled: 20 KB of the
 // bond-16 kernel's 77 KB, which no longer fits the 64 KB instruction cache)
-template <int R, int NC, int NT, int ONECH>
+// SAVED: `states` already holds every core's input state (the training forward stored them, convsbs_fwd_mfma_k's
+// `save`): the forward sweep is skipped, the last core's input state is loaded like the others
+template <int R, int NC, int NT, int ONECH, bool SAVED>
 __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bwd_mfma16_k(const float* __restrict__ x,
                                                             const float* __restrict__ dY,
                                                             float* __restrict__ states,
@@ -865,45 +880,57 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
 
     // ---------------- forward sweep (input state of every core stored for the way back)
     float v[2][SN][NT];
-    load_f(0);
-#pragma unroll
-    for (int s = 0; s < SN; ++s) {
-      const float* cp = lds + p.first_off + (4 * s + g) * 4;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        v[0][s][t] = cp[0] * f[0][t] + cp[1] * f[1][t] + cp[2] * f[2][t] + cp[3] * f[3][t];
-        v[1][s][t] = 0.f;
-      }
-    }
     int oacc = 1;
-    for (int c = 1; c + 1 < p.n; ++c) {
-      store_state(c, oacc, v);
-      const int oc = p.o[c];
-      load_f(c);
-      float nv[2][SN][NT];
+    if constexpr (SAVED) {
+      for (int c = 1; c + 1 < p.n; ++c) oacc *= p.o[c];
 #pragma unroll
-      for (int s = 0; s < SN; ++s)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { nv[0][s][t] = 0.f; nv[1][s][t] = 0.f; }
-      auto forward_pair = [&](auto A_, auto O_) {   // (a, o) as constants, as in the way back
-        constexpr int a = decltype(A_)::value, o = decltype(O_)::value;
-        f32x4 D[MT][NT];
-        u_tiles(c, o, v[a], D);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            nv[(a == 0 && o == 0) ? 0 : 1][mt][t] =
-                f[0][t] * D[mt][t][0] + f[1][t] * D[mt][t][1] + f[2][t] * D[mt][t][2] + f[3][t] * D[mt][t][3];
-      };
-      forward_pair(sbs_ic<0>{}, sbs_ic<0>{});
-      if (oc > 1) forward_pair(sbs_ic<0>{}, sbs_ic<1>{});
-      if (oacc > 1) forward_pair(sbs_ic<1>{}, sbs_ic<0>{});
-#pragma unroll
-      for (int s = 0; s < SN; ++s)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { v[0][s][t] = nv[0][s][t]; v[1][s][t] = nv[1][s][t]; }
-      oacc *= oc;
+        for (int s = 0; s < SN; ++s) {
+          v[0][s][t] = vt_ok[t] ? states[(p.st_off[p.n - 1] + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+          v[1][s][t] = (vt_ok[t] && oacc > 1) ? states[(p.st_off[p.n - 1] + R + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+        }
+    } else {
+      load_f(0);
+  #pragma unroll
+      for (int s = 0; s < SN; ++s) {
+        const float* cp = lds + p.first_off + (4 * s + g) * 4;
+  #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          v[0][s][t] = cp[0] * f[0][t] + cp[1] * f[1][t] + cp[2] * f[2][t] + cp[3] * f[3][t];
+          v[1][s][t] = 0.f;
+        }
+      }
+      for (int c = 1; c + 1 < p.n; ++c) {
+        store_state(c, oacc, v);
+        const int oc = p.o[c];
+        load_f(c);
+        float nv[2][SN][NT];
+  #pragma unroll
+        for (int s = 0; s < SN; ++s)
+  #pragma unroll
+          for (int t = 0; t < NT; ++t) { nv[0][s][t] = 0.f; nv[1][s][t] = 0.f; }
+        auto forward_pair = [&](auto A_, auto O_) {   // (a, o) as constants, as in the way back
+          constexpr int a = decltype(A_)::value, o = decltype(O_)::value;
+          f32x4 D[MT][NT];
+          u_tiles(c, o, v[a], D);
+  #pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+  #pragma unroll
+            for (int t = 0; t < NT; ++t)
+              nv[(a == 0 && o == 0) ? 0 : 1][mt][t] =
+                  f[0][t] * D[mt][t][0] + f[1][t] * D[mt][t][1] + f[2][t] * D[mt][t][2] + f[3][t] * D[mt][t][3];
+        };
+        forward_pair(sbs_ic<0>{}, sbs_ic<0>{});
+        if (oc > 1) forward_pair(sbs_ic<0>{}, sbs_ic<1>{});
+        if (oacc > 1) forward_pair(sbs_ic<1>{}, sbs_ic<0>{});
+  #pragma unroll
+        for (int s = 0; s < SN; ++s)
+  #pragma unroll
+          for (int t = 0; t < NT; ++t) { v[0][s][t] = nv[0][s][t]; v[1][s][t] = nv[1][s][t]; }
+        oacc *= oc;
+      }
+
     }
 
     SBS_STAMP(3);
@@ -1294,7 +1321,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   if (otot > 2 || out_sizes[0] != 1 || out_sizes[n - 1] != 1) return DCTN_ERR_UNSUPPORTED;
   p.n = n; p.C = C; p.B = B; p.H = H; p.W = W; p.q = q; p.qc = (int)qc; p.Otot = (int)otot;
-  p.ostride = (int)otot; p.obase = 0; p.accum = 0; p.out_accum = 0; p.last_stride = (int)qc;
+  p.ostride = (int)otot; p.obase = 0; p.accum = 0; p.out_accum = 0; p.last_stride = (int)qc; p.save = nullptr;
   int max_h = 0, max_w = 0;
   for (int c = 0; c < n; ++c) {
     p.o[c] = out_sizes[c]; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
@@ -1348,12 +1375,24 @@ struct SbsSlice {   // one launch of a string that runs in slices (many-valued c
 
 static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
                                 const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                                int C, int B, int H, int W, int q, int dtype, hipStream_t st, const SbsSlice& sl) {
+                                int C, int B, int H, int W, int q, int dtype, hipStream_t st, const SbsSlice& sl,
+                                float* save) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
   if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.out_accum = sl.out_accum; p.last_stride = sl.last_stride; }
+  if (save && !sl.sliced && R <= 16) {   // input states of cores 1 .. n-1 for the backward (same offsets as its own sweep)
+    long long so = 0;
+    int oacc = 1;
+    for (int c = 0; c < n; ++c) {
+      p.st_off[c] = so;
+      if (c >= 1) so += (long long)oacc * R;
+      oacc *= p.o[c];
+    }
+    p.st_off[n] = so;
+    p.save = save;
+  }
   const size_t lds = (size_t)off * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.ngroups + 3) / 4;
@@ -1433,13 +1472,35 @@ static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes
   return DCTN_OK;
 }
 
+// Bytes of the forward states a training forward can leave for the backward (0: this string recomputes them - slices,
+// bonds above 16, shapes outside the family).
+size_t convsbs_saved_states_bytes(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                  int C, int B, int H, int W, int q, int dtype) {
+  if (dtype != DCTN_F32 || n < 3 || n > SBSM_MAXC) return 0;
+  if (sbsm_many_output_core(n, out_sizes) != -1 || bond_sizes[0] != 1) return 0;
+  SbsMP p;
+  int R, off;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  const void* none[SBSM_MAXC] = {};
+  if (sbsm_fill(p, R, off, dummy, none, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype) != DCTN_OK || R > 16) return 0;
+  if (R < 8) return 0;   // bond <= 4: storing costs the forward what the backward saves (80 -> 83 us at the cfg4 shape)
+  long long so = 0;
+  int oacc = 1;
+  for (int c = 0; c < n; ++c) {
+    if (c >= 1) so += (long long)oacc * R;
+    oacc *= p.o[c];
+  }
+  return (size_t)so * (size_t)p.Wn * sizeof(float);
+}
+
 int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
                      const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
-                     int C, int B, int H, int W, int q, int dtype, hipStream_t st) {
+                     int C, int B, int H, int W, int q, int dtype, hipStream_t st, float* save_states) {
   if (dtype != DCTN_F32) return DCTN_ERR_UNSUPPORTED;
   return sbsm_for_slices(n, cores, out_sizes, bond_sizes, C, q,
                          [&](const void* const* cp, const int* outs, const int* bonds, const SbsSlice& sl, int, int) {
-                           return convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bonds, pos_h, pos_w, C, B, H, W, q, dtype, st, sl);
+                           return convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bonds, pos_h, pos_w, C, B, H, W, q, dtype, st, sl,
+                                                       save_states);
                          });
 }
 
@@ -1452,13 +1513,16 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
                                 float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                                 const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                                 int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes,
-                                const SbsSlice& sl) {
+                                const SbsSlice& sl, const float* saved) {
   SbsMP p;
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
   if (R > 16 || !dcores || !states) return DCTN_ERR_UNSUPPORTED;
   if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.accum = sl.accum; p.last_stride = sl.last_stride; }
+  // the training forward's stored states replace this launch's forward sweep (whole strings only: a slice has its own)
+  const bool use_saved = saved != nullptr && !sl.sliced;
+  if (use_saved) states = const_cast<float*>(saved);
   long long so = 0;
   int oacc = 1;
   for (int c = 0; c < n; ++c) {
@@ -1510,24 +1574,22 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
       if (blocks > 256 * per_cu2) blocks = 256 * per_cu2;
       if (blocks > SBS_MAX_PARTIAL_RECORDS - 64) blocks = SBS_MAX_PARTIAL_RECORDS - 64;   // room for the second-stage records
       q2.partials = (partials && partial_bytes >= (size_t)blocks * q2.core_off[n] * sizeof(float)) ? partials : nullptr;
+#define SBS_LAUNCH_B16_1(RR, NCV, NTV, CHV, SV)                                                    \
+  do {                                                                                            \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, CHV, SV>,           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);             \
+    hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, CHV, SV>), dim3((unsigned)blocks), dim3(256), lds2, st, \
+                       (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);       \
+  } while (0)
+#define SBS_LAUNCH_B16_S(RR, NCV, NTV, SV)                                                        \
+  do {                                                                                            \
+    if (chmode == 1) SBS_LAUNCH_B16_1(RR, NCV, NTV, 1, SV);                                       \
+    else if (chmode == 2) SBS_LAUNCH_B16_1(RR, NCV, NTV, 2, SV);                                  \
+    else SBS_LAUNCH_B16_1(RR, NCV, NTV, 0, SV);                                                   \
+  } while (0)
 #define SBS_LAUNCH_B16(RR, NCV, NTV)                                                              \
   do {                                                                                            \
-    if (chmode == 1) {                                                                            \
-      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>,               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
-      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 1>), dim3((unsigned)blocks), dim3(256), lds2, st, \
-                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
-    } else if (chmode == 2) {                                                                     \
-      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 2>,               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
-      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 2>), dim3((unsigned)blocks), dim3(256), lds2, st, \
-                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
-    } else {                                                                                      \
-      (void)hipFuncSetAttribute((const void*)convsbs_bwd_mfma16_k<RR, NCV, NTV, 0>,               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);           \
-      hipLaunchKernelGGL((convsbs_bwd_mfma16_k<RR, NCV, NTV, 0>), dim3((unsigned)blocks), dim3(256), lds2, st, \
-                         (const float*)x, (const float*)dY, states, gxw, q2, gxw != nullptr);     \
-    }                                                                                             \
+    if (use_saved) SBS_LAUNCH_B16_S(RR, NCV, NTV, true); else SBS_LAUNCH_B16_S(RR, NCV, NTV, false); \
   } while (0)
       switch (R) {   // up to 9 cores (mnist.py:189-223): register accumulators; longer strings: LDS accumulators
         case 4: if (n <= 9) SBS_LAUNCH_B16(4, 9, 2); else SBS_LAUNCH_B16(4, 0, 2); break;
@@ -1536,6 +1598,8 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
         default: return DCTN_ERR_UNSUPPORTED;
       }
 #undef SBS_LAUNCH_B16
+#undef SBS_LAUNCH_B16_S
+#undef SBS_LAUNCH_B16_1
       DCTN_CHECK_LAUNCH();
       if (q2.partials) {
         int nrec = (int)blocks;
@@ -1556,7 +1620,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     }
   }
   // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
-  if (sl.sliced || p.Ra != R) return DCTN_ERR_UNSUPPORTED;   // (slices and padded bonds: second version only)
+  if (sl.sliced || p.Ra != R || use_saved) return DCTN_ERR_UNSUPPORTED;   // (slices, padded bonds, saved states: second version only)
   p.ngroups = (p.Wn + 31) / 32;
   so = 0;
   oacc = 1;
@@ -1599,7 +1663,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
 int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* cores, const void* dY,
                      float* states, float* gxw, float* const* dcores, int n, const int* out_sizes,
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
-                     int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes) {
+                     int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes, const float* saved_states) {
   if (dtype != DCTN_F32 || !dcores) return DCTN_ERR_UNSUPPORTED;
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
@@ -1616,6 +1680,6 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                            }
                            if (sl.sliced && m >= 0) dcp[m] = dcores[m] + (long long)o0 * Rb * Rb * qc;
                            return convsbs_bwd_mfma_one(x, xs, cp, dY, states, gxw, dcp, n, outs, bonds, pos_h, pos_w, C, B, H,
-                                                       W, q, dtype, st, partials, partial_bytes, sl);
+                                                       W, q, dtype, st, partials, partial_bytes, sl, saved_states);
                          });
 }

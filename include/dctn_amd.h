@@ -176,6 +176,20 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
                      int C, int B, int H, int W, int q,
                      void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* A training forward can leave its forward states for the backward instead of having the backward recompute them
+ * (the backward's own forward sweep is a quarter of its time): pass dctn_convsbs_fwd a workspace of at least
+ * dctn_convsbs_saved_states_bytes(...) bytes (0: this string always recomputes - rings, many-valued cores, bonds above
+ * 16, float64 / bf16) and hand the same buffer, untouched, to dctn_convsbs_bwd_saved.  NULL / too small: exactly
+ * dctn_convsbs_bwd.  Replaces nothing in the reference (autograd keeps every intermediate there, dctn/conv_sbs.py:268-303). */
+size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B, int H,
+                                       int W, int q, const int* pos_h, const int* pos_w, int dtype);
+int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void* const* cores,
+                           const void* dY, void* dX, void* const* dCores, int n_cores,
+                           const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                           const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
+                           size_t workspace_bytes, const void* saved_states, size_t saved_states_bytes, int dtype,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * logmatmulexp — replaces dctn/logmatmulexp.py:5-14 (and the checkpointed :17-22; nothing of
  * size Theta*R*I is ever materialised here, forward or backward).
