@@ -650,7 +650,9 @@ __device__ __forceinline__ float pack16_element(const SbsMP& p, int c, int e) {
 // NMID > 0: at most NMID middle cores with at most two outputs each: every global load of the two packs is issued
 // before the first LDS store (one round trip for the whole string instead of one per core and pack: the packing was
 // 10 us of a 230 us kernel at bond 16).  NMID == 0: any string, core by core.
-template <int R, int NMID>
+// FWDPACK = false: only the adjoint packs (a backward that takes its forward states from the training forward never
+// applies the cores forwards)
+template <int R, int NMID, bool FWDPACK = true>
 __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid) {
   constexpr int MT = R / 4, KS = R / 4, PER_O = MT * KS * 64, PER = (PER_O + 255) / 256;
   if constexpr (NMID > 0) {
@@ -663,7 +665,7 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
         for (int j = 0; j < PER; ++j) {
           const int c = m + 1, e = tid + 256 * j;
           const bool live = c + 1 < p.n && o < p.o[c] && e < PER_O;
-          va[m][o][j] = live ? pack16_element<R, false>(p, c, o * PER_O + e) : 0.f;
+          va[m][o][j] = (FWDPACK && live) ? pack16_element<R, false>(p, c, o * PER_O + e) : 0.f;
           vb[m][o][j] = live ? pack16_element<R, true>(p, c, o * PER_O + e) : 0.f;
         }
 #pragma unroll
@@ -674,7 +676,7 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
         for (int j = 0; j < PER; ++j) {
           const int c = m + 1, e = tid + 256 * j;
           if (c + 1 < p.n && o < p.o[c] && e < PER_O) {
-            lds[p.apack_off[c] + o * PER_O + e] = va[m][o][j];
+            if (FWDPACK) lds[p.apack_off[c] + o * PER_O + e] = va[m][o][j];
             lds[p.apack2_off[c] + o * PER_O + e] = vb[m][o][j];
           }
         }
@@ -682,7 +684,7 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
     for (int c = 1; c + 1 < p.n; ++c) {
       const int oc = p.o[c];
       for (int e = tid; e < oc * PER_O; e += 256) {
-        lds[p.apack_off[c] + e] = pack16_element<R, false>(p, c, e);
+        if (FWDPACK) lds[p.apack_off[c] + e] = pack16_element<R, false>(p, c, e);
         lds[p.apack2_off[c] + e] = pack16_element<R, true>(p, c, e);   // the same fragment order, rows <-> (l, qq), k <-> r'
       }
     }
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
   bool first_group = true;
   (void)first_group;
   SBS_STAMP(0);
-  pack_cores16<R, (NC > 2 ? NC - 2 : 0)>(lds, p, tid);
+  pack_cores16<R, (NC > 2 ? NC - 2 : 0), !SAVED>(lds, p, tid);
   if constexpr (NC == 0) {   // (NC > 0: the accumulator region lies over the packs and is zeroed after the sweep)
     const int z0 = p.dacc_off[0], z1 = p.dacc_off[p.n];
     for (int e = z0 + tid; e < z1; e += 256) lds[e] = 0.f;
