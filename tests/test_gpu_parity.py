@@ -446,7 +446,8 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
         assert torch.equal(cd.grad, first[1]) and torch.equal(xd.grad, first[0])
 
 
-@pytest.mark.parametrize("which", ["eps_bigcore_f32", "eps_generic_q3", "convsbs_generic_bond3", "convsbs_ring_many_bond4"])
+@pytest.mark.parametrize("which", ["eps_bigcore_f32", "eps_generic_q3", "convsbs_generic_bond3", "convsbs_ring_many_bond4",
+                                   "convsbs_saved_states_bond8"])
 def test_graph_replays_start_their_accumulators_from_zero(which):
     """Kernels that accumulate into a zero-filled buffer (atomics, slices) must zero it with a kernel of their own: a
     `hipMemsetAsync` recorded into a torch HIP graph filled with garbage from the second replay on
@@ -466,6 +467,8 @@ def test_graph_replays_start_their_accumulators_from_zero(which):
         snake = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
         if which == "convsbs_generic_bond3":
             bonds, outs = (1,) + (3,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1)
+        elif which == "convsbs_saved_states_bond8":   # the training forward leaves its states for the backward
+            bonds, outs = (1,) + (8,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1)
         else:
             bonds, outs = (4,) * 9, (1, 1, 1, 1, 5, 1, 1, 1, 1)
         spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(snake, outs)), bonds, 2, 2)
