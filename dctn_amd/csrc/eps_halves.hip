@@ -477,6 +477,10 @@ __global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, con
 // SUF_f[l] (factors below f): both families of Kronecker prefix / suffix products are built level by level in
 // the wave's LDS (sum over levels < E entries each), so a term costs three LDS reads and two multiplies.
 // Lane -> (pair (f, q), slice of the (u, l) range); slices are summed through LDS.
+// floats of one PRE / SUF table of the dX kernel: levels 0 .. nd-1 with Q^f entries each = (E - 1) / (Q - 1) (< E / 2 from
+// Q = 3 on: the tables used to be given E entries each, and the LDS they did not need cost resident workgroups)
+__host__ __device__ inline int dx_half_table(int E, int Q) { return ((E - 1) / (Q - 1) + 4) & ~3; }
+
 template <int LOGQ, typename T, typename S = T>
 __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x, const T* __restrict__ dP,
                                                      T* __restrict__ gxw, HalfP h, int second, long long w0,
@@ -488,12 +492,13 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
   const int base = second ? h.n0 : 0, nd = second ? h.n1 : h.n0;
   const int E = (int)(second ? h.Bn : h.A);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int per_wave = nd * Q + 3 * E + 64;
+  const int TS = dx_half_table(E, Q);
+  const int per_wave = nd * Q + E + 2 * TS + 64;
   T* xs = sm + (size_t)wv * per_wave;   // [nd][Q]
   T* dps = xs + nd * Q;                 // [E]
   T* pre = dps + E;                     // levels 0 .. nd-1, level f has Q^f entries
-  T* suf = pre + E;                     // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
-  T* red = suf + E;                     // [64]
+  T* suf = pre + TS;                    // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
+  T* red = suf + TS;                    // [64]
   const int np = nd * Q;
   const int ppl = np < 64 ? np : 64, nsl = 64 / ppl;
   const int hw = p.Ho * p.Wo;
@@ -633,7 +638,7 @@ int launch_halves(const S* x, S* P0, S* P1, const HalfP& h, long long w0, long l
 size_t dx_half_lds(const HalfP& h, int second, size_t esz) {
   const int nd = second ? h.n1 : h.n0;
   const long long E = second ? h.Bn : h.A;
-  return (size_t)4 * ((size_t)nd * h.p.Q + 3 * (size_t)E + 64) * esz;
+  return (size_t)4 * ((size_t)nd * h.p.Q + (size_t)E + 2 * (size_t)dx_half_table((int)E, h.p.Q) + 64) * esz;
 }
 
 template <int LOGQ, typename T, typename S>
