@@ -480,6 +480,11 @@ __global__ __launch_bounds__(256) void halves_dp1_k(const T* __restrict__ Z, con
 // floats of one PRE / SUF table of the dX kernel: levels 0 .. nd-1 with Q^f entries each = (E - 1) / (Q - 1) (< E / 2 from
 // Q = 3 on: the tables used to be given E entries each, and the LDS they did not need cost resident workgroups)
 __host__ __device__ inline int dx_half_table(int E, int Q) { return ((E - 1) / (Q - 1) + 4) & ~3; }
+// position of gradient entry e in the wave's LDS row: one float of padding per 32, so that the lanes of a wave - which walk
+// the row with the power-of-two strides of their factors - do not all land on one bank (counters: 68 % of the kernel's
+// LDS cycles were bank conflicts and the LDS pipe was 78 % busy)
+// (float32 rows only: on the float64 rows of cfg1 the extra index arithmetic cost more than the conflicts it removed)
+__host__ __device__ inline int dx_half_pad(int e, size_t esz) { return esz == 4 ? e + (e >> 5) : e; }
 
 template <int LOGQ, typename T, typename S = T>
 __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x, const T* __restrict__ dP,
@@ -493,10 +498,11 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
   const int E = (int)(second ? h.Bn : h.A);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int TS = dx_half_table(E, Q);
-  const int per_wave = nd * Q + E + 2 * TS + 64;
+  const int EP = (dx_half_pad(E, sizeof(T)) + 3) & ~3;
+  const int per_wave = nd * Q + EP + 2 * TS + 64;
   T* xs = sm + (size_t)wv * per_wave;   // [nd][Q]
-  T* dps = xs + nd * Q;                 // [E]
-  T* pre = dps + E;                     // levels 0 .. nd-1, level f has Q^f entries
+  T* dps = xs + nd * Q;                 // [E], padded (dx_half_pad)
+  T* pre = dps + EP;                    // levels 0 .. nd-1, level f has Q^f entries
   T* suf = pre + TS;                    // levels nd-1 .. 0, level f has Q^(nd-1-f) entries
   T* red = suf + TS;                    // [64]
   const int np = nd * Q;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
       xs[e] = (T)x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
-    for (int e = lane; e < E; e += 64) dps[e] = dP[wl * E + e];
+    for (int e = lane; e < E; e += 64) dps[dx_half_pad(e, sizeof(T))] = dP[wl * E + e];
     if (lane == 0) pre[0] = 1.0, suf[0] = 1.0;   // level 0 of PRE (factor 0), level nd-1 of SUF (last factor)
     wave_sync_lds();
     // PRE level f (offset (Q^f - 1)/(Q - 1)): pre_f[u Q + q'] = pre_{f-1}[u] x_{f-1}[q']
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
             u = j / stride;
             l = j - u * stride;
           }
-          acc += dps[(u * Q + fq) * stride + l] * pre[off_pre + u] * suf[off_suf + l];
+          acc += dps[dx_half_pad((u * Q + fq) * stride + l, sizeof(T))] * pre[off_pre + u] * suf[off_suf + l];
         }
       }
       wave_sync_lds();
@@ -638,7 +644,7 @@ int launch_halves(const S* x, S* P0, S* P1, const HalfP& h, long long w0, long l
 size_t dx_half_lds(const HalfP& h, int second, size_t esz) {
   const int nd = second ? h.n1 : h.n0;
   const long long E = second ? h.Bn : h.A;
-  return (size_t)4 * ((size_t)nd * h.p.Q + (size_t)E + 2 * (size_t)dx_half_table((int)E, h.p.Q) + 64) * esz;
+  return (size_t)4 * ((size_t)nd * h.p.Q + (size_t)((dx_half_pad((int)E, esz) + 3) & ~3) + 2 * (size_t)dx_half_table((int)E, h.p.Q) + 64) * esz;
 }
 
 template <int LOGQ, typename T, typename S>
