@@ -744,7 +744,10 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
   // (8 rows at slot s, 8 rows at slot s ^ 1: MI355X_MICROARCH.md LDS table) then covers all 64 banks.  Padded rows
   // (136 bytes: 8-byte accesses only; 144 bytes: 2-way conflicts on exactly those groups, 47 % of the LDS cycles) lost.
   constexpr int BROW = BK;
-  auto sw = [](int row, int k) { return row * BK + ((((k >> 3) ^ (row >> 1)) & 7) << 3) + (k & 7); };   // element offset
+  // (the row's parity enters the XOR too: stores are banked mod 32, so rows 2j and 2j + 1 - 128 bytes apart, written by
+  // one 8-lane group - would otherwise share their four slots: 2-way conflicts on every ds_write_b128, a third of the
+  // kernel's LDS cycles)
+  auto sw = [](int row, int k) { return row * BK + ((((k >> 3) ^ (row >> 1) ^ ((row & 1) << 2)) & 7) << 3) + (k & 7); };   // element offset
   constexpr int UA = BM / 64, UB = BN / 64;   // staged row groups per thread
   __shared__ __align__(16) bf16_t smem[(BM + BN) * BROW];
   bf16_t* As = smem;               // [m][k]
