@@ -267,9 +267,19 @@ def eps_call_timers(core, x, need_dx, dev, head=None):
     wsf = L.workspace(lib.dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, pol), dev)
     wsb = L.workspace(lib.dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, pol, int(need_dx), 1), dev).clone()
 
+    # the training forward of a layer whose input needs a gradient keeps its GEMM result for the backward
+    nsaved = lib.dctn_eps_saved_bytes(C, B, H, W, Q, K, O, code, pol) if need_dx else 0
+    saved = torch.empty(nsaved, dtype=torch.uint8, device=dev) if nsaved else None
+    kept = [False]
+
     def fwd():
-        L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), wsf.data_ptr(),
-                                 wsf.numel(), C, B, H, W, Q, K, O, code, pol, L.stream_ptr(dev)), "fwd")
+        if saved is None:
+            L.check(lib.dctn_eps_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(), wsf.data_ptr(),
+                                     wsf.numel(), C, B, H, W, Q, K, O, code, pol, L.stream_ptr(dev)), "fwd")
+        else:
+            kept[0] = L.check(lib.dctn_eps_fwd_save(x.data_ptr(), L.strides5(x), core.data_ptr(), out.data_ptr(),
+                                                    saved.data_ptr(), saved.numel(), wsf.data_ptr(), wsf.numel(),
+                                                    C, B, H, W, Q, K, O, code, pol, L.stream_ptr(dev)), "fwd") == L.SAVED
 
     fused = False
     if head is not None:
@@ -290,14 +300,18 @@ def eps_call_timers(core, x, need_dx, dev, head=None):
                                           C, B, H, W, Q, K, O, cout, code, policy, L.stream_ptr(dev)), "head bwd")
     else:
         def bwd(policy=pol):
-            L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(),
-                                     None if dx is None else dx.data_ptr(), dcore.data_ptr(), wsb.data_ptr(), wsb.numel(),
-                                     C, B, H, W, Q, K, O, code, policy, L.stream_ptr(dev)), "bwd")
+            tail = (None if dx is None else dx.data_ptr(), dcore.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                    C, B, H, W, Q, K, O, code, policy, L.stream_ptr(dev))
+            if kept[0]:   # (the forward closure ran first and left `saved`)
+                L.check(lib.dctn_eps_bwd_saved(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(),
+                                               saved.data_ptr(), saved.numel(), *tail), "bwd")
+            else:
+                L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), *tail), "bwd")
     wn = B * Ho * Ho
     gemm = 2 * (Q ** N) * O   # flops per window of the core GEMM (fwd 2*Q^N*O; + the same per gradient)
     return {"fwd": fwd, "bwd": bwd, "fused": fused, "windows": wn, "gemm_flops": gemm, "K": K, "O": O, "N": N,
             "bytes_x": x.numel() * x.element_size(), "bytes_y": wn * O * x.element_size(),
-            "bytes_core": core.numel() * core.element_size(), "keep": (out, dy, dcore, dx, wsf, wsb)}
+            "bytes_core": core.numel() * core.element_size(), "saved_bytes": nsaved, "keep": (out, dy, dcore, dx, wsf, wsb, saved)}
 
 
 def headline_roofline(model, x, specs, steps):

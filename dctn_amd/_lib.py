@@ -18,8 +18,9 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F32, F64, BF16 = 0, 1, 2
 PREC_EXACT, PREC_BF16, PREC_MASK = 0, 1, 0xFF
-OPT_F32_PREFER_HALVES, OPT_SMALL_CHUNKS, OPT_MAIN_KERNEL_ONLY = 1 << 8, 1 << 9, 1 << 10
+OPT_F32_PREFER_HALVES, OPT_SMALL_CHUNKS, OPT_MAIN_KERNEL_ONLY, OPT_GENERIC_KERNELS = 1 << 8, 1 << 9, 1 << 10, 1 << 11
 ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_NULL = -1, -2, -3, -4, -5, -6
+SAVED, PARTIAL = 1, 2   # positive success codes (include/dctn_amd.h)
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16}
 
@@ -36,6 +37,10 @@ SIGNATURES = {
     "dctn_eps_family": (c_int, [c_int] * 9),
     "dctn_eps_fwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
     "dctn_eps_fwd": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_eps_saved_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
+    "dctn_eps_fwd_save": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
+    "dctn_eps_bwd_saved": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size, c_void, c_void, c_void, c_size]
+                           + [c_int] * 7 + [c_int, c_int, c_void]),
     "dctn_eps_fwd_stats_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 2),
     "dctn_eps_fwd_stats": (c_int, [c_void, _I64x5, c_void, c_void, c_void, c_size] + [c_int] * 7 + [c_int, c_int, c_void]),
     "dctn_eps_bwd_workspace_bytes": (c_size, [c_int] * 7 + [c_int] * 4),
@@ -166,9 +171,10 @@ def on_device(fn, *tensors: torch.Tensor):
     return type(out)(o.cpu() for o in out)
 
 
-def check(rc: int, what: str) -> None:
-    if rc == 0:
-        return
+def check(rc: int, what: str) -> int:
+    """Raises for the negative DCTN_ERR_* codes; returns the (non-negative) success code: DCTN_OK, DCTN_SAVED, DCTN_PARTIAL."""
+    if rc >= 0:
+        return rc
     msg = lib().dctn_strerror(rc).decode()
     if rc == ERR_BAD_SHAPE:
         raise AssertionError(f"{what}: {msg}")  # the reference signals shape errors with `assert`

@@ -125,12 +125,14 @@ class _ConvSBSFunction(torch.autograd.Function):
         else:
             states = None
             ws = L.workspace(_workspace_bytes(plan, B, H, W, code, 0), dev)
-        L.check(
+        rc = L.check(
             L.lib().dctn_convsbs_fwd(x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), out.data_ptr(), n,
                                      plan.outs, plan.bonds, plan.ph, plan.pw, C, B, H, W, q, ws.data_ptr(), ws.numel(), code,
                                      L.stream_ptr(dev)),
             "ConvSBS forward",
         )
+        if rc != L.SAVED:   # the forward says whether it wrote the states: an untouched buffer never reaches the backward
+            states = None
         if states is None:
             ctx.save_for_backward(x, *cores_c)
         else:

@@ -51,7 +51,7 @@ int dctn_zero_async(void* ptr, size_t bytes, hipStream_t st) {
 
 extern "C" {
 
-int dctn_version(void) { return 100; }
+int dctn_version(void) { return 300; }   // round 3: dctn_eps_saved_bytes / _fwd_save / _bwd_saved, policy bits checked
 
 const char* dctn_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 
@@ -90,15 +90,18 @@ int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, 
   const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return -1;
+  if (p.opts & DCTN_OPT_GENERIC_KERNELS) return DCTN_EPS_FAMILY_GENERIC;
   if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
   if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return DCTN_EPS_FAMILY_BIGCORE_F32;
   if (eps_halves_wanted(p, dtype)) return DCTN_EPS_FAMILY_HALVES;
   return DCTN_EPS_FAMILY_GENERIC;
 }
 
-int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
-                 void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q, int K,
-                 int O, int dtype, int policy, void* stream) {
+// forward with an optional buffer for what the backward would otherwise recompute; *kept = 1 when it was written
+static int eps_fwd_impl(const void* x, const int64_t x_strides[5], const void* core, void* out, void* saved,
+                        size_t saved_bytes, int* kept, void* workspace, size_t workspace_bytes, int C, int B, int H, int W,
+                        int Q, int K, int O, int dtype, int policy, void* stream) {
+  if (kept) *kept = 0;
   if (!x || !core || !out || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   EpsP p;
@@ -106,15 +109,50 @@ int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, vo
   int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (p.opts & DCTN_OPT_GENERIC_KERNELS) return eps_fwd_generic(x, core, out, p, dtype, st);
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   if (!f32_prefers_halves(p, dtype)) {
-    rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st);
+    const size_t zb = saved ? eps_bigcore_saved_bytes(p, dtype, precision) : 0;
+    const bool keep = zb > 0 && saved_bytes >= zb;
+    rc = eps_fwd_bigcore(x, core, out, workspace, workspace_bytes, p, dtype, precision, st, keep ? saved : nullptr);
+    if (rc == DCTN_OK && keep && kept) *kept = 1;
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
-  rc = eps_fwd_halves(x, core, out, workspace, workspace_bytes, p, dtype, st);
-  if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
+  {
+    const size_t hb = saved ? eps_halves_saved_bytes(p, dtype) : 0;
+    const bool keep = hb > 0 && saved_bytes >= hb;
+    rc = eps_fwd_halves(x, core, out, workspace, workspace_bytes, p, dtype, st, keep ? saved : nullptr);
+    if (rc == DCTN_OK && keep && kept) *kept = 1;
+    if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
+  }
   return eps_fwd_generic(x, core, out, p, dtype, st);
+}
+
+int dctn_eps_fwd(const void* x, const int64_t x_strides[5], const void* core, void* out,
+                 void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q, int K,
+                 int O, int dtype, int policy, void* stream) {
+  return eps_fwd_impl(x, x_strides, core, out, nullptr, 0, nullptr, workspace, workspace_bytes, C, B, H, W, Q, K, O, dtype,
+                      policy, stream);
+}
+
+size_t dctn_eps_saved_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy) {
+  EpsP p;
+  const int precision = policy & DCTN_PREC_MASK;
+  const int64_t dummy[5] = {0, 0, 0, 0, 1};
+  if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
+  if ((p.opts & DCTN_OPT_GENERIC_KERNELS) || eps_mfma_covers(p, dtype, precision)) return 0;
+  if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return eps_bigcore_saved_bytes(p, dtype, precision);
+  return eps_halves_saved_bytes(p, dtype);
+}
+
+int dctn_eps_fwd_save(const void* x, const int64_t x_strides[5], const void* core, void* out, void* saved,
+                      size_t saved_bytes, void* workspace, size_t workspace_bytes, int C, int B, int H, int W, int Q,
+                      int K, int O, int dtype, int policy, void* stream) {
+  int kept = 0;
+  const int rc = eps_fwd_impl(x, x_strides, core, out, saved, saved_bytes, &kept, workspace, workspace_bytes, C, B, H, W, Q,
+                              K, O, dtype, policy, stream);
+  return rc != DCTN_OK ? rc : (kept ? DCTN_SAVED : DCTN_OK);
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -206,9 +244,9 @@ int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* fea
                            Cout, dtype, precision, (hipStream_t)stream);
 }
 
-int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
-                 void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
-                 int H, int W, int Q, int K, int O, int dtype, int policy, void* stream) {
+static int eps_bwd_impl(const void* x, const int64_t x_strides[5], const void* core, const void* dY, const void* saved,
+                        size_t saved_bytes, void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
+                        int H, int W, int Q, int K, int O, int dtype, int policy, void* stream) {
   if (!x || !core || !dY || !x_strides) return DCTN_ERR_NULL;
   if (!dtype_ok(dtype)) return DCTN_ERR_BAD_DTYPE;
   if (!dX && !dCore) return DCTN_OK;
@@ -217,6 +255,7 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (p.opts & DCTN_OPT_GENERIC_KERNELS) return eps_bwd_generic(x, core, dY, dX, dCore, workspace, workspace_bytes, p, dtype, st);
   // dCore on the MFMA family when it covers the shape; whatever is left goes to the generic kernels
   unsigned char* ws = (unsigned char*)workspace;
   const size_t wa = align256(eps_bwd_mfma_workspace(p, dtype, precision, 0, dCore != nullptr));
@@ -233,7 +272,8 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
   // float64, and float32 shapes the bigcore family does not take: both gradients on the two-halves GEMM path
   if (dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision) || f32_prefers_halves(p, dtype)) {
-    rc = eps_bwd_halves(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st);
+    rc = eps_bwd_halves(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st, saved,
+                        saved_bytes);
     if (rc == DCTN_OK) return rc;
     if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) return rc;
   }
@@ -249,7 +289,7 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   if (dX) {
     // dX on the bigcore MFMA family (it shares the tail of the workspace with the generic kernels)
     rc = eps_bwd_dx_bigcore(x, core, dY, dX, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype,
-                            precision, st);
+                            precision, st, saved, saved_bytes);
     if (rc == DCTN_OK) {
       dX = nullptr;
     } else if (rc != DCTN_ERR_UNSUPPORTED && rc != DCTN_ERR_WORKSPACE) {
@@ -259,6 +299,21 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
   if (!dX && !dCore) return DCTN_OK;
   return eps_bwd_generic(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p,
                          dtype, st);
+}
+
+int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
+                 void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
+                 int H, int W, int Q, int K, int O, int dtype, int policy, void* stream) {
+  return eps_bwd_impl(x, x_strides, core, dY, nullptr, 0, dX, dCore, workspace, workspace_bytes, C, B, H, W, Q, K, O, dtype,
+                      policy, stream);
+}
+
+int dctn_eps_bwd_saved(const void* x, const int64_t x_strides[5], const void* core, const void* dY, const void* saved,
+                       size_t saved_bytes, void* dX, void* dCore, void* workspace, size_t workspace_bytes, int C, int B,
+                       int H, int W, int Q, int K, int O, int dtype, int policy, void* stream) {
+  if (!saved) return DCTN_ERR_NULL;
+  return eps_bwd_impl(x, x_strides, core, dY, saved, saved_bytes, dX, dCore, workspace, workspace_bytes, C, B, H, W, Q, K,
+                      O, dtype, policy, stream);
 }
 
 }  // extern "C"

@@ -69,14 +69,18 @@ int eps_gather_dx_launch(const void* gxw, void* dX, const EpsP& p, int dtype, hi
 
 // MFMA family "bigcore" (exact f32, LDS-streamed core) — eps_bigcore.hip
 size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision);
+// zsave (optional): room of eps_bigcore_saved_bytes() for the forward GEMM result Z, which eps_bwd_dx_bigcore then
+// reads instead of running its third GEMM (0 bytes: the shape keeps nothing)
+size_t eps_bigcore_saved_bytes(const EpsP& p, int dtype, int precision);
 int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t ws_bytes,
-                    const EpsP& p, int dtype, int precision, hipStream_t st);
+                    const EpsP& p, int dtype, int precision, hipStream_t st, void* zsave = nullptr);
 size_t eps_bwd_dcore_bigcore_workspace(const EpsP& p, int dtype, int precision);
 int eps_bwd_dcore_bigcore(const void* x, const void* dY, void* dCore, const EpsP& p, int dtype,
                           int precision, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision);
 int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
-                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st);
+                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st,
+                       const void* zsaved = nullptr, size_t zsaved_bytes = 0);
 
 // which family the forward of a shape dispatches to (dctn_eps_family)
 bool eps_mfma_covers(const EpsP& p, int dtype, int precision);
@@ -86,11 +90,14 @@ bool eps_bigcore_covers(const EpsP& p, int dtype, int precision);
 // and float32 (v_mfma_f32_16x16x4_f32) for shapes the other float32 families leave (odd Q, ...)
 bool eps_halves_wanted(const EpsP& p, int dtype);
 size_t eps_fwd_halves_workspace(const EpsP& p, int dtype);
+// saved (optional): room of eps_halves_saved_bytes() for the forward's halves and GEMM result, which eps_bwd_halves
+// then reads instead of rebuilding them
+size_t eps_halves_saved_bytes(const EpsP& p, int dtype);
 int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
-                   hipStream_t st);
+                   hipStream_t st, void* saved = nullptr);
 size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_dcore);
 int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
-                   const EpsP& p, int dtype, hipStream_t st);
+                   const EpsP& p, int dtype, hipStream_t st, const void* saved = nullptr, size_t saved_bytes = 0);
 
 // MFMA kernels for power-of-two Q — eps_mfma.hip.  Return DCTN_ERR_UNSUPPORTED when the shape
 // is outside the family so that the dispatcher can take the generic kernels.

@@ -540,6 +540,9 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
   float* save = (sb > 0 && workspace && workspace_bytes >= sb) ? (float*)workspace : nullptr;
   rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
                         dtype, st, save);
+  // the caller learns whether the states were WRITTEN: only the matrix-core sweep writes them, and it can still decline
+  // a string the size query accepted (its LDS plan); the generic sweep below leaves the buffer untouched
+  if (rc == DCTN_OK) return save ? DCTN_SAVED : DCTN_OK;
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   switch (dtype) {
     case DCTN_F32: return fwd_launch<float, float>(x, out, p, st);

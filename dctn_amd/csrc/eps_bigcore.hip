@@ -17,6 +17,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) int int2v;
 
 // The file is compiled three times (Makefile: -DBC_PART=0/1/2) so that its 60-odd kernel
@@ -49,6 +50,10 @@ struct BigP {
   //   of block hb is dY[w, o = hb >> lnhbo] * KR(high digits, hb & (2^lnhbo - 1)).
   int xo, lkh, lnhbo;
   unsigned odiv_m;            // ceil(2^32 / O)
+  // FWD, training: the GEMM result Z = T[(b,o), w] is kept for the backward (the reference's autograd saves it too,
+  // dctn/eps.py:25-30 step (0,1)), in row-quad-major order Z[R / 4][w][R % 4] - a lane's four accumulator registers
+  // of one row quad are one 16-byte store, 512 contiguous bytes per lane half.  NULL: nothing is kept.
+  float* zsave;
 };
 int launch_fwd_hi(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st);
 int launch_g(int mode, const void* x, const void* core, const void* dY, void* out, const BigP& b, size_t lds,
@@ -338,6 +343,21 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
         for (int t = 0; t < BC_TBL; ++t) av[t] = avn[t];
       }
       if (st + 1 < nstage) stage_commit((st + 1) & 1);
+    }
+
+    if (MODE == MODE_FWD && p.zsave) {
+      // accumulator register 4j + i of lane (wl32, h) is row mt*32 + 8j + 4h + i: row quad mt*8 + 2j + h
+#pragma unroll
+      for (int nt = 0; nt < BC_NT; ++nt) {
+        const long long w = w_block + (wv * BC_NT + nt) * 32 + wl32;
+        if (w < p.Wn) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 zv = {acc[nt][4 * j], acc[nt][4 * j + 1], acc[nt][4 * j + 2], acc[nt][4 * j + 3]};
+            __builtin_nontemporal_store(zv, (f32x4*)(p.zsave + ((long long)(mt * 8 + 2 * j + h) * p.Wn + w) * 4));
+          }
+        }
+      }
     }
 
     // ---- epilogue of this row tile
@@ -681,6 +701,7 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   if (b.OP > 32) return false;
   b.LOGO = ilog2i(b.OP);
   b.mode = mode;
+  b.zsave = nullptr;
   const int A = 1 << (b.n0 * b.LQ), BN = 1 << (b.n1 * b.LQ);
   b.xo = (p.O >= 3 && (p.O & (p.O - 1)) != 0 && p.O <= 16) ? 1 : 0;
   b.odiv_m = (unsigned)(((1ull << 32) + p.O - 1) / p.O);
@@ -778,9 +799,10 @@ __global__ void bigcore_sum_slices_k(const float* __restrict__ part, float* __re
   }
 }
 
-// dX from per-window factor gradients stored as `parts` slices gxw[part][N*Q][Wn]
+// dX from per-window factor gradients stored as slices gxw[part][N*Q][Wn]: the factors of half 0 (n < n0) fill
+// `parts0` slices, those of half 1 `parts1` (1 when they come from the saved Z)
 __global__ void bigcore_gather_dx_k(const float* __restrict__ gxw, float* __restrict__ dX, EpsP p,
-                                    int parts) {
+                                    int n0, int parts0, int parts1) {
   const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
   const long long slice = (long long)p.N * p.Q * p.Wn;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -799,11 +821,165 @@ __global__ void bigcore_gather_dx_k(const float* __restrict__ gxw, float* __rest
         const int wo = wi - dw;
         if (wo < 0 || wo >= p.Wo) continue;
         const long long win = ((long long)b * p.Ho + ho) * p.Wo + wo;
-        const long long e = (long long)(((dh * p.K + dw) * p.C + ch) * p.Q + q) * p.Wn + win;
+        const int n = (dh * p.K + dw) * p.C + ch;
+        const long long e = (long long)(n * p.Q + q) * p.Wn + win;
+        const int parts = n < n0 ? parts0 : parts1;
         for (int g = 0; g < parts; ++g) acc += gxw[g * slice + e];
       }
     }
     dX[idx] = acc;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------ dP1 from the saved Z
+// With the forward's GEMM result kept (BigP::zsave), dL/dP1[w,b] = sum_o dY[w,o] Z[w,(b,o)] is a bandwidth pass over
+// Z instead of the third GEMM G1 - what the reference's autograd does with the G it saved (dctn/eps.py:25-30).
+// A workgroup takes 64 windows (lane = window: a row quad of 64 windows is 1 KiB contiguous), its waves split the b
+// range; each lane turns its dP1 values into per-factor gradients of half 1 by leave-one-out products as the G
+// epilogue does, in its own LDS column; the waves' columns are summed at the end into gxw slice 0.
+struct Dp1P {
+  int C, K, Q, LQ, N, n0, n1, Ho, Wo, O, OX;   // OX: Z rows per b (O, or the padded power of two)
+  long long Wn;
+  long long s[5];
+  int S;                 // waves that share the b range
+  int b_per_split;       // BN / S
+};
+
+constexpr int DP1_THREADS = 256;
+
+constexpr int dp1_gcd4(int v) { return v % 4 == 0 ? 4 : (v % 2 == 0 ? 2 : 1); }
+
+// OXT: OX at compile time (dY in registers, static row -> (b, o) map), 0 = run time (dY from LDS)
+// ND1: leave-one-out digits (n1 padded with a row of ones)
+template <int OXT, int ND1>
+__global__ __launch_bounds__(DP1_THREADS) void eps_bigcore_dp1_k(const float* __restrict__ x,
+                                                                 const float* __restrict__ Z,
+                                                                 const float* __restrict__ dY,
+                                                                 float* __restrict__ gxw, Dp1P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nq1 = p.n1 * p.Q;
+  float* xs = smem;                       // [nq1 + 1][64]; row nq1 holds ones
+  float* dys = xs + (nq1 + 1) * 64;       // [OX][64]
+  float* gacc = dys + p.OX * 64;          // [nq1][DP1_THREADS]
+  const int tid = threadIdx.x, wl = tid & 63, sp = tid >> 6;
+  const long long w_block = (long long)blockIdx.x * 64;
+
+  for (int e = tid; e < 64 * p.n1; e += DP1_THREADS) {
+    const int wle = e & 63, d = e >> 6, n = p.n0 + d;
+    const long long w = w_block + wle;
+    const bool valid = w < p.Wn;
+    const long long ww = valid ? w : 0;
+    const int hw = p.Ho * p.Wo;
+    const long long bb = ww / hw;
+    const int rem = (int)(ww - bb * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const int pos = n / p.C, ch = n - pos * p.C;
+    const int dh = pos / p.K, dw = pos - dh * p.K;
+    const float* px = x + ch * p.s[0] + bb * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3];
+    for (int q = 0; q < p.Q; ++q) xs[(d * p.Q + q) * 64 + wle] = valid ? px[q * p.s[4]] : 0.f;
+  }
+  if (tid < 64) xs[nq1 * 64 + tid] = 1.f;
+  for (int e = tid; e < 64 * p.OX; e += DP1_THREADS) {
+    const int wle = e & 63, o = e >> 6;
+    const long long w = w_block + wle;
+    dys[e] = (w < p.Wn && o < p.O) ? dY[w * p.O + o] : 0.f;
+  }
+  for (int f = 0; f < nq1; ++f) gacc[f * DP1_THREADS + tid] = 0.f;
+  __syncthreads();
+
+  const long long w = w_block + wl;
+  if (sp < p.S && w < p.Wn) {
+    float* gcol = gacc + tid;
+    // dL/dP1[w][b] = g -> d/d(factor d of half 1, value digit_d(b)) += g * prod_(d' != d) x[d'][digit_d'(b)]
+    auto flush = [&](int b, float g) {
+      float xv[ND1], suf[ND1 + 1];
+      int slot[ND1];
+#pragma unroll
+      for (int d = 0; d < ND1; ++d) {
+        const bool real = d < p.n1;
+        const int sh = real ? (p.n1 - 1 - d) * p.LQ : 0;
+        const int dg = (b >> sh) & (p.Q - 1);
+        slot[d] = d * p.Q + dg;
+        xv[d] = xs[(real ? slot[d] : nq1) * 64 + wl];
+      }
+      suf[ND1] = 1.f;
+#pragma unroll
+      for (int d = ND1 - 1; d >= 0; --d) suf[d] = suf[d + 1] * xv[d];
+      float pre_p = g;
+#pragma unroll
+      for (int d = 0; d < ND1; ++d) {
+        if (d < p.n1) gcol[slot[d] * DP1_THREADS] += pre_p * suf[d + 1];
+        pre_p *= xv[d];
+      }
+    };
+    const int b0 = sp * p.b_per_split;
+    const f32x4* zp = (const f32x4*)Z + ((long long)b0 * p.OX / 4) * p.Wn + w;   // quad q of the split: zp[q * Wn]
+    if constexpr (OXT > 0) {
+      constexpr int L = OXT * 4 / dp1_gcd4(OXT);   // rows per iteration: whole quads and whole b's
+      constexpr int NQD = L / 4, NB = L / OXT;
+      constexpr int U = NQD >= 8 ? 1 : 8 / NQD;    // iterations whose loads are in flight together
+      float dyr[OXT];
+#pragma unroll
+      for (int o = 0; o < OXT; ++o) dyr[o] = dys[o * 64 + wl];
+      const int iters = p.b_per_split / NB;
+      int b = b0;
+      for (int it = 0; it < iters; it += U) {
+        f32x4 z[U][NQD];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int itc = it + u < iters ? it + u : iters - 1;
+#pragma unroll
+          for (int k = 0; k < NQD; ++k) z[u][k] = __builtin_nontemporal_load(zp + (long long)(itc * NQD + k) * p.Wn);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (it + u < iters) {
+            float dp[NB];
+#pragma unroll
+            for (int bl = 0; bl < NB; ++bl) dp[bl] = 0.f;
+#pragma unroll
+            for (int e = 0; e < L; ++e) dp[e / OXT] = fmaf(dyr[e % OXT], z[u][e / 4][e % 4], dp[e / OXT]);
+#pragma unroll
+            for (int bl = 0; bl < NB; ++bl) flush(b + bl, dp[bl]);
+            b += NB;
+          }
+        }
+      }
+    } else {
+      constexpr int U = 8;
+      const int quads = p.b_per_split * p.OX / 4;
+      int b = b0, o = 0;
+      float dp = 0.f;
+      for (int q0 = 0; q0 < quads; q0 += U) {
+        f32x4 z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int qc = q0 + u < quads ? q0 + u : quads - 1;
+          z[u] = __builtin_nontemporal_load(zp + (long long)qc * p.Wn);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (q0 + u < quads) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              dp = fmaf(dys[o * 64 + wl], z[u][i], dp);
+              if (++o == p.OX) { flush(b, dp); ++b; o = 0; dp = 0.f; }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nq1 * 64; e += DP1_THREADS) {
+    const int f = e >> 6, wle = e & 63;
+    const long long we = w_block + wle;
+    if (we < p.Wn) {
+      float sum = 0.f;
+      for (int s2 = 0; s2 < p.S; ++s2) sum += gacc[f * DP1_THREADS + s2 * 64 + wle];
+      gxw[((long long)p.n0 * p.Q + f) * p.Wn + we] = sum;
+    }
   }
 }
 
@@ -892,13 +1068,45 @@ size_t eps_fwd_bigcore_workspace(const EpsP& p, int dtype, int precision) {
   return b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
 }
 
+// plan of the dP1 pass over a saved Z (false: the shape keeps nothing and the backward runs G1)
+static bool dp1_plan(const EpsP& p, const BigP& bf, Dp1P& d, size_t& lds, size_t& zbytes) {
+  d.C = p.C; d.K = p.K; d.Q = p.Q; d.LQ = bf.LQ; d.N = p.N; d.n0 = bf.n0; d.n1 = bf.n1; d.Ho = p.Ho; d.Wo = p.Wo;
+  d.O = p.O; d.OX = bf.xo ? p.O : bf.OP;
+  d.Wn = p.Wn;
+  for (int i = 0; i < 5; ++i) d.s[i] = p.s[i];
+  const int BN = 1 << (bf.n1 * bf.LQ);
+  d.S = 0;
+  for (int S = 4; S >= 1; S >>= 1)
+    if (BN % S == 0 && ((long long)(BN / S) * d.OX) % 4 == 0) { d.S = S; break; }
+  if (d.S == 0) return false;
+  d.b_per_split = BN / d.S;
+  lds = ((size_t)(d.n1 * d.Q + 1) * 64 + (size_t)d.OX * 64 + (size_t)d.n1 * d.Q * DP1_THREADS) * sizeof(float);
+  if (lds > 64 * 1024) return false;
+  const size_t mtiles = ((size_t)bf.rows + 31) / 32;
+  zbytes = mtiles * 32 * (size_t)p.Wn * sizeof(float);
+  return zbytes <= ((size_t)16 << 30);   // bounded: beyond 16 GiB the backward recomputes
+}
+
+size_t eps_bigcore_saved_bytes(const EpsP& p, int dtype, int precision) {
+  if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
+  BigP b;
+  if (!fill_big(b, p, MODE_FWD) || big_lds(b) > DCTN_LDS_BUDGET) return 0;
+  BigP b0;
+  if (!fill_big(b0, p, MODE_G0) || big_lds(b0) > DCTN_LDS_BUDGET) return 0;
+  Dp1P d;
+  size_t lds, zbytes;
+  if (!dp1_plan(p, b, d, lds, zbytes)) return 0;
+  return zbytes;
+}
+
 int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t ws_bytes,
-                    const EpsP& p, int dtype, int precision, hipStream_t st) {
+                    const EpsP& p, int dtype, int precision, hipStream_t st, void* zsave) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
   BigP b;
   if (!fill_big(b, p, MODE_FWD)) return DCTN_ERR_UNSUPPORTED;
   const size_t lds = big_lds(b);
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
+  b.zsave = (float*)zsave;
   choose_row_groups(b, BC_NT_FWD, BC_MAX_RG, lds);
   const size_t need = b.rg_count > 1 ? (size_t)b.rg_count * p.Wn * p.O * sizeof(float) : 0;
   if (need > 0 && (!ws || ws_bytes < need)) {  // no scratch: keep every row tile in one workgroup
@@ -920,8 +1128,37 @@ int eps_fwd_bigcore(const void* x, const void* core, void* out, void* ws, size_t
                        b.rg_count);
     DCTN_CHECK_LAUNCH();
   }
-  dctn_set_last_kernel("eps_fwd_mfma_bigcore_f32");
+  dctn_set_last_kernel(zsave ? "eps_fwd_mfma_bigcore_f32_saving" : "eps_fwd_mfma_bigcore_f32");
   return DCTN_OK;
+}
+
+template <int OXT>
+static int launch_dp1_nd(const void* x, const void* Z, const void* dY, float* gxw, const Dp1P& d, size_t lds, hipStream_t st) {
+  const unsigned grid = (unsigned)((d.Wn + 63) / 64);
+#define DP1_GO(ND)                                                                                                 \
+  do {                                                                                                             \
+    (void)hipFuncSetAttribute((const void*)eps_bigcore_dp1_k<OXT, ND>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              (int)lds);                                                                           \
+    hipLaunchKernelGGL((eps_bigcore_dp1_k<OXT, ND>), dim3(grid), dim3(DP1_THREADS), lds, st, (const float*)x,      \
+                       (const float*)Z, (const float*)dY, gxw, d);                                                 \
+  } while (0)
+  if (d.n1 <= 2) DP1_GO(2);
+  else if (d.n1 <= 4) DP1_GO(4);
+  else DP1_GO(8);
+#undef DP1_GO
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+static int launch_dp1(const void* x, const void* Z, const void* dY, float* gxw, const Dp1P& d, size_t lds, hipStream_t st) {
+  switch (d.OX) {
+    case 2: return launch_dp1_nd<2>(x, Z, dY, gxw, d, lds, st);
+    case 4: return launch_dp1_nd<4>(x, Z, dY, gxw, d, lds, st);
+    case 6: return launch_dp1_nd<6>(x, Z, dY, gxw, d, lds, st);
+    case 8: return launch_dp1_nd<8>(x, Z, dY, gxw, d, lds, st);
+    case 16: return launch_dp1_nd<16>(x, Z, dY, gxw, d, lds, st);
+  }
+  return launch_dp1_nd<0>(x, Z, dY, gxw, d, lds, st);
 }
 
 // dX through the two transposed GEMMs G0, G1: per-window factor gradients into
@@ -942,16 +1179,49 @@ static bool dfactor_plan(const EpsP& p, BigP& b0, BigP& b1) {
   return b0.rg_count == b1.rg_count;
 }
 
+// G0 alone (half 1 comes from the saved Z): its own optimum split
+static bool g0_plan(const EpsP& p, BigP& b0) {
+  if (!fill_big(b0, p, MODE_G0) || big_lds(b0) > DCTN_LDS_BUDGET) return false;
+  choose_row_groups(b0, BC_NT_G, BC_MAX_RG, big_lds(b0));
+  return true;
+}
+
 size_t eps_bwd_dfactor_bigcore_workspace(const EpsP& p, int dtype, int precision) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return 0;
   BigP b0, b1;
   if (!dfactor_plan(p, b0, b1)) return 0;
-  return (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
+  int rg = b0.rg_count;
+  BigP g0;
+  if (g0_plan(p, g0) && g0.rg_count > rg) rg = g0.rg_count;
+  return (size_t)rg * p.N * p.Q * p.Wn * sizeof(float);
 }
 
 int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX, void* ws,
-                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st) {
+                       size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st,
+                       const void* zsaved, size_t zsaved_bytes) {
   if (dtype != DCTN_F32 || precision != DCTN_PREC_EXACT || !bigcore_wanted(p)) return DCTN_ERR_UNSUPPORTED;
+  const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
+  const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (zsaved) {
+    // the forward kept Z: half 0 by the GEMM G0, half 1 by one pass over Z
+    BigP bf, b0;
+    Dp1P d;
+    size_t lds1, zbytes;
+    if (fill_big(bf, p, MODE_FWD) && dp1_plan(p, bf, d, lds1, zbytes) && zsaved_bytes >= zbytes && g0_plan(p, b0)) {
+      const size_t need = (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
+      if (!ws || ws_bytes < need) return DCTN_ERR_WORKSPACE;
+      float* gxw = (float*)ws;
+      int rc = dctn_bc::launch_g(MODE_G0, x, core, dY, gxw, b0, big_lds(b0), st);
+      if (rc != DCTN_OK) return rc;
+      rc = launch_dp1(x, zsaved, dY, gxw, d, lds1, st);
+      if (rc != DCTN_OK) return rc;
+      hipLaunchKernelGGL(bigcore_gather_dx_k, dim3(g2), dim3(256), 0, st, (const float*)gxw, (float*)dX, p, b0.n0,
+                         b0.rg_count, 1);
+      DCTN_CHECK_LAUNCH();
+      dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32_savedz");
+      return DCTN_OK;
+    }
+  }
   BigP b0, b1;
   if (!dfactor_plan(p, b0, b1)) return DCTN_ERR_UNSUPPORTED;
   const size_t need = (size_t)b0.rg_count * p.N * p.Q * p.Wn * sizeof(float);
@@ -961,10 +1231,8 @@ int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX
   if (rc != DCTN_OK) return rc;
   rc = dctn_bc::launch_g(MODE_G1, x, core, dY, gxw, b1, big_lds(b1), st);
   if (rc != DCTN_OK) return rc;
-  const long long total = (long long)p.C * p.B * p.H * p.W * p.Q;
-  const unsigned g2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(bigcore_gather_dx_k, dim3(g2), dim3(256), 0, st, (const float*)gxw, (float*)dX, p,
-                     b0.rg_count);
+  hipLaunchKernelGGL(bigcore_gather_dx_k, dim3(g2), dim3(256), 0, st, (const float*)gxw, (float*)dX, p, b0.n0,
+                     b0.rg_count, b0.rg_count);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_bwd_mfma_bigcore_f32");
   return DCTN_OK;

@@ -337,6 +337,7 @@ template __global__ void convert_k<bf16_t, float>(const float*, bf16_t*, long lo
 // ================================================================================== host side
 int eps_fill_params(EpsP& p, const int64_t xs[5], int C, int B, int H, int W, int Q, int K, int O, int policy) {
   p.opts = policy & ~DCTN_PREC_MASK;
+  if ((p.opts & ~DCTN_OPT_ALL) || (policy & DCTN_PREC_MASK) > DCTN_PREC_BF16 || policy < 0) return DCTN_ERR_UNSUPPORTED;
   if (C < 1 || B < 1 || Q < 1 || K < 1 || O < 1 || H < K || W < K) return DCTN_ERR_BAD_SHAPE;
   p.C = C; p.B = B; p.H = H; p.W = W; p.Q = Q; p.K = K; p.O = O;
   p.N = K * K * C;

@@ -1259,8 +1259,14 @@ size_t eps_fwd_halves_workspace(const EpsP& p, int dtype) {
   return dtype == DCTN_F64 ? fwd_workspace_t<double>(p) : fwd_workspace_t<float>(p);
 }
 
+size_t eps_halves_saved_bytes(const EpsP& p, int dtype) {
+  (void)p; (void)dtype;
+  return 0;   // TODO(saved Z)
+}
+
 int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
-                   hipStream_t st) {
+                   hipStream_t st, void* saved) {
+  (void)saved;
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_fwd_halves_workspace(p, dtype)) return DCTN_ERR_WORKSPACE;
   if (dtype == DCTN_BF16) {
@@ -1281,7 +1287,8 @@ size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_
 }
 
 int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
-                   const EpsP& p, int dtype, hipStream_t st) {
+                   const EpsP& p, int dtype, hipStream_t st, const void* saved, size_t saved_bytes) {
+  (void)saved; (void)saved_bytes;
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_bwd_halves_workspace(p, dtype, dX != nullptr, dCore != nullptr)) return DCTN_ERR_WORKSPACE;
   if (dtype == DCTN_BF16) {

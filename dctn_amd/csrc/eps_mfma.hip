@@ -1379,7 +1379,7 @@ int bwd_launch_t(const void* x, const void* dY, void* dCore, void* ws, const Mfm
     DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, false, false, 0, 0>), g, b, DYN, st,
                        (const S*)x, (const S*)dY, (const S*)nullptr, (const S*)nullptr, (float*)ws, (float*)nullptr, m);
   DCTN_CHECK_LAUNCH();
-  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_OK;   // measurement option: partial sums only
+  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
   hipLaunchKernelGGL((eps_bwd_dcore_reduce_k<S>), dim3(BN * OP * AT), dim3(256), 0, st,
                      (const float*)ws, (S*)dCore, grid, A, BN, m.O, OP, AT * 32);
   DCTN_CHECK_LAUNCH();
@@ -1437,7 +1437,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   }
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
-  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_OK;   // measurement option: partial sums only
+  if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
   const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
   hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,

@@ -20,8 +20,12 @@ from . import _lib as L
 
 
 class _EpsFunction(torch.autograd.Function):
+    """``keep``: the training forward may leave its GEMM result for the backward (`dctn_eps_fwd_save`) - what torch's
+    autograd does on the reference's path (dctn/eps.py:25-30: the result of step (0,1) is saved and the backward runs
+    two GEMMs, not three).  Only the input gradient uses it, so it is kept when the input requires grad."""
+
     @staticmethod
-    def forward(ctx, core: Tensor, input: Tensor) -> Tensor:
+    def forward(ctx, core: Tensor, input: Tensor, keep: bool = True) -> Tensor:
         C, B, H, W, Q = input.shape
         K = math.isqrt((core.ndim - 1) // C)
         O = core.shape[-1]
@@ -32,13 +36,30 @@ class _EpsFunction(torch.autograd.Function):
         out = torch.empty((B, H - K + 1, W - K + 1, O), dtype=input.dtype, device=dev)
         prec = L.precision()
         code = L.dtype_code(input)
-        ws = L.workspace(L.lib().dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
-        L.check(
-            L.lib().dctn_eps_fwd(input.data_ptr(), L.strides5(input), core_c.data_ptr(), out.data_ptr(),
+        lib = L.lib()
+        ws = L.workspace(lib.dctn_eps_fwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec), dev)
+        saved = None
+        if keep and ctx.needs_input_grad[1]:
+            nsaved = lib.dctn_eps_saved_bytes(C, B, H, W, Q, K, O, code, prec)
+            if nsaved > 0:
+                saved = torch.empty(nsaved, dtype=torch.uint8, device=dev)
+        if saved is None:
+            L.check(
+                lib.dctn_eps_fwd(input.data_ptr(), L.strides5(input), core_c.data_ptr(), out.data_ptr(),
                                  ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
-            "eps forward",
-        )
+                "eps forward",
+            )
+        else:
+            rc = L.check(
+                lib.dctn_eps_fwd_save(input.data_ptr(), L.strides5(input), core_c.data_ptr(), out.data_ptr(),
+                                      saved.data_ptr(), saved.numel(), ws.data_ptr(), ws.numel(),
+                                      C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
+                "eps forward",
+            )
+            if rc != L.SAVED:   # the forward says whether it wrote the buffer; an untouched one never reaches the backward
+                saved = None
         ctx.save_for_backward(core_c, input)
+        ctx.saved_gemm = saved
         ctx.dims = (C, B, H, W, Q, K, O, prec)
         return out
 
@@ -46,7 +67,7 @@ class _EpsFunction(torch.autograd.Function):
     def backward(ctx, d_out: Tensor):
         core_c, input = ctx.saved_tensors
         C, B, H, W, Q, K, O, prec = ctx.dims
-        need_dcore, need_dx = ctx.needs_input_grad
+        need_dcore, need_dx = ctx.needs_input_grad[:2]
         dev = input.device
         g = d_out.contiguous()
         d_core = torch.empty_like(core_c) if need_dcore else None
@@ -54,14 +75,16 @@ class _EpsFunction(torch.autograd.Function):
         code = L.dtype_code(input)
         nbytes = L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, int(need_dx), int(need_dcore))
         ws = L.workspace(nbytes, dev)
-        L.check(
-            L.lib().dctn_eps_bwd(
-                input.data_ptr(), L.strides5(input), core_c.data_ptr(), g.data_ptr(),
-                None if d_x is None else d_x.data_ptr(), None if d_core is None else d_core.data_ptr(),
-                ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev)),
-            "eps backward",
-        )
-        return d_core, d_x
+        saved = ctx.saved_gemm
+        common = (None if d_x is None else d_x.data_ptr(), None if d_core is None else d_core.data_ptr(),
+                  ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev))
+        if saved is not None and need_dx:
+            rc = L.lib().dctn_eps_bwd_saved(input.data_ptr(), L.strides5(input), core_c.data_ptr(), g.data_ptr(),
+                                            saved.data_ptr(), saved.numel(), *common)
+        else:
+            rc = L.lib().dctn_eps_bwd(input.data_ptr(), L.strides5(input), core_c.data_ptr(), g.data_ptr(), *common)
+        L.check(rc, "eps backward")
+        return d_core, d_x, None
 
 
 def _check_core(core: Tensor, input: Tensor) -> None:
@@ -116,10 +139,14 @@ def _bf16_through_f32(core: Tensor, input: Tensor) -> bool:
 
 
 def eps_one_by_one(core: Tensor, input: Tensor) -> Tensor:
-    """Same contraction.  In the reference this is a second, factor-by-factor evaluation order
-    (dctn/eps.py:43-63) used by its tests; on the device both names run the same fused kernel."""
+    """Same contraction, evaluated another way.  In the reference this is a second, factor-by-factor evaluation order
+    (dctn/eps.py:43-63) that its tests hold against ``eps``; here it runs - forward and backward - on the generic
+    kernels (`DCTN_OPT_GENERIC_KERNELS`: one lane per window walks the core rows digit by digit, no matrix cores, no
+    Khatri-Rao halves, nothing shared with the MFMA families ``eps`` dispatches to), so the two names cross-check each
+    other on the device as they do in the reference.  Like there it is the slow one: tests only."""
     _check_core(core, input)
-    out = L.on_device(_EpsFunction.apply, core, input)
+    with L.options(L.OPT_GENERIC_KERNELS):
+        out = L.on_device(_EpsFunction.apply, core, input)
     num_channels, batch_size, height, width, _ = input.shape
     kernel_size = math.isqrt((core.ndim - 1) // num_channels)
     assert out.shape == (batch_size, height - kernel_size + 1, width - kernel_size + 1, core.shape[-1])

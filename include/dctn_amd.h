@@ -38,6 +38,13 @@ enum {
   DCTN_ERR_LAUNCH = -5,       /* HIP reported a launch error */
   DCTN_ERR_NULL = -6          /* required pointer is NULL */
 };
+/* positive success codes of the entry points that document them */
+enum {
+  DCTN_SAVED = 1,             /* dctn_eps_fwd_save / dctn_convsbs_fwd: the forward also WROTE the buffer a following
+                                 *_bwd_saved call reads; DCTN_OK (0) = forward done, buffer untouched */
+  DCTN_PARTIAL = 2            /* DCTN_OPT_MAIN_KERNEL_ONLY was honoured: only the dominant kernel ran, the
+                                 gradients are NOT complete */
+};
 
 /* `policy` argument of the EPS entry points: one DCTN_PREC_* value (precision policy for float32 tensors on the
  * MFMA paths), optionally OR-ed with DCTN_OPT_* flags.  A workspace query and the call it sizes take the same policy. */
@@ -55,8 +62,13 @@ enum {
   DCTN_OPT_SMALL_CHUNKS = 1 << 9,
   /* measurement only: dctn_eps_bwd / dctn_eps_head_bwd on the register-resident family launch their dominant
    * kernel (per-workgroup partial sums) and skip the small reduction kernel, so that the kernel can be timed
-   * alone; the gradients are NOT written */
-  DCTN_OPT_MAIN_KERNEL_ONLY = 1 << 10
+   * alone; the gradients are NOT written and the call returns DCTN_PARTIAL (2), not DCTN_OK */
+  DCTN_OPT_MAIN_KERNEL_ONLY = 1 << 10,
+  /* dctn_eps_fwd / dctn_eps_bwd on the generic kernels whatever the shape: one lane per window walks the core rows
+   * one factor digit after the other, no matrix cores, no Khatri-Rao halves - the independent evaluation order
+   * behind `eps_one_by_one` (dctn/eps.py:43-63), which the reference's tests use to cross-check `eps` */
+  DCTN_OPT_GENERIC_KERNELS = 1 << 11,
+  DCTN_OPT_ALL = (1 << 8) | (1 << 9) | (1 << 10) | (1 << 11)   /* any other bit above DCTN_PREC_MASK: DCTN_ERR_UNSUPPORTED */
 };
 
 int dctn_version(void);
@@ -116,6 +128,29 @@ int dctn_eps_bwd(const void* x, const int64_t x_strides[5], const void* core, co
                  void* dX, void* dCore, void* workspace, size_t workspace_bytes,
                  int C, int B, int H, int W, int Q, int K, int O,
                  int dtype, int policy, void* stream);
+
+/* Training forward / backward that keep the forward's GEMM result - what the reference's autograd does: torch saves
+ * the result G of path step (0,1) (dctn/eps.py:25-30, `core . K-R_0`) and its backward runs TWO GEMMs of that size
+ * (d core, d K-R_0) plus a product of G with dY; without the buffer dctn_eps_bwd has to run the forward GEMM a third
+ * time.  Only the input gradient needs it (dCore does not): pass it when dX will be asked for.
+ *   dctn_eps_saved_bytes : size of the buffer for this shape, 0 when the shape's kernel family keeps nothing
+ *                          (register-resident and generic families: nothing to save; also beyond 16 GiB)
+ *   dctn_eps_fwd_save    : dctn_eps_fwd + fills `saved`.  Returns DCTN_SAVED (1) when `saved` was written,
+ *                          DCTN_OK (0) when the forward ran but kept nothing (then call dctn_eps_bwd), < 0 on error
+ *   dctn_eps_bwd_saved   : dctn_eps_bwd reading `saved` as written by dctn_eps_fwd_save for the SAME x, core, shape,
+ *                          dtype and policy.  Same outputs as dctn_eps_bwd to rounding (the sums run in another order).
+ * large-core float32 family: Z[(b,o)][w] float32 in row-quad-major order, B*H'*W' * Q^n1 * O * 4 bytes (cfg3a layer 2:
+ * 416 MB); two-halves family: both Khatri-Rao halves and Z in the storage dtype. */
+size_t dctn_eps_saved_bytes(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy);
+int dctn_eps_fwd_save(const void* x, const int64_t x_strides[5], const void* core, void* out,
+                      void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                      int C, int B, int H, int W, int Q, int K, int O,
+                      int dtype, int policy, void* stream);
+int dctn_eps_bwd_saved(const void* x, const int64_t x_strides[5], const void* core, const void* dY,
+                       const void* saved, size_t saved_bytes,
+                       void* dX, void* dCore, void* workspace, size_t workspace_bytes,
+                       int C, int B, int H, int W, int Q, int K, int O,
+                       int dtype, int policy, void* stream);
 
 /* Forward of (EPS layer -> "b h w q -> b (h w q)" -> nn.Linear), the tail of EPSesPlusLinear.forward (reference:
  * dctn/eps_plus_linear.py:144-147), as ONE kernel: a workgroup holds all window positions of a few samples, so the
@@ -179,8 +214,9 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
 /* A training forward can leave its forward states for the backward instead of having the backward recompute them
  * (the backward's own forward sweep is a quarter of its time): pass dctn_convsbs_fwd a workspace of at least
  * dctn_convsbs_saved_states_bytes(...) bytes (0: this string always recomputes - rings, many-valued cores, bonds above
- * 16, float64 / bf16) and hand the same buffer, untouched, to dctn_convsbs_bwd_saved.  NULL / too small: exactly
- * dctn_convsbs_bwd.  Replaces nothing in the reference (autograd keeps every intermediate there, dctn/conv_sbs.py:268-303). */
+ * 16, float64 / bf16).  dctn_convsbs_fwd then returns DCTN_SAVED (1) when it WROTE the states - hand that buffer,
+ * untouched, to dctn_convsbs_bwd_saved - and DCTN_OK (0) when the forward ran on a kernel that keeps nothing (the
+ * buffer is then uninitialised: call dctn_convsbs_bwd).  NULL / too small saved_states: exactly dctn_convsbs_bwd.  Replaces nothing in the reference (autograd keeps every intermediate there, dctn/conv_sbs.py:268-303). */
 size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B, int H,
                                        int W, int q, const int* pos_h, const int* pos_w, int dtype);
 int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void* const* cores,

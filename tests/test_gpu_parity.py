@@ -274,6 +274,49 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
         assert close(c.grad, gc, torch.float32)
 
 
+def test_convsbs_forward_reports_whether_it_wrote_the_saved_states():
+    """`dctn_convsbs_fwd` returns DCTN_SAVED only when the matrix-core sweep wrote the forward states; a string the size
+    query accepts but the sweep's LDS plan declines (bond 16, 25 cores) runs the generic forward, the buffer stays
+    uninitialised and must never reach `dctn_convsbs_bwd_saved` - checked with a poisoned allocator and the oracle."""
+    lib = _lib.lib()
+    for side, r, expect in ((3, 8, _lib.SAVED), (5, 16, 0)):
+        pos = [(h, w if h % 2 == 0 else side - 1 - w) for h in range(side) for w in range(side)]   # boustrophedon snake
+        n = len(pos)
+        torch.manual_seed(n)
+        outs = tuple(2 if i == n // 2 else 1 for i in range(n))
+        spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), (1,) + (r,) * (n - 1), 1, 2)
+        m = ConvSBS(spec, DumbNormalInitialization((2 * r) ** -0.5 * 1.3)).to(DEV)
+        B, HW = 2, side + 3
+        x = torch.randn(1, B, HW, HW, 2, device=DEV, requires_grad=True)
+        plan_args = (n, _lib.int_array(outs), _lib.int_array(spec.bond_sizes), 1, B, HW, HW, 2,
+                     _lib.int_array([p[0] for p in pos]), _lib.int_array([p[1] for p in pos]), _lib.F32)
+        nstates = lib.dctn_convsbs_saved_states_bytes(*plan_args)
+        assert nstates > 0
+        # raw call: the return code says whether the buffer was written
+        cores_c = [c.detach().contiguous() for c in m.cores]
+        states = torch.full((nstates,), 0xFF, dtype=torch.uint8, device=DEV)
+        out = torch.empty(B, HW - side + 1, HW - side + 1, 2, device=DEV)
+        rc = lib.dctn_convsbs_fwd(x.data_ptr(), _lib.strides5(x), _lib.ptr_array(cores_c), out.data_ptr(), n, plan_args[1],
+                                  plan_args[2], plan_args[8], plan_args[9], 1, B, HW, HW, 2, states.data_ptr(), states.numel(),
+                                  _lib.F32, _lib.stream_ptr(DEV))
+        torch.cuda.synchronize()
+        assert rc == expect, (side, r, rc)
+        if rc != _lib.SAVED:
+            assert bool((states == 0xFF).all())   # untouched
+        del states
+        torch.empty(nstates + (1 << 20), dtype=torch.uint8, device=DEV).fill_(0xFF)   # poison what the module allocates next
+        y = m(x)
+        cores64 = [c.detach().cpu().double() for c in m.cores]
+        want = R.convsbs_forward(cores64, pos, x.detach().cpu().double())
+        assert close(y, want, torch.float32)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, pos, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
+        assert close(x.grad, gr[0], torch.float32)
+        for c, gc in zip(m.cores, gr[1:]):
+            assert close(c.grad, gc, torch.float32)
+
+
 # ------------------------------------------------------------------ logmatmulexp
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_logmatmulexp_golden(dtype):
@@ -427,13 +470,13 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
     xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
     y = eps(cd, xd)
     if Q < 16:  # Q = 16 exceeds the family's LDS budget and falls back to the generic kernels
-        assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+        assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32_saving"   # x needs a gradient: the GEMM result is kept
     want = R.eps_4step(core.double(), x.double())
     assert close(y, want, torch.float32)
     dy = torch.randn(*want.shape)
     y.backward(dy.to(DEV))
     if Q < 16:
-        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bigcore_f32"
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bigcore_f32_savedz"
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
     assert close(xd.grad, dx, torch.float32)
     assert close(cd.grad, dcore, torch.float32)
@@ -444,6 +487,69 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
         xd.grad = cd.grad = None
         eps(cd, xd).backward(dy.to(DEV))
         assert torch.equal(cd.grad, first[1]) and torch.equal(xd.grad, first[0])
+
+
+@pytest.mark.parametrize(
+    "C,B,H,W,Q,K,O",
+    [
+        (1, 3, 10, 10, 2, 4, 4),    # cfg3a layer 1 shape: n1 = 8, four Z rows per b
+        (1, 3, 7, 7, 4, 3, 6),      # cfg3a layer 2 shape: exact O = 6 (rows (b, o) in memory order, 3 quads = 2 b)
+        (1, 4, 6, 7, 8, 2, 8),      # cfg3b layer 2: n1 = 2
+        (2, 3, 6, 6, 2, 2, 16),     # two channels, sixteen Z rows per b
+        (1, 3, 9, 9, 2, 3, 5),      # odd O: run-time row -> (b, o) walk
+        (1, 70, 6, 6, 4, 2, 2),     # two b per row quad, more windows than one workgroup's 64
+    ],
+)
+def test_eps_f32_bigcore_saved_gemm_result(C, B, H, W, Q, K, O):
+    """Training forward that keeps the GEMM result Z for the backward (`dctn_eps_fwd_save` / `dctn_eps_bwd_saved`, the
+    reference's autograd saves it too: dctn/eps.py:25-30): same output bit for bit, input gradient against the oracle
+    and against the recomputing backward, buffer poisoned beforehand, HIP-graph replay."""
+    from dctn_amd.eps import _EpsFunction
+
+    torch.manual_seed(7)
+    N = K * K * C
+    x0 = torch.rand(C, B, H, W, Q, dtype=torch.float64) + 0.25
+    c0 = torch.randn(*([Q] * N), O, dtype=torch.float64) * (Q ** N) ** -0.5
+    dy0 = torch.randn(B, H - K + 1, W - K + 1, O, dtype=torch.float64)
+    x64, c64 = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    R.eps_4step(c64, x64).backward(dy0)
+    lib = _lib.lib()
+    nsaved = lib.dctn_eps_saved_bytes(C, B, H, W, Q, K, O, _lib.F32, 0)
+    assert nsaved >= B * (H - K + 1) * (W - K + 1) * Q ** (N // 2) * O * 4
+
+    def run(keep):
+        x, core = dev(x0, torch.float32, True), dev(c0, torch.float32, True)
+        y = _EpsFunction.apply(core, x, keep)
+        fwd = dctn_amd.last_kernel()
+        y.backward(dev(dy0, torch.float32))
+        return y.detach(), x.grad, core.grad, fwd, dctn_amd.last_kernel()
+
+    torch.empty(nsaved + (1 << 20), dtype=torch.uint8, device=DEV).fill_(0xFF)   # poison what the allocator hands out next
+    y1, dx1, dc1, f1, b1 = run(True)
+    y0, dx0, dc0, f0, b0 = run(False)
+    assert f1 == "eps_fwd_mfma_bigcore_f32_saving" and b1 == "eps_bwd_mfma_bigcore_f32_savedz", (f1, b1)
+    assert f0 == "eps_fwd_mfma_bigcore_f32" and b0 == "eps_bwd_mfma_bigcore_f32", (f0, b0)
+    assert torch.equal(y1, y0) and torch.equal(dc1, dc0)
+    f32 = torch.float32
+    assert close(dx1, x64.grad, f32) and close(dx0, x64.grad, f32)
+    assert close(dc1, c64.grad, f32)
+    # replayed from a HIP graph (the saved buffer comes from the graph's pool), with dirtied outputs in between
+    xs, cs = dev(x0, f32, True), dev(c0, f32, True)
+    dys = dev(dy0, f32)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            gx, gc = torch.autograd.grad(_EpsFunction.apply(cs, xs, True), (xs, cs), dys)
+    torch.cuda.current_stream().wait_stream(stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gx, gc = torch.autograd.grad(_EpsFunction.apply(cs, xs, True), (xs, cs), dys)
+    for _ in range(3):
+        gx.fill_(float("nan")); gc.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gx, dx1) and torch.equal(gc, dc1)
 
 
 @pytest.mark.parametrize("which", ["eps_bigcore_f32", "eps_generic_q3", "convsbs_generic_bond3", "convsbs_ring_many_bond4",
@@ -519,7 +625,7 @@ def test_eps_f32_large_core_under_the_bf16_policy():
     want = R.eps_4step(core.double(), x.double())
     xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
     y = eps(cd, xd)
-    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32"
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32_saving"   # x needs a gradient: the GEMM result is kept
     dctn_amd.set_float32_matmul_precision("bf16")
     try:
         y2 = eps(cd, xd)
