@@ -50,6 +50,10 @@ WORKLOADS = {
     "cfg3b_bf16": (((4, 8), (2, 8)), 28, 2, torch.bfloat16),
 }
 EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+# --workload also takes the two BASELINE configs that are not EPS models (configs[3] "ConvSBS ... DDP over 8xMI355X",
+# configs[4] "logmatmulexp ... 8xMI355X"): the same sharding, timing protocol and JSON line as the EPS workloads
+SIDE_WORKLOADS = ("cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg5")
+CFG5_SITES = 26 * 26   # windows per sample of cfg5: MNIST-sized window counts, 9 matrices of 16 x 16 per window
 SNAKE = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]   # mnist.py:190-199
 
 
@@ -214,7 +218,7 @@ def pmc_traffic(key):
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r02_pmc_traffic.json", "r03_pmc_traffic.json"):   # later rounds override earlier entries
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 try:
@@ -553,7 +557,8 @@ def extra_cfg4(r, dev, iters):
     torch.manual_seed(r)
     many = ManyConvSBS(C, q, r, False, spec, (DumbNormalInitialization((q ** C * r) ** -0.5),)).to(dev)
     x = torch.randn(C, B, HW, HW, q, device=dev, requires_grad=True)
-    (y,) = many(x)
+    with torch.no_grad():   # (no autograd graph may outlive this line: its AccumulateGrad nodes would tie the later
+        (y,) = many(x)      # HIP-graph capture of the step to the stream of this eager call)
     dy = torch.randn_like(y)
     windows = y.shape[0] * y.shape[1] * y.shape[2]
 
@@ -567,14 +572,21 @@ def extra_cfg4(r, dev, iters):
             prm.grad = None
         many(x)[0].backward(dy)
 
-    # whole step through the module (autograd bookkeeping included), and the two C-ABI calls on their own
-    t_f_mod, t_fb = device_time(fwd, dev, iters, graph=False), device_time(fwd_bwd, dev, iters, graph=False)
+    # The step is the nn.Module's forward + backward (the drop-in surface), replayed from a HIP graph like the headline
+    # (4 steps per launch; eagerly the r = 4 step is bound by the host's autograd bookkeeping: `module_eager_ms`);
+    # the two C-ABI calls on their own give the per-call durations the roofline prices
+    t_f_mod, t_fb_eager = device_time(fwd, dev, iters, graph=False), device_time(fwd_bwd, dev, iters, graph=False)
+
+    def four_steps():
+        for _ in range(4):
+            fwd_bwd()
+
+    t_fb = device_time(four_steps, dev, max(4, iters // 2), graph=True) / 4
     fwd_bwd()
     fam = dctn_amd.last_kernel()
     c_fwd, c_bwd, _keep = convsbs_call_timers(many.strings[0], x.detach(), dy, dev)
     t_f = device_time(c_fwd, dev, 5 * iters, graph=False)
     t_b = device_time(c_bwd, dev, 2 * iters, graph=False)
-    t_fb = min(t_fb, t_f + t_b)   # the module's step is host-bound at r = 4: the two calls back to back are the device time
     # algorithmic work per window in the reference's order: step A 2*q^C*sum(o*l*r), then the chain
     shapes = many.strings[0].spec.shapes
     step_a = 2 * q ** C * sum(s.out_quantum_dim_size * s.bond_left_size * s.bond_right_size for s in shapes)
@@ -606,7 +618,9 @@ def extra_cfg4(r, dev, iters):
     return {"workload": f"cfg4_r{r}: ConvSBS 9-core snake (mnist.py:190-199), open chain bond {r}, x (1,{B},32,32,3) CIFAR colour "
                         "layout, float32, fwd + bwd(dX, dCores)",
             "dtype": "f32", "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
-            "module_fwd_ms": t_f_mod * 1e3, "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
+            "module_fwd_ms": t_f_mod * 1e3, "module_eager_ms": t_fb_eager * 1e3, "calls_ms": (t_f + t_b) * 1e3,
+            "timing": "nn.Module forward + backward replayed from a HIP graph (4 steps per launch), HIP events",
+            "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
             "cpu_baseline": {"value": windows * Bc / B / dtc, "unit": "windows/s", "cores": cores_n, "kind": "port",
                              "sample": f"oracle step A + chain (torch CPU f32, {cores_n} threads, {cpu_model_name()}), batch {Bc} of {B}, "
                                        f"{it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
@@ -676,14 +690,15 @@ def run_extra(name, dev):
     raise SystemExit(f"unknown config {name}")
 
 
-def run_extra_in_child(name, no_cpu_baseline, timeout=420.0):
+def run_extra_in_child(name, no_cpu_baseline, timeout=420.0, device_index=0):
     import subprocess
 
-    cmd = [sys.executable, os.path.abspath(__file__), "--skip-headline", "--configs", name]
+    cmd = [sys.executable, os.path.abspath(__file__), "--skip-headline", "--configs", name, "--device", str(int(device_index or 0))]
     if no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     try:
-        res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=sys.stderr, timeout=timeout, text=True)
+        res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, timeout=timeout, text=True)
     except subprocess.TimeoutExpired:
         return {"workload": name, "error": f"timed out after {timeout:.0f} s"}
     if res.returncode != 0:
@@ -700,8 +715,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default 1024 for cfg2, 128 for cfg3)")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + list(SIDE_WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None,
+                    help="samples per GPU (default 1024 for cfg2 and cfg5, 128 for cfg3 and cfg4)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch samples per GPU whatever N; strong: --batch is the GLOBAL batch, split over the N GPUs")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured HIP graph")
@@ -718,6 +734,7 @@ def main():
                     help="the other BASELINE configs measured into `configs` at N = 1: all (default), none, or a comma list of "
                          + ", ".join(EXTRA_CONFIGS))
     ap.add_argument("--skip-headline", action="store_true", help="profiling aid: run only --configs and print their entries")
+    ap.add_argument("--device", type=int, default=0, help="GPU index of a --skip-headline run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rccl-proto", default=None, help="sets NCCL_PROTO (LL / LL128 / Simple) before the communicator comes up")
     ap.add_argument("--rccl-algo", default=None, help="sets NCCL_ALGO (Ring / Tree)")
@@ -736,7 +753,7 @@ def main():
     rccl_env = {k: os.environ.get(k) for k in ("NCCL_PROTO", "NCCL_ALGO", "NCCL_MIN_NCHANNELS")}
 
     if args.skip_headline:
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", args.device)
         torch.cuda.set_device(dev)
         names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
         out = []
@@ -784,23 +801,72 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
-    specs, image_size, q0, dtype = WORKLOADS[args.workload]
-    batch = args.batch or (1024 if args.workload.startswith("cfg2") else 128)
+    eps_model = args.workload in WORKLOADS
+    batch = args.batch or (1024 if args.workload.startswith("cfg2") or args.workload == "cfg5" else 128)
     if args.scaling == "strong":
         batch = max(1, batch // world)
 
     torch.manual_seed(0)
-    model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
-    ddp.broadcast_parameters(model.parameters())
-    x = synthetic_input(batch, image_size, q0, dtype, dev, seed=1 + rank)  # resident in HBM before timing
-    out_grad = torch.randn(batch, 10, device=dev).to(dtype)
-    reducer = (ddp.FlatGradAllReducer(model.parameters(), skip_single_rank=not force_reduce)
-               if (world > 1 or force_reduce) else None)
+    specs = image_size = q0 = model = None
+    if eps_model:
+        specs, image_size, q0, dtype = WORKLOADS[args.workload]
+        model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
+        params = list(model.parameters())
+        ddp.broadcast_parameters(params)
+        x = synthetic_input(batch, image_size, q0, dtype, dev, seed=1 + rank)  # resident in HBM before timing
+        out_grad = torch.randn(batch, 10, device=dev).to(dtype)
+        windows_rank = windows_per_sample(specs, image_size) * batch
+        what = (f"{args.workload}: EPSesPlusLinear({specs}) on MNIST-shaped {image_size}x{image_size} Q0={q0}, "
+                f"fwd + bwd(out_grad), batch {batch}/GPU")
 
-    def fwd_bwd():
-        for p in model.parameters():
-            p.grad = None
-        model(x).backward(out_grad)
+        def fwd_bwd():
+            for p in params:
+                p.grad = None
+            model(x).backward(out_grad)
+    elif args.workload.startswith("cfg4_r"):
+        # BASELINE configs[3]: the ConvSBS 9-core snake (mnist.py:190-199) on the CIFAR colour layout, batch sharded,
+        # the string's flat core-gradient buffer all-reduced in place (one RCCL launch per step)
+        from dctn_amd.conv_sbs import DumbNormalInitialization, ManyConvSBS
+        from dctn_amd.conv_sbs_spec import SBSSpecCore
+        from dctn_amd.pos2d import Pos2D
+
+        r, dtype = int(args.workload[6:]), torch.float32
+        spec = (tuple(SBSSpecCore(Pos2D(*p), 2 if i == 4 else 1) for i, p in enumerate(SNAKE)),)
+        torch.manual_seed(r)
+        many = ManyConvSBS(1, 3, r, False, spec, (DumbNormalInitialization((3 * r) ** -0.5),)).to(dev)
+        params = list(many.parameters())
+        ddp.broadcast_parameters(params)
+        x = torch.randn(1, batch, 32, 32, 3, device=dev, generator=torch.Generator(dev).manual_seed(1 + rank)).requires_grad_(True)
+        out_grad = torch.randn(batch, 30, 30, 2, device=dev)
+        windows_rank = batch * 30 * 30
+        what = (f"{args.workload}: ConvSBS 9-core snake (mnist.py:190-199), open chain bond {r}, x (1,{batch},32,32,3) CIFAR colour "
+                f"layout, float32, fwd + bwd(dX, dCores) through the nn.Module, batch {batch}/GPU")
+
+        def fwd_bwd():
+            x.grad = None
+            for p in params:
+                p.grad = None
+            many(x)[0].backward(out_grad)
+    else:
+        # BASELINE configs[4]: per window the left fold of 9 log-matrices (16 x 16); windows sharded over the ranks.  The
+        # fold has no parameters (the reference's logmatmulexp is wired into no model: SURVEY section 0), so there is no
+        # gradient to exchange: no data-path collective, N independent shards
+        from dctn_amd.logmatmulexp import logmatmulexp_fold
+
+        dtype = torch.float32
+        windows_rank = batch * CFG5_SITES
+        x = torch.randn(windows_rank, 9, 16, 16, device=dev, generator=torch.Generator(dev).manual_seed(1 + rank)).requires_grad_(True)
+        out_grad = torch.randn(windows_rank, 16, 16, device=dev)
+        params = []
+        what = (f"cfg5: per-window left fold of 9 log-matrices (16x16) (logmatmulexp), float32, fwd + bwd, "
+                f"{batch} samples x {CFG5_SITES} windows per GPU")
+
+        def fwd_bwd():
+            x.grad = None
+            logmatmulexp_fold(x).backward(out_grad)
+
+    reducer = (ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce)
+               if (params and (world > 1 or force_reduce)) else None)
 
     def fwd_bwd_reduce():
         fwd_bwd()
@@ -828,7 +894,7 @@ def main():
         if want_reduce:
             fwd_bwd_reduce()
             torch.cuda.synchronize(dev)
-            want = [p.grad.detach().float().clone() for p in model.parameters()]
+            want = [p.grad.detach().float().clone() for p in params]
             graph = safe_capture(several(fwd_bwd_reduce), dev, warm=3)
             if not ddp.all_ranks_agree(graph is not None, dev):
                 log("capturing the step with the all-reduce inside failed although the probe passed; no safe fallback "
@@ -839,7 +905,7 @@ def main():
             graph.replay()
             torch.cuda.synchronize(dev)
             same = all(torch.allclose(p.grad.float(), w, rtol=2e-2, atol=1e-6 + 2e-2 * float(w.abs().max()))
-                       for p, w in zip(model.parameters(), want))
+                       for p, w in zip(params, want))
             if not ddp.all_ranks_agree(same, dev):
                 log("the captured step with the all-reduce inside disagrees with the eager step")
                 sys.stdout.flush()
@@ -915,7 +981,25 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             allreduce_us, step_without_allreduce_us = float(t[0]), float(t[1])
 
-    windows_step = windows_per_sample(specs, image_size) * batch * world
+    # one step per graph launch beside the default several: what a training loop that feeds fresh data every step gets
+    # (GraphedTrainStep replays one iteration per launch); the difference is the command processor's per-launch work
+    one_step_us = None
+    if graph is not None and gsteps > 1 and (reducer is None or reduce_in_graph):
+        g1 = safe_capture(fwd_bwd_reduce if reduce_in_graph else fwd_bwd, dev, warm=1)
+        if g1 is not None:
+            n1 = max(20, args.steps)
+            for _ in range(5):
+                g1.replay()
+            barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n1):
+                g1.replay()
+            torch.cuda.synchronize(dev)
+            one_step_us = (time.perf_counter() - t0) / n1 * 1e6
+            del g1
+
+    windows_step = windows_rank * world
     line = {
         "metric": "EPS-contraction windows/sec (fwd+bwd)",
         "value": windows_step * args.steps / elapsed,
@@ -930,13 +1014,13 @@ def main():
         "dtype": DTYPE_NAME[dtype],
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: EPSesPlusLinear({specs}) on MNIST-shaped {image_size}x{image_size} Q0={q0}, "
-                        f"fwd + bwd(out_grad), batch {batch}/GPU",
+            "workload": what,
             "windows_per_step": windows_step,
             "per_gpu_batch": batch,
             "parallelism": f"dp{world}",
             "hip_graph": graph is not None,
             "steps_per_graph_launch": gsteps,
+            "us_per_step_at_one_step_per_graph_launch": one_step_us,
             "timing": f"median of {BLOCKS} blocks of {args.steps} steps (each block: barrier + synchronize on both sides, max over ranks)",
             "blocks_ms": [b * 1e3 for b in block_s],
             "allreduce_in_graph": reduce_in_graph,
@@ -946,20 +1030,33 @@ def main():
             "step_without_allreduce_us": step_without_allreduce_us,
             "rccl_env": rccl_env,
             "last_kernel": kernel_used,
-            "grad_allreduce": None if reducer is None else (
+            "grad_allreduce": ("none: the workload has no parameters (windows sharded, no data-path collective)" if not params else None) if reducer is None else (
                 "in place on the backward's flat gradient buffer (1 launch)" if getattr(reducer, "_flat_key", None)
                 else "gather -> all_reduce -> scatter (3 launches)"),
         },
     }
     if rank == 0:
-        log(f"headline: {line['ms_per_step']*1e3:.1f} us/step; timing its kernels")
-        line["roofline"] = headline_roofline(model, x, specs, args.steps)
-        if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline of the headline workload")
-            line["cpu_baseline"] = cpu_baseline_eps_model(specs, image_size, q0)
-            line["config"]["cpu_baseline_note"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
-                                                   f"{DTYPE_NAME[dtype]} at batch {batch}")
-        if world == 1 and args.configs != "none":
+        if eps_model:
+            log(f"headline: {line['ms_per_step']*1e3:.1f} us/step; timing its kernels")
+            line["roofline"] = headline_roofline(model, x, specs, args.steps)
+            if world == 1 and not args.no_cpu_baseline:
+                log("cpu baseline of the headline workload")
+                line["cpu_baseline"] = cpu_baseline_eps_model(specs, image_size, q0)
+                line["config"]["cpu_baseline_note"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
+                                                       f"{DTYPE_NAME[dtype]} at batch {batch}")
+        else:
+            # ConvSBS / logmatmulexp as the timed workload: roofline and CPU baseline of the same configuration, measured
+            # at its BASELINE size in a child process on this rank's GPU (the timed region is over)
+            del x, out_grad
+            torch.cuda.empty_cache()
+            log(f"{args.workload}: {line['ms_per_step']*1e3:.1f} us/step; roofline / cpu baseline of the configuration")
+            entry = run_extra_in_child(args.workload, args.no_cpu_baseline or world > 1, device_index=dev.index)
+            if "roofline" in entry:
+                line["roofline"] = entry["roofline"]
+            if "cpu_baseline" in entry:
+                line["cpu_baseline"] = entry["cpu_baseline"]
+            line["config"]["single_gpu_entry"] = {k: entry.get(k) for k in ("ms_per_step", "value", "windows_per_step", "error") if k in entry}
+        if world == 1 and args.configs != "none" and eps_model:
             names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
             entries = []
             for name in names:
@@ -970,6 +1067,14 @@ def main():
                 entries.append(run_extra_in_child(name, args.no_cpu_baseline))
                 entries[-1]["bench_seconds"] = round(time.perf_counter() - t0, 1)
             line["configs"] = entries
+            # the same numbers in compact form INSIDE `config` (a driver that keeps the contract's keys only keeps these):
+            # cfg -> [ms_per_step, windows_per_s, fraction of its roofline (dominant call), cpu oracle windows_per_s]
+            line["config"]["side"] = {
+                name: ([round(e["ms_per_step"], 5), round(e["value"]), round(e["roofline"]["frac"], 4),
+                        round(e["cpu_baseline"]["value"]) if "cpu_baseline" in e else None] if "value" in e
+                       else [None, None, None, e.get("error", "failed")])
+                for name, e in zip(names, entries)}
+            line["config"]["side_legend"] = "cfg: [ms_per_step, windows_per_s, roofline.frac of the dominant call, cpu_baseline windows_per_s]"
         print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():

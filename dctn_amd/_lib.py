@@ -21,6 +21,7 @@ PREC_EXACT, PREC_BF16, PREC_MASK = 0, 1, 0xFF
 OPT_F32_PREFER_HALVES, OPT_SMALL_CHUNKS, OPT_MAIN_KERNEL_ONLY, OPT_GENERIC_KERNELS = 1 << 8, 1 << 9, 1 << 10, 1 << 11
 ERR_BAD_SHAPE, ERR_BAD_DTYPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH, ERR_NULL = -1, -2, -3, -4, -5, -6
 SAVED, PARTIAL = 1, 2   # positive success codes (include/dctn_amd.h)
+SBS_MATRIX_CORE_SWEEP = 1 << 8   # OR-ed into the dtype argument of the dctn_convsbs_* calls
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16}
 

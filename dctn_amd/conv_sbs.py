@@ -98,6 +98,26 @@ def _workspace_bytes(plan: _StringPlan, B: int, H: int, W: int, code: int, backw
     return nbytes
 
 
+_sbs_flags = 0
+
+
+class matrix_core_sweep:
+    """``with matrix_core_sweep(): ...`` - strings whose bonds are all <= 4 run on the matrix-core sweep
+    (convsbs_mfma.hip) instead of the register-resident sweep (convsbs_reg.hip) that is their default: the tests use it
+    to hold both kernel families against the same expected values on the same strings (`DCTN_SBS_MATRIX_CORE_SWEEP`)."""
+
+    def __enter__(self):
+        global _sbs_flags
+        self._saved = _sbs_flags
+        _sbs_flags |= L.SBS_MATRIX_CORE_SWEEP
+        return self
+
+    def __exit__(self, *exc):
+        global _sbs_flags
+        _sbs_flags = self._saved
+        return False
+
+
 class _ConvSBSFunction(torch.autograd.Function):
     """x: (C, B, H, W, q) any strides; cores in string order."""
 
@@ -115,7 +135,7 @@ class _ConvSBSFunction(torch.autograd.Function):
         cores_c = [c.contiguous() for c in cores]
         Ho, Wo = H - plan.max_h, W - plan.max_w
         out = torch.empty((B, Ho, Wo, plan.out_total), dtype=x.dtype, device=dev)
-        code = L.dtype_code(x)
+        code = L.dtype_code(x) | _sbs_flags
         # a forward that will be differentiated leaves its forward states (a buffer of its own, alive until the backward)
         # instead of having the backward's first quarter recompute them
         saved_bytes = _workspace_bytes(plan, B, H, W, code, 2) if any(ctx.needs_input_grad) else 0

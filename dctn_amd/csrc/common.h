@@ -130,3 +130,15 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      const float* saved_states = nullptr);
 // room for the per-workgroup partial-gradient records of the MFMA backward (deterministic dCore)
 constexpr int SBS_MAX_PARTIAL_RECORDS = 2048;
+
+// Register-resident sweep for small bonds (every bond <= 4, float32 open chains, at most one two-valued core,
+// q^C <= 4) - convsbs_reg.hip.  The backward writes dX itself (no per-window gradients, no gather launch) and needs
+// `ws` only for its per-workgroup dCore records (convsbs_reg_bwd_workspace; 0 = the string is outside the family).
+size_t convsbs_reg_bwd_workspace(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                 int C, int B, int H, int W, int q, int dtype);
+int convsbs_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n, const int* out_sizes,
+                    const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype,
+                    hipStream_t st);
+int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
+                    float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                    const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);

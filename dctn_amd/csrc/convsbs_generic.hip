@@ -505,16 +505,20 @@ extern "C" {
 
 size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int* bond_sizes,
                                     int C, int B, int H, int W, int q, const int* pos_h,
-                                    const int* pos_w, int dtype, int backward) {
+                                    const int* pos_w, int dtype_flags, int backward) {
+  const int dtype = dtype_flags & DCTN_DTYPE_MASK;   // (the query covers every family: flags only select among them)
   SbsP p;
   if (!out_sizes || !bond_sizes || !pos_h || !pos_w) return 0;
   if (fill(p, nullptr, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q) != DCTN_OK)
     return 0;
-  return backward ? bwd_ws(p, dtype) + 256 : 256;
+  if (!backward) return 256;
+  const size_t a = bwd_ws(p, dtype), b = convsbs_reg_bwd_workspace(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  return (a > b ? a : b) + 256;
 }
 
 size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B, int H,
-                                       int W, int q, const int* pos_h, const int* pos_w, int dtype) {
+                                       int W, int q, const int* pos_h, const int* pos_w, int dtype_flags) {
+  const int dtype = dtype_flags & DCTN_DTYPE_MASK;
   if (!out_sizes || !bond_sizes || !pos_h || !pos_w) return 0;
   return convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
 }
@@ -522,9 +526,11 @@ size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const 
 int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* const* cores,
                      void* out, int n_cores, const int* out_sizes, const int* bond_sizes,
                      const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q,
-                     void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+                     void* workspace, size_t workspace_bytes, int dtype_flags, void* stream) {
   if (!x || !x_strides || !cores || !out || !out_sizes || !bond_sizes || !pos_h || !pos_w)
     return DCTN_ERR_NULL;
+  const int dtype = dtype_flags & DCTN_DTYPE_MASK;
+  if (dtype_flags & ~(DCTN_DTYPE_MASK | DCTN_SBS_MATRIX_CORE_SWEEP)) return DCTN_ERR_UNSUPPORTED;
   SbsP p;
   int rc = fill(p, x_strides, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q);
   if (rc != DCTN_OK) return rc;
@@ -536,6 +542,11 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
   hipStream_t st = (hipStream_t)stream;
   // a workspace of dctn_convsbs_saved_states_bytes(...) bytes: the forward leaves its states there for
   // dctn_convsbs_bwd_saved (a training forward); anything smaller: plain forward
+  // small bonds: the register-resident sweep (keeps nothing: its backward recomputes the chain in registers)
+  if (!(dtype_flags & DCTN_SBS_MATRIX_CORE_SWEEP)) {
+    rc = convsbs_fwd_reg(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
   const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   float* save = (sb > 0 && workspace && workspace_bytes >= sb) ? (float*)workspace : nullptr;
   rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
@@ -556,7 +567,8 @@ int dctn_convsbs_bwd(const void* x, const int64_t x_strides[5], const void* cons
                      const void* dY, void* dX, void* const* dCores, int n_cores,
                      const int* out_sizes, const int* bond_sizes, const int* pos_h,
                      const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
-                     size_t workspace_bytes, int dtype, void* stream) {
+                     size_t workspace_bytes, int dtype_flags, void* stream) {
+  const int dtype = dtype_flags;   // (decoded by dctn_convsbs_bwd_saved)
   return dctn_convsbs_bwd_saved(x, x_strides, cores, dY, dX, dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
                                 W, q, workspace, workspace_bytes, nullptr, 0, dtype, stream);
 }
@@ -565,10 +577,12 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
                            const void* dY, void* dX, void* const* dCores, int n_cores,
                            const int* out_sizes, const int* bond_sizes, const int* pos_h,
                            const int* pos_w, int C, int B, int H, int W, int q, void* workspace,
-                           size_t workspace_bytes, const void* saved_states, size_t saved_states_bytes, int dtype,
+                           size_t workspace_bytes, const void* saved_states, size_t saved_states_bytes, int dtype_flags,
                            void* stream) {
   if (!x || !x_strides || !cores || !dY || !out_sizes || !bond_sizes || !pos_h || !pos_w)
     return DCTN_ERR_NULL;
+  const int dtype = dtype_flags & DCTN_DTYPE_MASK;
+  if (dtype_flags & ~(DCTN_DTYPE_MASK | DCTN_SBS_MATRIX_CORE_SWEEP)) return DCTN_ERR_UNSUPPORTED;
   if (saved_states) {   // only what the forward of this very shape can have written
     const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
     if (sb == 0 || saved_states_bytes < sb) saved_states = nullptr;
@@ -583,6 +597,13 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
     p.dcore[c] = nullptr;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DCTN_F32 && !(dtype_flags & DCTN_SBS_MATRIX_CORE_SWEEP)) {
+    for (int c = 0; dCores && c < n_cores; ++c)
+      if (!dCores[c]) return DCTN_ERR_NULL;
+    rc = convsbs_bwd_reg(x, x_strides, cores, dY, dX, (float* const*)dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
+                         W, q, dtype, st, workspace, workspace_bytes);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
   switch (dtype) {
     case DCTN_F32:
       return bwd_launch<float, float>(x, dY, dX, dCores, workspace, workspace_bytes, p, dtype, st, saved_states);

@@ -189,6 +189,7 @@ struct GemmD {
   long long Bn;
   int O;
   int slices;             // k slices (set by gemm_launch)
+  T* zstore;              // EPI_FWD of a training forward: Z[m][n] (ld ldc) is ALSO stored for the backward; NULL: not
 };
 
 // WTM MFMA tiles per wave along m (block tile 32 WTM x 64), KC = k chunk
@@ -388,6 +389,17 @@ __global__ __launch_bounds__(256) void halves_gemm_k(const T* __restrict__ Ag, c
         for (int step = g.O; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
         if (lr < g.O) red[(wn * BM + r) * 16 + lr] = sum;
       }
+    if (g.zstore) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int m = m0 + 16 * WTM * wm + 16 * i + Mma<T>::row(v, lk), n = n0 + 32 * wn + 16 * j + lr;
+            if (m < g.M && n < g.N) g.zstore[(long long)m * g.ldc + n] = acc[i][j][v];
+          }
+    }
     __syncthreads();
     for (int e = tid; e < BM * g.O; e += 256) {
       const int r = e >> logo, o = e & (g.O - 1), m = m0 + r;
@@ -723,6 +735,9 @@ struct GemmB {
   const bf16_t* p1;    // forward epilogue: P1 (ld Bn)
   int Bn;
   int slices;
+  // BEPI_FWD of a training forward: Z'[m][n] is also stored (bf16, ld N) for the backward, each block of 64 columns in
+  // the order the accumulators hold it - column 16 j + lr of the block at position 4 lr + j, one 8-byte store per lane
+  bf16_t* zstore;
 };
 
 __device__ __forceinline__ bf16x8v zero8() { return bf16x8v{0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -853,6 +868,11 @@ __global__ __launch_bounds__(256) void bf16_gemm_k(const bf16_t* __restrict__ Ag
 #pragma unroll
           for (int step = 1; step < 16; step <<= 1) sum += __shfl_xor(sum, step, 64);
           if (lr == 0 && mrow < g.M) Cg[(long long)(nb / 64) * g.M + mrow] = sum;
+          if (g.zstore && mrow < g.M) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+            const bf16x4v zv = {(bf16_t)acc[i][0][v], (bf16_t)acc[i][1][v], (bf16_t)acc[i][2][v], (bf16_t)acc[i][3][v]};
+            *reinterpret_cast<bf16x4v*>(g.zstore + (long long)mrow * g.N + nb + 4 * lr) = zv;
+          }
         }
     }
     return;
@@ -939,6 +959,29 @@ __global__ __launch_bounds__(256) void bf16_out_sum_k(const float* __restrict__ 
   }
 }
 
+// dP1[w, i1] = sum_o dY[w, o] Z'[w, (o, i1)] from the Z' a training forward stored (GemmB::zstore: blocks of 64 columns
+// in accumulator order).  A thread takes 4 stored positions of a block (one 8-byte load per o) = columns 16 j + lr.
+__global__ __launch_bounds__(256) void bf16_dp1_saved_k(const bf16_t* __restrict__ Zs, const bf16_t* __restrict__ dY,
+                                                        float* __restrict__ dP1, long long nw, int Bn, int O) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+  const int per_w = Bn / 4;
+  const long long total = nw * per_w;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long w = idx / per_w;
+    const int t = (int)(idx - w * per_w), blk = t >> 4, lr = t & 15;
+    const bf16_t* z = Zs + w * (long long)Bn * O + blk * 64 + 4 * lr;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < O; ++o) {
+      const bf16x4v zv = *reinterpret_cast<const bf16x4v*>(z + (long long)o * Bn);
+      const float d = (float)dY[w * O + o];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += d * (float)zv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dP1[w * Bn + blk * 64 + 16 * j + lr] = s[j];
+  }
+}
+
 // chunk of windows of the bf16 path: no Z buffer; per window P0, P1 (bf16), their transposes, dP0, dP1 (float32) and the
 // forward partials
 HalfP make_half_bf16(const EpsP& p) {
@@ -978,8 +1021,21 @@ size_t bf16_fwd_workspace(const EpsP& p) {
          align_up((size_t)(h.NB / 64) * h.wc * 4) + 256;
 }
 
-int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st) {
+// what a training forward keeps: both halves and the GEMM result, for all windows
+struct SavedLayout { size_t p0, p1, z, total; };
+SavedLayout saved_layout(const HalfP& h, size_t esz) {
+  SavedLayout L;
+  L.p0 = 0;
+  L.p1 = align_up((size_t)h.p.Wn * h.A * esz);
+  L.z = L.p1 + align_up((size_t)h.p.Wn * h.Bn * esz);
+  L.total = L.z + align_up((size_t)h.p.Wn * h.NB * esz);
+  return L;
+}
+constexpr size_t SAVED_MAX_BYTES = (size_t)16 << 30;   // beyond: nothing is kept, the backward recomputes
+
+int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st, void* saved) {
   const HalfP h = make_half_bf16(p);
+  const SavedLayout SL = saved_layout(h, 2);
   const bf16_t* x = (const bf16_t*)xv;
   const bf16_t* core = (const bf16_t*)corev;
   bf16_t* out = (bf16_t*)outv;
@@ -999,9 +1055,14 @@ int bf16_fwd(const void* xv, const void* corev, void* outv, void* ws, const EpsP
   DCTN_CHECK_LAUNCH();
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
+    if (saved) {   // the halves of this chunk go where the backward will read them
+      P0 = (bf16_t*)((unsigned char*)saved + SL.p0) + w0 * h.A;
+      P1 = (bf16_t*)((unsigned char*)saved + SL.p1) + w0 * h.Bn;
+    }
     int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
     GemmB g{(int)nw, (int)h.NB, (int)h.A, h.A, h.A, h.A, 0, nullptr, nullptr, 0, 32, p.O, P1, (int)h.Bn};
+    g.zstore = saved ? (bf16_t*)((unsigned char*)saved + SL.z) + w0 * h.NB : nullptr;
     bf16_gemm_launch<BA_KFAST, BB_KFAST, BEPI_FWD>(P0, coreP, part, g, 1, st);
     DCTN_CHECK_LAUNCH();
     hipLaunchKernelGGL(bf16_out_sum_k, dim3(blocks_for(nw * p.O, 256)), dim3(256), 0, st, (const float*)part,
@@ -1024,9 +1085,10 @@ size_t bf16_bwd_workspace(const EpsP& p, int need_dx, int need_dcore) {
 }
 
 int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, const EpsP& p,
-             hipStream_t st) {
+             hipStream_t st, const void* saved) {
   const int need_dx = dXv != nullptr, need_dcore = dCorev != nullptr;
   const HalfP h = make_half_bf16(p);
+  const SavedLayout SL = saved_layout(h, 2);
   const bf16_t* x = (const bf16_t*)xv;
   const bf16_t* core = (const bf16_t*)corev;
   const bf16_t* dY = (const bf16_t*)dYv;
@@ -1054,16 +1116,24 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
     hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreP, h.A, h.Bn,
                        p.O, 0);
     DCTN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreQ, h.A, h.Bn,
-                       p.O, 1);
-    DCTN_CHECK_LAUNCH();
+    if (!saved) {
+      hipLaunchKernelGGL(bf16_core_permute_k, dim3(blocks_for(h.A * h.NB, 256)), dim3(256), 0, st, core, coreQ, h.A, h.Bn,
+                         p.O, 1);
+      DCTN_CHECK_LAUNCH();
+    }
   }
   int chunk = 0;
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc, ++chunk) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
     const bf16_t* dyc = dY + w0 * p.O;
-    int rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
-    if (rc != DCTN_OK) return rc;
+    int rc;
+    if (saved) {   // the training forward left both halves (and Z')
+      P0 = (bf16_t*)((unsigned char*)saved + SL.p0) + w0 * h.A;
+      P1 = (bf16_t*)((unsigned char*)saved + SL.p1) + w0 * h.Bn;
+    } else {
+      rc = launch_halves<float, bf16_t>(x, P0, P1, h, w0, nw, st);
+      if (rc != DCTN_OK) return rc;
+    }
     if (need_dcore) {
       // dCoreP[i0][(o, i1)] = sum_w P0[w, i0] dY[w, o] P1[w, i1]: k = windows, split over grid.z.  Both operands are
       // read along the window index, from transposed copies of the halves and of dY (zero beyond nw)
@@ -1093,11 +1163,19 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
       GemmB g0{(int)nw, (int)h.A, (int)h.NB, 0, h.NB, h.NB, 0, P1, dyc, h.Bn, (int)h.Bn, p.O, nullptr, (int)h.Bn};
       bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreP, dP0, g0, 1, st);
       DCTN_CHECK_LAUNCH();
-      // dP1[w, i1] = sum_(o, i0) (dY[w, o] P0[w, i0]) coreQ[i1][(o, i0)]
-      const long long KQ = h.A * p.O;
-      GemmB g1{(int)nw, (int)h.Bn, (int)KQ, 0, KQ, KQ, 0, P0, dyc, h.A, (int)h.A, p.O, nullptr, (int)h.Bn};
-      bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreQ, dP1, g1, 1, st);
-      DCTN_CHECK_LAUNCH();
+      if (saved) {
+        // dP1[w, i1] = sum_o dY[w, o] Z'[w, (o, i1)]: one pass over the Z' the forward kept instead of a third GEMM
+        const bf16_t* Zs = (const bf16_t*)((const unsigned char*)saved + SL.z) + w0 * h.NB;
+        hipLaunchKernelGGL(bf16_dp1_saved_k, dim3(blocks_for(nw * (h.Bn / 4), 256)), dim3(256), 0, st, Zs, dyc, dP1, nw,
+                           (int)h.Bn, p.O);
+        DCTN_CHECK_LAUNCH();
+      } else {
+        // dP1[w, i1] = sum_(o, i0) (dY[w, o] P0[w, i0]) coreQ[i1][(o, i0)]
+        const long long KQ = h.A * p.O;
+        GemmB g1{(int)nw, (int)h.Bn, (int)KQ, 0, KQ, KQ, 0, P0, dyc, h.A, (int)h.A, p.O, nullptr, (int)h.Bn};
+        bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreQ, dP1, g1, 1, st);
+        DCTN_CHECK_LAUNCH();
+      }
       rc = launch_dx_half<float, bf16_t>(x, dP0, gxw, h, 0, w0, nw, st);
       if (rc != DCTN_OK) return rc;
       rc = launch_dx_half<float, bf16_t>(x, dP1, gxw, h, 1, w0, nw, st);
@@ -1124,8 +1202,9 @@ size_t fwd_workspace_t(const EpsP& p) {
 }
 
 template <typename T>
-int fwd_t(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st) {
+int fwd_t(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p, hipStream_t st, void* saved) {
   const HalfP h = make_half(p, sizeof(T));
+  const SavedLayout SL = saved_layout(h, sizeof(T));
   const T* x = (const T*)xv;
   const T* core = (const T*)corev;
   T* out = (T*)outv;
@@ -1135,9 +1214,16 @@ int fwd_t(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p
   T* Z = (T*)((unsigned char*)P1 + align_up((size_t)h.wc * h.Bn * sizeof(T)));
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
+    T* Zs = nullptr;
+    if (saved) {   // halves and Z of this chunk go where the backward will read them
+      P0 = (T*)((unsigned char*)saved + SL.p0) + w0 * h.A;
+      P1 = (T*)((unsigned char*)saved + SL.p1) + w0 * h.Bn;
+      Zs = (T*)((unsigned char*)saved + SL.z) + w0 * h.NB;
+    }
     int rc = launch_halves<T>(x, P0, P1, h, w0, nw, st);
     if (rc != DCTN_OK) return rc;
     GemmD<T> g{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, P1, nullptr, h.Bn, p.O};
+    g.zstore = Zs;
     if (fused_epilogue_ok(p.O)) {
       // Z stays in the accumulators: per column tile partial sums [tile_n][w][o] (in the Z slot), then their sum
       const int tiles_n = (int)((h.NB + GT - 1) / GT);
@@ -1147,9 +1233,10 @@ int fwd_t(const void* xv, const void* corev, void* outv, void* ws, const EpsP& p
                          out + w0 * p.O, nw * p.O, tiles_n, 0);
       DCTN_CHECK_LAUNCH();
     } else {
-      gemm_launch<A_KFAST, B_NFAST, EPI_STORE, T>(P0, core, Z, g, 1, st);
+      T* Zc = Zs ? Zs : Z;
+      gemm_launch<A_KFAST, B_NFAST, EPI_STORE, T>(P0, core, Zc, g, 1, st);
       DCTN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(halves_fwd_contract_k<T>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, (const T*)Z,
+      hipLaunchKernelGGL(halves_fwd_contract_k<T>, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, (const T*)Zc,
                          (const T*)P1, out + w0 * p.O, nw, h.Bn, p.O);
       DCTN_CHECK_LAUNCH();
     }
@@ -1171,9 +1258,10 @@ size_t bwd_workspace_t(const EpsP& p, int need_dx, int need_dcore) {
 
 template <typename T>
 int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* dCorev, void* ws, const EpsP& p,
-          int dtype, hipStream_t st) {
+          int dtype, hipStream_t st, const void* saved) {
   const int need_dx = dXv != nullptr, need_dcore = dCorev != nullptr;
   const HalfP h = make_half(p, sizeof(T));
+  const SavedLayout SL = saved_layout(h, sizeof(T));
   const size_t e = sizeof(T);
   const T* x = (const T*)xv;
   const T* core = (const T*)corev;
@@ -1198,8 +1286,16 @@ int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* d
   for (long long w0 = 0; w0 < p.Wn; w0 += h.wc, ++chunk) {
     const long long nw = p.Wn - w0 < h.wc ? p.Wn - w0 : h.wc;
     const T* dyc = dY + w0 * p.O;
-    int rc = launch_halves<T>(x, P0, P1, h, w0, nw, st);
-    if (rc != DCTN_OK) return rc;
+    int rc;
+    const T* Zs = nullptr;
+    if (saved) {   // the training forward left both halves and Z
+      P0 = (T*)((unsigned char*)saved + SL.p0) + w0 * h.A;
+      P1 = (T*)((unsigned char*)saved + SL.p1) + w0 * h.Bn;
+      Zs = (const T*)((const unsigned char*)saved + SL.z) + w0 * h.NB;
+    } else {
+      rc = launch_halves<T>(x, P0, P1, h, w0, nw, st);
+      if (rc != DCTN_OK) return rc;
+    }
     if (need_dcore) {
       // dCore[(i0), (i1 o)] = sum_w P0[w, i0] T[w, (i1 o)]: K = windows, split over grid.z
       const long long ksl = ((nw + h.ksplit - 1) / h.ksplit + GK - 1) / GK * GK;
@@ -1218,7 +1314,12 @@ int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* d
       DCTN_CHECK_LAUNCH();
       // Z[w, (i1 o)] = sum_i0 P0[w, i0] Core[i0, (i1 o)], dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
       GemmD<T> g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, dyc, h.Bn, p.O};
-      if (fused_epilogue_ok(p.O)) {
+      if (Zs) {
+        // the forward kept Z: one pass over it instead of the forward GEMM a second time (the reference's autograd
+        // keeps the result of path step (0,1) too: dctn/eps.py:25-30)
+        hipLaunchKernelGGL(halves_dp1_k<T>, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, Zs, dyc, dP1, nw, h.Bn, p.O);
+        DCTN_CHECK_LAUNCH();
+      } else if (fused_epilogue_ok(p.O)) {
         gemm_launch<A_KFAST, B_NFAST, EPI_DP1, T>(P0, core, dP1, g1, 1, st);
         DCTN_CHECK_LAUNCH();
       } else {
@@ -1260,23 +1361,28 @@ size_t eps_fwd_halves_workspace(const EpsP& p, int dtype) {
 }
 
 size_t eps_halves_saved_bytes(const EpsP& p, int dtype) {
-  (void)p; (void)dtype;
-  return 0;   // TODO(saved Z)
+  if (!eps_halves_wanted(p, dtype)) return 0;
+  const size_t total = dtype == DCTN_BF16 ? saved_layout(make_half_bf16(p), 2).total
+                       : dtype == DCTN_F64 ? saved_layout(make_half(p, 8), 8).total
+                                           : saved_layout(make_half(p, 4), 4).total;
+  return total <= SAVED_MAX_BYTES ? total : 0;
 }
 
 int eps_fwd_halves(const void* x, const void* core, void* out, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
                    hipStream_t st, void* saved) {
-  (void)saved;
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_fwd_halves_workspace(p, dtype)) return DCTN_ERR_WORKSPACE;
+  if (saved && (uintptr_t)saved % 256) return DCTN_ERR_BAD_SHAPE;
   if (dtype == DCTN_BF16) {
     if ((uintptr_t)core % 16) return DCTN_ERR_UNSUPPORTED;   // 16-byte vector loads of core rows
-    const int rc = bf16_fwd(x, core, out, ws, p, st);
-    if (rc == DCTN_OK) dctn_set_last_kernel("eps_fwd_mfma_bf16_halves");
+    const int rc = bf16_fwd(x, core, out, ws, p, st, saved);
+    if (rc == DCTN_OK) dctn_set_last_kernel(saved ? "eps_fwd_mfma_bf16_halves_saving" : "eps_fwd_mfma_bf16_halves");
     return rc;
   }
-  const int rc = dtype == DCTN_F64 ? fwd_t<double>(x, core, out, ws, p, st) : fwd_t<float>(x, core, out, ws, p, st);
-  if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_fwd_mfma_f64_halves" : "eps_fwd_mfma_f32_halves");
+  const int rc = dtype == DCTN_F64 ? fwd_t<double>(x, core, out, ws, p, st, saved) : fwd_t<float>(x, core, out, ws, p, st, saved);
+  if (rc == DCTN_OK)
+    dctn_set_last_kernel(dtype == DCTN_F64 ? (saved ? "eps_fwd_mfma_f64_halves_saving" : "eps_fwd_mfma_f64_halves")
+                                           : (saved ? "eps_fwd_mfma_f32_halves_saving" : "eps_fwd_mfma_f32_halves"));
   return rc;
 }
 
@@ -1288,17 +1394,22 @@ size_t eps_bwd_halves_workspace(const EpsP& p, int dtype, int need_dx, int need_
 
 int eps_bwd_halves(const void* x, const void* core, const void* dY, void* dX, void* dCore, void* ws, size_t ws_bytes,
                    const EpsP& p, int dtype, hipStream_t st, const void* saved, size_t saved_bytes) {
-  (void)saved; (void)saved_bytes;
   if (!eps_halves_wanted(p, dtype)) return DCTN_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < eps_bwd_halves_workspace(p, dtype, dX != nullptr, dCore != nullptr)) return DCTN_ERR_WORKSPACE;
+  if (saved) {   // only what the training forward of this very shape can have written
+    const size_t need = eps_halves_saved_bytes(p, dtype);
+    if (need == 0 || saved_bytes < need || (uintptr_t)saved % 256) saved = nullptr;
+  }
   if (dtype == DCTN_BF16) {
     if ((uintptr_t)core % 16) return DCTN_ERR_UNSUPPORTED;
-    const int rc = bf16_bwd(x, core, dY, dX, dCore, ws, p, st);
-    if (rc == DCTN_OK) dctn_set_last_kernel("eps_bwd_mfma_bf16_halves");
+    const int rc = bf16_bwd(x, core, dY, dX, dCore, ws, p, st, saved);
+    if (rc == DCTN_OK) dctn_set_last_kernel(saved ? "eps_bwd_mfma_bf16_halves_savedz" : "eps_bwd_mfma_bf16_halves");
     return rc;
   }
-  const int rc = dtype == DCTN_F64 ? bwd_t<double>(x, core, dY, dX, dCore, ws, p, dtype, st)
-                                   : bwd_t<float>(x, core, dY, dX, dCore, ws, p, dtype, st);
-  if (rc == DCTN_OK) dctn_set_last_kernel(dtype == DCTN_F64 ? "eps_bwd_mfma_f64_halves" : "eps_bwd_mfma_f32_halves");
+  const int rc = dtype == DCTN_F64 ? bwd_t<double>(x, core, dY, dX, dCore, ws, p, dtype, st, saved)
+                                   : bwd_t<float>(x, core, dY, dX, dCore, ws, p, dtype, st, saved);
+  if (rc == DCTN_OK)
+    dctn_set_last_kernel(dtype == DCTN_F64 ? (saved ? "eps_bwd_mfma_f64_halves_savedz" : "eps_bwd_mfma_f64_halves")
+                                           : (saved ? "eps_bwd_mfma_f32_halves_savedz" : "eps_bwd_mfma_f32_halves"));
   return rc;
 }

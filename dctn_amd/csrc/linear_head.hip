@@ -243,6 +243,185 @@ bool head_ok(long long B, int F, int Cout, int dtype) {
   return dtype == DCTN_BF16 && B >= 1 && F >= 8 && F % 8 == 0 && Cout >= 1 && Cout <= HEAD_MAXC;
 }
 
+// ------------------------------------------------------------------------------------ generic head (any dtype, any F)
+// float32 / float64 models (the reference's own arithmetic: new_runner.py:417 float32, its tests float64) and bf16
+// feature counts that are not multiples of 8 (cfg3a: 23 x 23 x 6 = 3174) used to go to the library (`F.linear`, three
+// Tensile GEMM launches in the backward).  Same three streaming passes as above in scalar form: S = storage type,
+// A = accumulator (float; double for float64).  The work is tiny (B x F x Cout <= a few MFLOP) and bound by launch
+// latency and one pass over `feat`; no matrix cores needed.
+constexpr int HG_SPB = 4;   // samples per workgroup, forward
+
+template <typename S, typename A>
+__global__ __launch_bounds__(256) void head_fwd_gen_k(const S* __restrict__ feat, const S* __restrict__ W,
+                                                      const S* __restrict__ bias, S* __restrict__ out, long long B, int F,
+                                                      int Cout) {
+  __shared__ A red[4][HG_SPB * HEAD_MAXC];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long b0 = (long long)blockIdx.x * HG_SPB;
+  A acc[HG_SPB][HEAD_MAXC];
+#pragma unroll
+  for (int s2 = 0; s2 < HG_SPB; ++s2)
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) acc[s2][c] = A(0);
+  for (int f = tid; f < F; f += 256) {
+    A xv[HG_SPB];
+#pragma unroll
+    for (int s2 = 0; s2 < HG_SPB; ++s2) xv[s2] = b0 + s2 < B ? (A)feat[(b0 + s2) * (long long)F + f] : A(0);
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) {
+      if (c < Cout) {
+        const A w = (A)W[(long long)c * F + f];
+#pragma unroll
+        for (int s2 = 0; s2 < HG_SPB; ++s2) acc[s2][c] += xv[s2] * w;
+      }
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < HG_SPB; ++s2)
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) {
+      if (c < Cout) {
+        const A r = wave_reduce_sum(acc[s2][c]);
+        if (lane == 0) red[wv][s2 * HEAD_MAXC + c] = r;
+      }
+    }
+  __syncthreads();
+  if (tid < HG_SPB * HEAD_MAXC) {
+    const int s2 = tid / HEAD_MAXC, c = tid % HEAD_MAXC;
+    if (b0 + s2 < B && c < Cout)
+      out[(b0 + s2) * Cout + c] = (S)(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + (A)bias[c]);
+  }
+}
+
+// backward, both streaming passes in one launch (as head_bwd_k): workgroups [0, n_dfeat) -> dFeat, the rest -> dW slices
+template <typename S, typename A>
+__global__ __launch_bounds__(256) void head_bwd_gen_k(const S* __restrict__ feat, const S* __restrict__ W,
+                                                      const S* __restrict__ dOut, S* __restrict__ dFeat,
+                                                      A* __restrict__ partial, long long B, int F, int Cout, int n_dfeat,
+                                                      int gx) {
+  __shared__ A gs[DW_SPS][HEAD_MAXC];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  if (bid < n_dfeat) {
+    const int f = (bid % gx) * 256 + tid;
+    const long long b0 = (long long)(bid / gx) * DF_SPB;
+    if (tid < DF_SPB * HEAD_MAXC) {
+      const int s2 = tid / HEAD_MAXC, c = tid % HEAD_MAXC;
+      gs[s2][c] = (b0 + s2 < B && c < Cout) ? (A)dOut[(b0 + s2) * Cout + c] : A(0);
+    }
+    A w[HEAD_MAXC];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) w[c] = (c < Cout && f < F) ? (A)W[(long long)c * F + f] : A(0);
+    __syncthreads();
+    if (f < F) {
+#pragma unroll
+      for (int s2 = 0; s2 < DF_SPB; ++s2) {
+        if (b0 + s2 < B) {
+          A a = A(0);
+#pragma unroll
+          for (int c = 0; c < HEAD_MAXC; ++c) a += gs[s2][c] * w[c];
+          dFeat[(b0 + s2) * (long long)F + f] = (S)a;
+        }
+      }
+    }
+  } else {
+    const int r = bid - n_dfeat;
+    const int f = (r % gx) * 256 + tid, by = r / gx;
+    const long long b0 = (long long)by * DW_SPS;
+    for (int e = tid; e < DW_SPS * HEAD_MAXC; e += 256) {
+      const int s2 = e / HEAD_MAXC, c = e % HEAD_MAXC;
+      gs[s2][c] = (b0 + s2 < B && c < Cout) ? (A)dOut[(b0 + s2) * Cout + c] : A(0);
+    }
+    A raw[DW_SPS];
+#pragma unroll
+    for (int s2 = 0; s2 < DW_SPS; ++s2) {
+      const long long b = b0 + s2 < B ? b0 + s2 : B - 1;
+      raw[s2] = f < F ? (A)feat[b * (long long)F + f] : A(0);
+    }
+    __syncthreads();
+    A acc[HEAD_MAXC];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAXC; ++c) acc[c] = A(0);
+#pragma unroll
+    for (int s2 = 0; s2 < DW_SPS; ++s2)
+#pragma unroll
+      for (int c = 0; c < HEAD_MAXC; ++c) acc[c] += gs[s2][c] * raw[s2];   // gs is zero for samples past B
+    if (f < F) {
+      A* dst = partial + (long long)by * Cout * F;
+#pragma unroll
+      for (int c = 0; c < HEAD_MAXC; ++c)
+        if (c < Cout) dst[(long long)c * F + f] = acc[c];
+    }
+  }
+}
+
+template <typename S, typename A>
+__global__ __launch_bounds__(256) void head_bwd_gen_reduce_k(const A* __restrict__ partial, const S* __restrict__ dOut,
+                                                             S* __restrict__ dW, S* __restrict__ dBias, long long B, int F,
+                                                             int Cout, int splits) {
+  const long long n = (long long)Cout * F;
+  if (blockIdx.x + 1 < gridDim.x) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && dW) {
+      A a[4] = {A(0), A(0), A(0), A(0)};
+      int k = 0;
+      for (; k + 4 <= splits; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += partial[(k + u) * n + i];
+      }
+      for (; k < splits; ++k) a[0] += partial[k * n + i];
+      dW[i] = (S)((a[0] + a[1]) + (a[2] + a[3]));
+    }
+  } else if (dBias) {
+    __shared__ A red[256];
+    const int rpp = 256 / Cout, stride = rpp * Cout;
+    A s2 = A(0);
+    if ((int)threadIdx.x < stride) {
+      const int c = threadIdx.x % Cout;
+      for (long long b = threadIdx.x / Cout; b < B; b += rpp) s2 += (A)dOut[b * Cout + c];
+    }
+    red[threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < Cout) {
+      A t = A(0);
+      for (int k = 0; k < rpp; ++k) t += red[k * Cout + threadIdx.x];
+      dBias[threadIdx.x] = (S)t;
+    }
+  }
+}
+
+bool head_gen_ok(long long B, int F, int Cout, int dtype) {
+  return (dtype == DCTN_BF16 || dtype == DCTN_F32 || dtype == DCTN_F64) && B >= 1 && F >= 1 && Cout >= 1 && Cout <= HEAD_MAXC;
+}
+
+template <typename S, typename A>
+int head_fwd_gen(const void* feat, const void* weight, const void* bias, void* out, long long B, int F, int Cout, hipStream_t st) {
+  hipLaunchKernelGGL((head_fwd_gen_k<S, A>), dim3((unsigned)((B + HG_SPB - 1) / HG_SPB)), dim3(256), 0, st, (const S*)feat,
+                     (const S*)weight, (const S*)bias, (S*)out, B, F, Cout);
+  DCTN_CHECK_LAUNCH();
+  return DCTN_OK;
+}
+
+template <typename S, typename A>
+int head_bwd_gen(const void* feat, const void* weight, const void* dOut, void* dFeat, void* dWeight, void* dBias, void* ws,
+                 long long B, int F, int Cout, hipStream_t st) {
+  const int splits = dw_splits(B);
+  const int gx = (F + 255) / 256;
+  const int n_dfeat = dFeat ? gx * (int)((B + DF_SPB - 1) / DF_SPB) : 0;
+  const int n_dw = dWeight ? gx * splits : 0;
+  if (n_dfeat + n_dw > 0) {
+    hipLaunchKernelGGL((head_bwd_gen_k<S, A>), dim3((unsigned)(n_dfeat + n_dw)), dim3(256), 0, st, (const S*)feat,
+                       (const S*)weight, (const S*)dOut, (S*)dFeat, (A*)ws, B, F, Cout, n_dfeat, gx);
+    DCTN_CHECK_LAUNCH();
+  }
+  if (dWeight || dBias) {
+    const long long n = (long long)Cout * F;
+    hipLaunchKernelGGL((head_bwd_gen_reduce_k<S, A>), dim3((unsigned)(dWeight ? (n + 255) / 256 : 0) + 1), dim3(256), 0, st,
+                       (const A*)ws, (const S*)dOut, (S*)dWeight, (S*)dBias, B, F, Cout, splits);
+    DCTN_CHECK_LAUNCH();
+  }
+  return DCTN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -251,8 +430,16 @@ int dctn_linear_head_fwd(const void* feat, const void* weight, const void* bias,
                          int64_t B, int F, int Cout, int dtype, void* stream) {
   if (!feat || !weight || !bias || !out) return DCTN_ERR_NULL;
   if (B < 1 || F < 1 || Cout < 1) return DCTN_ERR_BAD_SHAPE;
-  if (!head_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
-  if (((uintptr_t)feat % 16) || ((uintptr_t)weight % 16)) return DCTN_ERR_UNSUPPORTED;
+  if (!head_ok(B, F, Cout, dtype) || ((uintptr_t)feat % 16) || ((uintptr_t)weight % 16)) {
+    // float32 / float64, feature counts that are not multiples of 8, unaligned views: the scalar kernels
+    if (!head_gen_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
+    int rc;
+    if (dtype == DCTN_F64) rc = head_fwd_gen<double, double>(feat, weight, bias, out, B, F, Cout, (hipStream_t)stream);
+    else if (dtype == DCTN_F32) rc = head_fwd_gen<float, float>(feat, weight, bias, out, B, F, Cout, (hipStream_t)stream);
+    else rc = head_fwd_gen<bf16_t, float>(feat, weight, bias, out, B, F, Cout, (hipStream_t)stream);
+    if (rc == DCTN_OK) dctn_set_last_kernel("linear_head_fwd_generic");
+    return rc;
+  }
   if ((B + 15) / 16 >= 256)
     hipLaunchKernelGGL(head_fwd_k<16>, dim3((unsigned)((B + 15) / 16)), dim3(512), 0, (hipStream_t)stream,
                        (const bf16_t*)feat, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out,
@@ -267,8 +454,8 @@ int dctn_linear_head_fwd(const void* feat, const void* weight, const void* bias,
 }
 
 size_t dctn_linear_head_bwd_workspace_bytes(int64_t B, int F, int Cout, int dtype) {
-  if (!head_ok(B, F, Cout, dtype)) return 0;
-  return (size_t)dw_splits(B) * Cout * F * sizeof(float) + 256;
+  if (!head_gen_ok(B, F, Cout, dtype)) return 0;
+  return (size_t)dw_splits(B) * Cout * F * (dtype == DCTN_F64 ? sizeof(double) : sizeof(float)) + 256;
 }
 
 int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut, void* dFeat,
@@ -276,11 +463,20 @@ int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut,
                          int64_t B, int F, int Cout, int dtype, void* stream) {
   if (!feat || !weight || !dOut) return DCTN_ERR_NULL;
   if (B < 1 || F < 1 || Cout < 1) return DCTN_ERR_BAD_SHAPE;
-  if (!head_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
-  if (((uintptr_t)feat % 16) || ((uintptr_t)weight % 16) || (dFeat && ((uintptr_t)dFeat % 16)))
-    return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int splits = dw_splits(B);
+  if (!head_ok(B, F, Cout, dtype) || ((uintptr_t)feat % 16) || ((uintptr_t)weight % 16) || (dFeat && ((uintptr_t)dFeat % 16))) {
+    if (!head_gen_ok(B, F, Cout, dtype)) return DCTN_ERR_UNSUPPORTED;
+    const size_t asz = dtype == DCTN_F64 ? sizeof(double) : sizeof(float);
+    if (dWeight && (!workspace || workspace_bytes < (size_t)splits * Cout * F * asz || ((uintptr_t)workspace % 8)))
+      return DCTN_ERR_WORKSPACE;
+    int rc;
+    if (dtype == DCTN_F64) rc = head_bwd_gen<double, double>(feat, weight, dOut, dFeat, dWeight, dBias, workspace, B, F, Cout, st);
+    else if (dtype == DCTN_F32) rc = head_bwd_gen<float, float>(feat, weight, dOut, dFeat, dWeight, dBias, workspace, B, F, Cout, st);
+    else rc = head_bwd_gen<bf16_t, float>(feat, weight, dOut, dFeat, dWeight, dBias, workspace, B, F, Cout, st);
+    if (rc == DCTN_OK) dctn_set_last_kernel("linear_head_bwd_generic");
+    return rc;
+  }
   if (dWeight && (!workspace || workspace_bytes < (size_t)splits * Cout * F * sizeof(float)))
     return DCTN_ERR_WORKSPACE;
   const int dfeat_gx = (F / 8 + 255) / 256, dfeat_gy = (int)((B + DF_SPB - 1) / DF_SPB);

@@ -38,24 +38,45 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
 
 
 def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: torch.dtype = torch.bfloat16,
-                            port_offset: int = 53) -> bool:
+                            port_offset: int = 53, rank: Optional[int] = None, world_size: Optional[int] = None,
+                            master_addr: Optional[str] = None, master_port: Optional[int] = None) -> bool:
     """Whether an RCCL all-reduce can be captured into a HIP graph on this machine with this world size, found
     out in CHILD processes (`dctn_amd._probe_allreduce_capture`): every rank calls this at the same point, each
-    starts one child on its own GPU, the children form a process group of their own on MASTER_PORT + port_offset,
+    starts one child on its own GPU, the children form a process group of their own on master_port + port_offset,
     capture + replay one all-reduce and report through their exit code.  A failed capture cannot be recovered
     from inside a process (later collectives fail), so the attempt is made where it is free.  Returns this
-    rank's verdict; combine the ranks' verdicts with `all_ranks_agree` once the parent group exists."""
+    rank's verdict; combine the ranks' verdicts with `all_ranks_agree` once the parent group exists.
+
+    The children must form a group of the SAME size as the parent's: rank / world size come from the arguments, else
+    from the parent's initialised process group, else from RANK / WORLD_SIZE; the rendezvous address from the arguments,
+    else MASTER_ADDR / MASTER_PORT.  A world of more than one rank without a known rendezvous address (mp.spawn with an
+    explicit init_method and no environment) cannot be probed: False, i.e. the collective stays outside the graph."""
     import subprocess
     import sys
 
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else int(os.environ.get("WORLD_SIZE", "1"))
+    if master_addr is None:
+        master_addr = os.environ.get("MASTER_ADDR")
+    if master_port is None and os.environ.get("MASTER_PORT"):
+        master_port = int(os.environ["MASTER_PORT"])
+    if world_size > 1 and (master_addr is None or master_port is None):
+        return False   # nowhere for the children to meet: a world-1 probe would say nothing about this world
+    if master_addr is None:
+        master_addr = "127.0.0.1"
+    if master_port is None:
+        master_port = 29500
+    local_rank = torch.cuda.current_device() if torch.cuda.is_available() else int(os.environ.get("LOCAL_RANK", "0"))
     # the children rendezvous among themselves: under torchrun the parent's environment says "use the agent's store"
     # (TORCHELASTIC_USE_AGENT_STORE), which on another port would wait for a server nobody starts
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + port_offset)
-    env.setdefault("RANK", "0")
-    env.setdefault("LOCAL_RANK", "0")
-    env.setdefault("WORLD_SIZE", "1")
+    env["MASTER_ADDR"] = str(master_addr)
+    env["MASTER_PORT"] = str(int(master_port) + port_offset)
+    env["RANK"] = str(int(rank))
+    env["LOCAL_RANK"] = str(int(local_rank))
+    env["WORLD_SIZE"] = str(int(world_size))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["DCTN_PROBE_NUMEL"] = str(int(numel))
     env["DCTN_PROBE_DTYPE"] = str(dtype).replace("torch.", "")

@@ -87,6 +87,29 @@ class _EpsFunction(torch.autograd.Function):
         return d_core, d_x, None
 
 
+_keep_gemm_result = True
+
+
+class keep_gemm_result:
+    """``with keep_gemm_result(False): ...`` - forwards inside the block keep nothing for their backward, which then
+    recomputes (the pre-round-3 behaviour: less memory held between forward and backward - cfg3a layer 2: 416 MB -, one
+    more GEMM in the backward).  Default True, as torch's autograd does on the reference's path."""
+
+    def __init__(self, keep: bool):
+        self.keep = bool(keep)
+
+    def __enter__(self):
+        global _keep_gemm_result
+        self._saved = _keep_gemm_result
+        _keep_gemm_result = self.keep
+        return self
+
+    def __exit__(self, *exc):
+        global _keep_gemm_result
+        _keep_gemm_result = self._saved
+        return False
+
+
 def _check_core(core: Tensor, input: Tensor) -> None:
     num_channels, batch_size, height, width, in_size = input.shape
     kernel_size = math.isqrt((core.ndim - 1) // num_channels)
@@ -103,10 +126,10 @@ def eps(core: Tensor, input: Tensor) -> Tensor:
 
 def _eps_on_device(core: Tensor, input: Tensor) -> Tensor:
     if _bf16_through_f32(core, input):
-        return _EpsFunction.apply(core.float(), input.float()).to(torch.bfloat16)
+        return _EpsFunction.apply(core.float(), input.float(), _keep_gemm_result).to(torch.bfloat16)
     if _f32_through_bf16(core, input):
-        return _EpsFunction.apply(core.bfloat16(), input.bfloat16()).float()
-    return _EpsFunction.apply(core, input)
+        return _EpsFunction.apply(core.bfloat16(), input.bfloat16(), _keep_gemm_result).float()
+    return _EpsFunction.apply(core, input, _keep_gemm_result)
 
 
 def _f32_through_bf16(core: Tensor, input: Tensor) -> bool:

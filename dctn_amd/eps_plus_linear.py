@@ -43,26 +43,24 @@ Initialization = Union[UnitEmpiricalOutputStd, UnitTheoreticalOutputStd, Manuall
 
 # Host-side routing switches (plain module attributes; tests flip them to compare the paths):
 #   FUSED_HEAD  - last EPS layer + flatten + linear head as one autograd node (`_EpsLinearHeadFunction`)
-#   HEAD_BWD    - backward of the stand-alone linear head: "blas" (library GEMMs, measured faster) or "hip"
+#   HEAD_BWD    - backward of the stand-alone linear head: "hip" (`dctn_linear_head_bwd`, the default) or "blas" (library GEMMs)
 #   FUSED_HEAD_FWD - inside that node: forward of layer + head as one kernel (`dctn_eps_head_fwd`) or as two
 FUSED_HEAD = True
 FUSED_HEAD_FWD = True
-HEAD_BWD = "blas"
+HEAD_BWD = "hip"
 
 
 class _LinearHeadFunction(torch.autograd.Function):
-    """`F.linear(feat, weight, bias)` for a skinny output (<= 16 classes), bf16, on the HIP kernels of
-    dctn_amd/csrc/linear_head.hip (the three library GEMMs of a 10-class head cost more than the
-    EPS contraction at batch 1024)."""
+    """`F.linear(feat, weight, bias)` for a skinny output (<= 16 classes) on the HIP kernels of
+    dctn_amd/csrc/linear_head.hip, forward and backward (the three library GEMMs of a 10-class head cost more than the
+    EPS contraction at batch 1024): float32, float64 and bfloat16, any feature count (bf16 with a multiple of 8 features
+    and 16-byte aligned tensors on the vectorised matrix-core kernels, everything else on the scalar streaming ones)."""
 
     @staticmethod
     def supported(feat: Tensor, weight: Tensor, bias) -> bool:
         return (
-            feat.is_cuda and bias is not None and feat.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
-            and feat.ndim == 2 and weight.shape[0] <= 16 and feat.shape[1] % 8 == 0
-            # the kernels read 16-byte vectors: a parameter re-pointed into a flat buffer (FlatSGD) at an odd
-            # offset, or a sliced feature tensor, takes the library GEMM instead
-            and feat.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+            feat.is_cuda and bias is not None and feat.dtype in (torch.bfloat16, torch.float32, torch.float64)
+            and weight.dtype == feat.dtype and bias.dtype == feat.dtype and feat.ndim == 2 and weight.shape[0] <= 16
         )
 
     @staticmethod
@@ -79,33 +77,35 @@ class _LinearHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
-        """Measured on MI355X at batch 1024 (profiles/README.md): the HIP backward kernels
-        (`dctn_linear_head_bwd`) only tie the library GEMMs (25.8 vs 21.6 us), so the backward
-        stays on rocBLAS; `eps_plus_linear.HEAD_BWD = "hip"` selects the HIP kernels."""
+        """`dctn_linear_head_bwd`: dFeat and the dWeight slices in one launch, a second one sums the slices (fixed
+        order) and emits dBias.  `eps_plus_linear.HEAD_BWD = "blas"` selects three library GEMM / reduction launches
+        instead (bf16 at batch 1024: 21.6 us against 25.8; float32 / odd feature counts: the library was the only path
+        until round 3)."""
         f, w = ctx.saved_tensors
         need_f, need_w, need_b = ctx.needs_input_grad
-        if HEAD_BWD != "hip":
-            d_f = d_out @ w if need_f else None
-            d_w = d_out.t() @ f if need_w else None
-            d_b = d_out.sum(0) if need_b else None
-            return d_f, d_w, d_b
-        dev = f.device
-        B, F_ = f.shape
-        C = w.shape[0]
-        g = d_out.contiguous()
-        d_f = torch.empty_like(f) if need_f else None
-        d_w = torch.empty_like(w) if (need_w or need_b) else None
-        d_b = torch.empty((C,), dtype=w.dtype, device=dev) if (need_w or need_b) else None
-        code = L.dtype_code(f)
-        ws = L.workspace(L.lib().dctn_linear_head_bwd_workspace_bytes(B, F_, C, code), dev)
-        L.check(
-            L.lib().dctn_linear_head_bwd(
-                f.data_ptr(), w.data_ptr(), g.data_ptr(), None if d_f is None else d_f.data_ptr(),
-                None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(),
-                ws.data_ptr(), ws.numel(), B, F_, C, code, L.stream_ptr(dev)),
-            "linear head backward",
-        )
-        return d_f, (d_w if need_w else None), (d_b if need_b else None)
+        return _head_backward(f, w, d_out.contiguous(), need_f, need_w, need_b)
+
+
+def _head_backward(f: Tensor, w: Tensor, g: Tensor, need_f: bool, need_w: bool, need_b: bool):
+    """(dFeat, dWeight, dBias) of ``f @ w.T + bias`` for the incoming gradient ``g`` (contiguous)."""
+    if HEAD_BWD != "hip" or w.shape[0] > 16:
+        return (g @ w if need_f else None), (g.t() @ f if need_w else None), (g.sum(0) if need_b else None)
+    dev = f.device
+    B, F_ = f.shape
+    C = w.shape[0]
+    d_f = torch.empty_like(f) if need_f else None
+    d_w = torch.empty_like(w) if (need_w or need_b) else None
+    d_b = torch.empty((C,), dtype=w.dtype, device=dev) if (need_w or need_b) else None
+    code = L.dtype_code(f)
+    ws = L.workspace(L.lib().dctn_linear_head_bwd_workspace_bytes(B, F_, C, code), dev)
+    L.check(
+        L.lib().dctn_linear_head_bwd(
+            f.data_ptr(), w.data_ptr(), g.data_ptr(), None if d_f is None else d_f.data_ptr(),
+            None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(),
+            ws.data_ptr(), ws.numel(), B, F_, C, code, L.stream_ptr(dev)),
+        "linear head backward",
+    )
+    return d_f, (d_w if need_w else None), (d_b if need_b else None)
 
 
 class _EpsLinearHeadFunction(torch.autograd.Function):
@@ -169,7 +169,8 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
         dev, code = x.device, L.dtype_code(x)
         g = d_out.contiguous()
         if not need_core:
-            return None, None, (g.t() @ feat if need_w else None), (g.sum(0) if need_b else None)
+            _, d_w, d_b = _head_backward(feat, w, g, False, need_w, need_b)
+            return None, None, d_w, d_b
         cout = w.shape[0]
         # the three gradients are carved out of ONE buffer, in parameter order (epses[-1], linear.weight,
         # linear.bias): ddp.FlatGradAllReducer then all-reduces that buffer in place, with no gather /
@@ -185,15 +186,17 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
             x.data_ptr(), L.strides5(x), feat.data_ptr(), g.data_ptr(), w.data_ptr(), d_core.data_ptr(),
             None if d_w is None else d_w.data_ptr(), None if d_b is None else d_b.data_ptr(), ws.data_ptr(),
             ws.numel(), C, B, H, W, Q, K, O, cout, code, prec, L.stream_ptr(dev))
-        if rc == L.ERR_UNSUPPORTED:   # outside the fused family: library GEMMs + the plain EPS backward
-            d_w = g.t() @ feat if need_w else None
-            d_b = g.sum(0) if need_b else None
-            d_feat = (g @ w).contiguous()
+        if rc == L.ERR_UNSUPPORTED:   # outside the fused family: the head's own backward + the plain EPS backward
+            d_feat, d_w, d_b = _head_backward(feat, w, g, True, need_w, need_b)
             rc = L.lib().dctn_eps_bwd(x.data_ptr(), L.strides5(x), core_c.data_ptr(), d_feat.data_ptr(), None,
                                       d_core.data_ptr(), ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code,
                                       prec, L.stream_ptr(dev))
         L.check(rc, "eps + linear head backward")
         return d_core, None, d_w, d_b
+
+
+def _refresh_p_after_load(module, _incompatible_keys) -> None:
+    module._refresh_p()
 
 
 class EPSesPlusLinear(nn.Module):
@@ -256,9 +259,10 @@ class EPSesPlusLinear(nn.Module):
         # synchronisation, impossible under graph capture).  `p` is part of the state_dict, so the copy is
         # refreshed whenever a checkpoint is loaded.
         self._p_float = float(p)
-        self.register_load_state_dict_post_hook(lambda module, _incompatible: module._refresh_p())
+        self.register_load_state_dict_post_hook(_refresh_p_after_load)   # a module-level function: the model stays picklable
 
     def _refresh_p(self) -> None:
+        """Call after changing the ``p`` buffer in place (loading a state_dict does it by itself)."""
         self._p_float = float(self.p)
 
     def forward(self, input: Tensor) -> Tensor:

@@ -1,4 +1,4 @@
-"""Initialisation tags and small helpers shared by the models (reference: dctn/utils.py:10-59)."""
+"""Initialisation tags and the two helpers the models on the path use (reference: dctn/utils.py:10-17,20-36,54-59)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -33,23 +33,6 @@ def transform_dataset(f: Callable[[Tensor], Tensor], x: Tensor, batch_size: int 
     """Applies an ``eps``-like ``f`` to ``x`` (channel, sample, height, width, quantum) slice by
     slice along the sample dim; returns (1, sample, height', width', quantum')."""
     return torch.cat([f(part) for part in x.split(batch_size, dim=1)]).unsqueeze(0)
-
-
-def implies(x: bool, y: bool) -> bool:
-    return (not x) or y
-
-
-def xor(*args: bool) -> bool:
-    return sum(bool(a) for a in args) % 2 == 1
-
-
-def exactly_one_true(*args: bool) -> bool:
-    assert all(isinstance(a, bool) for a in args)
-    return sum(args) == 1
-
-
-def raise_exception(exception: BaseException):
-    raise exception
 
 
 def id_assert_shape_matches(tensor: Tensor, shape: Sequence[int]) -> Tensor:

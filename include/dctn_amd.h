@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-enum { DCTN_F32 = 0, DCTN_F64 = 1, DCTN_BF16 = 2 };
+enum { DCTN_F32 = 0, DCTN_F64 = 1, DCTN_BF16 = 2, DCTN_DTYPE_MASK = 0xFF };
+/* OR-ed into the `dtype` argument of the dctn_convsbs_* entry points (any other bit above DCTN_DTYPE_MASK:
+ * DCTN_ERR_UNSUPPORTED): strings with every bond <= 4 run on the matrix-core sweep instead of the register-resident
+ * sweep that is their default (cross-check of the two kernel families; same results to f32 rounding) */
+enum { DCTN_SBS_MATRIX_CORE_SWEEP = 1 << 8 };
 
 enum {
   DCTN_OK = 0,
@@ -269,8 +273,9 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats,
  * Linear classifier head — replaces `self.linear(features)` of dctn/eps_plus_linear.py:147
  * (nn.Linear(H'*W'*Q, 10)) for skinny outputs.
  *   feat (B, F), weight (Cout, F), bias (Cout), out (B, Cout), all contiguous;
- *   this build covers bf16, Cout <= 16, F % 8 == 0 (DCTN_ERR_UNSUPPORTED otherwise: the host
- *   layer then uses the framework's library GEMM).
+ *   float32, float64 and bf16 (float32 accumulation; float64 for float64), Cout <= 16, any F.  bf16 with F % 8 == 0 and
+ *   16-byte aligned pointers runs the vectorised matrix-core kernels, everything else the scalar streaming kernels
+ *   (DCTN_ERR_UNSUPPORTED only for Cout > 16: the host layer then uses the framework's library GEMM).
  *   Backward: dFeat (B, F), dWeight (Cout, F), dBias (Cout) are OVERWRITTEN; dFeat may be NULL;
  *   dWeight and dBias are produced together (dBias may be NULL).
  * ------------------------------------------------------------------------------------------ */

@@ -195,3 +195,60 @@ def test_reference_training_loop_two_ranks(tmp_path):
             at_iter_start=[], after_back=[], after_param_upd=[T.make_stopper_after_n_iters(4)])
     for a, p in zip(got[0], model.parameters()):
         assert torch.allclose(a, p.detach(), atol=1e-6)
+
+
+# ------------------------------------------------------------------ ConvSBS classifier: gradient layout over two ranks
+def _sbs_layout_worker(rank, world, port, q):
+    """CPU: the model's parameters and the gradient LAYOUT its backward produces (one flat buffer per string, the cores'
+    gradients views of it in string order - dctn_amd/conv_sbs.py `_ConvSBSFunction.backward`); the arithmetic itself runs
+    on the GPU only (tests/test_gpu_ddp.py)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tests.sbs_classifier import ConvSBSClassifier
+
+    ddp.init_from_env("gloo")
+    torch.manual_seed(50 + rank)
+    model = ConvSBSClassifier(bond=4)
+    ddp.broadcast_parameters(model.parameters())
+    flat0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat0) for _ in range(world)]
+    dist.all_gather(gathered, flat0)
+    assert torch.equal(gathered[0], gathered[1])
+    strings = [s for layer in model.layers for s in layer.strings]
+    assert len(strings) == 5
+    gen = torch.Generator().manual_seed(7 + rank)
+    flats = []
+    for s in strings:
+        n = sum(c.numel() for c in s.cores)
+        flat = torch.randn(n, generator=gen)
+        flats.append(flat.clone())
+        off = 0
+        for c in s.cores:
+            c.grad = flat[off : off + c.numel()].view_as(c)
+            off += c.numel()
+    # one string: its gradients ARE one bucket - all-reduced in place, one collective
+    red1 = ddp.FlatGradAllReducer(strings[0].parameters(), average=False)
+    assert red1._contiguous_flat([c.grad for c in strings[0].cores]) is not None
+    # whole model: five buffers - gathered into one bucket, ONE collective, scattered back
+    red = ddp.FlatGradAllReducer(model.parameters(), average=True)
+    assert red._contiguous_flat([p.grad for p in model.parameters()]) is None
+    red()
+    q.put((rank, flats, [torch.cat([c.grad.reshape(-1) for c in s.cores]) for s in strings]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_convsbs_classifier_gradient_buckets_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sbs_layout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (f, g) for r, f, g in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for s in range(5):
+        mean = (got[0][0][s] + got[1][0][s]) / 2
+        assert torch.allclose(got[0][1][s], mean) and torch.equal(got[0][1][s], got[1][1][s])

@@ -153,3 +153,105 @@ def test_rccl_single_rank_whole_iteration_in_one_graph():
         step(x, y)
     for a, p in zip(params, model.parameters()):
         assert torch.equal(torch.from_numpy(a), p.detach().float().cpu())   # averaging over one rank changes nothing
+
+
+# ------------------------------------------------------------------ the ConvSBS classifier and the logmatmulexp fold
+def _sbs_data(dev):
+    g = torch.Generator().manual_seed(23)
+    return torch.rand(1, 8, 9, 9, 2, generator=g).to(dev), torch.randint(0, 10, (8,), generator=g).to(dev)
+
+
+def _sbs_model(dev):
+    from tests.sbs_classifier import ConvSBSClassifier
+
+    torch.manual_seed(5)
+    m = ConvSBSClassifier(bond=4).to(dev)
+    m.scales = [2.0, 3.0, 4.0]   # fixed (not calibrated per rank: both ranks and the single process must agree)
+    return m
+
+
+def _sbs_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+    from dctn_amd.logmatmulexp import logmatmulexp_fold
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("gloo")
+    model = _sbs_model(dev)
+    if rank != 0:                              # deliberately different initial parameters: rank 0's are broadcast
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p))
+    ddp.broadcast_parameters(model.parameters())
+    x, y = _sbs_data(dev)
+    xs, ys = ddp.shard_batch(x, rank, world), y[rank * 4 : rank * 4 + 4]
+    red = ddp.FlatGradAllReducer(model.parameters(), average=False)
+    # eager step and a HIP-graph replay of forward + backward, each followed by the all-reduce of the gradients
+    torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum").backward()
+    red()
+    eager = [p.grad.detach().clone() for p in model.parameters()]
+    # the gradients of ONE string sit back to back (the backward's flat buffer): a per-string reducer all-reduces in place
+    s0 = model.layers[0].strings[0]
+    red0 = ddp.FlatGradAllReducer(s0.parameters(), average=False)
+    assert red0._contiguous_flat([p.grad for p in s0.parameters()]) is not None
+
+    def fwd_bwd():
+        for p in model.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(model(xs), ys, reduction="sum").backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd_bwd()
+    g.replay()
+    red()
+    torch.cuda.synchronize(dev)
+    for p, e in zip(model.parameters(), eager):
+        assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6 * float(e.abs().max()))
+    # the logmatmulexp fold shards by windows with nothing to exchange: each rank folds its half
+    gm = torch.Generator().manual_seed(3)
+    mats = torch.randn(64, 9, 16, 16, generator=gm).to(dev)
+    mine = logmatmulexp_fold(mats[rank * 32 : rank * 32 + 32])
+    q.put((rank, [e.cpu().numpy() for e in eager], mine.cpu().numpy()))   # by value: the worker may exit before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_convsbs_classifier_and_fold_two_ranks_on_one_gpu():
+    """BASELINE configs[3] / [4] data-parallel: the reference's three-layer ConvSBS classifier (mnist.py:169-284) on two
+    ranks sharing one MI355X (gloo): broadcast parameters, per-rank shard, all-reduced gradients = the single-process
+    gradients of the whole batch; the window-sharded logmatmulexp fold = the single-process fold."""
+    from dctn_amd.logmatmulexp import logmatmulexp_fold
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sbs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (g, f) for r, g, f in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    dev = torch.device("cuda", 0)
+    model = _sbs_model(dev)
+    x, y = _sbs_data(dev)
+    torch.nn.functional.cross_entropy(model(x), y, reduction="sum").backward()
+    for a, b, p in zip(got[0][0], got[1][0], model.parameters()):
+        a, b = torch.from_numpy(a), torch.from_numpy(b)
+        assert torch.equal(a, b)
+        ref = p.grad.cpu()
+        assert torch.allclose(a, ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max())), "ranks vs single process"
+    gm = torch.Generator().manual_seed(3)
+    mats = torch.randn(64, 9, 16, 16, generator=gm).to(dev)
+    whole = logmatmulexp_fold(mats).cpu()
+    assert torch.allclose(torch.cat([torch.from_numpy(got[0][1]), torch.from_numpy(got[1][1])]), whole, rtol=1e-5, atol=1e-5)

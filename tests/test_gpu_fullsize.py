@@ -64,7 +64,7 @@ def test_cfg1_full_batch_64_f64():
     def grads(lo, hi):
         c, xs = core.clone().requires_grad_(True), x[:, lo:hi].clone().requires_grad_(True)
         eps(c, xs).backward(dy[lo:hi])
-        assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves"
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves_savedz"   # the forward kept P0, P1 and Z
         return c.grad.cpu(), xs.grad.cpu()
 
     dc_whole, dx_whole = grads(0, 64)

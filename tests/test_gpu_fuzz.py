@@ -6,9 +6,9 @@ import pytest
 import torch
 
 import dctn_amd
-from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization
+from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization, matrix_core_sweep
 from dctn_amd.conv_sbs_spec import SBSSpecCore, SBSSpecString
-from dctn_amd.eps import eps
+from dctn_amd.eps import eps, keep_gemm_result
 from dctn_amd.logmatmulexp import logmatmulexp, logmatmulexp_batched, logmatmulexp_fold
 from dctn_amd.pos2d import Pos2D
 from oracle import ref_cpu as R
@@ -127,8 +127,16 @@ F64_CASES = [(1, 3, 2, 4, 5, 9, 8, False), (2, 2, 3, 3, 3, 7, 9, True), (1, 2, 8
              (1, 4, 2, 2, 2, 10, 9, False), (3, 2, 2, 6, 3, 8, 5, True), (1, 3, 3, 1, 2, 8, 9, False)]
 
 
+@pytest.mark.parametrize("keep", [True, False], ids=["savedz", "recompute"])
 @pytest.mark.parametrize("case", F64_CASES, ids=lambda c: "C%dK%dQ%dO%dB%d_%dx%d%s" % (c[:7] + ("_strided" if c[7] else "",)))
-def test_eps_f64_matrix_core_path(case):
+def test_eps_f64_matrix_core_path(case, keep):
+    """keep: the training forward leaves both Khatri-Rao halves and the GEMM result for the backward
+    (`dctn_eps_fwd_save` / `dctn_eps_bwd_saved`), or the backward rebuilds them."""
+    with keep_gemm_result(keep):
+        _eps_f64_matrix_core_path(case, "_saving" if keep else "", "_savedz" if keep else "")
+
+
+def _eps_f64_matrix_core_path(case, fsuf, bsuf):
     C, K, Q, O, B, H, W, strided = case
     torch.manual_seed(sum(case[:7]))
     N = K * K * C
@@ -140,12 +148,12 @@ def test_eps_f64_matrix_core_path(case):
     xd = xd.requires_grad_(True)
     cd = core.to(DEV).requires_grad_(True)
     y = eps(cd, xd)
-    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f64_halves"
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f64_halves" + fsuf
     want = R.eps_4step(core, x)
     check(y, want, torch.float64, "forward")
     dy = torch.randn(*want.shape, dtype=torch.float64)
     y.backward(dy.to(DEV))
-    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves"
+    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f64_halves" + bsuf
     dcore, dx = R.grads(R.eps_4step, [core, x], dy)
     check(xd.grad, dx, torch.float64, "dX")
     check(cd.grad, dcore, torch.float64, "dCore")
@@ -201,8 +209,14 @@ F32_HALVES_CASES = [(2, 2, 3, 3, 3, 7, 9, True), (1, 2, 5, 4, 4, 8, 8, False), (
 
 
 @pytest.mark.parametrize("case", F32_HALVES_CASES, ids=lambda c: "C%dK%dQ%dO%dB%d_%dx%d%s" % (c[:7] + ("_strided" if c[7] else "",)))
+@pytest.mark.parametrize("keep", [True, False], ids=["savedz", "recompute"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_eps_f32_halves_path_for_odd_q(case, dtype):
+def test_eps_f32_halves_path_for_odd_q(case, dtype, keep):
+    with keep_gemm_result(keep):
+        _eps_f32_halves_path_for_odd_q(case, dtype, "_saving" if keep else "", "_savedz" if keep else "")
+
+
+def _eps_f32_halves_path_for_odd_q(case, dtype, fsuf, bsuf):
     C, K, Q, O, B, H, W, strided = case
     torch.manual_seed(sum(case[:7]) + 1)
     N = K * K * C
@@ -214,12 +228,12 @@ def test_eps_f32_halves_path_for_odd_q(case, dtype):
     xd = xd.requires_grad_(True)
     cd = core.to(DEV).requires_grad_(True)
     y = eps(cd, xd)
-    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f32_halves" and y.dtype == dtype   # bf16: storage only
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_f32_halves" + fsuf and y.dtype == dtype   # bf16: storage only
     want = R.eps_4step(core.double(), x.double())
     check(y, want, dtype, "forward")
     dy = torch.randn(*want.shape).to(dtype)
     y.backward(dy.to(DEV))
-    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f32_halves"
+    assert dctn_amd.last_kernel() == "eps_bwd_mfma_f32_halves" + bsuf
     dcore, dx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
     check(xd.grad, dx, dtype, "dX")
     check(cd.grad, dcore, dtype, "dCore")
@@ -300,15 +314,21 @@ BIGCORE_XO_CASES = [(1, 2, 7, 7, 4, 2, 5), (1, 2, 6, 6, 2, 3, 6), (1, 2, 9, 9, 4
                     (1, 1, 5, 5, 8, 2, 3), (1, 2, 6, 6, 4, 2, 12), (1, 5, 11, 8, 2, 4, 3)]
 
 
+@pytest.mark.parametrize("keep", [True, False], ids=["savedz", "recompute"])
 @pytest.mark.parametrize("C,B,H,W,Q,K,O", BIGCORE_XO_CASES)
-def test_eps_bigcore_exact_out_size(C, B, H, W, Q, K, O):
+def test_eps_bigcore_exact_out_size(C, B, H, W, Q, K, O, keep):
+    with keep_gemm_result(keep):
+        _eps_bigcore_exact_out_size(C, B, H, W, Q, K, O, "_saving" if keep else "")
+
+
+def _eps_bigcore_exact_out_size(C, B, H, W, Q, K, O, fsuf):
     torch.manual_seed(C + 10 * B + 100 * H + Q + K + O)
     N = K * K * C
     core = torch.randn(*(Q,) * N, O) * Q ** (-N / 2) * 3
     x = torch.rand(C, B, H, W, Q) + 0.1
     cd, xd = core.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
     y = eps(cd, xd)
-    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32_saving"   # x needs a gradient: the GEMM result is kept
+    assert dctn_amd.last_kernel() == "eps_fwd_mfma_bigcore_f32" + fsuf   # x needs a gradient: the GEMM result can be kept
     want = R.eps_4step(core.double(), x.double())
     check(y, want, torch.float32, "forward")
     dy = torch.randn(y.shape)
@@ -390,9 +410,33 @@ def sbs_mfma_cases():
     return cases
 
 
+def sbs_reg_family_takes(pos, bonds, outs, C, q):
+    """Strings the register-resident small-bond sweep (convsbs_reg.hip) takes by default: float32 open chains of at most
+    9 cores, every bond <= 4, at most one two-valued core, q^C <= 4."""
+    prod = 1
+    for o in outs:
+        prod *= o
+    return (len(pos) <= 9 and bonds[0] == 1 and 2 <= max(bonds) <= 4 and all(o in (1, 2) for o in outs) and prod <= 2
+            and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2)))
+
+
+@pytest.mark.parametrize("family", ["default", "matrix_cores"])
 @pytest.mark.parametrize("case", sbs_mfma_cases(), ids=lambda c: "n%d_r%d_o%s_C%dq%d" % (
     len(c[0]), c[1][1], "".join(map(str, c[2])), c[3], c[4]))
-def test_convsbs_mfma_family_random(case):
+def test_convsbs_mfma_family_random(case, family):
+    """family: small-bond strings run on the register-resident sweep by default; `matrix_core_sweep()` sends them to the
+    matrix-core sweep, so both families meet the oracle on the same strings."""
+    reg = sbs_reg_family_takes(*case)
+    if family == "matrix_cores":
+        if not reg:
+            pytest.skip("the default already is the matrix-core sweep")
+        with matrix_core_sweep():
+            _convsbs_family_case(case, "mfma")
+    else:
+        _convsbs_family_case(case, "reg" if reg else "mfma")
+
+
+def _convsbs_family_case(case, fam):
     pos, bonds, outs, C, q = case
     torch.manual_seed(len(pos) * 10 + bonds[1])
     spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
@@ -400,13 +444,13 @@ def test_convsbs_mfma_family_random(case):
     B, H, W = 3, spec.max_height_pos + 6, spec.max_width_pos + 7      # 126 windows: three full groups and a ragged one
     x = torch.randn(C, B, H, W, q, device=DEV, requires_grad=True)
     y = m(x)
-    assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, list(pos), x.detach().cpu().double())
     check(y, want, torch.float32, "forward")
     dy = torch.randn_like(y)
     y.backward(dy)
-    assert dctn_amd.last_kernel() == "convsbs_bwd_mfma_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_bwd_{fam}_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     check(x.grad, gr[0], torch.float32, "dX")
     for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
@@ -420,3 +464,65 @@ def test_convsbs_mfma_family_random(case):
     x.grad = None
     m(x).backward(dy)
     assert all(torch.equal(a, c.grad) for a, c in zip(g1, m.cores))
+
+
+# ------------------------------------------------------------------ register-resident small-bond sweep (convsbs_reg.hip)
+SNAKE9 = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
+REG_CASES = [
+    # (positions, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided)
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 5, 32, 32, True, True, False),    # cfg4 geometry (2 bands of 16 rows at B = 128; six bands with halo rows here)
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 130, 20, 20, True, True, False),  # B * bands >= 256: two bands per image
+    (SNAKE9, (1, 2, 3, 4, 4, 3, 2, 4, 2), (1,) * 9, 1, 2, 3, 9, 40, True, True, False),            # unequal bonds, one output, wide image
+    (SNAKE9, (1,) + (2,) * 8, (2, 1, 1, 1, 1, 1, 1, 1, 1), 2, 2, 4, 8, 9, True, True, True),       # bond 2, two channels, two-valued FIRST core, strided x
+    (SNAKE9, (1,) + (3,) * 8, (1, 1, 1, 1, 1, 1, 1, 1, 2), 1, 4, 2, 7, 7, True, True, False),      # q = 4, two-valued LAST core
+    (((0, 0), (0, 1), (1, 1), (1, 0)), (1, 4, 4, 4), (1, 2, 1, 1), 1, 3, 6, 6, 5, True, True, False),   # 2 x 2 window, 4 cores
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 2, 2, 3, 10, 10, False, True, False),   # x without gradient
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 2, 3, 10, 10, True, False, False),   # cores without gradient
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 2, 6, 300, True, True, False),    # more windows per band than lanes in a workgroup
+]
+
+
+@pytest.mark.parametrize("case", REG_CASES, ids=lambda c: "n%d_b%s_o%s_C%dq%d_B%d_%dx%d%s%s%s" % (
+    len(c[0]), max(c[1]), "".join(map(str, c[2])), c[3], c[4], c[5], c[6], c[7], "" if c[8] else "_nodx", "" if c[9] else "_nodcore",
+    "_strided" if c[10] else ""))
+def test_convsbs_reg_family_shapes(case):
+    """Lane = window, chain state and every core's input state in registers, dX written by the kernel that owns the
+    band of pixel rows, dCore through per-workgroup records: bands, halo rows, ragged waves, looping lanes, unequal
+    bonds, both channel modes - against the oracle, and bit-reproducible."""
+    pos, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided = case
+    assert sbs_reg_family_takes(pos, bonds, outs, C, q)
+    torch.manual_seed(B + H + W)
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
+    m = ConvSBS(spec, DumbNormalInitialization((q ** C * max(bonds)) ** -0.5 * 1.2)).to(DEV)
+    for c in m.cores:
+        c.requires_grad_(core_grad)
+    x0 = torch.randn(C, B, H, W, q)
+    x = x0.to(DEV)
+    if strided:
+        x = x.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    x.requires_grad_(x_grad)
+    y = m(x)
+    assert dctn_amd.last_kernel() == "convsbs_fwd_reg_f32"
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, list(pos), x0.double())
+    check(y, want, torch.float32, "forward")
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert dctn_amd.last_kernel() == "convsbs_bwd_reg_f32"
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x0.double()] + cores64, dy.cpu().double())
+    if x_grad:
+        check(x.grad, gr[0], torch.float32, "dX")
+    else:
+        assert x.grad is None
+    for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
+        if core_grad:
+            check(c.grad, gc, torch.float32, f"dCore{i}")
+        else:
+            assert c.grad is None
+    first = ([c.grad.clone() for c in m.cores] if core_grad else []) + ([x.grad.clone()] if x_grad else [])
+    for c in m.cores:
+        c.grad = None
+    x.grad = None
+    m(x).backward(dy)
+    again = ([c.grad for c in m.cores] if core_grad else []) + ([x.grad] if x_grad else [])
+    assert all(torch.equal(a, b) for a, b in zip(first, again))

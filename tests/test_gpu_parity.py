@@ -17,7 +17,7 @@ import dctn_amd
 from dctn_amd import _lib
 from dctn_amd.conv_sbs import ConvSBS, DumbNormalInitialization, ManyConvSBS
 from dctn_amd.conv_sbs_spec import SBSSpecCore, SBSSpecString
-from dctn_amd.eps import eps, eps_one_by_one, transform_in_slices
+from dctn_amd.eps import eps, eps_one_by_one, keep_gemm_result, transform_in_slices
 from dctn_amd.epses_composition import contract_with_input
 from dctn_amd.logmatmulexp import logmatmulexp, logmatmulexp_batched, logmatmulexp_fold, logmatmulexp_lowmem
 from dctn_amd.pos2d import Pos2D
@@ -248,6 +248,18 @@ def test_conversion_all_24_permutations():  # reference test: tests/test_convers
         assert torch.allclose(ye, ys)
         ye.backward(dy)
         assert torch.allclose(x.grad, g_sbs)
+        # ... and neither side is only checked against the other HIP path: the oracle's own `as_eps`, forward and input
+        # gradient (oracle/ref_cpu.py: dctn/conv_sbs.py:226-304 restated) for every one of the 24 orders
+        cores64 = [c.detach().cpu() for c in m.cores]
+        pos = [(c.position.h, c.position.w) for c in perm]
+        want_eps = R.convsbs_as_eps(cores64, pos)
+        assert close(eps_tensor, want_eps, torch.float64)
+        xc = x.detach().cpu().requires_grad_(True)
+        want_y = R.convsbs_forward(cores64, pos, xc)
+        want_y.backward(dy.cpu())
+        assert close(ys, want_y.detach(), torch.float64) and close(ye, want_y.detach(), torch.float64)
+        assert close(g_sbs, xc.grad, torch.float64) and close(x.grad, xc.grad, torch.float64)
+        assert close(R.eps_4step(want_eps, x.detach().cpu()), want_y.detach(), torch.float64)   # the oracle agrees with itself
 
 
 @pytest.mark.parametrize("r,q,C,B,HW", [(4, 3, 1, 3, 12), (8, 3, 1, 2, 10), (16, 3, 1, 2, 8), (16, 2, 2, 2, 7)])
@@ -261,13 +273,14 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
     m = many.strings[0].to(DEV)
     x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
     (y,) = many(x)
-    assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32"   # register-resident MFMA sweep
+    fam = "reg" if r <= 4 else "mfma"   # bond <= 4: lane-per-window register sweep; above: the matrix-core sweep
+    assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, snake, x.detach().cpu().double())
     assert close(y, want, torch.float32)
     dy = torch.randn_like(y)
     y.backward(dy)
-    assert dctn_amd.last_kernel() == "convsbs_bwd_mfma_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_bwd_{fam}_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, snake, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     assert close(x.grad, gr[0], torch.float32)
     for c, gc in zip(m.cores, gr[1:]):
@@ -276,33 +289,37 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
 
 def test_convsbs_forward_reports_whether_it_wrote_the_saved_states():
     """`dctn_convsbs_fwd` returns DCTN_SAVED only when the matrix-core sweep wrote the forward states; a string the size
-    query accepts but the sweep's LDS plan declines (bond 16, 25 cores) runs the generic forward, the buffer stays
+    query accepts but the sweep's LDS plan declines (bond 16, long strings) runs the generic forward, the buffer stays
     uninitialised and must never reach `dctn_convsbs_bwd_saved` - checked with a poisoned allocator and the oracle."""
     lib = _lib.lib()
-    for side, r, expect in ((3, 8, _lib.SAVED), (5, 16, 0)):
-        pos = [(h, w if h % 2 == 0 else side - 1 - w) for h in range(side) for w in range(side)]   # boustrophedon snake
+    seen = set()
+    for rows, cols, r, q in ((3, 3, 8, 2), (5, 5, 16, 2), (4, 6, 16, 2)):
+        pos = [(h, w if h % 2 == 0 else cols - 1 - w) for h in range(rows) for w in range(cols)]   # boustrophedon snake
         n = len(pos)
         torch.manual_seed(n)
         outs = tuple(2 if i == n // 2 else 1 for i in range(n))
-        spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), (1,) + (r,) * (n - 1), 1, 2)
-        m = ConvSBS(spec, DumbNormalInitialization((2 * r) ** -0.5 * 1.3)).to(DEV)
-        B, HW = 2, side + 3
-        x = torch.randn(1, B, HW, HW, 2, device=DEV, requires_grad=True)
-        plan_args = (n, _lib.int_array(outs), _lib.int_array(spec.bond_sizes), 1, B, HW, HW, 2,
+        spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), (1,) + (r,) * (n - 1), 1, q)
+        m = ConvSBS(spec, DumbNormalInitialization((q * r) ** -0.5 * 1.3)).to(DEV)
+        B, HW = 2, max(rows, cols) + 3
+        x = torch.randn(1, B, HW, HW, q, device=DEV, requires_grad=True)
+        plan_args = (n, _lib.int_array(outs), _lib.int_array(spec.bond_sizes), 1, B, HW, HW, q,
                      _lib.int_array([p[0] for p in pos]), _lib.int_array([p[1] for p in pos]), _lib.F32)
         nstates = lib.dctn_convsbs_saved_states_bytes(*plan_args)
         assert nstates > 0
         # raw call: the return code says whether the buffer was written
         cores_c = [c.detach().contiguous() for c in m.cores]
         states = torch.full((nstates,), 0xFF, dtype=torch.uint8, device=DEV)
-        out = torch.empty(B, HW - side + 1, HW - side + 1, 2, device=DEV)
+        out = torch.empty(B, HW - rows + 1, HW - cols + 1, 2, device=DEV)
         rc = lib.dctn_convsbs_fwd(x.data_ptr(), _lib.strides5(x), _lib.ptr_array(cores_c), out.data_ptr(), n, plan_args[1],
-                                  plan_args[2], plan_args[8], plan_args[9], 1, B, HW, HW, 2, states.data_ptr(), states.numel(),
+                                  plan_args[2], plan_args[8], plan_args[9], 1, B, HW, HW, q, states.data_ptr(), states.numel(),
                                   _lib.F32, _lib.stream_ptr(DEV))
         torch.cuda.synchronize()
-        assert rc == expect, (side, r, rc)
-        if rc != _lib.SAVED:
-            assert bool((states == 0xFF).all())   # untouched
+        assert rc in (0, _lib.SAVED), (rows, cols, r, rc)
+        seen.add(rc)
+        if rc == _lib.SAVED:
+            assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32" and not bool((states == 0xFF).all())
+        else:
+            assert dctn_amd.last_kernel() == "convsbs_fwd_generic" and bool((states == 0xFF).all())   # untouched
         del states
         torch.empty(nstates + (1 << 20), dtype=torch.uint8, device=DEV).fill_(0xFF)   # poison what the module allocates next
         y = m(x)
@@ -315,6 +332,7 @@ def test_convsbs_forward_reports_whether_it_wrote_the_saved_states():
         assert close(x.grad, gr[0], torch.float32)
         for c, gc in zip(m.cores, gr[1:]):
             assert close(c.grad, gc, torch.float32)
+    assert _lib.SAVED in seen   # (whether a string is declined depends on the LDS plan; the bond-8 snake always saves)
 
 
 # ------------------------------------------------------------------ logmatmulexp
@@ -629,7 +647,7 @@ def test_eps_f32_large_core_under_the_bf16_policy():
     dctn_amd.set_float32_matmul_precision("bf16")
     try:
         y2 = eps(cd, xd)
-        assert y2.dtype == torch.float32 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves"
+        assert y2.dtype == torch.float32 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves_saving"
         # the policy's definition: the OPERANDS are rounded to bf16 (16 factors of 2^-9 each on a window product), so
         # the oracle is evaluated on the rounded operands; against the unrounded ones only the gross bound holds
         cb, xb = core.bfloat16().double(), x.bfloat16().double()
@@ -645,9 +663,16 @@ def test_eps_f32_large_core_under_the_bf16_policy():
     assert float((y.detach().cpu().double() - want).abs().max()) < 3e-4 * float(want.abs().max())
 
 
-def test_eps_bf16_large_core_runs_on_the_matrix_cores():
+@pytest.mark.parametrize("keep", [True, False], ids=["savedz", "recompute"])
+def test_eps_bf16_large_core_runs_on_the_matrix_cores(keep):
     """bf16 tensors with a core outside the bf16 register family (a deeper / wider layer): two-halves GEMMs on
-    v_mfma_f32_16x16x32_bf16 (bf16 P0 / P1 / T, float32 accumulate) — not the generic kernels."""
+    v_mfma_f32_16x16x32_bf16 (bf16 P0 / P1 / T, float32 accumulate) — not the generic kernels.  keep: the training forward
+    leaves P0, P1 and Z' (bf16) for the backward, whose dP1 is then one pass over Z' instead of a GEMM."""
+    with keep_gemm_result(keep):
+        _eps_bf16_large_core(("_saving", "_savedz") if keep else ("", ""))
+
+
+def _eps_bf16_large_core(suf):
     torch.manual_seed(31)
     # halves of 256 x 256, 256 x 1024 (odd O) and 64 x 64 (a 128-column tile spans two outputs; 5 outputs)
     for (C, B, H, W, Q, K, O) in ((1, 5, 9, 8, 2, 4, 4), (1, 3, 7, 7, 4, 3, 6), (1, 7, 9, 10, 8, 2, 5)):
@@ -656,12 +681,12 @@ def test_eps_bf16_large_core_runs_on_the_matrix_cores():
         core = (torch.randn(*(Q,) * N, O) * Q ** (-N / 4)).to(torch.bfloat16)
         xd, cd = x.to(DEV).requires_grad_(True), core.to(DEV).requires_grad_(True)
         y = eps(cd, xd)
-        assert y.dtype == torch.bfloat16 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves"
+        assert y.dtype == torch.bfloat16 and dctn_amd.last_kernel() == "eps_fwd_mfma_bf16_halves" + suf[0]
         want = R.eps_4step(core.double(), x.double())
         assert bf16_close(y, want)
         dy = torch.randn(*want.shape).to(torch.bfloat16)
         y.backward(dy.to(DEV))
-        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bf16_halves"
+        assert dctn_amd.last_kernel() == "eps_bwd_mfma_bf16_halves" + suf[1]
         assert xd.grad.dtype == torch.bfloat16 and cd.grad.dtype == torch.bfloat16
         gc, gx = R.grads(R.eps_4step, [core.double(), x.double()], dy.double())
         assert bf16_close(cd.grad, gc) and bf16_close(xd.grad, gx)
@@ -686,16 +711,54 @@ def test_linear_head_vs_torch_reference(B, F, C):
     assert bf16_close(out, want.detach())
     g = torch.randn(B, C).bfloat16()
     want.backward(g.double())
-    for mode in ("blas", "hip"):  # library-GEMM backward (default) and the HIP backward kernels
+    for mode in ("blas", "hip"):  # library-GEMM backward and the HIP backward kernels (the default)
         import dctn_amd.eps_plus_linear as EPL
+        assert EPL.HEAD_BWD == "hip"
         EPL.HEAD_BWD = mode
         try:
             for t in (fd, wd, bd):
                 t.grad = None
             _LinearHeadFunction.apply(fd, wd, bd).backward(g.to(DEV))
+            if mode == "hip":
+                assert dctn_amd.last_kernel() == "linear_head_bwd"
         finally:
-            EPL.HEAD_BWD = "blas"
+            EPL.HEAD_BWD = "hip"
         assert bf16_close(fd.grad, f64.grad) and bf16_close(wd.grad, w64.grad) and bf16_close(bd.grad, b64.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("B,F,C", [(128, 3174, 10), (37, 201, 10), (5, 7, 3), (1, 64, 16), (70, 1000, 1)])
+def test_linear_head_scalar_kernels_any_dtype_any_feature_count(B, F, C, dtype):
+    """float32 / float64 heads (the reference's own arithmetic) and feature counts that are not multiples of 8 (cfg3a:
+    23 x 23 x 6 = 3174) on the scalar streaming kernels - no library GEMM on the path; needs_input_grad honoured."""
+    from dctn_amd.eps_plus_linear import _LinearHeadFunction
+
+    torch.manual_seed(B + F + C)
+    feat = torch.randn(B, F).to(dtype)
+    w = (torch.randn(C, F) / F**0.5).to(dtype)
+    bias = torch.randn(C).to(dtype)
+    fd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (feat, w, bias))
+    assert _LinearHeadFunction.supported(fd, wd, bd)
+    out = _LinearHeadFunction.apply(fd, wd, bd)
+    assert dctn_amd.last_kernel() == ("linear_head_fwd_mfma" if dtype == torch.bfloat16 and F % 8 == 0 else "linear_head_fwd_generic")
+    f64, w64, b64 = (t.double().requires_grad_(True) for t in (feat, w, bias))
+    want = torch.nn.functional.linear(f64, w64, b64)
+    g = torch.randn(B, C).to(dtype)
+    want.backward(g.double())
+    out.backward(g.to(DEV))
+    assert dctn_amd.last_kernel() in ("linear_head_bwd_generic", "linear_head_bwd")
+    pairs = ((out, want.detach()), (fd.grad, f64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad))
+    if dtype == torch.bfloat16:
+        assert all(bf16_close(a, b) for a, b in pairs)
+    else:
+        assert all(close(a, b, dtype) for a, b in pairs)
+    # only dWeight / dBias (a frozen earlier layer), only dFeat (a frozen head)
+    f2, w2, b2 = fd.detach().clone(), wd.detach().clone().requires_grad_(True), bd.detach().clone().requires_grad_(True)
+    _LinearHeadFunction.apply(f2, w2, b2).backward(g.to(DEV))
+    assert f2.grad is None and torch.equal(w2.grad, wd.grad) and torch.equal(b2.grad, bd.grad)
+    f3 = fd.detach().clone().requires_grad_(True)
+    _LinearHeadFunction.apply(f3, wd.detach(), bd.detach()).backward(g.to(DEV))
+    assert torch.equal(f3.grad, fd.grad)
 
 
 @pytest.mark.parametrize("K,O,size,B", [(3, 4, 28, 5), (3, 4, 8, 19), (3, 2, 12, 9), (3, 4, 40, 3)])

@@ -402,3 +402,18 @@ def test_allreduce_capture_probe_says_no_without_a_gpu():
 
     assert ddp.probe_allreduce_capture(timeout=120.0) is False
     assert ddp.all_ranks_agree(True) is True and ddp.all_ranks_agree(False) is False
+
+
+def test_eps_plus_linear_model_is_picklable_and_refreshes_p_on_load():
+    """The dropout gate's host copy of `p` is refreshed by a module-level load_state_dict hook (a lambda stored on the
+    module made `torch.save(model)` / spawn arguments fail)."""
+    import pickle
+
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    m = EPSesPlusLinear(((2, 2),), UnitTheoreticalOutputStd(), 0.5, torch.device("cpu"), torch.float32, image_size=6)
+    m2 = pickle.loads(pickle.dumps(m))
+    sd = m.state_dict()
+    sd["p"] = torch.tensor(0.25)
+    m2.load_state_dict(sd)
+    assert m2._p_float == 0.25 and m._p_float == 0.5
