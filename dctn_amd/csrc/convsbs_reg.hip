@@ -28,6 +28,20 @@
 
 typedef __attribute__((ext_vector_type(2))) int sr_int2;
 
+// diagnostic build only (make EXTRA=-DDCTN_STAMPS, tools/stamp_sbs_reg.py): wave 0 of every workgroup leaves the
+// s_memtime value of each phase boundary behind the dCore records in the workspace (the public workspace query sizes
+// it for the matrix-core family too: tens of MB of room)
+#ifdef DCTN_STAMPS
+#define SR_STAMP(k)                                                                                         \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && p.part)                                                                         \
+      reinterpret_cast<long long*>(p.part + (((long long)p.coff[SU_NC] * p.nrec + 63) / 64 * 64))[blockIdx.x * 8 + (k)] = \
+          (long long)__builtin_readcyclecounter();                                                          \
+  } while (0)
+#else
+#define SR_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int SR_MAXC = 9;        // cores per string (compile-time unrolled backward: 9 = the 3 x 3 snake; shorter strings run too)
@@ -73,16 +87,65 @@ __device__ __forceinline__ void sr_fill_pack(float* pack, const SrP& p, int ncor
 
 // f[qq] of core c for the window at (b, ho, wo): product of the pixel's channel values, channel 0 most significant.
 // xr (two channels of two values): the raw values x_ch[qv] at xr[ch * 2 + qv]
+typedef float sr_v2 __attribute__((ext_vector_type(2)));
+typedef float sr_v3 __attribute__((ext_vector_type(3)));
+typedef float sr_v4 __attribute__((ext_vector_type(4)));
+typedef sr_v2 sr_v2u __attribute__((aligned(4)));   // dword-aligned multi-dword loads (one instruction per pixel)
+typedef sr_v3 sr_v3u __attribute__((aligned(4)));
+typedef sr_v4 sr_v4u __attribute__((aligned(4)));
+
+template <int Q>
+__device__ __forceinline__ void sr_load_pixel(const float* px, long long s4, float* f) {
+  if (s4 == 1) {   // the values of a pixel are contiguous (collate_quantum's layout): one load
+    if constexpr (Q == 2) { const sr_v2 t = *reinterpret_cast<const sr_v2u*>(px); f[0] = t[0]; f[1] = t[1]; }
+    else if constexpr (Q == 3) { const sr_v3 t = *reinterpret_cast<const sr_v3u*>(px); f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; }
+    else { const sr_v4 t = *reinterpret_cast<const sr_v4u*>(px); f[0] = t[0]; f[1] = t[1]; f[2] = t[2]; f[3] = t[3]; }
+  } else {
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) f[qq] = px[qq * s4];
+  }
+}
+
 template <int QC, bool TWOCH>
 __device__ __forceinline__ void sr_features(const SrP& p, int c, long long b, int ho, int wo, float* f, float* xr) {
   const float* px = p.x + b * p.xs[1] + (long long)(ho + p.ph[c]) * p.xs[2] + (long long)(wo + p.pw[c]) * p.xs[3];
   if constexpr (TWOCH) {
-    const float a0 = px[0], a1 = px[p.xs[4]], b0 = px[p.xs[0]], b1 = px[p.xs[0] + p.xs[4]];
-    xr[0] = a0; xr[1] = a1; xr[2] = b0; xr[3] = b1;
-    f[0] = a0 * b0; f[1] = a0 * b1; f[2] = a1 * b0; f[3] = a1 * b1;
+    sr_load_pixel<2>(px, p.xs[4], xr);
+    sr_load_pixel<2>(px + p.xs[0], p.xs[4], xr + 2);
+    f[0] = xr[0] * xr[2]; f[1] = xr[0] * xr[3]; f[2] = xr[1] * xr[2]; f[3] = xr[1] * xr[3];
   } else {
+    sr_load_pixel<QC>(px, p.xs[4], f);
+  }
+}
+
+// dX of a band of pixel rows from the per-window feature gradients in LDS: a thread takes a pixel (all its q values),
+// sums the windows that cover it in core order (fixed order, no atomics) and writes it once.
+template <int NCT, int Q>
+__device__ __forceinline__ void sr_write_dx_band(const SrP& p, const float* dfl, int ncores, int img, int r0, int r1, int wr0,
+                                                 int tid, int nthreads) {
+  const int nrows = r1 - r0, Cq = p.C * Q, NCq = ncores * Cq;
+  const int npix = p.C * nrows * p.W;
+  for (int e = tid; e < npix; e += nthreads) {
+    const int ch = e / (nrows * p.W), r2 = e - ch * nrows * p.W;
+    const int hr = r2 / p.W, wc = r2 - hr * p.W;
+    const int hp = r0 + hr;
+    float acc[Q];
 #pragma unroll
-    for (int qq = 0; qq < QC; ++qq) f[qq] = px[qq * p.xs[4]];
+    for (int qv = 0; qv < Q; ++qv) acc[qv] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      if (c < ncores) {
+        const int ho = hp - p.ph[c], wo = wc - p.pw[c];
+        if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo) {
+          const float* d = dfl + (size_t)((ho - wr0) * p.Wo + wo) * NCq + (c * p.C + ch) * Q;
+#pragma unroll
+          for (int qv = 0; qv < Q; ++qv) acc[qv] += d[qv];
+        }
+      }
+    }
+    float* dst = p.dX + ((((long long)ch * p.B + img) * p.H + hp) * p.W + wc) * Q;
+#pragma unroll
+    for (int qv = 0; qv < Q; ++qv) dst[qv] = acc[qv];
   }
 }
 
@@ -210,7 +273,7 @@ __device__ __forceinline__ void sr_row_sum4(float& a, float& b, float& c, float&
 // multiple of 16: four row-sum groups of four): after the two halving levels row rho (= lane / 16) holds the entries
 // [rho * EP/4, (rho + 1) * EP/4).
 template <int E>
-__device__ __forceinline__ void sr_wave_reduce_add(const float* prod, float* wacc, int lane) {
+__device__ __forceinline__ void sr_wave_reduce_add(const float* prod, float* wacc, int lane, bool first) {
   constexpr int EP = (E + 15) / 16 * 16;
   float t[EP / 2];
 #pragma unroll
@@ -227,9 +290,15 @@ __device__ __forceinline__ void sr_wave_reduce_add(const float* prod, float* wac
     // this lane's entries: half h = lane / 32 took [h EP/2, (h+1) EP/2) at the first level, row parity the lower / upper
     // quarter of that at the second
     const int e0 = (lane >> 5) * (EP / 2) + ((lane >> 4) & 1) * (EP / 4);
+    if (first) {   // the wave's first window group: a plain store (no LDS read to wait for)
 #pragma unroll
-    for (int j = 0; j < EP / 4; ++j)
-      if (e0 + j < E) wacc[e0 + j] += u[j];
+      for (int j = 0; j < EP / 4; ++j)
+        if (e0 + j < E) wacc[e0 + j] = u[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < EP / 4; ++j)
+        if (e0 + j < E) wacc[e0 + j] += u[j];
+    }
   }
 }
 
@@ -365,7 +434,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_reg_k(SrP p) {
               dF[qq] = fmaf(vg[l][r], pks[(l * R + r) * QC + qq], dF[qq]);
               prod[(l * R + r) * QC + qq] = vg[l][r] * fo[qq];
             }
-        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wacc + wave * PK + c * PKC + SL * E, lane);
+        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wacc + wave * PK + c * PKC + SL * E, lane, base == wave * 64);
       };
       slice(std::integral_constant<int, 0>{});
       if (oc == 2) slice(std::integral_constant<int, 1>{});
@@ -390,24 +459,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_reg_k(SrP p) {
   __syncthreads();
 
   // ---- dX of the band: every pixel value sums the windows that cover it, in core order (fixed order, no atomics)
-  if (p.dX != nullptr) {
-    const int nrows = r1 - r0;
-    const int total = p.C * nrows * p.W * p.q;
-    for (int e = tid; e < total; e += SR_BWD_THREADS) {
-      int t = e;
-      const int qv = t % p.q; t /= p.q;
-      const int wc = t % p.W; t /= p.W;
-      const int hr = t % nrows;
-      const int ch = t / nrows;
-      const int hp = r0 + hr;
-      float acc = 0.f;
-      for (int c = 0; c < p.n; ++c) {
-        const int ho = hp - p.ph[c], wo = wc - p.pw[c];
-        if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo) acc += dfl[(size_t)((ho - wr0) * p.Wo + wo) * NCq + (c * p.C + ch) * p.q + qv];
-      }
-      p.dX[((((long long)ch * p.B + img) * p.H + hp) * p.W + wc) * p.q + qv] = acc;
-    }
-  }
+  if (p.dX != nullptr) sr_write_dx_band<NC, (TWOCH ? 2 : QC)>(p, dfl, p.n, img, r0, r1, wr0, tid, SR_BWD_THREADS);
   // ---- this workgroup's dCore record (entry-major: the tail kernel reads a row of records coalesced)
   if (p.part != nullptr) {
     for (int e = tid; e < PK; e += SR_BWD_THREADS) {
@@ -610,8 +662,10 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
   const int wr0 = max(0, r0 - p.max_h), wr1 = min(p.Ho, r1);
   const int nwin = wr1 > wr0 ? (wr1 - wr0) * p.Wo : 0;
   const bool want_dcore = p.part != nullptr;
+  SR_STAMP(0);
   for (int e = tid; e < NWAVES * tot; e += SR_BWD_THREADS) wacc[e] = 0.f;
   __syncthreads();
+  SR_STAMP(1);
   float* wa = wacc + wave * tot;
 
   for (int base = wave * 64; base < nwin; base += SR_BWD_THREADS) {
@@ -622,6 +676,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
     const int ho = wr0 + hrow, wo = ic - hrow * p.Wo;
     const long long w = ((long long)img * p.Ho + ho) * p.Wo + wo;
     const bool owner = valid && ho >= r0 && want_dcore;
+    const bool first = base == wave * 64;
 
     // ---- features of every core (all loads in flight together), dY
     float fs[NC][QC], xr[TWOCH ? NC : 1][4];
@@ -649,6 +704,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     rows_in[NC - 1] = rows;
+    SR_STAMP(2);
 
     auto store_df = [&](int c, const float* dF) {
       if (valid && p.dX != nullptr) {
@@ -707,7 +763,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
             dF[qq] = fmaf(vg[l], ks[l * QC + qq], dF[qq]);
             prod[l * QC + qq] = vg[l] * fo[qq];
           }
-        if (want_dcore) sr_wave_reduce_add<EE>(prod, wa + p.coff[c] + SL * EE, lane);
+        if (want_dcore) sr_wave_reduce_add<EE>(prod, wa + p.coff[c] + SL * EE, lane, first);
       };
       slice(std::integral_constant<int, 0>{});
       if (ol == 2) slice(std::integral_constant<int, 1>{});
@@ -774,7 +830,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
               dF[qq] = fmaf(vg[l][r], ks[(l * R + r) * QC + qq], dF[qq]);
               prod[(l * R + r) * QC + qq] = vg[l][r] * fo[qq];
             }
-        if (want_dcore) sr_wave_reduce_add<EM>(prod, wa + p.coff[c] + SL * EM, lane);
+        if (want_dcore) sr_wave_reduce_add<EM>(prod, wa + p.coff[c] + SL * EM, lane, first);
       };
       slice(std::integral_constant<int, 0>{});
       if (oc == 2) slice(std::integral_constant<int, 1>{});
@@ -801,35 +857,20 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
             dF[qq] = fmaf(G[SL][r], ks[r * QC + qq], dF[qq]);
             prod[r * QC + qq] = G[SL][r] * fo[qq];
           }
-        if (want_dcore) sr_wave_reduce_add<EE>(prod, wa + p.coff[0] + SL * EE, lane);
+        if (want_dcore) sr_wave_reduce_add<EE>(prod, wa + p.coff[0] + SL * EE, lane, first);
       };
       slice(std::integral_constant<int, 0>{});
       if (o0 == 2) slice(std::integral_constant<int, 1>{});
       store_df(0, dF);
     }
   }
+  SR_STAMP(3);
   __syncthreads();
+  SR_STAMP(4);
 
   // ---- dX of the band (fixed summation order)
-  if (p.dX != nullptr) {
-    const int nrows = r1 - r0;
-    const int total = p.C * nrows * p.W * p.q;
-    for (int e = tid; e < total; e += SR_BWD_THREADS) {
-      int t = e;
-      const int qv = t % p.q; t /= p.q;
-      const int wc = t % p.W; t /= p.W;
-      const int hr = t % nrows;
-      const int ch = t / nrows;
-      const int hp = r0 + hr;
-      float acc = 0.f;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int ho = hp - p.ph[c], wo = wc - p.pw[c];
-        if (ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo) acc += dfl[(size_t)((ho - wr0) * p.Wo + wo) * NCq + (c * p.C + ch) * p.q + qv];
-      }
-      p.dX[((((long long)ch * p.B + img) * p.H + hp) * p.W + wc) * p.q + qv] = acc;
-    }
-  }
+  if (p.dX != nullptr) sr_write_dx_band<NC, (TWOCH ? 2 : QC)>(p, dfl, NC, img, r0, r1, wr0, tid, SR_BWD_THREADS);
+  SR_STAMP(5);
   // ---- this workgroup's record: the flat dCore, entry-major
   if (want_dcore) {
     for (int e = tid; e < tot; e += SR_BWD_THREADS) {
@@ -839,6 +880,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
       p.part[(long long)e * p.nrec + blockIdx.x] = s2;
     }
   }
+  SR_STAMP(6);
 }
 
 // uniform strings: dCore[c][local] = sum over the records of entry coff[c] + local

@@ -515,7 +515,7 @@ def test_eps_f32_bigcore_vs_oracle(C, B, H, W, Q, K, O):
         (1, 4, 6, 7, 8, 2, 8),      # cfg3b layer 2: n1 = 2
         (2, 3, 6, 6, 2, 2, 16),     # two channels, sixteen Z rows per b
         (1, 3, 9, 9, 2, 3, 5),      # odd O: run-time row -> (b, o) walk
-        (1, 70, 6, 6, 4, 2, 2),     # two b per row quad, more windows than one workgroup's 64
+        (1, 70, 6, 6, 2, 3, 2),     # two b per row quad (N = 9: halves of 5 and 4 factors), more windows than one workgroup's 64
     ],
 )
 def test_eps_f32_bigcore_saved_gemm_result(C, B, H, W, Q, K, O):
