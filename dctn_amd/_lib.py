@@ -58,6 +58,8 @@ SIGNATURES = {
     "dctn_sgd_l2_step": (c_int, [c_void, c_void, c_void, c_void, c_i64, c_i64, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, c_int, c_int, c_void]),
     "dctn_window_stats": (c_int, [c_void, _I64x5, c_void] + [c_int] * 6 + [c_int, c_void]),
+    "dctn_phi_window_stats": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
+    "dctn_phi_expand": (c_int, [c_void, c_void, c_i64, ctypes.c_float, c_int, c_void]),
     "dctn_convsbs_workspace_bytes": (c_size, [c_int, _IntP, _IntP] + [c_int] * 5 + [_IntP, _IntP, c_int, c_int]),
     "dctn_convsbs_fwd": (c_int, [c_void, _I64x5, _PtrP, c_void, c_int, _IntP, _IntP, _IntP, _IntP]
                          + [c_int] * 5 + [c_void, c_size, c_int, c_void]),

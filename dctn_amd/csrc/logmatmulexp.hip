@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
 constexpr int LME_BWD_WAVES = 4;
 
 template <int LMAX>
-__global__ __launch_bounds__(64 * LME_BWD_WAVES) void lme_fold16_bwd_mfma_k(
+__device__ __forceinline__ void lme_fold16_bwd_body(
     const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
     int* __restrict__ flags, long long Wn, int L) {
   __shared__ __align__(16) float scratch[LME_BWD_WAVES][2][LME_TILE];
@@ -439,6 +439,17 @@ long long resident_blocks(const void* fn, int threads) {
   return (long long)per_cu * cus;
 }
 
+template <int LMAX>
+__global__ __launch_bounds__(64 * LME_BWD_WAVES) void lme_fold16_bwd_mfma_k(
+    const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
+    int* __restrict__ flags, long long Wn, int L) {
+  lme_fold16_bwd_body<LMAX>(mats, dOut, dMats, flags, Wn, L);
+}
+
+// (Round 3: the same body held to 128 registers with amdgpu_waves_per_eu(4, 4) - four waves per SIMD instead of three,
+// 14 spilled registers - measured SLOWER at L = 9: 3.93 against 3.37 ms for 692 224 windows.  The kernel's three pipes
+// are together ~100 % busy (vector 46 %, matrix 29 %, LDS 24 %: profiles/r02_sq_cfg5.json); the spill traffic costs
+// more than the fourth wave's overlap gains.)
 template <int LMAX>
 void fold16_bwd_launch(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, int L,
                        hipStream_t st) {

@@ -177,3 +177,97 @@ extern "C" int dctn_window_stats(const void* x, const int64_t x_strides[5], void
   dctn_set_last_kernel("window_stats");
   return DCTN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ feature map on the device
+// phi_cos_sin_squared_1 (dctn/dataset_loading.py:33-36): u -> (2 sin^2(pi u / 2), 2 cos^2(pi u / 2)), evaluated in
+// float32 like the reference evaluates it on its float32 images.
+__device__ __forceinline__ void phi_cs2(float u, float& a, float& b) {
+  float sn, cs;
+  sincosf(u * 1.57079632679489661923f, &sn, &cs);
+  a = 2.f * sn * sn;
+  b = 2.f * cs * cs;
+}
+
+// x[0, b, h, w, :] = scale * phi(images[b, h, w]): the (1, samples, h, w, 2) tensor of dataset_loading.py:63 written once,
+// in the model's dtype, with the scaling factor of new_runner.py's autoscale folded in (no float32 copy, no second pass)
+template <typename S>
+__global__ __launch_bounds__(256) void phi_expand_k(const float* __restrict__ img, S* __restrict__ x, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float a, b;
+    phi_cs2(img[i], a, b);
+    x[2 * i] = (S)(scale * a);
+    x[2 * i + 1] = (S)(scale * b);
+  }
+}
+
+// Window statistics straight from the raw images: one workgroup per image applies phi to every pixel ONCE (per-pixel
+// sum and sum of squares of the two features, float64, in LDS) and forms the K x K window products from there - neither
+// the expanded (1, N, H, W, 2) tensor nor the K*K stacked window copies of dataset_loading.py:79-94 exist.
+__global__ __launch_bounds__(256) void phi_window_stats_k(const float* __restrict__ img, double* __restrict__ sums, int H,
+                                                          int W, int K) {
+  extern __shared__ double pix[];   // [H*W][2]: t = a + b, u = a^2 + b^2
+  __shared__ double red[2][4];
+  const float* im = img + (long long)blockIdx.x * H * W;
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    float a, b;
+    phi_cs2(im[i], a, b);
+    pix[2 * i] = (double)a + (double)b;
+    pix[2 * i + 1] = (double)a * (double)a + (double)b * (double)b;
+  }
+  __syncthreads();
+  const int Ho = H - K + 1, Wo = W - K + 1;
+  double s_sum = 0.0, s_sq = 0.0;
+  for (int w = threadIdx.x; w < Ho * Wo; w += 256) {
+    const int ho = w / Wo, wo = w - ho * Wo;
+    double ps = 1.0, pq = 1.0;
+    for (int dh = 0; dh < K; ++dh)
+      for (int dw = 0; dw < K; ++dw) {
+        const int i = (ho + dh) * W + wo + dw;
+        ps *= pix[2 * i];
+        pq *= pix[2 * i + 1];
+      }
+    s_sum += ps;
+    s_sq += pq;
+  }
+  s_sum = wave_reduce_sum(s_sum);
+  s_sq = wave_reduce_sum(s_sq);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = s_sum; red[1][wv] = s_sq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&sums[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+extern "C" int dctn_phi_expand(const void* images, void* x, int64_t n_pixels, float scale, int dtype, void* stream) {
+  if (!images || !x) return DCTN_ERR_NULL;
+  if (n_pixels < 1) return DCTN_ERR_BAD_SHAPE;
+  long long blocks = (n_pixels + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const dim3 g((unsigned)blocks), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case DCTN_F32: hipLaunchKernelGGL(phi_expand_k<float>, g, b, 0, st, (const float*)images, (float*)x, (long long)n_pixels, scale); break;
+    case DCTN_F64: hipLaunchKernelGGL(phi_expand_k<double>, g, b, 0, st, (const float*)images, (double*)x, (long long)n_pixels, scale); break;
+    case DCTN_BF16: hipLaunchKernelGGL(phi_expand_k<bf16_t>, g, b, 0, st, (const float*)images, (bf16_t*)x, (long long)n_pixels, scale); break;
+    default: return DCTN_ERR_BAD_DTYPE;
+  }
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("phi_expand");
+  return DCTN_OK;
+}
+
+extern "C" int dctn_phi_window_stats(const void* images, void* sums, int B, int H, int W, int K, void* stream) {
+  if (!images || !sums) return DCTN_ERR_NULL;
+  if (B < 1 || K < 1 || H < K || W < K) return DCTN_ERR_BAD_SHAPE;
+  const size_t lds = (size_t)H * W * 2 * sizeof(double);
+  if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;   // (images beyond ~97 x 97: expand, then dctn_window_stats)
+  hipStream_t st = (hipStream_t)stream;
+  if (dctn_zero_async(sums, 2 * sizeof(double), st) != DCTN_OK) return DCTN_ERR_LAUNCH;
+  (void)hipFuncSetAttribute((const void*)phi_window_stats_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(phi_window_stats_k, dim3((unsigned)B), dim3(256), lds, st, (const float*)images, (double*)sums, H, W, K);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("phi_window_stats");
+  return DCTN_OK;
+}

@@ -73,3 +73,39 @@ def calc_scaling_factor(ds: Union[Tensor, object], kernel_size: int, device=None
         x = x.to(device)
     mean, var = window_mean_var(x.double(), kernel_size)
     return float((mean**2 + var) ** (-1 / (2 * kernel_size**2)))
+
+
+# ------------------------------------------------------------------------------------------------ phi on the device
+def _raw_images_on_device(images: Tensor, device) -> Tensor:
+    dev = torch.device(device) if device is not None else (images.device if images.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+    return images.to(dev, torch.float32).contiguous()
+
+
+def calc_scaling_factor_from_images(images: Tensor, kernel_size: int, device=None) -> float:
+    """`calc_scaling_factor` (dctn/dataset_loading.py:79-94) from the RAW (samples, height, width) intensities: the
+    feature map is applied inside the statistics kernel (`dctn_phi_window_stats`), so neither the expanded
+    (1, samples, h, w, 2) tensor nor the K*K stacked window copies are ever built.  First 10 880 samples, like there."""
+    img = _raw_images_on_device(images[:10880], device)
+    B, H, W = img.shape
+    sums = torch.empty(2, dtype=torch.float64, device=img.device)
+    rc = L.lib().dctn_phi_window_stats(img.data_ptr(), sums.data_ptr(), B, H, W, kernel_size, L.stream_ptr(img.device))
+    if rc == L.ERR_UNSUPPORTED:   # image too large for the per-pixel table in LDS: expand on the device, then the general kernel
+        return calc_scaling_factor(apply_feature_map_on_device(img, 1.0, torch.float64), kernel_size)
+    L.check(rc, "window statistics of the feature map")
+    n = B * (H - kernel_size + 1) * (W - kernel_size + 1) * 2.0 ** (kernel_size * kernel_size)
+    total, sq = sums.unbind(0)
+    mean = total / n
+    var = sq / (n - 1) - 2 * total / (n - 1) * mean + n / (n - 1) * mean**2
+    return float((mean**2 + var) ** (-1 / (2 * kernel_size**2)))
+
+
+def apply_feature_map_on_device(images: Tensor, scale: float = 1.0, dtype: torch.dtype = torch.float32, device=None) -> Tensor:
+    """(samples, height, width) intensities -> scale * phi, shape (1, samples, height, width, 2), written once on the
+    device in ``dtype`` (`dctn_phi_expand`): the data-set tensor of dataset_loading.py:63 with the autoscale factor of
+    the runner folded in, without a float32 intermediate."""
+    img = _raw_images_on_device(images, device)
+    B, H, W = img.shape
+    x = torch.empty((1, B, H, W, 2), dtype=dtype, device=img.device)
+    L.check(L.lib().dctn_phi_expand(img.data_ptr(), x.data_ptr(), B * H * W, float(scale), L.dtype_code(x), L.stream_ptr(img.device)),
+            "feature map")
+    return x

@@ -299,6 +299,17 @@ int dctn_linear_head_bwd(const void* feat, const void* weight, const void* dOut,
 int dctn_window_stats(const void* x, const int64_t x_strides[5], void* sums,
                       int C, int B, int H, int W, int Q, int K, int dtype, void* stream);
 
+/* The feature map itself on the device - replaces `phi_cos_sin_squared_1` as applied to the whole data set in
+ * dctn/dataset_loading.py:33-36,63 (u -> (2 sin^2(pi u / 2), 2 cos^2(pi u / 2)), float32 arithmetic like the reference's):
+ *   dctn_phi_window_stats : the two sums of dctn_window_stats straight from the RAW images (B, H, W) float32 contiguous,
+ *       phi applied once per pixel inside the kernel: neither the expanded (1, B, H, W, 2) tensor nor the K*K stacked
+ *       window copies of calc_scaling_factor (dataset_loading.py:79-94) exist.  sums: two float64, OVERWRITTEN.
+ *       DCTN_ERR_UNSUPPORTED for images whose per-pixel table does not fit LDS (beyond ~97 x 97).
+ *   dctn_phi_expand       : x[0, b, h, w, :] = scale * phi(images[b, h, w]) written once in the model's dtype
+ *       (`dtype` of x: f32 / f64 / bf16), the scaling factor folded in; n_pixels = B * H * W. */
+int dctn_phi_window_stats(const void* images, void* sums, int B, int H, int W, int K, void* stream);
+int dctn_phi_expand(const void* images, void* x, int64_t n_pixels, float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tail of a training iteration (reference: dctn/training.py:77-84 with
  * F.cross_entropy, the L2 regularisers of dctn/eps_plus_linear.py:149-159 and torch.optim.SGD).

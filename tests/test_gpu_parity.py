@@ -942,6 +942,34 @@ def test_window_statistics_kernel_against_reference_fixture_and_oracle():
     assert torch.allclose(s_cpu, window_sums(x.double().to(DEV), 3).cpu(), rtol=1e-12, atol=0)
 
 
+def test_feature_map_and_its_window_statistics_on_the_device():
+    """phi_cos_sin_squared_1 (dctn/dataset_loading.py:33-36) on the device - inside the statistics kernel
+    (`dctn_phi_window_stats`: raw images in, the two sums out, no expanded tensor, no stacked windows) and as one
+    write of the scaled data-set tensor in the model's dtype (`dctn_phi_expand`) - against the reference's own float32
+    lambdas and `calc_scaling_factor` on their output."""
+    from dctn_amd.window_stats import (apply_feature_map, apply_feature_map_on_device, calc_scaling_factor,
+                                       calc_scaling_factor_from_images, window_mean_var)
+
+    torch.manual_seed(34)
+    images = torch.rand(300, 28, 28)
+    images[0, 0, :4] = torch.tensor([0.0, 1.0, 0.5, 0.25])
+    x_ref = apply_feature_map(images)                 # the reference's lambdas, float32 on the CPU
+    for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 2e-6), (torch.bfloat16, 2 ** -7)):
+        x = apply_feature_map_on_device(images, 0.75, dtype, DEV)
+        assert dctn_amd.last_kernel() == "phi_expand" and x.shape == (1, 300, 28, 28, 2) and x.dtype == dtype
+        assert float((x.cpu().double() - 0.75 * x_ref.double()).abs().max()) <= tol * 2.0
+    for K in (2, 3, 4):
+        want = calc_scaling_factor(x_ref, K, DEV)     # float32 phi values, float64 statistics (dataset_loading.py:82)
+        got = calc_scaling_factor_from_images(images, K, DEV)
+        assert dctn_amd.last_kernel() == "phi_window_stats"
+        assert abs(got / want - 1.0) < 1e-6, (K, got, want)
+        m2, v2 = window_mean_var(apply_feature_map_on_device(images, got, torch.float64, DEV), K)
+        assert abs(float(m2**2 + v2) - 1.0) < 1e-5
+    # an image too large for the kernel's per-pixel table takes the expanding fallback, same number
+    big = torch.rand(3, 120, 110)
+    assert abs(calc_scaling_factor_from_images(big, 3, DEV) / calc_scaling_factor(apply_feature_map(big), 3, DEV) - 1.0) < 1e-6
+
+
 def test_log_intermediate_reps_stats_reports_the_reference_window_statistics(caplog):
     """EPSesPlusLinear.log_intermediate_reps_stats (dctn/eps_plus_linear.py:161-196): the w_n lines carry the
     mean / std of the K x K windows as rank-one tensors — here from the one-pass kernel, checked against the
