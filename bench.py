@@ -19,7 +19,7 @@ block moved by 20 % from run to run in round 1 - and every block's time is in `c
 Prints ONE JSON line on rank 0.  Beside the headline fields it carries `roofline` and `cpu_baseline` for the
 headline workload and, at N = 1, `configs`: one entry per other BASELINE / SURVEY 8(d) configuration (cfg1 f64,
 cfg3a f32, cfg3b f32, cfg4 ConvSBS r = 4 and r = 16, cfg5 logmatmulexp fold), each timed here with the protocol
-of dctn/benchmark.py:14-56 and priced against its own roofline (see README / DESIGN.md section 6).
+of dctn/benchmark.py:14-56 and priced against its own roofline (see README / DESIGN.md section 5).
 """
 import argparse
 import json
@@ -212,13 +212,13 @@ _TRAFFIC = None
 
 
 def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/r02_pmc_traffic.json, produced by
+    """HBM-side bytes per launch from the committed PMC passes (profiles/r03_pmc_traffic.json, produced by
     tools/pmc_traffic.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script); None when the
     kernel has not been profiled."""
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("r02_pmc_traffic.json", "r03_pmc_traffic.json"):   # later rounds override earlier entries
+        for name in ("r03_pmc_traffic.json",):   # the current round's passes only (tools/profile_round.sh + condense_round.py)
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 try:
@@ -473,9 +473,10 @@ def extra_eps_model(name, dev, iters):
                      l["_nb"] * l["windows"] * t["gemm_flops"],
                      t["bytes_x"] * l["_nb"] + t["bytes_y"] + t["bytes_core"] * 2))
     us, what, call, fam, fl, by = max(cand)
-    kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k"}.get(fam, fam)
+    kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k",
+              "eps_bwd_mfma_bigcore_f32_savedz": "eps_bigcore_k (G0) + eps_bigcore_dp1_k (saved Z) + eps_bigcore_dcore_k"}.get(fam, fam)
     roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:eps_bigcore_k",
-                          traffic_scope=("longest eps_bigcore_k instantiation of the profiled config (profiles/r02_pmc_traffic.json)"
+                          traffic_scope=("longest eps_bigcore_k instantiation of the profiled config (profiles/r03_pmc_traffic.json)"
                                          if dtype == torch.float32 else "not collected for this config"),
                           step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS[str(dtype).replace("torch.", "")],
                           step_algorithmic_flops=int(step_flops))
@@ -523,7 +524,7 @@ def extra_cfg1(dev, iters):
     sb = device_time(t["bwd"], dev, iters, graph=False)
     gemm = t["gemm_flops"] * windows
     by_b = 2 * t["bytes_x"] + t["bytes_y"] + 2 * t["bytes_core"]
-    roof = roofline_entry("mfma", "halves_gemm_k<double> (4 GEMMs: Z, dCore, dP0, Z again)", "dctn_eps_bwd", sb, 2 * gemm, by_b, dt,
+    roof = roofline_entry("mfma", "halves_gemm_k<double> (3 GEMMs: Z in the forward - kept -, dCore and dP0 in the backward)", "dctn_eps_bwd", sb, 2 * gemm, by_b, dt,
                           traffic_key="cfg1:halves_gemm_k", traffic_scope="longest halves_gemm_k instantiation (one of the four GEMMs of the call)", fwd_call_us=sf * 1e6, fwd_tflops=gemm / sf / 1e12,
                           step_tflops=3 * gemm / t_fb / 1e12, step_frac=3 * gemm / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float64"],
                           family=fam)
@@ -599,13 +600,13 @@ def extra_cfg4(r, dev, iters):
     by_fwd = x.numel() * 4 + y.numel() * 4 + n_par * 4
     by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
     if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
-        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
+        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else "convsbs_bwd_regu_k (+ convsbs_regu_tail_k)", "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)" if "mfma" in fam else "dctn_convsbs_bwd (register-resident sweep: nothing kept by the forward)", t_b, 2 * flops_fwd,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:" + ("convsbs_bwd_mfma" if "mfma" in fam else "convsbs_bwd_reg"), fwd_us=t_f * 1e6,
                               fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
                               step_frac=3 * flops_fwd / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"], family=fam)
     else:         # HBM / launch-latency bound: bytes of the fused ideal against the HBM peak
-        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else fam, "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:convsbs_bwd_mfma", fwd_us=t_f * 1e6,
+        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else "convsbs_bwd_regu_k (+ convsbs_regu_tail_k)", "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)" if "mfma" in fam else "dctn_convsbs_bwd (register-resident sweep: nothing kept by the forward)", t_b, 2 * flops_fwd,
+                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:" + ("convsbs_bwd_mfma" if "mfma" in fam else "convsbs_bwd_reg"), fwd_us=t_f * 1e6,
                               fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
                               step_frac=by_fb / t_fb / 1e9 / HBM_PEAK_GBS, family=fam)
     cores_n = usable_cores()

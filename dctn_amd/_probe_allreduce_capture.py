@@ -5,7 +5,7 @@ MASTER_PORT in the environment (a port of its own: the children of all ranks for
 Exit code 0 = the captured collective replays and gives the right sum; anything else = do not capture.
 
 Why a child: a capture that fails leaves the HIP runtime of the process in a state in which later collectives
-return "invalid argument"  - so the attempt is made where a failure costs nothing.  The
+return "invalid argument" (NOTEBOOK.md, round-2 section 7) - so the attempt is made where a failure costs nothing.  The
 parent starts this before (or regardless of) its own GPU work and never replaces itself with it.
 """
 import os

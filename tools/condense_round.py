@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_r02/ (written by tools/profile_r02.sh on the GPU box) into the committed evidence:
+"""Condenses gpurun_out/prof_<round>/ (written by tools/profile_round.sh on the GPU box) into the committed evidence:
 
-    profiles/r02_<cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (top rows, names cut to 200 chars)
-    profiles/r02_bench_under_rocprof.json the JSON lines the profiled runs printed
-    profiles/r02_pmc_traffic.json         HBM-side bytes per launch and kernel instantiation:
-                                          (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes (FETCH_SIZE is
-                                          doubled as MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads)
-    profiles/r02_cfg2_sq_counters.json    SQ busy / wait counters of the cfg2 kernels at the bench configuration
+    profiles/<round>_<cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (top rows, names cut to 200 chars)
+    profiles/<round>_bench_under_rocprof.json the JSON lines the profiled runs printed
+    profiles/<round>_pmc_traffic.json         HBM-side bytes per launch and kernel instantiation:
+                                              (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes (FETCH_SIZE is
+                                              doubled as MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads)
+    profiles/<round>_cfg2_sq_counters.json    SQ busy / wait counters of the cfg2 kernels at the bench configuration
+    profiles/<round>_sq_<cfg>.json            the same counters for the side configs profiled with them (SQCFGS)
 
-    python tools/condense_r02.py [gpurun_out/prof_r02] [profiles]
+    python tools/condense_round.py r03 [gpurun_out/prof_r03] [profiles]
 """
 import collections
 import csv
@@ -17,7 +18,7 @@ import json
 import os
 import sys
 
-CONFIGS = ("headline", "cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+CONFIGS = ("headline", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
 HEADLINE_KEYS = ("eps_fwd_head_q2reg_k", "eps_fwd_q2reg_k", "eps_bwd_dcore_q2reg_k", "eps_head_reduce_k", "eps_bwd_dcore_reduce_k",
                  "head_fwd_k")
 
@@ -49,8 +50,9 @@ def ours(name):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
+    dst = sys.argv[3] if len(sys.argv) > 3 else "profiles"
     traffic, lines = {"_note": "HBM-side bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is "
                                "doubled as MI355X_MICROARCH.md prescribes for gfx950 coalesced reads); avg_us from the kernel-trace "
                                "pass of the same command.  Per config: the kernel instantiations of this library, longest first."}, {}
@@ -58,7 +60,7 @@ def main():
         d = os.path.join(src, cfg)
         stats = kernel_stats(d)
         if stats:
-            with open(os.path.join(dst, f"r02_{'bench_cfg2' if cfg == 'headline' else cfg}_kernel_stats.csv"), "w", newline="") as f:
+            with open(os.path.join(dst, f"{rnd}_{'bench_cfg2' if cfg == 'headline' else cfg}_kernel_stats.csv"), "w", newline="") as f:
                 w = csv.writer(f)
                 w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
                 for r in stats[:25]:
@@ -91,8 +93,8 @@ def main():
                 for key in HEADLINE_KEYS:
                     if key + "<" in e["kernel"] or key + "(" in e["kernel"] or ("N_1" in e["kernel"] and key in e["kernel"]):
                         traffic.setdefault(f"{key}:B1024", e["traffic_bytes"])
-    json.dump(traffic, open(os.path.join(dst, "r02_pmc_traffic.json"), "w"), indent=1)
-    json.dump(lines, open(os.path.join(dst, "r02_bench_under_rocprof.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+    json.dump(lines, open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w"), indent=1)
     sq = {}
     for tag in ("headline_sq1", "headline_sq2"):
         for k, cs in counters(os.path.join(src, tag)).items():
@@ -103,7 +105,19 @@ def main():
         sq["_note"] = ("per-dispatch means, cfg2 bf16 B = 1024, eager launches (--graph 0) under --pmc; SQ_ACTIVE_INST_* / SQ_WAIT_* / "
                        "SQ_WAVE_CYCLES count quad-cycles summed over waves, SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs, "
                        "GRBM_GUI_ACTIVE cycles summed over the 8 XCDs")
-        json.dump(sq, open(os.path.join(dst, "r02_cfg2_sq_counters.json"), "w"), indent=1)
+        json.dump(sq, open(os.path.join(dst, f"{rnd}_cfg2_sq_counters.json"), "w"), indent=1)
+    # side configs profiled with SQ counters (profile_round.sh SQCFGS): every kernel of this library, per-dispatch means
+    for cfg in CONFIGS[1:]:
+        per = {}
+        for tag in (cfg + "_sq1", cfg + "_sq2"):
+            for k, cs in counters(os.path.join(src, tag)).items():
+                if ours(k):
+                    per.setdefault(k[:160], {}).update({c: round(v[0]) for c, v in cs.items()})
+                    per[k[:160]]["launches"] = max(v[1] for v in cs.values())
+        if per:
+            per["_note"] = ("per-dispatch means under --pmc (two passes); SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles "
+                            "summed over waves; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs")
+            json.dump(per, open(os.path.join(dst, f"{rnd}_sq_{cfg}.json"), "w"), indent=1)
     print(json.dumps({k: (v if not isinstance(v, list) else [(e["kernel"][:60], e["avg_us"], e["traffic_bytes"]) for e in v[:4]])
                       for k, v in traffic.items() if k != "_note"}, indent=1))
 
