@@ -498,10 +498,20 @@ __host__ __device__ inline int dx_half_table(int E, int Q) { return ((E - 1) / (
 // (float32 rows only: on the float64 rows of cfg1 the extra index arithmetic cost more than the conflicts it removed)
 __host__ __device__ inline int dx_half_pad(int e, size_t esz) { return esz == 4 ? e + (e >> 5) : e; }
 
+// A saved forward (dctn_eps_fwd_save) leaves Z: the second half's dP1[w, i] = sum_o dY[w, o] Z[w, (i, o)] is then formed
+// HERE, on the way into the wave's LDS row, instead of by a kernel of its own writing dP1 to memory and this one reading
+// it back (float64 / float32 path, Z[w][i][o]: cfg1 backward 659 -> 622 us.  The bf16 path keeps a kernel of its own with
+// 8-byte loads of its permuted Z': through this loader's 2-byte loads its layer-2 backward was slower).
+struct DxSavedZ {
+  const void* z;    // NULL: dP comes from memory
+  const void* dy;   // dY rows of the chunk, storage dtype
+  int O, mode;      // mode 1: Z[w][i][o]
+};
+
 template <int LOGQ, typename T, typename S = T>
 __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x, const T* __restrict__ dP,
                                                      T* __restrict__ gxw, HalfP h, int second, long long w0,
-                                                     long long nw) {
+                                                     long long nw, DxSavedZ sz) {
   extern __shared__ __align__(16) unsigned char sm_raw[];
   T* sm = reinterpret_cast<T*>(sm_raw);
   const EpsP& p = h.p;
@@ -531,7 +541,17 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
       const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
       xs[e] = (T)x[ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3] + q * p.s[4]];
     }
-    for (int e = lane; e < E; e += 64) dps[dx_half_pad(e, sizeof(T))] = dP[wl * E + e];
+    if (sz.mode == 0) {
+      for (int e = lane; e < E; e += 64) dps[dx_half_pad(e, sizeof(T))] = dP[wl * E + e];
+    } else {
+      const S* zrow = reinterpret_cast<const S*>(sz.z) + wl * (long long)E * sz.O;
+      const S* dyr = reinterpret_cast<const S*>(sz.dy) + wl * sz.O;
+      for (int e = lane; e < E; e += 64) {
+        T acc = 0.0;
+        for (int o = 0; o < sz.O; ++o) acc += (T)dyr[o] * (T)zrow[(long long)e * sz.O + o];
+        dps[dx_half_pad(e, sizeof(T))] = acc;
+      }
+    }
     if (lane == 0) pre[0] = 1.0, suf[0] = 1.0;   // level 0 of PRE (factor 0), level nd-1 of SUF (last factor)
     wave_sync_lds();
     // PRE level f (offset (Q^f - 1)/(Q - 1)): pre_f[u Q + q'] = pre_{f-1}[u] x_{f-1}[q']
@@ -661,23 +681,23 @@ size_t dx_half_lds(const HalfP& h, int second, size_t esz) {
 
 template <int LOGQ, typename T, typename S>
 int launch_dx_half_q(const S* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
-                     long long nw, hipStream_t st) {
+                     long long nw, hipStream_t st, DxSavedZ sz) {
   const size_t lds = dx_half_lds(h, second, sizeof(T));
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)halves_dx_half_k<LOGQ, T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((halves_dx_half_k<LOGQ, T, S>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw);
+  hipLaunchKernelGGL((halves_dx_half_k<LOGQ, T, S>), dim3(blocks_for(nw, 4)), dim3(256), lds, st, x, dP, gxw, h, second, w0, nw, sz);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }
 
 template <typename T, typename S = T>
 int launch_dx_half(const S* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
-                   long long nw, hipStream_t st) {
+                   long long nw, hipStream_t st, DxSavedZ sz = DxSavedZ{nullptr, nullptr, 0, 0}) {
   switch (ilog2_pow2(h.p.Q)) {
-    case 1: return launch_dx_half_q<1, T, S>(x, dP, gxw, h, second, w0, nw, st);
-    case 2: return launch_dx_half_q<2, T, S>(x, dP, gxw, h, second, w0, nw, st);
-    case 3: return launch_dx_half_q<3, T, S>(x, dP, gxw, h, second, w0, nw, st);
-    default: return launch_dx_half_q<0, T, S>(x, dP, gxw, h, second, w0, nw, st);
+    case 1: return launch_dx_half_q<1, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
+    case 2: return launch_dx_half_q<2, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
+    case 3: return launch_dx_half_q<3, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
+    default: return launch_dx_half_q<0, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
   }
 }
 
@@ -1164,7 +1184,9 @@ int bf16_bwd(const void* xv, const void* corev, const void* dYv, void* dXv, void
       bf16_gemm_launch<BA_SCALED, BB_KFAST>(nullptr, coreP, dP0, g0, 1, st);
       DCTN_CHECK_LAUNCH();
       if (saved) {
-        // dP1[w, i1] = sum_o dY[w, o] Z'[w, (o, i1)]: one pass over the Z' the forward kept instead of a third GEMM
+        // dP1[w, i1] = sum_o dY[w, o] Z'[w, (o, i1)]: one pass over the Z' the forward kept instead of a third GEMM (a
+        // kernel of its own with 8-byte loads: formed inside the leave-one-out kernel's loader - 2-byte loads - the layer-2
+        // backward was slower, 1 231 against 1 111 us)
         const bf16_t* Zs = (const bf16_t*)((const unsigned char*)saved + SL.z) + w0 * h.NB;
         hipLaunchKernelGGL(bf16_dp1_saved_k, dim3(blocks_for(nw * (h.Bn / 4), 256)), dim3(256), 0, st, Zs, dyc, dP1, nw,
                            (int)h.Bn, p.O);
@@ -1315,10 +1337,8 @@ int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* d
       // Z[w, (i1 o)] = sum_i0 P0[w, i0] Core[i0, (i1 o)], dP1[w, i1] = sum_o dY[w, o] Z[w, i1, o]
       GemmD<T> g1{(int)nw, (int)h.NB, (int)h.A, h.A, h.NB, h.NB, h.A, 0, nullptr, dyc, h.Bn, p.O};
       if (Zs) {
-        // the forward kept Z: one pass over it instead of the forward GEMM a second time (the reference's autograd
-        // keeps the result of path step (0,1) too: dctn/eps.py:25-30)
-        hipLaunchKernelGGL(halves_dp1_k<T>, dim3(blocks_for(nw * h.Bn, 256)), dim3(256), 0, st, Zs, dyc, dP1, nw, h.Bn, p.O);
-        DCTN_CHECK_LAUNCH();
+        // the forward kept Z (the reference's autograd keeps the result of path step (0,1) too: dctn/eps.py:25-30): dP1 is
+        // formed from it inside the leave-one-out kernel's loader below - no GEMM, no dP1 round trip through memory
       } else if (fused_epilogue_ok(p.O)) {
         gemm_launch<A_KFAST, B_NFAST, EPI_DP1, T>(P0, core, dP1, g1, 1, st);
         DCTN_CHECK_LAUNCH();
@@ -1331,7 +1351,7 @@ int bwd_t(const void* xv, const void* corev, const void* dYv, void* dXv, void* d
       }
       rc = launch_dx_half<T>(x, dP0, gxw, h, 0, w0, nw, st);
       if (rc != DCTN_OK) return rc;
-      rc = launch_dx_half<T>(x, dP1, gxw, h, 1, w0, nw, st);
+      rc = launch_dx_half<T>(x, dP1, gxw, h, 1, w0, nw, st, Zs ? DxSavedZ{Zs, dyc, p.O, 1} : DxSavedZ{nullptr, nullptr, 0, 0});
       if (rc != DCTN_OK) return rc;
     }
   }
