@@ -68,6 +68,10 @@ SIGNATURES = {
     "dctn_convsbs_saved_states_bytes": (c_size, [c_int, _IntP, _IntP] + [c_int] * 5 + [_IntP, _IntP, c_int]),
     "dctn_convsbs_bwd_saved": (c_int, [c_void, _I64x5, _PtrP, c_void, c_void, _PtrP, c_int, _IntP, _IntP, _IntP, _IntP]
                                + [c_int] * 5 + [c_void, c_size, c_void, c_size, c_int, c_void]),
+    "dctn_convsbs_many_workspace_bytes": (c_size, [c_int, c_int, _IntP, _IntP] + [c_int] * 5 + [_IntP, _IntP, c_int]),
+    "dctn_convsbs_many_fwd": (c_int, [c_void, _I64x5, _PtrP, _PtrP, c_int, c_int, _IntP, _IntP, _IntP, _IntP] + [c_int] * 5 + [c_int, c_void]),
+    "dctn_convsbs_many_bwd": (c_int, [c_void, _I64x5, _PtrP, _PtrP, c_void, _PtrP, c_int, c_int, _IntP, _IntP, _IntP, _IntP]
+                              + [c_int] * 5 + [c_void, c_size, c_int, c_void]),
     "dctn_logmatmulexp_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int]),
     "dctn_logmatmulexp_fwd": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void]),
     "dctn_logmatmulexp_bwd": (c_int, [c_void] * 7 + [c_size, c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void]),

@@ -56,20 +56,26 @@ class _StringPlan:
     int arrays of the C-ABI, output size.  Rebuilding them on every call was a third of the host time of a small
     layer's forward."""
 
-    __slots__ = ("n", "shape_tuples", "outs", "bonds", "ph", "pw", "max_h", "max_w", "out_total", "C", "q", "ws")
+    __slots__ = ("n", "shape_tuples", "outs", "bonds", "ph", "pw", "max_h", "max_w", "out_total", "C", "q", "ws",
+                 "outs_list", "bonds_list", "ph_list", "pw_list", "many_ok")
 
     def __init__(self, spec: SBSSpecString):
         shapes = spec.shapes
         self.n = len(spec)
         self.shape_tuples = tuple(s.as_tuple() for s in shapes)
-        self.outs = L.int_array([s.out_quantum_dim_size for s in shapes])
-        self.bonds = L.int_array(spec.bond_sizes)
-        self.ph = L.int_array([p.h for p in spec.positions])
-        self.pw = L.int_array([p.w for p in spec.positions])
+        self.outs_list = [s.out_quantum_dim_size for s in shapes]
+        self.bonds_list = list(spec.bond_sizes)
+        self.ph_list = [p.h for p in spec.positions]
+        self.pw_list = [p.w for p in spec.positions]
+        self.outs = L.int_array(self.outs_list)
+        self.bonds = L.int_array(self.bonds_list)
+        self.ph = L.int_array(self.ph_list)
+        self.pw = L.int_array(self.pw_list)
         self.max_h, self.max_w = spec.max_height_pos, spec.max_width_pos
         self.out_total = spec.out_total_quantum_dim_size
         self.C, self.q = spec.in_num_channels, spec.in_quantum_dim_size
         self.ws = {}   # (B, H, W, dtype code, backward) -> workspace bytes
+        self.many_ok = {}   # ((B, H, W), partner plans) -> workspace bytes of the several-strings-per-launch path (0: unsupported)
 
 
 _PLANS: dict = {}
@@ -196,6 +202,99 @@ class _ConvSBSFunction(torch.autograd.Function):
             dc if need else None for dc, need in zip(d_cores, ctx.needs_input_grad[2:])
         ]
         return (d_x, None, *grads)
+
+
+class _ManyConvSBSFunction(torch.autograd.Function):
+    """All strings of one `ManyConvSBS` layer (dctn/conv_sbs.py:367-370) in one launch each way, for the layers the
+    library takes that way (`dctn_convsbs_many_fwd`: nine-core strings of one bond <= 4 over the same window positions, the
+    reference's two-snake layers of mnist.py:189-252): the input is read by one kernel, and the backward writes dX once,
+    already summed over the strings.  `supported` asks the library (a workspace query: 0 = take the strings one by one)."""
+
+    @staticmethod
+    def supported(x: Tensor, specs) -> bool:
+        if not (x.is_cuda and x.dtype == torch.float32 and 2 <= len(specs) <= 2 and _sbs_flags == 0):
+            return False
+        n = len(specs[0])
+        if any(len(sp) != n for sp in specs):
+            return False
+        C, B, H, W, q = x.shape
+        plans = [_plan(sp) for sp in specs]
+        key = (B, H, W)
+        cache = plans[0].many_ok
+        tag = (key, tuple(id(p) for p in plans[1:]))
+        if tag not in cache:
+            args = _many_arrays(plans)
+            cache[tag] = L.lib().dctn_convsbs_many_workspace_bytes(len(specs), n, args[0], args[1], C, B, H, W, q, args[2], args[3],
+                                                                    L.F32)
+        return cache[tag] > 0
+
+    @staticmethod
+    def forward(ctx, x: Tensor, specs, *cores: Tensor):
+        dev = L.require_device(x, *cores)
+        C, B, H, W, q = x.shape
+        plans = [_plan(sp) for sp in specs]
+        ns, n = len(plans), plans[0].n
+        cores_c = [c.contiguous() for c in cores]
+        for core, shape in zip(cores_c, [t for p in plans for t in p.shape_tuples]):
+            assert tuple(core.shape) == shape
+            if core.dtype != x.dtype:
+                raise TypeError(f"ConvSBS: core is {core.dtype} but input is {x.dtype}")
+        outs_arr, bonds_arr, ph_arr, pw_arr = _many_arrays(plans)
+        outs = [torch.empty((B, H - p.max_h, W - p.max_w, p.out_total), dtype=x.dtype, device=dev) for p in plans]
+        L.check(
+            L.lib().dctn_convsbs_many_fwd(x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), L.ptr_array(outs), ns, n, outs_arr,
+                                          bonds_arr, ph_arr, pw_arr, C, B, H, W, q, L.F32, L.stream_ptr(dev)),
+            "ManyConvSBS forward",
+        )
+        ctx.save_for_backward(x, *cores_c)
+        ctx.meta = (plans, C, B, H, W, q)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        plans, C, B, H, W, q = ctx.meta
+        x, *cores_c = ctx.saved_tensors
+        dev = x.device
+        ns, n = len(plans), plans[0].n
+        need_dx = ctx.needs_input_grad[0]
+        need_dcores = any(ctx.needs_input_grad[2:])
+        gs = []
+        for p, g in zip(plans, d_outs):   # an output nobody used arrives as None
+            gs.append(torch.zeros((B, H - p.max_h, W - p.max_w, p.out_total), dtype=x.dtype, device=dev) if g is None
+                      else g.contiguous())
+        d_x = torch.empty((C, B, H, W, q), dtype=x.dtype, device=dev) if need_dx else None
+        d_cores = None
+        if need_dcores:
+            # one flat buffer per string (what a single string's backward produces too: a per-string reducer all-reduces in place)
+            d_cores, k = [], 0
+            for p in plans:
+                cs = cores_c[k : k + n]
+                flat = torch.empty(sum(c.numel() for c in cs), dtype=x.dtype, device=dev)
+                off = 0
+                for c in cs:
+                    d_cores.append(flat[off : off + c.numel()].view_as(c))
+                    off += c.numel()
+                k += n
+        outs_arr, bonds_arr, ph_arr, pw_arr = _many_arrays(plans)
+        nbytes = L.lib().dctn_convsbs_many_workspace_bytes(ns, n, outs_arr, bonds_arr, C, B, H, W, q, ph_arr, pw_arr, L.F32)
+        ws = L.workspace(nbytes, dev)
+        L.check(
+            L.lib().dctn_convsbs_many_bwd(
+                x.data_ptr(), L.strides5(x), L.ptr_array(cores_c), L.ptr_array(gs), None if d_x is None else d_x.data_ptr(),
+                None if d_cores is None else L.ptr_array(d_cores), ns, n, outs_arr, bonds_arr, ph_arr, pw_arr, C, B, H, W, q,
+                ws.data_ptr(), ws.numel(), L.F32, L.stream_ptr(dev)),
+            "ManyConvSBS backward",
+        )
+        grads = [None] * (ns * n) if d_cores is None else [
+            dc if need else None for dc, need in zip(d_cores, ctx.needs_input_grad[2:])
+        ]
+        return (d_x, None, *grads)
+
+
+def _many_arrays(plans):
+    """(out sizes, bond sizes, pos_h, pos_w) of several strings, string-major, as C int arrays."""
+    cat = lambda name: L.int_array([v for p in plans for v in getattr(p, name)])
+    return cat("outs_list"), cat("bonds_list"), cat("ph_list"), cat("pw_list")
 
 
 class ConvSBS(nn.Module):
@@ -369,4 +468,7 @@ class ManyConvSBS(nn.Module):
             return tuple(
                 _ConvSBSFunction.apply(xd, s.spec, *(c.to(dev) for c in s.cores)).cpu() for s in self.strings
             )
+        specs = tuple(string.spec for string in self.strings)
+        if _ManyConvSBSFunction.supported(x, specs):   # the strings of the layer in one launch each way
+            return _ManyConvSBSFunction.apply(x, specs, *(c for string in self.strings for c in string.cores))
         return tuple(string(x) for string in self.strings)

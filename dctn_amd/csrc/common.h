@@ -142,3 +142,12 @@ int convsbs_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores
 int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
                     float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);
+// several uniform strings of one layer in one launch each way (DCTN_ERR_UNSUPPORTED: run them one by one)
+size_t convsbs_many_reg_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                      int C, int B, int H, int W, int q, int dtype);
+int convsbs_many_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,
+                         const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H,
+                         int W, int q, int dtype, hipStream_t st);
+int convsbs_many_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores, const void* const* dYs, void* dX,
+                         float* const* dcores, int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                         const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);

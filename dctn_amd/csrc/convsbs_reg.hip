@@ -61,13 +61,19 @@ struct SrP {
   float* part;        // [padded entry][record] per-workgroup dCore sums, or NULL (no core gradient wanted)
   int band_rows, bands, nrec;
   int coff[SR_MAXC + 1];   // uniform-bond kernels: element offset of core c in the record (natural core layouts back to back)
+  // several strings of one layer in one launch (ManyConvSBS, dctn/conv_sbs.py:367-370): every string has its own block
+  float* out;              // forward output of this string
+  int slot[SR_MAXC];       // core c's pixel = slot-th pixel of the FIRST string (all strings cover the same window positions):
+                           // where its feature gradient goes in the per-window LDS row that the dX writer sums
+  int tot_all;             // elements of all strings' cores together (coff is absolute inside that record)
 };
 
+constexpr int SR_MAXS = 2;        // strings per launch
 struct SrTailP {
-  float* dcore[SR_MAXC];
+  float* dcore[SR_MAXS * SR_MAXC];
   int o[SR_MAXC], bl[SR_MAXC], br[SR_MAXC];
   int n, nrec;
-  int coff[SR_MAXC + 1];
+  int coff[SR_MAXS * SR_MAXC + 1];
 };
 
 // padded pack: pk[((c * 2 + o) * R + l) * R * QC + r * QC + qq], zero outside the core's real extents
@@ -618,8 +624,10 @@ __device__ __forceinline__ void su_last(su_kptr kl, int ol, const float* f, cons
   out2[1] = o1;
 }
 
-template <int R, int QC, bool TWOCH>
-__global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regu_k(SrP p, float* __restrict__ out) {
+template <int R, int QC, bool TWOCH, bool MULTI>
+__global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regu_k(SrP pa, SrP pb) {
+  const SrP& p = (MULTI && blockIdx.y) ? pb : pa;   // one string per grid.y slice (independent outputs)
+  float* __restrict__ out = p.out;
   const int tid = threadIdx.x;
   const int hw = p.Ho * p.Wo;
   for (long long w = (long long)blockIdx.x * SR_FWD_THREADS + tid; w < p.Wn; w += (long long)gridDim.x * SR_FWD_THREADS) {
@@ -647,12 +655,15 @@ __global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regu_k(SrP p, floa
   }
 }
 
-template <int R, int QC, bool TWOCH>
-__global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
+// MULTI: several strings per launch (the loop over strings reads each string's block through a run-time pointer; the
+// single-string instantiation keeps its block in SGPRs as before: 24.4 against 28.9 us at the cfg4 shape)
+template <int R, int QC, bool TWOCH, bool MULTI>
+__global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP pa, SrP pb, int nstr) {
   constexpr int NC = SU_NC, EE = R * QC, EM = R * R * QC;
   constexpr int NWAVES = SR_BWD_THREADS / 64;
   extern __shared__ __align__(16) float smem[];
-  const int tot = p.coff[NC];
+  const SrP& p = pa;                  // geometry, x, dX, records: common to the strings
+  const int tot = pa.tot_all;
   float* wacc = smem;                 // [NWAVES][tot]: per-wave dCore sums, natural layout
   float* dfl = wacc + NWAVES * tot;   // [windows of the band][NC * C * q]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -677,6 +688,9 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
     const long long w = ((long long)img * p.Ho + ho) * p.Wo + wo;
     const bool owner = valid && ho >= r0 && want_dcore;
     const bool first = base == wave * 64;
+#pragma unroll 1
+    for (int si = 0; si < (MULTI ? nstr : 1); ++si) {
+    const SrP& p = (MULTI && si) ? pb : pa;      // this string's cores, positions, dY (shadows the common block)
 
     // ---- features of every core (all loads in flight together), dY
     float fs[NC][QC], xr[TWOCH ? NC : 1][4];
@@ -708,16 +722,24 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
 
     auto store_df = [&](int c, const float* dF) {
       if (valid && p.dX != nullptr) {
-        float* d = dfl + (size_t)i * NCq + c * Cq;
+        float* d = dfl + (size_t)i * NCq + (MULTI ? p.slot[c] : c) * Cq;   // the first string stores, the others add (same lane: no race)
+        float g[TWOCH ? 4 : QC];
         if constexpr (TWOCH) {
           const float* xv = xr[TWOCH ? c : 0];
-          d[0] = dF[0] * xv[2] + dF[1] * xv[3];
-          d[1] = dF[2] * xv[2] + dF[3] * xv[3];
-          d[2] = dF[0] * xv[0] + dF[2] * xv[1];
-          d[3] = dF[1] * xv[0] + dF[3] * xv[1];
+          g[0] = dF[0] * xv[2] + dF[1] * xv[3];
+          g[1] = dF[2] * xv[2] + dF[3] * xv[3];
+          g[2] = dF[0] * xv[0] + dF[2] * xv[1];
+          g[3] = dF[1] * xv[0] + dF[3] * xv[1];
         } else {
 #pragma unroll
-          for (int qq = 0; qq < QC; ++qq) d[qq] = dF[qq];
+          for (int qq = 0; qq < QC; ++qq) g[qq] = dF[qq];
+        }
+        if (!MULTI || si == 0) {
+#pragma unroll
+          for (int qq = 0; qq < (TWOCH ? 4 : QC); ++qq) d[qq] = g[qq];
+        } else {
+#pragma unroll
+          for (int qq = 0; qq < (TWOCH ? 4 : QC); ++qq) d[qq] += g[qq];
         }
       }
     };
@@ -863,6 +885,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP p) {
       if (o0 == 2) slice(std::integral_constant<int, 1>{});
       store_df(0, dF);
     }
+    }   // strings
   }
   SR_STAMP(3);
   __syncthreads();
@@ -945,6 +968,9 @@ bool sr_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void*
   p.coff[0] = 0;
   for (int c = 0; c < SR_MAXC; ++c) p.coff[c + 1] = p.coff[c] + (c < n ? p.o[c] * p.bl[c] * p.br[c] * qc : 0);
   pl.tot = p.coff[SR_MAXC];
+  p.out = nullptr;
+  p.tot_all = pl.tot;
+  for (int c = 0; c < SR_MAXC; ++c) p.slot[c] = c;
   // bands of pixel rows: the fewest per image whose windows fit one pass of the workgroup's lanes, more (down to
   // ~2 workgroups per CU) when the batch is small
   const int NCq = n * C * q;
@@ -995,10 +1021,11 @@ int convsbs_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores
   if (!sr_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
   long long blocks = (p.Wn + SR_FWD_THREADS - 1) / SR_FWD_THREADS;
   if (blocks > 2048) blocks = 2048;
+  p.out = (float*)out;
 #define SR_FWD(RR, QQ, TC)                                                                                         \
   hipLaunchKernelGGL((convsbs_fwd_reg_k<RR, QQ, TC>), dim3((unsigned)blocks), dim3(SR_FWD_THREADS), 0, st, p, (float*)out)
 #define SU_FWD(RR, QQ, TC)                                                                                         \
-  hipLaunchKernelGGL((convsbs_fwd_regu_k<RR, QQ, TC>), dim3((unsigned)blocks), dim3(SR_FWD_THREADS), 0, st, p, (float*)out)
+  hipLaunchKernelGGL((convsbs_fwd_regu_k<RR, QQ, TC, false>), dim3((unsigned)blocks, 1), dim3(SR_FWD_THREADS), 0, st, p, p)
 #define SU_FWD_R(RR)                                                                                               \
   do {                                                                                                             \
     if (pl.twoch) SU_FWD(RR, 4, true);                                                                             \
@@ -1056,12 +1083,13 @@ int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores
     t.o[c] = p.o[c]; t.bl[c] = p.bl[c]; t.br[c] = p.br[c];
   }
   t.n = n; t.nrec = pl.nrec;
-  for (int c = 0; c <= SR_MAXC; ++c) t.coff[c] = p.coff[c];
+  for (int c = 0; c <= SR_MAXS * SR_MAXC; ++c) t.coff[c] = c <= SR_MAXC ? p.coff[c] : p.coff[SR_MAXC];
+  for (int c = SR_MAXC; c < SR_MAXS * SR_MAXC; ++c) t.dcore[c] = nullptr;
 #define SU_BWD(RR, QQ, TC)                                                                                            \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_regu_k<RR, QQ, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_regu_k<RR, QQ, TC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)pl.lds_bwd);                                                                       \
-    hipLaunchKernelGGL((convsbs_bwd_regu_k<RR, QQ, TC>), dim3(grid), dim3(SR_BWD_THREADS), pl.lds_bwd, st, p);        \
+    hipLaunchKernelGGL((convsbs_bwd_regu_k<RR, QQ, TC, false>), dim3(grid), dim3(SR_BWD_THREADS), pl.lds_bwd, st, p, p, 1);  \
   } while (0)
 #define SU_BWD_R(RR)                                                                                                  \
   do {                                                                                                                \
@@ -1091,5 +1119,133 @@ int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores
 #undef SU_BWD_R
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("convsbs_bwd_reg_f32");
+  return DCTN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ several strings per launch
+// ManyConvSBS (dctn/conv_sbs.py:314-370): the strings of one layer read the same input.  When all of them are uniform
+// nine-core strings of one bond over the same window positions (the reference's layers: two snakes through the same 3 x 3
+// window, mnist.py:189-252) they run as ONE forward launch (grid.y = string) and ONE backward launch (each lane walks
+// its window through every string; the strings' feature gradients meet in the same per-window LDS row, so dX is written
+// once, already summed) plus the one tail kernel.
+namespace {
+bool su_plan_many(SrP* ps, SrPlan& pl, int ns, const void* x, const int64_t xs[5], const void* const* cores, int n,
+                  const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                  int q, int dtype) {
+  if (ns < 1 || ns > SR_MAXS) return false;
+  int base = 0;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    SrPlan pls;
+    if (!sr_fill(ps[s2], pls, x, xs, cores ? cores + s2 * n : nullptr, n, out_sizes + s2 * n, bond_sizes + s2 * n, pos_h + s2 * n,
+                 pos_w + s2 * n, C, B, H, W, q, dtype))
+      return false;
+    if (!pls.uniform) return false;
+    if (s2 == 0) pl = pls;
+    else if (pls.R != pl.R || pls.QC != pl.QC || pls.twoch != pl.twoch || ps[s2].max_h != ps[0].max_h || ps[s2].Wo != ps[0].Wo)
+      return false;
+    for (int c = 0; c < n; ++c) {   // the pixel of core c in the first string's order
+      int found = -1;
+      for (int c0 = 0; c0 < n; ++c0)
+        if (ps[0].ph[c0] == ps[s2].ph[c] && ps[0].pw[c0] == ps[s2].pw[c]) found = c0;
+      if (found < 0) return false;
+      ps[s2].slot[c] = found;
+    }
+    for (int c = 0; c <= SR_MAXC; ++c) ps[s2].coff[c] += base;
+    base += pls.tot;
+  }
+  for (int s2 = 0; s2 < ns; ++s2) ps[s2].tot_all = base;
+  pl.tot = base;
+  pl.lds_bwd = ((size_t)base * (SR_BWD_THREADS / 64) + (size_t)pl.max_w_in_band * n * C * q) * sizeof(float);
+  return pl.lds_bwd <= DCTN_LDS_BUDGET;
+}
+}  // namespace
+
+size_t convsbs_many_reg_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                      int C, int B, int H, int W, int q, int dtype) {
+  SrP ps[SR_MAXS];
+  SrPlan pl;
+  if (!su_plan_many(ps, pl, ns, nullptr, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return 0;
+  return (size_t)pl.tot * pl.nrec * sizeof(float) + 256;
+}
+
+int convsbs_many_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,
+                         const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H,
+                         int W, int q, int dtype, hipStream_t st) {
+  SrP ps[SR_MAXS];
+  SrPlan pl;
+  if (!su_plan_many(ps, pl, ns, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    if (!outs[s2]) return DCTN_ERR_NULL;
+    ps[s2].out = (float*)outs[s2];
+  }
+  long long blocks = (ps[0].Wn + SR_FWD_THREADS - 1) / SR_FWD_THREADS;
+  if (blocks > 2048) blocks = 2048;
+  const SrP& pa = ps[0];
+  const SrP& pb = ps[ns > 1 ? 1 : 0];
+#define SU_FWD(RR, QQ, TC)                                                                                         \
+  hipLaunchKernelGGL((convsbs_fwd_regu_k<RR, QQ, TC, true>), dim3((unsigned)blocks, (unsigned)ns), dim3(SR_FWD_THREADS), 0, st, pa, pb)
+#define SU_FWD_R(RR)                                                                                               \
+  do {                                                                                                             \
+    if (pl.twoch) SU_FWD(RR, 4, true);                                                                             \
+    else if (pl.QC == 2) SU_FWD(RR, 2, false);                                                                     \
+    else if (pl.QC == 3) SU_FWD(RR, 3, false);                                                                     \
+    else SU_FWD(RR, 4, false);                                                                                     \
+  } while (0)
+  if (pl.R == 2) SU_FWD_R(2); else if (pl.R == 3) SU_FWD_R(3); else SU_FWD_R(4);
+#undef SU_FWD
+#undef SU_FWD_R
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("convsbs_many_fwd_reg_f32");
+  return DCTN_OK;
+}
+
+int convsbs_many_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores, const void* const* dYs, void* dX,
+                         float* const* dcores, int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                         const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes) {
+  SrP ps[SR_MAXS];
+  SrPlan pl;
+  if (!su_plan_many(ps, pl, ns, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+  const size_t need = (size_t)pl.tot * pl.nrec * sizeof(float);
+  if (dcores && (!ws || ws_bytes < need || ((uintptr_t)ws % 16))) return DCTN_ERR_WORKSPACE;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    if (!dYs[s2]) return DCTN_ERR_NULL;
+    ps[s2].dY = (const float*)dYs[s2];
+    ps[s2].dX = (float*)dX;
+    ps[s2].part = dcores ? (float*)ws : nullptr;
+  }
+  SrTailP t;
+  for (int c = 0; c < SR_MAXC; ++c) { t.o[c] = 1; t.bl[c] = 1; t.br[c] = 1; }
+  for (int s2 = 0; s2 < SR_MAXS; ++s2)
+    for (int c = 0; c < SR_MAXC; ++c) {
+      const bool live = s2 < ns && c < n;
+      t.dcore[s2 * SR_MAXC + c] = (dcores && live) ? dcores[s2 * n + c] : nullptr;
+      t.coff[s2 * SR_MAXC + c] = s2 < ns ? ps[s2].coff[c] : pl.tot;
+    }
+  t.coff[SR_MAXS * SR_MAXC] = pl.tot;
+  t.n = SR_MAXS * SR_MAXC;
+  t.nrec = pl.nrec;
+  const unsigned grid = (unsigned)pl.nrec;
+  const SrP& pa = ps[0];
+  const SrP& pb = ps[ns > 1 ? 1 : 0];
+#define SU_BWD(RR, QQ, TC)                                                                                            \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_regu_k<RR, QQ, TC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)pl.lds_bwd);                                                                       \
+    hipLaunchKernelGGL((convsbs_bwd_regu_k<RR, QQ, TC, true>), dim3(grid), dim3(SR_BWD_THREADS), pl.lds_bwd, st, pa, pb, ns); \
+  } while (0)
+#define SU_BWD_R(RR)                                                                                                  \
+  do {                                                                                                                \
+    if (pl.twoch) SU_BWD(RR, 4, true);                                                                                \
+    else if (pl.QC == 2) SU_BWD(RR, 2, false);                                                                        \
+    else if (pl.QC == 3) SU_BWD(RR, 3, false);                                                                        \
+    else SU_BWD(RR, 4, false);                                                                                        \
+  } while (0)
+  if (pl.R == 2) SU_BWD_R(2); else if (pl.R == 3) SU_BWD_R(3); else SU_BWD_R(4);
+#undef SU_BWD
+#undef SU_BWD_R
+  if (dcores)
+    hipLaunchKernelGGL(convsbs_regu_tail_k, dim3((unsigned)((pl.tot + 3) / 4)), dim3(256), 0, st, (const float*)ws, t, pl.tot);
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("convsbs_many_bwd_reg_f32");
   return DCTN_OK;
 }

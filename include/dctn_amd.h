@@ -230,6 +230,23 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
                            size_t workspace_bytes, const void* saved_states, size_t saved_states_bytes, int dtype,
                            void* stream);
 
+/* Several strings of one layer at once - replaces the loop of `ManyConvSBS.forward` (dctn/conv_sbs.py:367-370: every
+ * string contracts the same input) for layers whose strings are all nine-core strings of one bond <= 4 over the same
+ * window positions (the reference's layers: two snakes through one 3 x 3 window, mnist.py:189-252): ONE forward launch,
+ * ONE backward launch (+ the small reduction), dX written once, already summed over the strings.
+ *   cores / dCores : n_strings * n_cores pointers, string-major;  out_sizes, bond_sizes, pos_h, pos_w likewise
+ *   outs / dYs     : one (B, H', W', prod(out_sizes of the string)) tensor per string
+ * DCTN_ERR_UNSUPPORTED for any other layer: call dctn_convsbs_fwd / _bwd per string (and add the dX). */
+size_t dctn_convsbs_many_workspace_bytes(int n_strings, int n_cores, const int* out_sizes, const int* bond_sizes,
+                                         int C, int B, int H, int W, int q, const int* pos_h, const int* pos_w, int dtype);
+int dctn_convsbs_many_fwd(const void* x, const int64_t x_strides[5], const void* const* cores, void* const* outs,
+                          int n_strings, int n_cores, const int* out_sizes, const int* bond_sizes,
+                          const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype, void* stream);
+int dctn_convsbs_many_bwd(const void* x, const int64_t x_strides[5], const void* const* cores, const void* const* dYs,
+                          void* dX, void* const* dCores, int n_strings, int n_cores,
+                          const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                          int C, int B, int H, int W, int q, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * logmatmulexp — replaces dctn/logmatmulexp.py:5-14 (and the checkpointed :17-22; nothing of
  * size Theta*R*I is ever materialised here, forward or backward).

@@ -163,15 +163,17 @@ def test_cfg3a_full_batch_128_f32():
         assert float((a - c).abs().max()) < 2e-4 * float(a.abs().max()), i
 
 
-def test_cfg4_convsbs_full_batch_128():
-    """BASELINE cfg4: the mnist.py snake string on the CIFAR colour layout, r = 16, B = 128."""
+@pytest.mark.parametrize("r", [16, 4])
+def test_cfg4_convsbs_full_batch_128(r):
+    """BASELINE cfg4: the mnist.py snake string on the CIFAR colour layout, B = 128: r = 16 (matrix-core sweep) and r = 4
+    (register-resident sweep: two bands of pixel rows per image, 256 workgroups, halo rows computed twice)."""
     snake = [(0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2)]
     spec = (tuple(SBSSpecCore(Pos2D(*p), 2 if i == 4 else 1) for i, p in enumerate(snake)),)
     torch.manual_seed(4)
-    many = ManyConvSBS(1, 3, 16, False, spec, (DumbNormalInitialization((3 * 16) ** -0.5),)).to(DEV)
+    many = ManyConvSBS(1, 3, r, False, spec, (DumbNormalInitialization((3 * r) ** -0.5),)).to(DEV)
     x = torch.randn(1, 128, 32, 32, 3, generator=torch.Generator().manual_seed(6)).to(DEV).requires_grad_(True)
     (y,) = many(x)
-    assert y.shape == (128, 30, 30, 2) and "mfma" in dctn_amd.last_kernel()
+    assert y.shape == (128, 30, 30, 2) and ("mfma" if r == 16 else "reg") in dctn_amd.last_kernel()
     for lo, hi in ((0, 1), (7, 100), (127, 128)):
         assert rel_err(many(x[:, lo:hi].detach())[0], y[lo:hi].detach().cpu()) < 2e-6
     cores = [c.detach().cpu().double() for c in many.strings[0].cores]
@@ -182,6 +184,10 @@ def test_cfg4_convsbs_full_batch_128():
     y.backward(dy)
     whole = [c.grad.detach().double().cpu() for c in many.strings[0].cores]
     dx_whole = x.grad.detach().clone()
+    # oracle gradients on two samples (dX is per sample; dCore of the pair by additivity below)
+    xo = x[:, idx].detach().cpu().double().requires_grad_(True)
+    R.convsbs_forward(cores, snake, xo).backward(dy[idx].cpu().double())
+    assert rel_err(dx_whole[:, idx], xo.grad) < 1e-4
     acc = [torch.zeros_like(w) for w in whole]
     for lo, hi in ((0, 40), (40, 41), (41, 128)):
         for c in many.strings[0].cores:

@@ -526,3 +526,62 @@ def test_convsbs_reg_family_shapes(case):
     m(x).backward(dy)
     again = ([c.grad for c in m.cores] if core_grad else []) + ([x.grad] if x_grad else [])
     assert all(torch.equal(a, b) for a, b in zip(first, again))
+
+
+SNAKE9B = ((0, 0), (1, 0), (2, 0), (2, 1), (1, 1), (0, 1), (0, 2), (1, 2), (2, 2))   # mnist.py:201-210
+
+
+@pytest.mark.parametrize("bond,C,q,outs_a,outs_b,B,H,W", [
+    (4, 1, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), (1, 1, 1, 1, 2, 1, 1, 1, 1), 5, 12, 11),     # the classifier's first layer
+    (2, 2, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), (1, 1, 1, 1, 2, 1, 1, 1, 1), 130, 10, 10),   # its second layer, bond 2, several bands
+    (3, 1, 3, (2, 1, 1, 1, 1, 1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1, 2), 3, 9, 30),      # bond 3, q = 3, different two-valued cores
+    (4, 1, 4, (1,) * 9, (1,) * 9, 2, 8, 8),                                              # one output each
+])
+def test_many_convsbs_strings_in_one_launch(bond, C, q, outs_a, outs_b, B, H, W):
+    """`ManyConvSBS.forward` (dctn/conv_sbs.py:367-370) for a layer of two nine-core strings over the same 3 x 3 window:
+    one forward launch, one backward launch (dX written once, summed over the strings) - against the oracle per string and
+    against the same layer run string by string; only one of the two outputs used (the other's gradient arrives as None)."""
+    from dctn_amd.conv_sbs import ManyConvSBS, matrix_core_sweep
+
+    torch.manual_seed(bond * 100 + B)
+    specs = (tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(SNAKE9, outs_a)),
+             tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(SNAKE9B, outs_b)))
+    init = DumbNormalInitialization((q ** C * bond) ** -0.5 * 1.2)
+    many = ManyConvSBS(C, q, bond, False, specs, (init, init)).to(DEV)
+    x0 = torch.randn(C, B, H, W, q)
+    x = x0.to(DEV).requires_grad_(True)
+    ya, yb = many(x)
+    assert dctn_amd.last_kernel() == "convsbs_many_fwd_reg_f32"
+    dya, dyb = torch.randn_like(ya), torch.randn_like(yb)
+    ((ya * dya).sum() + (yb * dyb).sum()).backward()
+    assert dctn_amd.last_kernel() == "convsbs_many_bwd_reg_f32"
+    dx_sum = torch.zeros_like(x0, dtype=torch.float64)
+    for string, pos, y, dy in ((many.strings[0], SNAKE9, ya, dya), (many.strings[1], SNAKE9B, yb, dyb)):
+        cores64 = [c.detach().cpu().double() for c in string.cores]
+        check(y, R.convsbs_forward(cores64, list(pos), x0.double()), torch.float32, "forward")
+        gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x0.double()] + cores64, dy.cpu().double())
+        dx_sum += gr[0]
+        for i, (c, gc) in enumerate(zip(string.cores, gr[1:])):
+            check(c.grad, gc, torch.float32, f"dCore{i}")
+    check(x.grad, dx_sum, torch.float32, "dX")
+    # the same layer string by string (the matrix-core family: launches per string) gives the same numbers
+    first = [x.grad.clone()] + [p.grad.clone() for p in many.parameters()]
+    x.grad = None
+    for p in many.parameters():
+        p.grad = None
+    with matrix_core_sweep():
+        za, zb = many(x)
+        assert "many" not in dctn_amd.last_kernel()
+        ((za * dya).sum() + (zb * dyb).sum()).backward()
+    for a, b in zip(first, [x.grad] + [p.grad for p in many.parameters()]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5 * float(a.abs().max()))
+    # only the second output is used
+    x.grad = None
+    for p in many.parameters():
+        p.grad = None
+    _, yb2 = many(x)
+    (yb2 * dyb).sum().backward()
+    assert all(float(c.grad.abs().max()) == 0.0 for c in many.strings[0].cores)
+    cores64 = [c.detach().cpu().double() for c in many.strings[1].cores]
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(SNAKE9B), xx), [x0.double()] + cores64, dyb.cpu().double())
+    check(x.grad, gr[0], torch.float32, "dX (one output used)")
