@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     if (rep == 2) report("eps_fwd_head_q2reg_k (layer + head)", hs, NB, 5, hl);
     CK(hipMemset(stamps, 0, NB * 8 * 8));
     p.opts = DCTN_OPT_MAIN_KERNEL_ONLY;
-    if (eps_head_bwd_mfma(x, feat, dl, wgt, dcore, dw, db, ws, wsb, p, Cout, DCTN_BF16, 0, st) != DCTN_OK) return 1;
+    if (eps_head_bwd_mfma(x, feat, dl, wgt, dcore, dw, db, ws, wsb, p, Cout, DCTN_BF16, 0, st) != DCTN_PARTIAL) return 1;
     p.opts = 0;
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(hs.data(), stamps, NB * 8 * 8, hipMemcpyDeviceToHost));
