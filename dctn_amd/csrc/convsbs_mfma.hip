@@ -1,5 +1,6 @@
-// MFMA ConvSBS forward sweep: open chain (bond_sizes[0] == 1), uniform internal bond r in
-// {4, 8, 16, 32}, q^C <= 4, at most 2 outputs in total, float32 (exact: v_mfma_f32_32x32x2_f32).
+// MFMA ConvSBS forward sweep: open chain (bond_sizes[0] == 1), internal bonds <= 32 padded to one tile size r in
+// {4, 8, 16, 32} (they need not be equal), q^C <= 4, at most 2 outputs in total, float32 (exact: v_mfma_f32_32x32x2_f32);
+// rings, cores with many outputs, several cores with outputs: as slices of that family (sbsm_for_slices).
 // This is the string family of the reference's models (mnist.py:189-223: 9-core snakes with one
 // 2-output core) on MNIST (q=2), its second layer (C=2, q=2) and the CIFAR colour layout (q=3).
 //
@@ -21,8 +22,9 @@ typedef __attribute__((ext_vector_type(2))) int int2v;
 
 struct SbsMP {
   int n, C, B, H, W, q, qc, Ho, Wo, Otot;
-  int Ra;                     // the string's bond (<= the kernels' R: packs, tables and states are zero beyond it)
-  int ostride, obase;         // row length of out / dY and the first output of this launch (many-output strings run in slices)
+  int Ra;                     // the string's largest bond (<= the kernels' R: packs, tables and states are zero beyond a core's bonds)
+  int bl[SBSM_MAXC], br[SBSM_MAXC];   // left / right bond of core c (1 at the open ends); they need not be equal
+  int ostride, obase, ostep;  // row length of out / dY, the first output of this launch and the distance to its second (many-output strings run in slices)
   int accum;                  // backward: add to gxw and to the core gradients instead of setting them (slices after the first)
   int out_accum;              // forward: add to out (rings: one launch per value of the closing bond)
   float* save;                // forward: store every core's input state here for a following backward (or NULL)
@@ -195,16 +197,15 @@ __device__ __forceinline__ void pack_cores(float* lds, const SbsMP& p, int tid) 
       const int o = t2 / TILES;
       const int l = 2 * s + hh, rp = 8 * t + (i >> 2), qq = i & 3;
       float v = 0.f;
-      if (l < p.Ra && rp < p.Ra && qq < p.qc) v = p.core[c][(long long)((o * p.Ra + l) * p.Ra + rp) * p.qc + qq];
+      if (l < p.bl[c] && rp < p.br[c] && qq < p.qc) v = p.core[c][(long long)((o * p.bl[c] + l) * p.br[c] + rp) * p.qc + qq];
       lds[p.apack_off[c] + e] = v;
     }
   }
   // first core (1, 1, R, qc) as [r'][4]; last core (1, R, 1, qc) as [l][4]
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
-    const bool in = qq < p.qc && rr < p.Ra;
-    lds[p.first_off + e] = in ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = in ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
+    lds[p.first_off + e] = (qq < p.qc && rr < p.br[0]) ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void convsbs_fwd_mfma_k(const float* __restric
     if (valid && h == 0) {
       float* op = out + w * p.ostride + p.obase;
       op[0] = p.out_accum ? op[0] + r0 : r0;
-      if (p.Otot > 1) op[1] = p.out_accum ? op[1] + r1 : r1;
+      if (p.Otot > 1) op[p.ostep] = p.out_accum ? op[p.ostep] + r1 : r1;
     }
   }
 }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
     const int rem = (int)(ww - b * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     const float dy0 = valid ? dY[w * p.ostride + p.obase] : 0.f;
-    const float dy1 = (valid && p.Otot > 1) ? dY[w * p.ostride + p.obase + 1] : 0.f;
+    const float dy1 = (valid && p.Otot > 1) ? dY[w * p.ostride + p.obase + p.ostep] : 0.f;
     float f[4];
     float* fs = lds + p.fs_off + (tid >> 6) * p.n * 128;
     stage_features(x, p, b, ho, wo, valid, fs, lane);
@@ -644,7 +645,7 @@ __device__ __forceinline__ float pack16_element(const SbsMP& p, int c, int e) {
   const int l = ADJ ? 4 * mt + (i >> 2) : 4 * s + kg;
   const int rp = ADJ ? 4 * s + kg : 4 * mt + (i >> 2);
   const int qq = i & 3;
-  return (qq < p.qc && l < p.Ra && rp < p.Ra) ? p.core[c][(long long)((o * p.Ra + l) * p.Ra + rp) * p.qc + qq] : 0.f;
+  return (qq < p.qc && l < p.bl[c] && rp < p.br[c]) ? p.core[c][(long long)((o * p.bl[c] + l) * p.br[c] + rp) * p.qc + qq] : 0.f;
 }
 
 // NMID > 0: at most NMID middle cores with at most two outputs each: every global load of the two packs is issued
@@ -691,9 +692,8 @@ __device__ __forceinline__ void pack_cores16(float* lds, const SbsMP& p, int tid
   }
   for (int e = tid; e < R * 4; e += 256) {
     const int rr = e >> 2, qq = e & 3;
-    const bool in = qq < p.qc && rr < p.Ra;
-    lds[p.first_off + e] = in ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
-    lds[p.last_off + e] = in ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
+    lds[p.first_off + e] = (qq < p.qc && rr < p.br[0]) ? p.core[0][(long long)rr * p.qc + qq] : 0.f;
+    lds[p.last_off + e] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][(long long)rr * p.last_stride + qq] : 0.f;
   }
 }
 
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       dy[0][t] = vt_ok[t] ? dY[wt[t] * p.ostride + p.obase] : 0.f;
-      dy[1][t] = (vt_ok[t] && p.Otot > 1) ? dY[wt[t] * p.ostride + p.obase + 1] : 0.f;
+      dy[1][t] = (vt_ok[t] && p.Otot > 1) ? dY[wt[t] * p.ostride + p.obase + p.ostep] : 0.f;
     }
     float f[4][NT];
     auto load_f = [&](int c) {
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
   for (int c = 0; c < p.n; ++c) {
     const float* src = lds + p.dacc_off[c];
     if (c == 0 || c == p.n - 1) {
-      const int E = p.Ra * p.qc;   // [bond index][q]: the rows below the string's bond are a prefix of the padded table
+      const int E = (c == 0 ? p.br[0] : p.bl[c]) * p.qc;   // [bond index][q]: the rows below the core's bond are a prefix of the padded table
       for (int e = tid; e < E; e += 256) {
         if (rec) rec[p.core_off[c] + e] = src[e];
         else atomicAdd(&p.dcore[c][c == 0 ? e : (e / p.qc) * p.last_stride + e % p.qc], src[e]);
@@ -1231,8 +1231,8 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
         const int ln = e & 63, l = ln & 15, gg = ln >> 4, vv = (e >> 6) & 3;
         const int mt = (e >> 8) % MT, o = (e >> 8) / MT;
         const int rp = 4 * mt + gg;
-        if (l < p.Ra && rp < p.Ra && vv < p.qc) {
-          const int idx = ((o * p.Ra + l) * p.Ra + rp) * p.qc + vv;
+        if (l < p.bl[c] && rp < p.br[c] && vv < p.qc) {
+          const int idx = ((o * p.bl[c] + l) * p.br[c] + rp) * p.qc + vv;
           if (rec) rec[p.core_off[c] + idx] = src[e]; else atomicAdd(&p.dcore[c][idx], src[e]);
         }
       }
@@ -1300,14 +1300,22 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
                      const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
                      int C, int B, int H, int W, int q, int dtype) {
   if (dtype != DCTN_F32 || n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
-  // any uniform bond 2..32 runs on the next of the kernels' tile sizes {4, 8, 16, 32}: packs and tables are zero beyond
-  // the string's bond, so are the states, and only the real entries of a gradient are written back
-  const int Ra = bond_sizes[1];
-  if (bond_sizes[0] != 1 || Ra < 2 || Ra > 32) return DCTN_ERR_UNSUPPORTED;
-  for (int c = 2; c < n; ++c)
-    if (bond_sizes[c] != Ra) return DCTN_ERR_UNSUPPORTED;
+  // any bonds 1..32 (they need not be equal) run on the next of the kernels' tile sizes {4, 8, 16, 32} above the largest:
+  // packs and tables are zero beyond a core's own bonds, so are the states, and only the real entries of a gradient are
+  // written back
+  if (bond_sizes[0] != 1) return DCTN_ERR_UNSUPPORTED;
+  int Ra = 0;
+  for (int c = 1; c < n; ++c) {
+    if (bond_sizes[c] < 1 || bond_sizes[c] > 32) return DCTN_ERR_UNSUPPORTED;
+    Ra = bond_sizes[c] > Ra ? bond_sizes[c] : Ra;
+  }
+  if (Ra < 2) return DCTN_ERR_UNSUPPORTED;
   R = Ra <= 4 ? 4 : Ra <= 8 ? 8 : Ra <= 16 ? 16 : 32;
   p.Ra = Ra;
+  for (int c = 0; c < n; ++c) {
+    p.bl[c] = c == 0 ? 1 : bond_sizes[c];
+    p.br[c] = c == n - 1 ? 1 : bond_sizes[c + 1];
+  }
   long long qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
   if (qc > 4 || C > 2 || q > 4) return DCTN_ERR_UNSUPPORTED;
@@ -1323,7 +1331,7 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
   }
   if (otot > 2 || out_sizes[0] != 1 || out_sizes[n - 1] != 1) return DCTN_ERR_UNSUPPORTED;
   p.n = n; p.C = C; p.B = B; p.H = H; p.W = W; p.q = q; p.qc = (int)qc; p.Otot = (int)otot;
-  p.ostride = (int)otot; p.obase = 0; p.accum = 0; p.out_accum = 0; p.last_stride = (int)qc; p.save = nullptr;
+  p.ostride = (int)otot; p.obase = 0; p.ostep = 1; p.accum = 0; p.out_accum = 0; p.last_stride = (int)qc; p.save = nullptr;
   int max_h = 0, max_w = 0;
   for (int c = 0; c < n; ++c) {
     p.o[c] = out_sizes[c]; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
@@ -1356,23 +1364,8 @@ static int sbsm_fill(SbsMP& p, int& R, int& lds_floats, const int64_t xs[5], con
 // [o][l][r][q] layout makes a slice a pointer offset), writes columns 2j.. of out and reads those of dY; the gradients of
 // the other cores and of x add up over the slices.  Returns the index of that core, -1 when the string has none, -2 when
 // the outputs have another shape (the generic sweep takes those).
-static int sbsm_many_output_core(int n, const int* out_sizes) {
-  int m = -1;
-  for (int c = 0; c < n; ++c) {
-    if (out_sizes[c] < 1) return -2;
-    if (out_sizes[c] > 2) {
-      if (m >= 0 || c == 0 || c == n - 1 || out_sizes[c] > 64) return -2;
-      m = c;
-    }
-  }
-  if (m < 0) return -1;
-  for (int c = 0; c < n; ++c)
-    if (c != m && out_sizes[c] != 1) return -2;
-  return m;
-}
-
 struct SbsSlice {   // one launch of a string that runs in slices (many-valued core and / or ring); sliced == 0: the whole string
-  int sliced, obase, ostride, accum, out_accum, last_stride;
+  int sliced, obase, ostride, accum, out_accum, last_stride, ostep;
 };
 
 static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n,
@@ -1383,7 +1376,7 @@ static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* 
   int R, off;
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
-  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.out_accum = sl.out_accum; p.last_stride = sl.last_stride; }
+  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.ostep = sl.ostep; p.out_accum = sl.out_accum; p.last_stride = sl.last_stride; }
   if (save && !sl.sliced && R <= 16) {   // input states of cores 1 .. n-1 for the backward (same offsets as its own sweep)
     long long so = 0;
     int oacc = 1;
@@ -1427,49 +1420,81 @@ static int convsbs_fwd_mfma_one(const void* x, const int64_t xs[5], const void* 
   return DCTN_OK;
 }
 
-// The slices of a string: rings (bond_sizes[0] == the inner bond: Tr(prod T_c) = sum over the closing bond value l0 of the
-// open chain whose first core is row l0 of core 0 - contiguous in its [o][l][r][q] layout - and whose last core is column
-// l0 of core n-1 - a strided view) times the two-output slices of a many-valued core.  `visit` gets the slice's core
-// pointers, output sizes and SbsSlice; a non-OK return stops the walk (the first slice decides: all later ones have the
-// same or a smaller LDS plan).
+// The slices of a string.  One launch handles an open chain with at most two outputs, both on one middle core.  Anything
+// else runs as several launches over VIEWS of the same cores:
+//   * a ring (bond_sizes[0] > 1): Tr(prod T_c) = sum over the closing bond value l0 of the open chain whose first core is
+//     row l0 of core 0 (contiguous in its [o][l][r][q] layout) and whose last core is column l0 of core n-1 (a strided view);
+//   * the PAIR core m = the last middle core with more than one output: its outputs go two per launch;
+//   * every other core with several outputs is walked one output at a time (the [l][r][q] block of that output).
+// The flat output index is row-major over the cores in string order, so a slice's two outputs are prod(o_c, c > m) apart.
+// `visit` gets the slice's core views (as element offsets into the cores - the gradients use the same), output sizes, bonds
+// and SbsSlice; a non-OK return stops the walk (the first slice decides: all later ones have the same LDS plan).
+constexpr int SBSM_MAX_SLICES = 96;   // beyond that the generic sweep's single launch wins
+static bool sbsm_whole(int n, const int* out_sizes, const int* bond_sizes) {
+  long long otot = 1;
+  for (int c = 0; c < n; ++c) otot *= out_sizes[c];
+  return bond_sizes[0] == 1 && otot <= 2 && out_sizes[0] == 1 && out_sizes[n - 1] == 1;
+}
 template <typename F>
 static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes, const int* bond_sizes, int C, int q, F visit) {
   if (n < 3 || n > SBSM_MAXC) return DCTN_ERR_UNSUPPORTED;
-  const int m = sbsm_many_output_core(n, out_sizes);
-  if (m == -2) return DCTN_ERR_UNSUPPORTED;
-  const int Rb = bond_sizes[1];
-  const bool ring = bond_sizes[0] == Rb && Rb > 1;
-  int outs[SBSM_MAXC], bonds[SBSM_MAXC];
-  const void* cp[SBSM_MAXC];
-  long long otot = 1;
-  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; bonds[c] = bond_sizes[c]; cp[c] = cores[c]; otot *= out_sizes[c]; }
-  if (m < 0 && !ring) {
-    const SbsSlice whole{0, 0, 0, 0, 0, 0};
-    return visit(cp, outs, bonds, whole, 0, 0);
+  long long otot = 1, qc = 1;
+  for (int c = 0; c < n; ++c) {
+    if (out_sizes[c] < 1 || out_sizes[c] > 64 || bond_sizes[c] < 1) return DCTN_ERR_UNSUPPORTED;
+    otot *= out_sizes[c];
   }
-  if (ring && (out_sizes[0] != 1 || out_sizes[n - 1] != 1)) return DCTN_ERR_UNSUPPORTED;
+  for (int c = 0; c < C; ++c) qc *= q;
+  if (otot > (1 << 20)) return DCTN_ERR_UNSUPPORTED;
+  int outs[SBSM_MAXC], bonds[SBSM_MAXC];
+  long long coff[SBSM_MAXC];
+  for (int c = 0; c < n; ++c) { outs[c] = out_sizes[c]; bonds[c] = bond_sizes[c]; coff[c] = 0; }
+  if (sbsm_whole(n, out_sizes, bond_sizes)) {
+    const SbsSlice whole{0, 0, 0, 0, 0, 0, 1};
+    return visit(coff, outs, bonds, whole);
+  }
+  const int R0 = bond_sizes[0];   // the closing bond of a ring (1: open chain)
+  const bool ring = R0 > 1;
+  int m = -1;
+  for (int c = 1; c + 1 < n; ++c)
+    if (out_sizes[c] > 1) m = c;
+  long long ostr[SBSM_MAXC], per_o[SBSM_MAXC], nsl = ring ? R0 : 1;
+  for (int c = n - 1, acc = 1; c >= 0; --c) { ostr[c] = acc; acc *= out_sizes[c]; }
+  for (int c = 0; c < n; ++c) {
+    per_o[c] = (long long)bond_sizes[c] * bond_sizes[(c + 1) % n] * qc;   // a core is [o][l][r][q...]
+    nsl *= c == m ? (out_sizes[c] + 1) / 2 : out_sizes[c];
+  }
   // (Slices pay a launch and a recomputed prefix each; with the compiled two-channel mode they beat the generic sweep's
   // single launch at every bond - ten labels, C = 2, 61 952 windows, device time of fwd + bwd: bond 2 0.49 ms generic /
   // 0.41 ms sliced, bond 3 0.63 / 0.41, bond 4 1.2 / 0.41; rings bond 2: 0.74 / 0.35, bond 3: 1.29 / 0.48.)
-  long long qc = 1;
-  for (int c = 0; c < C; ++c) qc *= q;
+  if (nsl > SBSM_MAX_SLICES) return DCTN_ERR_UNSUPPORTED;
   bonds[0] = 1;   // every slice is an open chain
-  const long long per_o = (long long)Rb * Rb * qc;   // a many-valued middle core is [o][l][r][q...]
-  const int om = m >= 0 ? out_sizes[m] : 0;
-  for (int l0 = 0; l0 < (ring ? Rb : 1); ++l0) {
-    if (ring) {
-      cp[0] = (const float*)cores[0] + (long long)l0 * Rb * qc;
-      cp[n - 1] = (const float*)cores[n - 1] + (long long)l0 * qc;
-    }
-    for (int o0 = 0; o0 < (m >= 0 ? om : 1); o0 += 2) {
-      if (m >= 0) {
-        outs[m] = om - o0 < 2 ? om - o0 : 2;
-        cp[m] = (const float*)cores[m] + (long long)o0 * per_o;
+  int idx[SBSM_MAXC] = {};   // the walked output of every core but the pair core; the first output of the pair core's slice
+  bool first = true;
+  for (;;) {
+    for (int l0 = 0; l0 < (ring ? R0 : 1); ++l0) {
+      long long obase = 0;
+      for (int c = 0; c < n; ++c) {
+        coff[c] = idx[c] * per_o[c];
+        obase += idx[c] * ostr[c];
+        outs[c] = 1;
       }
-      const SbsSlice sl{1, m >= 0 ? o0 : 0, (int)otot, l0 > 0 || o0 > 0, l0 > 0, (int)(ring ? Rb * qc : qc)};
-      const int rc = visit(cp, outs, bonds, sl, l0, o0);
+      if (m >= 0) outs[m] = out_sizes[m] - idx[m] < 2 ? out_sizes[m] - idx[m] : 2;
+      if (ring) {
+        coff[0] += (long long)l0 * bond_sizes[1] * qc;
+        coff[n - 1] += (long long)l0 * qc;
+      }
+      const SbsSlice sl{1, (int)obase, (int)otot, !first, l0 > 0, (int)(ring ? R0 * qc : qc), m >= 0 ? (int)ostr[m] : 1};
+      const int rc = visit(coff, outs, bonds, sl);
       if (rc != DCTN_OK) return rc;
+      first = false;
     }
+    int c = n - 1;   // next combination of outputs (the last core runs fastest)
+    for (; c >= 0; --c) {
+      idx[c] += c == m ? 2 : 1;
+      if (idx[c] < out_sizes[c]) break;
+      idx[c] = 0;
+    }
+    if (c < 0) break;
   }
   return DCTN_OK;
 }
@@ -1479,7 +1504,7 @@ static int sbsm_for_slices(int n, const void* const* cores, const int* out_sizes
 size_t convsbs_saved_states_bytes(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
                                   int C, int B, int H, int W, int q, int dtype) {
   if (dtype != DCTN_F32 || n < 3 || n > SBSM_MAXC) return 0;
-  if (sbsm_many_output_core(n, out_sizes) != -1 || bond_sizes[0] != 1) return 0;
+  if (!sbsm_whole(n, out_sizes, bond_sizes)) return 0;
   SbsMP p;
   int R, off;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
@@ -1500,7 +1525,9 @@ int convsbs_fwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      int C, int B, int H, int W, int q, int dtype, hipStream_t st, float* save_states) {
   if (dtype != DCTN_F32) return DCTN_ERR_UNSUPPORTED;
   return sbsm_for_slices(n, cores, out_sizes, bond_sizes, C, q,
-                         [&](const void* const* cp, const int* outs, const int* bonds, const SbsSlice& sl, int, int) {
+                         [&](const long long* coff, const int* outs, const int* bonds, const SbsSlice& sl) {
+                           const void* cp[SBSM_MAXC];
+                           for (int c = 0; c < n; ++c) cp[c] = (const float*)cores[c] + coff[c];
                            return convsbs_fwd_mfma_one(x, xs, cp, out, n, outs, bonds, pos_h, pos_w, C, B, H, W, q, dtype, st, sl,
                                                        save_states);
                          });
@@ -1521,7 +1548,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
   const int rcf = sbsm_fill(p, R, off, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   if (rcf != DCTN_OK) return rcf;
   if (R > 16 || !dcores || !states) return DCTN_ERR_UNSUPPORTED;
-  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.accum = sl.accum; p.last_stride = sl.last_stride; }
+  if (sl.sliced) { p.ostride = sl.ostride; p.obase = sl.obase; p.ostep = sl.ostep; p.accum = sl.accum; p.last_stride = sl.last_stride; }
   // the training forward's stored states replace this launch's forward sweep (whole strings only: a slice has its own)
   const bool use_saved = saved != nullptr && !sl.sliced;
   if (use_saved) states = const_cast<float*>(saved);
@@ -1563,8 +1590,7 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     q2.ngroups = p.ngroups;
     q2.core_off[0] = 0;
     for (int c = 0; c < n; ++c) {
-      const int L = c == 0 ? 1 : p.Ra, Rr = c == n - 1 ? 1 : p.Ra;
-      q2.core_off[c + 1] = q2.core_off[c] + p.o[c] * L * Rr * p.qc;
+      q2.core_off[c + 1] = q2.core_off[c] + p.o[c] * p.bl[c] * p.br[c] * p.qc;
     }
     if (lds2 <= DCTN_LDS_BUDGET) {
       long long blocks = (p.ngroups + 3) / 4;
@@ -1622,7 +1648,9 @@ static int convsbs_bwd_mfma_one(const void* x, const int64_t xs[5], const void* 
     }
   }
   // first version (32x32x2 tiles, R <= 16): strings whose packs do not fit the second version's LDS plan
-  if (sl.sliced || p.Ra != R || use_saved) return DCTN_ERR_UNSUPPORTED;   // (slices, padded bonds, saved states: second version only)
+  bool full_tiles = true;   // every inner bond equal to the tile size
+  for (int c = 1; c < n; ++c) full_tiles = full_tiles && bond_sizes[c] == R;
+  if (sl.sliced || !full_tiles || use_saved) return DCTN_ERR_UNSUPPORTED;   // (slices, padded bonds, saved states: second version only)
   p.ngroups = (p.Wn + 31) / 32;
   so = 0;
   oacc = 1;
@@ -1667,20 +1695,14 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                      int q, int dtype, hipStream_t st, float* partials, size_t partial_bytes, const float* saved_states) {
   if (dtype != DCTN_F32 || !dcores) return DCTN_ERR_UNSUPPORTED;
-  long long qc = 1;
-  for (int c = 0; c < C; ++c) qc *= q;
-  const int m = sbsm_many_output_core(n, out_sizes);
-  const int Rb = n > 1 ? bond_sizes[1] : 1;
-  const bool ring = n > 1 && bond_sizes[0] == Rb && Rb > 1;
   return sbsm_for_slices(n, cores, out_sizes, bond_sizes, C, q,
-                         [&](const void* const* cp, const int* outs, const int* bonds, const SbsSlice& sl, int l0, int o0) {
+                         [&](const long long* coff, const int* outs, const int* bonds, const SbsSlice& sl) {
+                           const void* cp[SBSM_MAXC];
                            float* dcp[SBSM_MAXC];   // the gradient views follow the core views
-                           for (int c = 0; c < n; ++c) dcp[c] = dcores[c];
-                           if (sl.sliced && ring) {
-                             dcp[0] = dcores[0] + (long long)l0 * Rb * qc;
-                             dcp[n - 1] = dcores[n - 1] + (long long)l0 * qc;
+                           for (int c = 0; c < n; ++c) {
+                             cp[c] = (const float*)cores[c] + coff[c];
+                             dcp[c] = dcores[c] + coff[c];
                            }
-                           if (sl.sliced && m >= 0) dcp[m] = dcores[m] + (long long)o0 * Rb * Rb * qc;
                            return convsbs_bwd_mfma_one(x, xs, cp, dY, states, gxw, dcp, n, outs, bonds, pos_h, pos_w, C, B, H,
                                                        W, q, dtype, st, partials, partial_bytes, sl, saved_states);
                          });

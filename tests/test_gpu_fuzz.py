@@ -407,6 +407,14 @@ def sbs_mfma_cases():
                                 (6, 1, 3, (1, 1, 1, 1, 2, 1, 1, 1, 1), True), (12, 2, 2, (1, 1, 1, 1, 5, 1, 1, 1, 1), False),
                                 (5, 1, 2, (1, 2, 1, 1), False), (2, 2, 2, (1, 1, 1, 1, 10, 1, 1, 1, 1), True)]:
         cases.append((snake[:len(outs)], ((r if ring else 1),) + (r,) * (len(outs) - 1), tuple(outs), C, q))
+    # unequal bonds (every core padded to the tile of the largest), several cores with outputs, outputs on the end cores:
+    # slices over views of the cores - the ring of the reference's conversion test, tests/test_conversion_of_convsbs_to_eps.py:25-28
+    cases.append((snake, (1, 3, 5, 8, 6, 2, 7, 4, 8), (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 2))
+    cases.append((snake, (1, 16, 12, 16, 9, 16, 16, 10, 16), (1,) * 9, 1, 3))
+    cases.append((((0, 0), (0, 1), (1, 1), (1, 0)), (3, 4, 5, 6), (1, 3, 2, 4), 2, 2))
+    cases.append((((0, 1), (0, 0), (1, 0), (1, 1)), (3, 4, 5, 6), (4, 2, 1, 3), 2, 2))
+    cases.append((snake[:5], (1, 4, 6, 6, 4), (2, 1, 3, 1, 2), 1, 3))
+    cases.append((snake[:6], (1, 4, 4, 4, 4, 4), (1, 2, 1, 2, 1, 1), 1, 2))
     return cases
 
 
@@ -421,8 +429,8 @@ def sbs_reg_family_takes(pos, bonds, outs, C, q):
 
 
 @pytest.mark.parametrize("family", ["default", "matrix_cores"])
-@pytest.mark.parametrize("case", sbs_mfma_cases(), ids=lambda c: "n%d_r%d_o%s_C%dq%d" % (
-    len(c[0]), c[1][1], "".join(map(str, c[2])), c[3], c[4]))
+@pytest.mark.parametrize("case", sbs_mfma_cases(), ids=lambda c: "n%d_r%s_o%s_C%dq%d" % (
+    len(c[0]), c[1][1] if len(set(c[1][1:])) == 1 else "".join("%x" % b for b in c[1]), "".join(map(str, c[2])), c[3], c[4]))
 def test_convsbs_mfma_family_random(case, family):
     """family: small-bond strings run on the register-resident sweep by default; `matrix_core_sweep()` sends them to the
     matrix-core sweep, so both families meet the oracle on the same strings."""

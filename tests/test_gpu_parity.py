@@ -262,6 +262,29 @@ def test_conversion_all_24_permutations():  # reference test: tests/test_convers
         assert close(R.eps_4step(want_eps, x.detach().cpu()), want_y.detach(), torch.float64)   # the oracle agrees with itself
 
 
+def test_conversion_ring_float32_runs_on_the_matrix_core_sweep():
+    """The ring of the reference's conversion test (bonds (3, 4, 5, 6), outputs (1, 3, 2, 4), every order of the cores;
+    tests/test_conversion_of_convsbs_to_eps.py:13-56) in float32: unequal bonds are padded to one tile, the closing bond and
+    the cores with several outputs run as slices - forward and backward both on the matrix-core sweep, against the oracle."""
+    cores = (SBSSpecCore(Pos2D(0, 0), 1), SBSSpecCore(Pos2D(0, 1), 3), SBSSpecCore(Pos2D(1, 0), 2), SBSSpecCore(Pos2D(1, 1), 4))
+    torch.manual_seed(25)
+    for perm in itertools.permutations(cores):
+        m = ConvSBS(SBSSpecString(perm, (3, 4, 5, 6), 2, 2)).to(DEV)
+        x = torch.randn(2, 3, 4, 5, 2, device=DEV, requires_grad=True)
+        ys = m(x)
+        assert dctn_amd.last_kernel() == "convsbs_fwd_mfma_f32"
+        dy = torch.randn_like(ys)
+        ys.backward(dy)
+        assert dctn_amd.last_kernel() == "convsbs_bwd_mfma_f32"
+        cores64 = [c.detach().cpu().double() for c in m.cores]
+        pos = [(c.position.h, c.position.w) for c in perm]
+        gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, pos, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
+        assert close(ys, R.convsbs_forward(cores64, pos, x.detach().cpu().double()), torch.float32)
+        assert close(x.grad, gr[0], torch.float32)
+        for c, gc in zip(m.cores, gr[1:]):
+            assert close(c.grad, gc, torch.float32)
+
+
 @pytest.mark.parametrize("r,q,C,B,HW", [(4, 3, 1, 3, 12), (8, 3, 1, 2, 10), (16, 3, 1, 2, 8), (16, 2, 2, 2, 7)])
 def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
     """BASELINE cfg4: the 9-core snake of mnist.py:190-199 on the CIFAR colour layout (q=3) and its
