@@ -246,22 +246,54 @@ __device__ __forceinline__ void lds_transpose16(float* scr, int c, int g, const 
   for (int s = 0; s < 4; ++s) col[s] = scr[(4 * g + s) * LME_PST + c];
 }
 
-// One factored step in the base-2 domain.  v: state (lane (t = c, g): acc'[t][4g + s]); mcol: the
-// right matrix, k-major (lane (i = c, g): M'[4g + s][i]).  Returns S (lane (t = c, g): S[t][4g + reg])
-// and the two shifts (a_t in lane c = t, b_i in lane c = i).
-__device__ __forceinline__ f32x4_t lme_step16(const float (&v)[4], const float (&mcol)[4], float& amax,
-                                              float& bmax) {
-  amax = wave16_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-  bmax = wave16_max(fmaxf(fmaxf(mcol[0], mcol[1]), fmaxf(mcol[2], mcol[3])));
+__device__ __forceinline__ bool lme_step_ok(const f32x4_t& S) {
+  return (S[0] >= LME_SMIN) && (S[1] >= LME_SMIN) && (S[2] >= LME_SMIN) && (S[3] >= LME_SMIN);
+}
+
+// The running prefix is carried in SCALED form, not in the log domain: P[t][r] = a_t + log2 E[t][r] with max_r E[t][r] = 1
+// (the "scaled forward algorithm").  E IS the left operand of the next product (2^(P - a_t)), so a step needs no exp for
+// it and no log for its result:
+//   S = E x EM (EM = 2^(M - b_i), b_i = max_r M[r][i]);   T[t][i] = S[t][i] * 2^(b_i - b_0);   E' = T / max_i T,
+//   a' = a + b_0 + log2 max_i T:   per lane 4 + 1 v_exp, 1 v_rcp, 1 v_log per step instead of 8 v_exp + 4 v_log
+// (these are quarter-rate instructions: 40 % of the vector time of the log-domain version).  Entries more than 2^-126
+// below their row maximum flush to zero exactly where the log-domain version's 2^(P - a_t) did; the LAST step still forms
+// its result as a + b_i + log2 S, so nothing flushes on the way out.  2^(b_i - b_0) overflows only when column maxima of
+// one matrix differ by 2^127: the step is then rejected like any other the factorisation cannot represent.
+constexpr float LME_BIG = 1.0e38f;
+
+__device__ __forceinline__ float max4(const float (&v)[4]) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
+
+// log-domain row (state layout) -> scaled form; a row of -inf gets shift 0 and E = 0, a row holding +inf or NaN gets
+// E = NaN: either way the next product rejects the step
+__device__ __forceinline__ void lme_to_scaled(const float (&v)[4], float (&E)[4], float& a) {
+  const float m = wave16_max(max4(v));
+  a = (m == neg_inf<float>()) ? 0.f : m;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) E[s] = ex2(v[s] - a);
+}
+
+// S = E x 2^(M - b) for the k-major matrix mcol; bmax: b_i in the lanes whose c equals i
+__device__ __forceinline__ f32x4_t lme_step16s(const float (&E)[4], const float (&mcol)[4], float& bmax) {
+  bmax = wave16_max(max4(mcol));
   f32x4_t S = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(mcol[s] - bmax), ex2(v[s] - amax), S, 0, 0, 0);
+  for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(mcol[s] - bmax), E[s], S, 0, 0, 0);
   return S;
 }
 
-__device__ __forceinline__ bool lme_step_ok(const f32x4_t& S) {
-  return (S[0] >= LME_SMIN) && (S[1] >= LME_SMIN) && (S[2] >= LME_SMIN) && (S[3] >= LME_SMIN);
+// E' and the row's new shift from S; returns false (in any lane of the row) when 2^(b_i - b_0) overflowed
+__device__ __forceinline__ bool lme_rescale(const f32x4_t& S, float bmax, int g, float (&En)[4], float& da) {
+  const float bref = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bmax)));   // b_0
+  const float cb = ex2(bmax - bref);
+  float T[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) T[reg] = S[reg] * __shfl(cb, 4 * g + reg, 64);
+  const float rmax = wave16_max(max4(T));
+  const float rinv = __builtin_amdgcn_rcpf(rmax);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) En[reg] = T[reg] * rinv;
+  da = bref + lg2(rmax);
+  return rmax < LME_BIG;
 }
 
 __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __restrict__ mats,
@@ -276,8 +308,16 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
   for (long long w = wave; w < Wn; w += nwaves) {
     const float* base = mats + w * (long long)L * 256;
     const float4 v4 = *reinterpret_cast<const float4*>(base + gl_off);
-    // state (base-2 domain): v[s] = log2(e) * acc[t = c][4g + s]
-    float v[4] = {v4.x * LME_LOG2E, v4.y * LME_LOG2E, v4.z * LME_LOG2E, v4.w * LME_LOG2E};
+    if (L == 1) {   // nothing to fold
+      *reinterpret_cast<float4*>(out + w * 256 + gl_off) = v4;
+      continue;
+    }
+    // state: P[t = c][4g + s] = a + log2 E[s] (base-2 domain)
+    float E[4], a;
+    {
+      const float v[4] = {v4.x * LME_LOG2E, v4.y * LME_LOG2E, v4.z * LME_LOG2E, v4.w * LME_LOG2E};
+      lme_to_scaled(v, E, a);
+    }
     // three matrices in flight per wave
     float4 q0 = *reinterpret_cast<const float4*>(base + (long long)(1 < L ? 1 : 0) * 256 + gl_off);
     float4 q1 = *reinterpret_cast<const float4*>(base + (long long)(2 < L ? 2 : L - 1) * 256 + gl_off);
@@ -287,61 +327,74 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
       float mcol[4];
       lds_transpose16(scr, c, g, make_float4(q0.x * LME_LOG2E, q0.y * LME_LOG2E, q0.z * LME_LOG2E, q0.w * LME_LOG2E),
                       mcol);                                              // mcol[s] = M'_l[4g + s][c]
-      float amax, bmax;
-      const f32x4_t S = lme_step16(v, mcol, amax, bmax);
-      if (__all(lme_step_ok(S))) {
-        // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
+      float bmax, En[4], da;
+      const f32x4_t S = lme_step16s(E, mcol, bmax);
+      const bool last = l == L - 1;
+      bool ok = lme_step_ok(S);
+      if (!last) ok = lme_rescale(S, bmax, g, En, da) && ok;
+      if (__all(ok)) {
+        if (last) {
+          // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
+          float r[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) v[reg] = lg2(S[reg]) + amax + __shfl(bmax, 4 * g + reg, 64);
-      } else {
-        // exact path (rare, natural-log domain, kept small on purpose: rolled loops so that it does not
-        // set the kernel's register budget): acc[t][r] comes from the 4 lanes of row t, M[r][4g..4g+3]
-        // from memory
-        const float* mb = base + (long long)l * 256;
-        float vn[4], res[4];
+          for (int reg = 0; reg < 4; ++reg) r[reg] = (lg2(S[reg]) + a + __shfl(bmax, 4 * g + reg, 64)) * LME_LN2;
+          *reinterpret_cast<float4*>(out + w * 256 + gl_off) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+          a += da;
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) vn[s2] = v[s2] * LME_LN2;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int i = 4 * g + reg;
-          float m = neg_inf<float>();
-#pragma unroll 1
-          for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-              m = xmax(m, __shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i]);
-          }
-          const float mm = xisinf(m) ? 0.f : m;
-          float sacc = 0.f;
-#pragma unroll 1
-          for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-              sacc += expf(__shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i] - mm);
-          }
-          res[reg] = logf(sacc) + mm;
+          for (int reg = 0; reg < 4; ++reg) E[reg] = En[reg];
         }
+      } else {
+        // A step the factorisation cannot represent (rare): the scaled prefix has already flushed the entries far below
+        // their row maximum, and here they may be the ones that matter - so the WINDOW starts again in the log domain,
+        // every step by the max-shifted sum (same semantics as torch.logsumexp).  Natural-log domain, rolled loops
+        // (kept small on purpose: it must not set the kernel's register budget): acc[t][r] comes from the 4 lanes of
+        // row t, M[r][4g..4g+3] from memory.
+        float vn[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll 1
+        for (int l2 = 1; l2 < L; ++l2) {
+          const float* mb = base + (long long)l2 * 256;
+          float res[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) v[reg] = res[reg] * LME_LOG2E;
+          for (int reg = 0; reg < 4; ++reg) {
+            const int i = 4 * g + reg;
+            float m = neg_inf<float>();
+#pragma unroll 1
+            for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+              for (int s2 = 0; s2 < 4; ++s2)
+                m = xmax(m, __shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i]);
+            }
+            const float mm = xisinf(m) ? 0.f : m;
+            float sacc = 0.f;
+#pragma unroll 1
+            for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+              for (int s2 = 0; s2 < 4; ++s2)
+                sacc += expf(__shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i] - mm);
+            }
+            res[reg] = logf(sacc) + mm;
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) vn[reg] = res[reg];
+        }
+        *reinterpret_cast<float4*>(out + w * 256 + gl_off) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+        break;
       }
       q0 = q1; q1 = q2; q2 = q3;
     }
-    *reinterpret_cast<float4*>(out + w * 256 + gl_off) =
-        make_float4(v[0] * LME_LN2, v[1] * LME_LN2, v[2] * LME_LN2, v[3] * LME_LN2);
   }
 }
 
 // Factored backward of the same fold (D = 16, float32), one wave per window.  Pass 1 reads every
-// matrix once (all loads in flight together), recomputes the prefix folds P_1..P_{L-1} exactly as the
-// forward kernel does and keeps matrices, prefixes and both shifts of every step in registers
-// (LMAX is the compile-time bound on L); pass 2 walks back with, per step (P = P_{l-1}, M = M_l,
-// Pn = P_l, everything in the base-2 domain):
-//   EP = 2^(P - a_t), EM = 2^(M - b_i), H = G * 2^(a_t + b_i - Pn)               (= G / S)
-//   dP = EP .* (H x EM^T)          dM = EM .* (EP^T x H)
-// i.e. two 16x16x16 products on v_mfma_f32_16x16x4_f32 plus 12 v_exp_f32 per lane instead of
-// 2*4096 exps per window and step.  dP^T comes out of the matrix core in the state layout (lane
-// (t, g) holds columns 4g..4g+3 of row t) so it feeds the next step directly; the operands of dM need
-// t on the k index, so EP and H take one trip through a per-wave LDS scratch tile.  A window with a
+// matrix once (all loads in flight together), recomputes the scaled prefixes E_1..E_{L-1} exactly as the
+// forward kernel does and keeps, per step, E, the product S and EM = 2^(M - b_i) (in the place of the matrix)
+// in registers (LMAX is the compile-time bound on L); pass 2 walks back with, per step (EP = E_{l-1}, EM, S of step l):
+//   H = G / S              dP = EP .* (H x EM^T)          dM = EM .* (EP^T x H)
+// (the shifts 2^(a_t), 2^(b_i) cancel between the numerator and S), i.e. two 16x16x16 products on
+// v_mfma_f32_16x16x4_f32 plus 4 v_rcp_f32 per lane - every exp of the step was taken in pass 1.  dP^T comes out of
+// the matrix core in the state layout (lane (t, g) holds columns 4g..4g+3 of row t) so it feeds the next step directly;
+// the operands of dM need t on the k index, so EP and H take one trip through a per-wave LDS scratch tile.  A window with a
 // step the factorisation cannot represent is flagged and left to the exact kernel.
 constexpr int LME_BWD_WAVES = 4;
 
@@ -360,27 +413,32 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
   for (long long w = wave; w < Wn; w += nwaves) {
     const float* base = mats + w * (long long)L * 256;
     // ---------------- pass 1
-    float Mr[LMAX][4];     // M'_l[r = c][4g + s]
+    float Mr[LMAX][4];     // M'_l[r = c][4g + s], then EM_l in the same layout
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       const float4 q = *reinterpret_cast<const float4*>(base + (long long)(l < L ? l : L - 1) * 256 + gl_off);
       Mr[l][0] = q.x * LME_LOG2E; Mr[l][1] = q.y * LME_LOG2E; Mr[l][2] = q.z * LME_LOG2E; Mr[l][3] = q.w * LME_LOG2E;
     }
-    float pre[LMAX][4];    // P'_l in the state layout
-    float sa[LMAX], sb[LMAX];   // shifts of step l: a_t (lane c = t), b_i (lane c = i)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) pre[0][s] = Mr[0][s];
+    float Es[LMAX][4];     // E_l in the state layout
+    float Ss[LMAX][4];     // S of step l
+    {
+      float a0;
+      lme_to_scaled(Mr[0], Es[0], a0);
+    }
     bool ok = true;
 #pragma unroll
     for (int l = 1; l < LMAX; ++l) {
       if (l < L) {
-        float mcol[4];
+        float mcol[4], bmax, da;
         lds_transpose16(scrE, c, g, make_float4(Mr[l][0], Mr[l][1], Mr[l][2], Mr[l][3]), mcol);
-        const f32x4_t S = lme_step16(pre[l - 1], mcol, sa[l], sb[l]);
+        const f32x4_t S = lme_step16s(Es[l - 1], mcol, bmax);
         ok = ok && lme_step_ok(S);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          pre[l][reg] = lg2(S[reg]) + sa[l] + __shfl(sb[l], 4 * g + reg, 64);
+        for (int reg = 0; reg < 4; ++reg) {
+          Ss[l][reg] = S[reg];
+          Mr[l][reg] = ex2(Mr[l][reg] - __shfl(bmax, 4 * g + reg, 64));   // EM[r = c][i = 4g + reg]
+        }
+        if (l + 1 < L) ok = lme_rescale(S, bmax, g, Es[l], da) && ok;
       }
     }
     const bool all_ok = __all(ok);
@@ -392,18 +450,11 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
 #pragma unroll
     for (int l = LMAX - 1; l >= 1; --l) {
       if (l < L) {
-        const float* M = Mr[l];
-        const float* P = pre[l - 1];
-        const float* Pn = pre[l];
-        const float a = sa[l];
-        float EP[4], EM[4], H[4];
+        const float* EM = Mr[l];
+        const float* EP = Es[l - 1];
+        float H[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float bs = __shfl(sb[l], 4 * g + s, 64);               // b_i, i = 4g + s
-          EP[s] = ex2(P[s] - a);
-          EM[s] = ex2(M[s] - bs);
-          H[s] = G[s] * ex2((a - Pn[s]) + bs);
-        }
+        for (int s = 0; s < 4; ++s) H[s] = G[s] * __builtin_amdgcn_rcpf(Ss[l][s]);
         wave_lds_sync();   // the previous step's reads of the scratch tiles are done
         *reinterpret_cast<float4*>(scrE + st_off) = make_float4(EP[0], EP[1], EP[2], EP[3]);
         *reinterpret_cast<float4*>(scrH + st_off) = make_float4(H[0], H[1], H[2], H[3]);
