@@ -216,14 +216,27 @@ constexpr float LME_SMIN = 7.888609052210118e-31f;   // 2^-100
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
 
+// v_max_f32 / v_max3_f32 as they are: fmaxf() on a value that came through a lane swap is preceded by a canonicalising
+// v_max(x, x) per operand (8 of a reduction's 17 instructions).  A NaN operand may be dropped here - harmless: the NaN
+// still reaches the product through its own exp and the step is rejected on S.
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // max over the four lanes (c, 0..3) that share c; result in all four
 __device__ __forceinline__ float wave16_max(float v) {
   int iv = __float_as_int(v);
   lme_int2v r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
-  v = fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+  v = vmax(__int_as_float(r[0]), __int_as_float(r[1]));
   iv = __float_as_int(v);
   r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
-  return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+  return vmax(__int_as_float(r[0]), __int_as_float(r[1]));
 }
 
 constexpr int LME_PST = 20;                 // padded row stride of a 16x16 tile in LDS
@@ -261,30 +274,34 @@ __device__ __forceinline__ bool lme_step_ok(const f32x4_t& S) {
 // one matrix differ by 2^127: the step is then rejected like any other the factorisation cannot represent.
 constexpr float LME_BIG = 1.0e38f;
 
-__device__ __forceinline__ float max4(const float (&v)[4]) { return fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])); }
+__device__ __forceinline__ float max4(const float (&v)[4]) { return vmax(vmax3(v[0], v[1], v[2]), v[3]); }
 
-// log-domain row (state layout) -> scaled form; a row of -inf gets shift 0 and E = 0, a row holding +inf or NaN gets
-// E = NaN: either way the next product rejects the step
+// The matrices stay in the NATURAL-log domain as loaded; log2(e) rides in the multiply-add in front of every v_exp_f32
+// (2^(m log2e - b log2e)) instead of a multiply per loaded value.
+
+// natural-log row (state layout) -> scaled form (a in the base-2 domain); a row of -inf gets shift 0 and E = 0, a row
+// holding +inf or NaN gets E = NaN: either way the next product rejects the step
 __device__ __forceinline__ void lme_to_scaled(const float (&v)[4], float (&E)[4], float& a) {
   const float m = wave16_max(max4(v));
-  a = (m == neg_inf<float>()) ? 0.f : m;
+  a = (m == neg_inf<float>()) ? 0.f : m * LME_LOG2E;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) E[s] = ex2(v[s] - a);
+  for (int s = 0; s < 4; ++s) E[s] = ex2(__builtin_fmaf(v[s], LME_LOG2E, -a));
 }
 
-// S = E x 2^(M - b) for the k-major matrix mcol; bmax: b_i in the lanes whose c equals i
-__device__ __forceinline__ f32x4_t lme_step16s(const float (&E)[4], const float (&mcol)[4], float& bmax) {
-  bmax = wave16_max(max4(mcol));
+// S = E x 2^((M - b) log2e) for the k-major matrix mcol (natural log); nb = -b_i log2e in the lanes whose c equals i
+__device__ __forceinline__ f32x4_t lme_step16s(const float (&E)[4], const float (&mcol)[4], float& nb) {
+  nb = wave16_max(max4(mcol)) * -LME_LOG2E;
   f32x4_t S = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(mcol[s] - bmax), E[s], S, 0, 0, 0);
+  for (int s = 0; s < 4; ++s)
+    S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(__builtin_fmaf(mcol[s], LME_LOG2E, nb)), E[s], S, 0, 0, 0);
   return S;
 }
 
-// E' and the row's new shift from S; returns false (in any lane of the row) when 2^(b_i - b_0) overflowed
-__device__ __forceinline__ bool lme_rescale(const f32x4_t& S, float bmax, int g, float (&En)[4], float& da) {
-  const float bref = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bmax)));   // b_0
-  const float cb = ex2(bmax - bref);
+// E' and the row's new shift (base-2 domain) from S; returns false (in any lane of the row) when 2^(b_i - b_0) overflowed
+__device__ __forceinline__ bool lme_rescale(const f32x4_t& S, float nb, int g, float (&En)[4], float& da) {
+  const float nref = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nb)));   // -b_0 log2e
+  const float cb = ex2(nref - nb);
   float T[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) T[reg] = S[reg] * __shfl(cb, 4 * g + reg, 64);
@@ -292,10 +309,114 @@ __device__ __forceinline__ bool lme_rescale(const f32x4_t& S, float bmax, int g,
   const float rinv = __builtin_amdgcn_rcpf(rmax);
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) En[reg] = T[reg] * rinv;
-  da = bref + lg2(rmax);
+  da = lg2(rmax) - nref;
   return rmax < LME_BIG;
 }
 
+// The max-shifted sums of a whole window in the natural-log domain (same semantics as torch.logsumexp), rolled loops:
+// the way out for a window with a step the factorisation cannot represent.  The scaled prefix has already flushed
+// the entries far below their row maximum, and in such a step they may be the ones that matter - so the window starts
+// again from its first matrix.  acc[t][r] comes from the 4 lanes of row t, M[r][4g..4g+3] from memory.
+__device__ __forceinline__ void lme_exact_window(const float* __restrict__ base, float* __restrict__ outw, int L, int c, int g) {
+  const float4 v4 = *reinterpret_cast<const float4*>(base + c * 16 + 4 * g);
+  float vn[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll 1
+  for (int l2 = 1; l2 < L; ++l2) {
+    const float* mb = base + (long long)l2 * 256;
+    float res[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = 4 * g + reg;
+      float m = neg_inf<float>();
+#pragma unroll 1
+      for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) m = xmax(m, __shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i]);
+      }
+      const float mm = xisinf(m) ? 0.f : m;
+      float sacc = 0.f;
+#pragma unroll 1
+      for (int kq = 0; kq < 4; ++kq) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) sacc += expf(__shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i] - mm);
+      }
+      res[reg] = logf(sacc) + mm;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) vn[reg] = res[reg];
+  }
+  *reinterpret_cast<float4*>(outw + c * 16 + 4 * g) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+}
+
+// One step of the forward fold on the state (E, a); `last`: the result goes out instead of becoming the next state.
+// Returns false when the step was rejected (uniform over the wave).
+__device__ __forceinline__ bool lme_fwd_step(float* scr, int c, int g, const float4& qm, float (&E)[4], float& a, bool last,
+                                             float* __restrict__ outp) {
+  float mcol[4];
+  lds_transpose16(scr, c, g, qm, mcol);   // mcol[s] = M_l[4g + s][c]
+  float nb, En[4], da;
+  const f32x4_t S = lme_step16s(E, mcol, nb);
+  bool ok = lme_step_ok(S);
+  if (!last) ok = lme_rescale(S, nb, g, En, da) && ok;
+  if (!__all(ok)) return false;
+  if (last) {
+    // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
+    float r[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) r[reg] = (lg2(S[reg]) + a - __shfl(nb, 4 * g + reg, 64)) * LME_LN2;
+    *reinterpret_cast<float4*>(outp) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    a += da;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) E[reg] = En[reg];
+  }
+  return true;
+}
+
+// L <= LMAX: slot l holds matrix l of the wave's current window until step l has used it and is refilled at once with
+// matrix l of the wave's NEXT window - the steps are unrolled, so every slot is a fixed set of registers (a rotating
+// queue of four cost 12 v_mov per step) and up to LMAX KiB per wave are in flight across the window boundary.
+template <int LMAX>
+__global__ __launch_bounds__(256) void lme_fold16_fwd_slots_k(const float* __restrict__ mats, float* __restrict__ out,
+                                                              long long Wn, int L) {
+  __shared__ __align__(16) float scratch[4][LME_TILE];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  float* scr = scratch[threadIdx.x >> 6];
+  const int gl_off = c * 16 + 4 * g;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * 4;
+  if (wave >= Wn) return;
+  float4 Mq[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l)
+    Mq[l] = *reinterpret_cast<const float4*>(mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
+  for (long long w = wave; w < Wn; w += nwaves) {
+    const float* nbase = mats + (w + nwaves < Wn ? w + nwaves : w) * (long long)L * 256 + gl_off;   // (the last window re-reads itself)
+    const float4 v4 = Mq[0];
+    Mq[0] = *reinterpret_cast<const float4*>(nbase);
+    if (L == 1) {   // nothing to fold
+      *reinterpret_cast<float4*>(out + w * 256 + gl_off) = v4;
+      continue;
+    }
+    float E[4], a;
+    {
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      lme_to_scaled(v, E, a);
+    }
+    bool good = true;
+#pragma unroll
+    for (int l = 1; l < LMAX; ++l) {
+      if (l < L) {
+        const float4 qm = Mq[l];
+        Mq[l] = *reinterpret_cast<const float4*>(nbase + (long long)l * 256);
+        if (good) good = lme_fwd_step(scr, c, g, qm, E, a, l == L - 1, out + w * 256 + gl_off);
+      }
+    }
+    if (!good) lme_exact_window(mats + w * (long long)L * 256, out + w * 256, L, c, g);
+  }
+}
+
+// any L: four matrices of the wave's stream in flight in a rotating queue
 __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __restrict__ mats,
                                                              float* __restrict__ out, long long Wn,
                                                              int L) {
@@ -305,84 +426,35 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
   const int gl_off = c * 16 + 4 * g;
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * 4;
+  long long pw = wave;   // stream position of the next matrix to request: window pw, matrix pl
+  int pl = 0;
+  auto fetch = [&]() {
+    const bool in = pw < Wn;
+    const float4 q = *reinterpret_cast<const float4*>(mats + ((in ? pw : wave) * (long long)L + (in ? pl : 0)) * 256 + gl_off);
+    if (++pl == L) { pl = 0; pw += nwaves; }
+    return q;
+  };
+  if (wave >= Wn) return;
+  float4 q0 = fetch(), q1 = fetch(), q2 = fetch(), q3 = fetch();
   for (long long w = wave; w < Wn; w += nwaves) {
-    const float* base = mats + w * (long long)L * 256;
-    const float4 v4 = *reinterpret_cast<const float4*>(base + gl_off);
+    const float4 v4 = q0;
+    q0 = q1; q1 = q2; q2 = q3; q3 = fetch();
     if (L == 1) {   // nothing to fold
       *reinterpret_cast<float4*>(out + w * 256 + gl_off) = v4;
       continue;
     }
-    // state: P[t = c][4g + s] = a + log2 E[s] (base-2 domain)
     float E[4], a;
     {
-      const float v[4] = {v4.x * LME_LOG2E, v4.y * LME_LOG2E, v4.z * LME_LOG2E, v4.w * LME_LOG2E};
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
       lme_to_scaled(v, E, a);
     }
-    // three matrices in flight per wave
-    float4 q0 = *reinterpret_cast<const float4*>(base + (long long)(1 < L ? 1 : 0) * 256 + gl_off);
-    float4 q1 = *reinterpret_cast<const float4*>(base + (long long)(2 < L ? 2 : L - 1) * 256 + gl_off);
-    float4 q2 = *reinterpret_cast<const float4*>(base + (long long)(3 < L ? 3 : L - 1) * 256 + gl_off);
+    bool good = true;
     for (int l = 1; l < L; ++l) {
-      const float4 q3 = *reinterpret_cast<const float4*>(base + (long long)(l + 3 < L ? l + 3 : L - 1) * 256 + gl_off);
-      float mcol[4];
-      lds_transpose16(scr, c, g, make_float4(q0.x * LME_LOG2E, q0.y * LME_LOG2E, q0.z * LME_LOG2E, q0.w * LME_LOG2E),
-                      mcol);                                              // mcol[s] = M'_l[4g + s][c]
-      float bmax, En[4], da;
-      const f32x4_t S = lme_step16s(E, mcol, bmax);
-      const bool last = l == L - 1;
-      bool ok = lme_step_ok(S);
-      if (!last) ok = lme_rescale(S, bmax, g, En, da) && ok;
-      if (__all(ok)) {
-        if (last) {
-          // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
-          float r[4];
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) r[reg] = (lg2(S[reg]) + a + __shfl(bmax, 4 * g + reg, 64)) * LME_LN2;
-          *reinterpret_cast<float4*>(out + w * 256 + gl_off) = make_float4(r[0], r[1], r[2], r[3]);
-        } else {
-          a += da;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) E[reg] = En[reg];
-        }
-      } else {
-        // A step the factorisation cannot represent (rare): the scaled prefix has already flushed the entries far below
-        // their row maximum, and here they may be the ones that matter - so the WINDOW starts again in the log domain,
-        // every step by the max-shifted sum (same semantics as torch.logsumexp).  Natural-log domain, rolled loops
-        // (kept small on purpose: it must not set the kernel's register budget): acc[t][r] comes from the 4 lanes of
-        // row t, M[r][4g..4g+3] from memory.
-        float vn[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll 1
-        for (int l2 = 1; l2 < L; ++l2) {
-          const float* mb = base + (long long)l2 * 256;
-          float res[4];
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int i = 4 * g + reg;
-            float m = neg_inf<float>();
-#pragma unroll 1
-            for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-              for (int s2 = 0; s2 < 4; ++s2)
-                m = xmax(m, __shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i]);
-            }
-            const float mm = xisinf(m) ? 0.f : m;
-            float sacc = 0.f;
-#pragma unroll 1
-            for (int kq = 0; kq < 4; ++kq) {
-#pragma unroll
-              for (int s2 = 0; s2 < 4; ++s2)
-                sacc += expf(__shfl(vn[s2], c + 16 * kq, 64) + mb[(4 * kq + s2) * 16 + i] - mm);
-            }
-            res[reg] = logf(sacc) + mm;
-          }
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) vn[reg] = res[reg];
-        }
-        *reinterpret_cast<float4*>(out + w * 256 + gl_off) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-        break;
-      }
-      q0 = q1; q1 = q2; q2 = q3;
+      const float4 qm = q0;
+      q0 = q1; q1 = q2; q2 = q3; q3 = fetch();   // (a rejected window keeps the stream's place)
+      if (good) good = lme_fwd_step(scr, c, g, qm, E, a, l == L - 1, out + w * 256 + gl_off);
     }
+    if (!good) lme_exact_window(mats + w * (long long)L * 256, out + w * 256, L, c, g);
   }
 }
 
@@ -413,11 +485,11 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
   for (long long w = wave; w < Wn; w += nwaves) {
     const float* base = mats + w * (long long)L * 256;
     // ---------------- pass 1
-    float Mr[LMAX][4];     // M'_l[r = c][4g + s], then EM_l in the same layout
+    float Mr[LMAX][4];     // M_l[r = c][4g + s] (natural log), then EM_l in the same layout
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       const float4 q = *reinterpret_cast<const float4*>(base + (long long)(l < L ? l : L - 1) * 256 + gl_off);
-      Mr[l][0] = q.x * LME_LOG2E; Mr[l][1] = q.y * LME_LOG2E; Mr[l][2] = q.z * LME_LOG2E; Mr[l][3] = q.w * LME_LOG2E;
+      Mr[l][0] = q.x; Mr[l][1] = q.y; Mr[l][2] = q.z; Mr[l][3] = q.w;
     }
     float Es[LMAX][4];     // E_l in the state layout
     float Ss[LMAX][4];     // S of step l
@@ -429,16 +501,16 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
 #pragma unroll
     for (int l = 1; l < LMAX; ++l) {
       if (l < L) {
-        float mcol[4], bmax, da;
+        float mcol[4], nb, da;
         lds_transpose16(scrE, c, g, make_float4(Mr[l][0], Mr[l][1], Mr[l][2], Mr[l][3]), mcol);
-        const f32x4_t S = lme_step16s(Es[l - 1], mcol, bmax);
+        const f32x4_t S = lme_step16s(Es[l - 1], mcol, nb);
         ok = ok && lme_step_ok(S);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           Ss[l][reg] = S[reg];
-          Mr[l][reg] = ex2(Mr[l][reg] - __shfl(bmax, 4 * g + reg, 64));   // EM[r = c][i = 4g + reg]
+          Mr[l][reg] = ex2(__builtin_fmaf(Mr[l][reg], LME_LOG2E, __shfl(nb, 4 * g + reg, 64)));   // EM[r = c][i = 4g + reg]
         }
-        if (l + 1 < L) ok = lme_rescale(S, bmax, g, Es[l], da) && ok;
+        if (l + 1 < L) ok = lme_rescale(S, nb, g, Es[l], da) && ok;
       }
     }
     const bool all_ok = __all(ok);
@@ -659,11 +731,16 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
   if (D > 32) return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCTN_F32 && D == 16 && ((uintptr_t)mats % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+    const void* fn = L <= 5 ? (const void*)lme_fold16_fwd_slots_k<5> : L <= 9 ? (const void*)lme_fold16_fwd_slots_k<9>
+                     : L <= 16 ? (const void*)lme_fold16_fwd_slots_k<16> : (const void*)lme_fold16_fwd_mfma_k;
     long long blocks = (Wn + 3) / 4;
-    const long long cap = resident_blocks((const void*)lme_fold16_fwd_mfma_k, 256);
+    const long long cap = resident_blocks(fn, 256);
     if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
-    hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)mats,
-                       (float*)out, (long long)Wn, L);
+    const dim3 g((unsigned)blocks), b(256);
+    if (L <= 5) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<5>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+    else if (L <= 9) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<9>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+    else if (L <= 16) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<16>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+    else hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
     DCTN_CHECK_LAUNCH();
     dctn_set_last_kernel("logmatmulexp_fold_fwd_mfma16");
     return DCTN_OK;
