@@ -482,20 +482,29 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
   const int gl_off = c * 16 + 4 * g;
   const long long wave = (long long)blockIdx.x * LME_BWD_WAVES + wv;
   const long long nwaves = (long long)gridDim.x * LME_BWD_WAVES;
-  for (long long w = wave; w < Wn; w += nwaves) {
-    const float* base = mats + w * (long long)L * 256;
-    // ---------------- pass 1
-    float Mr[LMAX][4];     // M_l[r = c][4g + s] (natural log), then EM_l in the same layout
+  if (wave >= Wn) return;
+  // Slot l: matrix l of the current window (natural log) until pass 1 has turned it into EM_l, EM_l until pass 2 has used
+  // it, then matrix l of the wave's NEXT window at once - the loads of a window are spread over the previous window's
+  // way back instead of standing, all nine, in front of its first step (the kernel was short of bytes in flight: a wave
+  // had loads outstanding for a fifth of its time).  Matrix 1, whose slot frees last and is needed first, waits in N1.
+  float Mr[LMAX][4], N1[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load4 = [&](float (&dst)[4], const float* src) {
+    const float4 q = *reinterpret_cast<const float4*>(src);
+    dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+  };
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      const float4 q = *reinterpret_cast<const float4*>(base + (long long)(l < L ? l : L - 1) * 256 + gl_off);
-      Mr[l][0] = q.x; Mr[l][1] = q.y; Mr[l][2] = q.z; Mr[l][3] = q.w;
-    }
+  for (int l = 0; l < LMAX; ++l) load4(Mr[l], mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
+  for (long long w = wave; w < Wn; w += nwaves) {
+    const float* nbase = mats + (w + nwaves < Wn ? w + nwaves : w) * (long long)L * 256 + gl_off;   // (the last window re-reads itself)
+    float G[4];
+    load4(G, dOut + w * 256 + gl_off);   // needed after pass 1: its round trip hides behind it
+    // ---------------- pass 1
     float Es[LMAX][4];     // E_l in the state layout
     float Ss[LMAX][4];     // S of step l
     {
       float a0;
       lme_to_scaled(Mr[0], Es[0], a0);
+      load4(Mr[0], nbase);
     }
     bool ok = true;
 #pragma unroll
@@ -515,10 +524,14 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
     }
     const bool all_ok = __all(ok);
     if (lane == 0) flags[w] = all_ok ? 0 : 1;
-    if (!all_ok) continue;
+    if (!all_ok) {   // left to the exact kernel: only the slots move on
+#pragma unroll
+      for (int l = 1; l < LMAX; ++l)
+        if (l < L) load4(Mr[l], nbase + (long long)l * 256);
+      continue;
+    }
     // ---------------- pass 2: walk back
-    const float4 g4 = *reinterpret_cast<const float4*>(dOut + w * 256 + gl_off);
-    float G[4] = {g4.x, g4.y, g4.z, g4.w};
+    if (L > 1) load4(N1, nbase + 256);
 #pragma unroll
     for (int l = LMAX - 1; l >= 1; --l) {
       if (l < L) {
@@ -547,9 +560,12 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
             make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) G[s] = T1[s] * EP[s];
+        if (l >= 2) load4(Mr[l], nbase + (long long)l * 256);
       }
     }
     *reinterpret_cast<float4*>(dMats + (w * L) * 256 + gl_off) = make_float4(G[0], G[1], G[2], G[3]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Mr[1 < LMAX ? 1 : 0][s] = N1[s];
   }
 }
 
@@ -563,7 +579,7 @@ long long resident_blocks(const void* fn, int threads) {
 }
 
 template <int LMAX>
-__global__ __launch_bounds__(64 * LME_BWD_WAVES) void lme_fold16_bwd_mfma_k(
+__global__ __launch_bounds__(64 * LME_BWD_WAVES) __attribute__((amdgpu_waves_per_eu(LMAX <= 9 ? 3 : 1))) void lme_fold16_bwd_mfma_k(
     const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
     int* __restrict__ flags, long long Wn, int L) {
   lme_fold16_bwd_body<LMAX>(mats, dOut, dMats, flags, Wn, L);
