@@ -604,15 +604,56 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
   const unsigned voff_x = valid ? ho * p.s2b + wo * p.s3b : p.x_bytes;
   const unsigned voff_o = valid ? pu * (unsigned)(OP * 2) : p.o_bytes;
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
+  // Order of the prologue's loads (a wave's loads return in order, and the workgroup's 11 waves share one 64 B/clk
+  // vector-memory path): the core's first batch and the FIRST sample's rows go out before the barrier that publishes the
+  // core; the other samples of the group and the head weight (17 sixteen-byte loads per lane, 190 KB per CU) only after
+  // it - issued in front, every wave sat in their queue before it could reach the barrier.
+  S core_first[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ec = tid + i * (int)blockDim.x, e = ec < TOT ? ec : TOT - 1, o = e % OP, ab = e / OP;   // clamped: no branch
+    core_first[i] = core[(long long)ab * p.O + (o < p.O ? o : 0)];                                    // around the load
+  }
+  __builtin_amdgcn_sched_barrier(0);
   // a group's samples are all in flight before the first is used (a sample's rows are fresh lines: ~1.5 us from
   // HBM / MALL, two to three steps of arithmetic; a one-deep prefetch left the SIMDs waiting), and a slot is re-issued
   // for the next group as soon as it has been unpacked
   RawWindow<S, N, true, ROWS> raw[HEAD_FWD_HS];
+  auto first_of_group = [&](int u) { return b0 + u < b1 ? b0 + u : (b1 > b0 ? b1 - 1 : b0); };
+  issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)first_of_group(0) * p.s1b, p, raw[0]);   // (a workgroup without
+                                                                                                 // samples reads zeros past the end)
+  // core -> LDS in fragment order (as eps_fwd_q2reg_k), by however many threads the workgroup has: batches of 4
+  // elements per thread, the 4 loads of a batch in flight together
+  auto core_commit = [&](int e0, const S (&tmp)[4]) {
 #pragma unroll
-  for (int u = 0; u < HEAD_FWD_HS; ++u) {
-    const int bu = b0 + u < b1 ? b0 + u : (b1 > b0 ? b1 - 1 : b0);
-    if (b0 < b1) issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)bu * p.s1b, p, raw[u]);
+    for (int i = 0; i < 4; ++i) {
+      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP, bb = ab % BN, aa = ab / BN;
+      const int code = ((bb >> 1) << LOGO) | o;
+      const int row = (((code >> 2) & 3) << 3) | ((bb & 1) << 2) | (code & 3);
+      const int dst = ((((code >> 4) * KS + (aa >> 4)) * 64 + ((aa >> 3) & 1) * 32 + row) << 3) | (aa & 7);
+      if (e < TOT) cs[dst] = o < p.O ? tmp[i] : (bf16_t)0.f;
+    }
+  };
+  core_commit(0, core_first);
+  for (int e0 = 4 * (int)blockDim.x; e0 < TOT; e0 += 4 * (int)blockDim.x) {   // small workgroups: the rest of the core
+    S tmp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP;
+      tmp[i] = e < TOT ? core[(long long)ab * p.O + (o < p.O ? o : 0)] : (S)0.f;
+    }
+    core_commit(e0, tmp);
   }
+  __syncthreads();
+  bf16x8 cf[MT][KS];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
+#pragma unroll
+  for (int u = 1; u < HEAD_FWD_HS; ++u)
+    issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)first_of_group(u) * p.s1b, p, raw[u]);
   // A fragments of the head GEMM: lane (c = lane % 16, g = lane / 16) holds W[c, k = 32 ks + 8 g .. + 7] of this wave's
   // positions; rows c >= Cout and bytes past the end of the weight read zeros (range check).  A position past P
   // inside a row meets a zero feature (lanes without a position produce zeros), so it needs no mask.
@@ -625,31 +666,7 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
     for (int ks = 0; ks < HK; ++ks)
       wf[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hw, base, (unsigned)(ks * 64), 0));
   }
-  // core -> LDS in fragment order (as eps_fwd_q2reg_k), by however many threads the workgroup has: batches of 4
-  // elements per thread, the 4 loads of a batch in flight together
-  for (int e0 = 0; e0 < TOT; e0 += 4 * (int)blockDim.x) {
-    S tmp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP;
-      tmp[i] = e < TOT ? core[(long long)ab * p.O + (o < p.O ? o : 0)] : (S)0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = e0 + tid + i * (int)blockDim.x, o = e % OP, ab = e / OP, bb = ab % BN, aa = ab / BN;
-      const int code = ((bb >> 1) << LOGO) | o;
-      const int row = (((code >> 2) & 3) << 3) | ((bb & 1) << 2) | (code & 3);
-      const int dst = ((((code >> 4) * KS + (aa >> 4)) * 64 + ((aa >> 3) & 1) * 32 + row) << 3) | (aa & 7);
-      if (e < TOT) cs[dst] = o < p.O ? tmp[i] : (bf16_t)0.f;
-    }
-  }
-  __syncthreads();
-  bf16x8 cf[MT][KS];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-      cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
+  __builtin_amdgcn_sched_barrier(0);
 
   short* tile = &ftile[wv][0];
   // B fragment reads: lane (column = sample lane % 16, clamped to the group; k group lane / 16)
@@ -834,13 +851,20 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
   unsigned dlraw[DLW];
   RawRow<S, OP> rr[HEADC > 0 ? HEADC : 1];
-  if constexpr (HEADC > 0) {
-    const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
-    const unsigned voff_hw = job.valid ? (unsigned)job.pos * (unsigned)(OP * 2) : p.hw_bytes;
+  // LATE (the cfg2 shape with the head fused): the first sample's window goes out BEFORE the head-weight slice (a wave's
+  // loads return in order) and dY / dW are formed after the window's own products, so the 150 instructions that need only
+  // x run while the weight slice is still on its way
+  constexpr bool LATE = HEADC > 0 && LDST;
+  auto issue_head_weight = [&]() {
+    if constexpr (HEADC > 0) {
+      const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
+      const unsigned voff_hw = job.valid ? (unsigned)job.pos * (unsigned)(OP * 2) : p.hw_bytes;
 #pragma unroll
-    for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
-      issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
-  }
+      for (int c = 0; c < HEADC; ++c)   // rows >= Cout: out of range -> zeros
+        issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
+    }
+  };
+  if constexpr (!LATE) issue_head_weight();
   RawWindow<S, N, XVEC, ROWS> raw;
   RawRow<S, OP> rawdy;
   if (job.b0 < job.b1) {
@@ -854,7 +878,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     }
     issue_row<S, OP, OVEC>(rs_dy, job.voff_o, (unsigned)job.b0 * p.o_s1b, p.O, rawdy);
   }
-  if constexpr (HEADC > 0) {   // the weight slice arrives together with the first sample's loads
+  if constexpr (LATE) issue_head_weight();
+  if constexpr (HEADC > 0 && !LATE) {   // the weight slice arrives together with the first sample's loads
 #pragma unroll
     for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
   }
@@ -864,20 +889,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     unpack_window<S, N, XVEC, ROWS>(raw, xv);
     if (b == job.b0) DCTN_STAMP(p, 2);
     float dy[OP];
-    if constexpr (HEADC > 0) {
-      float ft[OP];   // forward output of the window (zeros for lanes without a position)
-      unpack_row<S, OP, OVEC>(rawdy, ft);
+    float ft[OP];                 // head: forward output of the window (zeros for lanes without a position)
+    unsigned dlnow[DLW];          // head: dLogits of this sample (the prefetch below overwrites dlraw)
+    auto head_dy_dw = [&]() {
 #pragma unroll
       for (int o = 0; o < OP; ++o) dy[o] = 0.f;
 #pragma unroll
       for (int c = 0; c < HEADC; ++c) {
-        const float dl = (c & 1) ? __uint_as_float(dlraw[c >> 1] & 0xffff0000u) : __uint_as_float(dlraw[c >> 1] << 16);
+        const float dl = (c & 1) ? __uint_as_float(dlnow[c >> 1] & 0xffff0000u) : __uint_as_float(dlnow[c >> 1] << 16);
 #pragma unroll
         for (int o = 0; o < OP; ++o) {
           dy[o] = __builtin_fmaf(dl, hwf[c][o], dy[o]);
           dwacc[c][o] = __builtin_fmaf(dl, ft[o], dwacc[c][o]);
         }
       }
+    };
+    if constexpr (HEADC > 0) {
+      unpack_row<S, OP, OVEC>(rawdy, ft);
+#pragma unroll
+      for (int i = 0; i < DLW; ++i) dlnow[i] = dlraw[i];
+      if constexpr (!LATE) head_dy_dw();
     } else {
       unpack_row<S, OP, OVEC>(rawdy, dy);
     }
@@ -916,6 +947,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       for (int s2 = 0; s2 < KS; ++s2) {
         *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2]) = X[s2];
         *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2 + 1]) = Y[s2];
+      }
+      if constexpr (LATE) {
+        if (b == job.b0) {   // the weight slice has had the whole P0 / P1 build to arrive
+#pragma unroll
+          for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
+        }
+        head_dy_dw();
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t)
