@@ -250,6 +250,12 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     }
     if (o < p.O) okmask |= 1u << i;
   }
+  // The 16 elements of a thread are 16 raw buffer loads at a per-thread constant offset plus a uniform one; an element
+  // outside the core's extents (padded output o >= O, row >= rows, k >= kdim) carries an out-of-range offset and reads 0:
+  // no exec-masked branch (the predicated global loads cost ~400 instructions per stage and wave - 28 branches - against
+  // 128 MFMAs of work, in both workgroups of a CU at the same time).
+  const unsigned core_bytes = (unsigned)(((long long)1 << (p.N * p.LQ)) * p.O * 4);   // < 2^31 (fill_big)
+  const __amdgpu_buffer_rsrc_t rs_core = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(core), 0, (int)core_bytes, 0x00020000);
   auto stage_fetch = [&](int mt, int st) {
     unsigned u;
     if (p.xo) {
@@ -261,13 +267,15 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     } else if (MODE == MODE_FWD) u = (unsigned)st * 128u * p.BnO + (unsigned)mt * (32 >> p.LOGO) * p.O;
     else if (MODE == MODE_G0) u = (unsigned)mt * 32u * p.BnO + (unsigned)st * (128 >> p.LOGO) * p.O;
     else u = (unsigned)st * (128 >> p.LOGO) * p.BnO + (unsigned)mt * 32u * p.O;
+    const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane((int)(u * 4u));
+    const int kleft = p.kdim - st * BC_KSTG * 2, rleft = p.rows - mt * 32;   // valid k-values / rows from this stage / tile on
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid + 64 * BC_WAVES * i;
       const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
       const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
-      const bool ok = ((okmask >> i) & 1u) && (st * BC_KSTG * 2 + kl < p.kdim) && (mt * 32 + row < p.rows);
-      pre[i] = ok ? core[u + coff[i]] : 0.f;
+      const bool ok = ((okmask >> i) & 1u) && kl < kleft && row < rleft;
+      pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_core, ok ? coff[i] * 4u : core_bytes, ub, 0));
     }
   };
   auto stage_commit = [&](int buf) {
@@ -321,22 +329,31 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
         float hin[BC_NT], avn[BC_TBL];
         const int hbn = hbi + 1 < p.nhb ? hbi + 1 : hbi;
         const int hbl = hb + 1 < nhb_here ? hb + 1 : hb;
+        // the generated operands of a BATCH of MFMAs first (8: 4 k-steps x 2 column tiles), then the batch back to back: a
+        // v_mul directly in front of every MFMA holds the matrix pipe at 0.85 of its rate with two waves per SIMD
+        // (tools/probes/mfma_f32_rate.hip), batches of 8 at 0.93
+        constexpr int BT = BC_TBL / 2 < 4 ? BC_TBL / 2 : 4;   // k-steps per batch
+        auto mfma_batch = [&](int t0) {
+          float bop[BC_NT][BT];
 #pragma unroll
-        for (int t = 0; t < BC_TBL / 2; ++t) {
+          for (int t = 0; t < BT; ++t)
 #pragma unroll
-          for (int nt = 0; nt < BC_NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
-        }
+            for (int nt = 0; nt < BC_NT; ++nt) bop[nt][t] = hi[nt] * tab[nt][t0 + t];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < BC_NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t0 + t], bop[nt][t], acc[nt], 0, 0, 0);
+        };
+#pragma unroll
+        for (int t0 = 0; t0 < BC_TBL / 2; t0 += BT) mfma_batch(t0);
 #pragma unroll
         for (int nt = 0; nt < BC_NT; ++nt) hin[nt] = hi_of(hbn, nt);
 #pragma unroll
         for (int t = 0; t < BC_TBL; ++t) avn[t] = sb[2 * (hbl * BC_TBL + t) * BC_SROW];
 #pragma unroll
-        for (int t = BC_TBL / 2; t < BC_TBL; ++t) {
-#pragma unroll
-          for (int nt = 0; nt < BC_NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], hi[nt] * tab[nt][t], acc[nt], 0, 0, 0);
-        }
+        for (int t0 = BC_TBL / 2; t0 < BC_TBL; t0 += BT) mfma_batch(t0);
 #pragma unroll
         for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hin[nt];
 #pragma unroll
@@ -746,7 +763,7 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
     if (b.lnhbo < 0) return false;
   }
   b.BnO = BN * p.O;
-  if (p.R * p.O >= (1LL << 31)) return false;  // 32-bit core offsets
+  if (p.R * p.O * 4 >= (1LL << 31)) return false;  // 32-bit byte offsets into the core (raw buffer loads)
   b.rg_count = 1;
   b.mt_per_rg = (b.rows + 31) / 32;
   return true;
