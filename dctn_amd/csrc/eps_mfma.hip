@@ -47,6 +47,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(2))) int int2v;
 typedef __attribute__((ext_vector_type(4))) int int4v;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -841,22 +842,30 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes);
   // non-head: rows of dY; head: rows of the forward output (same layout)
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(HEADC > 0 ? feat : dY, p.o_bytes);
-  float hwf[HEADC > 0 ? HEADC : 1][OP];
-  float dwacc[HEADC > 0 ? HEADC : 1][OP];
+  // HEADMM (the head fused, cfg2's shape): dY and dW of a group of 8 samples come from small matrix-core products instead
+  // of 2 * Cout * OP multiply-adds per window on the vector ALU (84 of the loop's 290 vector instructions).
+  constexpr bool HEADMM = HEADC > 0 && HEADC <= 16 && LDST && OVEC && XVEC && sizeof(S) == 2 && OP == 4;
+  float hwf[HEADC > 0 && !HEADMM ? HEADC : 1][OP];
+  float dwacc[HEADC > 0 && !HEADMM ? HEADC : 1][OP];
+  f32x16 dwm[HEADMM ? OP : 1];   // HEADMM: dW[class v][the lane's position][o] in register v of dwm[o]
 #pragma unroll
-  for (int c = 0; c < (HEADC > 0 ? HEADC : 1); ++c)
+  for (int c = 0; c < (HEADC > 0 && !HEADMM ? HEADC : 1); ++c)
 #pragma unroll
     for (int o = 0; o < OP; ++o) dwacc[c][o] = 0.f;
+#pragma unroll
+  for (int o = 0; o < (HEADMM ? OP : 1); ++o)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dwm[o][v] = 0.f;
   constexpr int DLW = HEADC > 0 ? HEADC / 2 : 1;   // dwords of one row of dLogits (bf16 pairs)
   const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
   unsigned dlraw[DLW];
-  RawRow<S, OP> rr[HEADC > 0 ? HEADC : 1];
+  RawRow<S, OP> rr[HEADC > 0 && !HEADMM ? HEADC : 1];
   // LATE (the cfg2 shape with the head fused): the first sample's window goes out BEFORE the head-weight slice (a wave's
   // loads return in order) and dY / dW are formed after the window's own products, so the 150 instructions that need only
   // x run while the weight slice is still on its way
-  constexpr bool LATE = HEADC > 0 && LDST;
+  constexpr bool LATE = HEADC > 0 && LDST && !HEADMM;
   auto issue_head_weight = [&]() {
-    if constexpr (HEADC > 0) {
+    if constexpr (HEADC > 0 && !HEADMM) {
       const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
       const unsigned voff_hw = job.valid ? (unsigned)job.pos * (unsigned)(OP * 2) : p.hw_bytes;
 #pragma unroll
@@ -864,6 +873,170 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
         issue_row<S, OP, true>(rs_hw, c < p.Cout ? voff_hw : p.hw_bytes, (unsigned)c * p.hw_rowb, OP, rr[c]);
     }
   };
+  // One 64-window step of the LDST shapes: the lane's rows of P0 and Z = P1 (x) dY go to the wave's transposition tiles,
+  // come back with the windows on the k index and meet on the matrix core.  `make_dy` supplies dY of the lane's window
+  // after the P0 / P1 products have been formed and P0 written (whatever it waits for has had that long to arrive).
+  auto ldst_step = [&](const float (&xv)[N][2], auto&& make_dy) {
+    if constexpr (LDST) {
+      bf16x8 X[KS], Y[KS];
+      build_p0<N0>(xv, X, Y);
+      float p1[BN];   // built by doubling: 2 + 4 + ... + BN multiplies instead of (N1 - 1) * BN
+      p1[0] = xv[N - 1][0];
+      p1[1] = xv[N - 1][1];
+#pragma unroll
+      for (int u = 1; u < N1; ++u)
+#pragma unroll
+        for (int bb = (1 << u) - 1; bb >= 0; --bb) {
+          const float lo = p1[bb];
+          p1[bb | (1 << u)] = lo * xv[N - 1 - u][1];
+          p1[bb] = lo * xv[N - 1 - u][0];
+        }
+      wave_lds_sync();   // the previous step's transposed reads are done
+      // the lane's window = its row of every tile; features in natural a order: 16 s + j, 16 s + 8 + j
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2]) = X[s2];
+        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2 + 1]) = Y[s2];
+      }
+      float dyl[OP];
+      make_dy(dyl);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          float z[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int m = (t << 5) | (c4 << 3) | j;
+            z[j] = p1[m >> LOGO] * dyl[m & (OP - 1)];
+          }
+          *reinterpret_cast<bf16x8*>(tiles + (1 + t) * 64 * LROW + trl.wr[c4]) =
+              pack8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+        }
+      wave_lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 p0t = tr_frag(tiles, ks, trl);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const bf16x8 zt = tr_frag(tiles + (1 + t) * 64 * LROW, ks, trl);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt, p0t, acc[t][0], 0, 0, 0);
+        }
+      }
+    }
+  };
+  if constexpr (HEADMM) {
+    // Roles of the lane in the two small products of a group of 8 samples (32x32x16 tiles, lane = (r, h)):
+    //   dY[sample][pos] = sum_class dLogits[sample][class] W[class][pos][o]:   A row r <-> sample slot 4 (r >> 3) + (r & 3) of
+    //     the lane half (r >> 2) & 1 whose positions the tile holds (rows of the other half are zero), so the two tiles
+    //     of an output (positions 0-31 / 32-63 of the wave) add into ONE accumulator and register v of lane (r, h) is
+    //     sample v at the lane's own position;
+    //   dW[class][pos] += sum_sample dLogits[sample][class] feat[sample][pos][o]:   A row r <-> class 4 (r >> 3) + (r & 3),
+    //     non-zero only in the k half (= lane half of the B operand = of the positions) equal to (r >> 2) & 1: one tile
+    //     per output, register v of lane (r, h) is class v at the lane's own position.
+    // The head-weight operand is the same for the workgroup's 8 waves (same positions): 16 classes x 64 positions x 8 bytes
+    // are staged ONCE through LDS (one 16-byte load per thread, behind the tiles) - loaded per wave it was 64 KB per CU
+    // through the vector-memory path in front of the first sample.
+    static_assert(BWD_WAVES * 64 * 16 == 16 * 64 * OP * 2, "one 16-byte load per thread stages the weight slice");
+    RawWindow<S, N, XVEC, ROWS> rawm;
+    if (job.b0 < job.b1) issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)job.b0 * p.s1b, p, rawm);
+    const unsigned dl_bytes = (unsigned)p.B * (unsigned)p.Cout * 2u, dlrow = (unsigned)p.Cout * 2u;
+    const __amdgpu_buffer_rsrc_t rs_dl = make_rsrc(dY, dl_bytes);
+    const int slot = 4 * (r >> 3) + (r & 3);
+    const bool rlow = ((r >> 2) & 1) == 0;
+    const unsigned voff_t = (rlow == (h == 0) && slot < p.Cout) ? (unsigned)slot * 2u : dl_bytes;
+    // a group's operands: 16 bytes of dLogits per lane, 8 single values of its transpose, the features of the lane's
+    // position for the 8 samples
+    u32x4 fa;
+    unsigned ft[8];
+    u32x2 rf[8];
+    auto issue_group = [&](int g0) {
+      const unsigned voff_a = (r < 16 && g0 + slot < job.b1 && 8 * h < p.Cout) ? (unsigned)slot * dlrow + 16u * h : dl_bytes;
+      fa = __builtin_amdgcn_raw_buffer_load_b128(rs_dl, voff_a, (unsigned)g0 * dlrow, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        ft[j] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+            rs_dl, voff_t, g0 + j < job.b1 ? (unsigned)(g0 + j) * dlrow : dl_bytes, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rf[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, job.voff_o, (unsigned)(g0 + j) * p.o_s1b, 0);
+    };
+    u32x4 wv4;
+    {
+      const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
+      const int e = 2 * tid, c = e >> 6, posl = e & 63, pos = job.pos - lane + posl;   // two positions of one class
+      const unsigned voff = pos < p.P ? (unsigned)pos * (unsigned)(OP * 2) : p.hw_bytes;   // (a class >= Cout lies past the end: zeros)
+      wv4 = __builtin_amdgcn_raw_buffer_load_b128(rs_hw, voff, (unsigned)c * p.hw_rowb, 0);
+    }
+    *reinterpret_cast<u32x4*>(dsm + dcore_dyn_lds_bytes(MT) + (size_t)tid * 16) = wv4;
+    __syncthreads();
+    const unsigned* wlds = reinterpret_cast<const unsigned*>(dsm + dcore_dyn_lds_bytes(MT));   // [class][position][2 dwords]
+    DCTN_STAMP(p, 1);
+    for (int g0 = job.b0; g0 < job.b1; g0 += 8) {
+      issue_group(g0);   // (issued in front of the barrier that publishes the weight slice the first group's loads made
+                         // the kernel slower, 250 VGPRs: 32.3 against 32.1 us per step)
+      f32x8 dyg[OP];   // registers 0..7 = the 8 samples of the group at the lane's position
+      // dY of the group's samples and the group's share of dW (formed in front of the group's first sample: inside its
+      // step, behind the window's own products, the operands' registers met P0 / P1's and the kernel spilled: 15.3 us)
+      auto group_products = [&]() {
+        int4v a0, a1, at;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const bool dv = 8 * h + 2 * d < p.Cout;   // classes past Cout: the next sample's row, not zeros
+          const int v = (int)(d == 0 ? fa.x : d == 1 ? fa.y : d == 2 ? fa.z : fa.w);
+          a0[d] = (dv && rlow) ? v : 0;
+          a1[d] = (dv && !rlow) ? v : 0;
+          at[d] = (int)(ft[2 * d] | (ft[2 * d + 1] << 16));
+        }
+#pragma unroll
+        for (int o = 0; o < OP; ++o) {
+          const unsigned sel = (o & 1) ? 0x07060302u : 0x05040100u;   // the odd / even halves of two dwords
+          f32x16 dya;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) dya[v] = 0.f;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            int4v bw;   // B[k = class 8 h + 2 d, 2 d + 1][column = position 32 hh + r]
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const unsigned lo = wlds[((8 * h + 2 * d) * 64 + 32 * hh + r) * 2 + (o >> 1)];
+              const unsigned hi = wlds[((8 * h + 2 * d + 1) * 64 + 32 * hh + r) * 2 + (o >> 1)];
+              bw[d] = (int)__builtin_amdgcn_perm(hi, lo, sel);
+            }
+            dya = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hh == 0 ? a0 : a1),
+                                                           __builtin_bit_cast(bf16x8, bw), dya, 0, 0, 0);
+          }
+          dyg[o] = __builtin_shufflevector(dya, dya, 0, 1, 2, 3, 4, 5, 6, 7);
+          int4v bf;
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            bf[d] = (int)__builtin_amdgcn_perm((o >> 1) ? rf[2 * d + 1].y : rf[2 * d + 1].x, (o >> 1) ? rf[2 * d].y : rf[2 * d].x, sel);
+          dwm[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at), __builtin_bit_cast(bf16x8, bf),
+                                                            dwm[o], 0, 0, 0);
+        }
+      };
+      group_products();
+      // the 8 samples unrolled: dY of sample s is a fixed register (a run-time index costs a 7-deep select chain each)
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx) {
+        const int b = g0 + sidx;
+        if (b < job.b1) {
+          float xv[N][2];
+          unpack_window<S, N, XVEC, ROWS>(rawm, xv);
+          {
+            const int bn = b + 1 < job.b1 ? b + 1 : b;
+            issue_window<S, N, XVEC, ROWS>(rs_x, job.voff_x, (unsigned)bn * p.s1b, p, rawm);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          ldst_step(xv, [&](float (&dyo)[OP]) {
+#pragma unroll
+            for (int o = 0; o < OP; ++o) dyo[o] = dyg[o][sidx];
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          if (sidx == 0 && g0 == job.b0) DCTN_STAMP(p, 2);
+        }
+      }
+    }
+  } else {
   if constexpr (!LATE) issue_head_weight();
   RawWindow<S, N, XVEC, ROWS> raw;
   RawRow<S, OP> rawdy;
@@ -928,56 +1101,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     // lanes without a window position read zeros for x: their P0 is 0 and they contribute nothing
 
     if constexpr (LDST) {
-      bf16x8 X[KS], Y[KS];
-      build_p0<N0>(xv, X, Y);
-      float p1[BN];   // built by doubling: 2 + 4 + ... + BN multiplies instead of (N1 - 1) * BN
-      p1[0] = xv[N - 1][0];
-      p1[1] = xv[N - 1][1];
+      ldst_step(xv, [&](float (&dyo)[OP]) {
+        if constexpr (LATE) {
+          if (b == job.b0) {   // the weight slice has had the whole P0 / P1 build to arrive
 #pragma unroll
-      for (int u = 1; u < N1; ++u)
-#pragma unroll
-        for (int bb = (1 << u) - 1; bb >= 0; --bb) {
-          const float lo = p1[bb];
-          p1[bb | (1 << u)] = lo * xv[N - 1 - u][1];
-          p1[bb] = lo * xv[N - 1 - u][0];
-        }
-      wave_lds_sync();   // the previous step's transposed reads are done
-      // the lane's window = its row of every tile; features in natural a order: 16 s + j, 16 s + 8 + j
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2]) = X[s2];
-        *reinterpret_cast<bf16x8*>(tiles + trl.wr[2 * s2 + 1]) = Y[s2];
-      }
-      if constexpr (LATE) {
-        if (b == job.b0) {   // the weight slice has had the whole P0 / P1 build to arrive
-#pragma unroll
-          for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
-        }
-        head_dy_dw();
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-          float z[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int m = (t << 5) | (c4 << 3) | j;
-            z[j] = p1[m >> LOGO] * dy[m & (OP - 1)];
+            for (int c = 0; c < HEADC; ++c) unpack_row<S, OP, true>(rr[c], hwf[c]);
           }
-          *reinterpret_cast<bf16x8*>(tiles + (1 + t) * 64 * LROW + trl.wr[c4]) =
-              pack8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+          head_dy_dw();
         }
-      wave_lds_sync();
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 p0t = tr_frag(tiles, ks, trl);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const bf16x8 zt = tr_frag(tiles + (1 + t) * 64 * LROW, ks, trl);
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zt, p0t, acc[t][0], 0, 0, 0);
-        }
-      }
+        for (int o = 0; o < OP; ++o) dyo[o] = dy[o];
+      });
       continue;
     }
 
@@ -1051,6 +1185,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       }
     }
   }
+  }   // !HEADMM
 
   DCTN_STAMP(p, 3);
   // workgroup reduction of the per-wave partial dCoreT tiles, then one coalesced store per block
@@ -1121,7 +1256,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
           // static register index: unrolled over every (c0, cc) pair that can occur
           float v = 0.f;
 #pragma unroll
-          for (int c = 0; c < HEADC; ++c) v = (c == c0 + cc) ? dwacc[c][o] : v;
+          for (int c = 0; c < HEADC; ++c) {
+            if constexpr (HEADMM) v = (c == c0 + cc) ? dwm[o][c] : v;
+            else v = (c == c0 + cc) ? dwacc[c][o] : v;
+          }
           red1[wv * SLOT + (cc * 64 + lane) * OP + o] = v;
         }
       __syncthreads();
@@ -1464,7 +1602,7 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
 #define DCTN_HEAD_LAUNCH(XV, ROWSV, HC)                                                                        \
-  DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, DYN, st, (const S*)x, \
+  DCTN_DCORE_LAUNCH((eps_bwd_dcore_q2reg_k<S, N0, N1, OP, XV, true, ROWSV, HC>), g, b, (DYN > 0 ? DYN + 8192 : 0), st, (const S*)x, \
                      (const S*)dL, (const S*)hw, (const S*)feat, (float*)ws, dwpart, m)
   if (m.rowvec_ok && m.vec_ok) {
     if (m.Cout <= 10) DCTN_HEAD_LAUNCH(true, RW, 10); else DCTN_HEAD_LAUNCH(true, RW, 16);
