@@ -365,6 +365,49 @@ def test_logmatmulexp_fold16_all_chain_lengths(Wn, L):
         assert float((got[w] - g[w]).abs().max()) < 3e-4 * scale, w
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_logmatmulexp_fold16_dynamic_ranges(seed):
+    """D = 16 float32 fold with the prefix carried in scaled form (logmatmulexp.hip): windows of very different dynamic
+    range in one batch - spreads the scaled form represents (accepted steps), spreads it flushes (the window restarts in the
+    log domain / is left to the exact backward kernel), isolated -inf entries, columns that differ by hundreds of nats -
+    forward and gradient against the float64 oracle (dctn/logmatmulexp.py:5-14 folded as the benchmark does, :30)."""
+    rng = random.Random(1000 + seed)
+    torch.manual_seed(1000 + seed)
+    L = rng.choice([2, 4, 7, 9, 12, 16, 19])
+    Wn = rng.randrange(3, 70)
+    m = torch.randn(Wn, L, 16, 16)
+    for w in range(Wn):
+        kind = rng.randrange(6)
+        if kind == 0:
+            m[w] *= rng.choice([5.0, 20.0, 60.0])                      # wide spread everywhere
+        elif kind == 1:
+            m[w, rng.randrange(L)] *= 80.0                              # one factor with a huge range
+        elif kind == 2:
+            m[w, rng.randrange(L), :, rng.randrange(16)] += rng.choice([-300.0, 300.0])   # one column far away from the others
+        elif kind == 3:
+            m[w, rng.randrange(L), rng.randrange(16), rng.randrange(16)] = -float("inf")  # an isolated -inf entry
+        elif kind == 4:
+            # a common shift: the scaled form carries it in the row shifts (error 3e-7 at any L <= 16); beyond 16 factors the
+            # backward is the log-domain recomputing kernel, whose float32 prefixes of magnitude L * shift lose what torch's
+            # float32 logsumexp loses (5e-4 at 500), so the shift stays small there
+            m[w] += rng.choice([-1.0, 1.0]) * (500.0 if L <= 16 else 20.0)
+    md = m.to(DEV).requires_grad_(True)
+    y = logmatmulexp_fold(md)
+    want = R.logmatmulexp_fold_batched(m.double())
+    yc = y.detach().cpu().double()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(yc), fin)
+    assert float(((yc[fin] - want[fin]).abs() / (1.0 + want[fin].abs())).max()) < 5e-5
+    dy = torch.randn(Wn, 16, 16)
+    y.backward(dy.to(DEV))
+    (g,) = R.grads(R.logmatmulexp_fold_batched, [m.double()], dy.double())
+    got = md.grad.cpu().double()
+    assert torch.isfinite(got).all()
+    for w in range(Wn):
+        scale = float(g[w].abs().max().clamp_min(1.0))
+        assert float((got[w] - g[w]).abs().max()) < 3e-4 * scale, w
+
+
 def sbs_mfma_cases():
     """Open chains with a uniform bond in {4, 8, 16}: the MFMA sweep family.  String lengths on both sides of the
     9-core specialisation (register accumulators up to 9 cores, LDS accumulators beyond), the one two-output core at
