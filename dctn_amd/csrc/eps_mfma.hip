@@ -966,6 +966,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       const int e = 2 * tid, c = e >> 6, posl = e & 63, pos = job.pos - lane + posl;   // two positions of one class
       const unsigned voff = pos < p.P ? (unsigned)pos * (unsigned)(OP * 2) : p.hw_bytes;   // (a class >= Cout lies past the end: zeros)
       wv4 = __builtin_amdgcn_raw_buffer_load_b128(rs_hw, voff, (unsigned)c * p.hw_rowb, 0);
+      if (pos + 1 >= p.P) { wv4.z = 0u; wv4.w = 0u; }   // the second position lies in the next class's row (or past the end)
     }
     *reinterpret_cast<u32x4*>(dsm + dcore_dyn_lds_bytes(MT) + (size_t)tid * 16) = wv4;
     __syncthreads();
