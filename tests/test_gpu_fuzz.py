@@ -274,7 +274,8 @@ def test_logmatmulexp_fold_random(Wn, L, D, dtype):
 # idle lanes (P < 64, P not a multiple of 64), fewer samples than waves, odd batches, both core
 # splits (N = 9: LDS transpose path, N = 8: identity-MFMA path), several class counts
 HEAD_CASES = [(1, 3, 10, 1, 4, 10), (1, 3, 12, 7, 2, 4), (2, 2, 9, 13, 4, 16), (1, 3, 12, 70, 4, 2),
-              (1, 3, 70, 2, 4, 10), (2, 2, 13, 33, 2, 10), (1, 3, 30, 19, 4, 6), (1, 3, 28, 9, 2, 16)]
+              (1, 3, 70, 2, 4, 10), (2, 2, 13, 33, 2, 10), (1, 3, 30, 19, 4, 6), (1, 3, 28, 9, 2, 16),
+              (1, 3, 70, 250, 4, 10)]   # 11 samples per wave: two groups of the matrix-core dY / dW products (8 + 3)
 
 
 @pytest.mark.parametrize("C,K,size,B,O,Cout", HEAD_CASES)
