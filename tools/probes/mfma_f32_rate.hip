@@ -54,6 +54,65 @@ __global__ void rate(float* out, int iters, float a0, float b0) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// As eps_bigcore_dcore_k feeds it: per k-step 2 + 4 operands, each the product of two (three) ds_read_b32 values of a
+// table in LDS, then 8 MFMAs (2 x 4 accumulators).
+__global__ __launch_bounds__(512) void rate_lds(float* out, int iters, int stride) {
+  extern __shared__ float tb[];
+  for (int e = threadIdx.x; e < 128 * 125; e += blockDim.x) tb[e] = 1.0f + 1e-6f * e;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, il = lane & 31, kk = lane >> 5;
+  f32x16 c[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) c[a][b][v] = 0.f;
+  int oa_lo[2], oa_hi[2], ob_lo[4], ob_hi[4], ob_dy[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { oa_lo[a] = il; oa_hi[a] = 64 + a; }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { ob_lo[b] = 80 + (il & 15); ob_hi[b] = 96 + b; ob_dy[b] = 112 + (il & 7); }
+  for (int it = 0; it < iters; ++it) {
+    const float* tw = tb + kk * stride;
+#pragma unroll 2
+    for (int ks = 0; ks < 64; ++ks, tw += 2 * stride) {
+      float pa[2], pz[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) pa[a] = tw[oa_lo[a]] * tw[oa_hi[a]];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) pz[b] = tw[ob_lo[b]] * tw[ob_hi[b]] * tw[ob_dy[b]];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[a], pz[b], c[a][b], 0, 0, 0);
+    }
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r += c[a][b][a + b];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+void run_lds(float* d) {
+  const int iters = 40, stride = 121;
+  (void)hipFuncSetAttribute((const void*)rate_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 125 * 4);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(rate_lds, dim3(256), dim3(512), 128 * 125 * 4, 0, d, 2, stride);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL(rate_lds, dim3(256), dim3(512), 128 * 125 * 4, 0, d, iters, stride);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double mf = 256.0 * 8 * iters * 64 * 8;
+  printf("operands from LDS tables as in the dCore kernel (16 ds_read_b32 + 10 v_mul per 8 MFMAs), 2 waves per SIMD: %.1f TFLOP/s (%.2f of 157)\n",
+         mf * 4096.0 / ms * 1e-9, mf * 4096.0 / ms * 1e-9 / 157.3);
+}
+
 template <int NACC, int VMUL>
 void run(float* d) {
   const int iters = 4000;
@@ -74,7 +133,7 @@ void run(float* d) {
 }
 int main() {
   float* d;
-  (void)hipMalloc(&d, 256 * 3 * 256 * sizeof(float));
-  run<1, 0>(d); run<2, 0>(d); run<2, 1>(d); run<4, 1>(d); run<2, 2>(d);
+  (void)hipMalloc(&d, 256 * 3 * 512 * sizeof(float));
+  run<1, 0>(d); run<2, 0>(d); run<2, 1>(d); run<4, 1>(d); run<2, 2>(d); run_lds(d);
   return 0;
 }
