@@ -4,14 +4,31 @@
 // dctn/epses_composition.py:144-146) and the optimizer update — is a few kilobytes of data, but as
 // library calls it is ~30 launches of 4-5 us each, 3x the time of the forward + backward kernels of
 // BASELINE config 2.  Three kernels replace them:
-//   ce_fwd_k   : mean cross-entropy of bf16/f32 logits (max-shifted log-sum-exp, float32)
-//   ce_bwd_k   : dLogits = (softmax - onehot) * dLoss / B, in the logits' dtype
+//   ce_fwd_k   : mean cross-entropy of bf16/f32 logits (max-shifted log-sum-exp, float32; rows labelled -100 are skipped
+//                and do not count in the mean, as F.cross_entropy's default ignore_index)
+//   ce_bwd_k   : dLogits = (softmax - onehot) * dLoss / n, in the logits' dtype
 //   sgd_l2_k   : over ONE flat buffer holding all parameters: g += 2 * l2 * w on the regularised
 //                prefix, buf = momentum * buf + g, w -= lr * buf; the regulariser's value
 //                sum w^2 is left as one partial sum per workgroup (float32 master arithmetic, storage dtype kept)
 #include "common.h"
 
 namespace {
+
+constexpr long long DCTN_CE_IGNORE = -100;   // torch.nn.functional.cross_entropy's default ignore_index
+
+// Number of rows that count in the mean: every workgroup scans all labels itself (8 bytes per row out of L2; the mean's
+// divisor is needed before the first gradient row is written, and a workgroup cannot wait for the others)
+__device__ __forceinline__ float ce_count_valid(const long long* __restrict__ labels, long long B, float* red) {
+  float n = 0.f;
+  for (long long b = threadIdx.x; b < B; b += blockDim.x) n += labels[b] != DCTN_CE_IGNORE ? 1.f : 0.f;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+  __syncthreads();
+  float total = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += red[k];
+  __syncthreads();   // `red` is reused by the caller
+  return total;
+}
 
 // SINGLE: the whole batch in one workgroup of 1024 threads — the result is stored, not accumulated, so no fill
 // precedes the kernel (one graph node instead of two; these kernels are launch-latency, not work)
@@ -20,8 +37,11 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restr
                                                                 const long long* __restrict__ labels,
                                                                 float* __restrict__ loss, S* __restrict__ dunit,
                                                                 long long B, int C) {
-  // dunit (optional): (softmax - onehot) / B, the gradient of the mean loss for an incoming gradient of 1
+  // dunit (optional): (softmax - onehot) / n, the gradient of the mean loss for an incoming gradient of 1; n = the number
+  // of rows whose label is not DCTN_CE_IGNORE (F.cross_entropy's default ignore_index): such rows add nothing to the loss,
+  // get a zero gradient row and do not count in the mean
   __shared__ float red[16];
+  const float n_valid = ce_count_valid(labels, B, red);
   float part = 0.f;
   for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
     const S* row = logits + b * C;
@@ -30,12 +50,12 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restr
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
     const long long y = labels[b];
-    // a label outside [0, C) poisons the loss and its row of the gradient with NaN: F.cross_entropy raises /
-    // device-asserts on such labels (it has no ignore_index here); a plausible-looking number would hide the bug
-    const bool valid = y >= 0 && y < C;
-    part += valid ? (m + logf(s)) - (float)row[y] : __builtin_nanf("");
+    // any OTHER label outside [0, C) poisons the loss and its row of the gradient with NaN: F.cross_entropy raises /
+    // device-asserts on such labels; a plausible-looking number would hide the bug
+    const bool skip = y == DCTN_CE_IGNORE, valid = y >= 0 && y < C;
+    part += skip ? 0.f : valid ? (m + logf(s)) - (float)row[y] : __builtin_nanf("");
     if (dunit) {
-      const float inv = 1.f / s, scale = valid ? 1.f / (float)B : __builtin_nanf("");
+      const float inv = 1.f / s, scale = skip ? 0.f : valid ? 1.f / n_valid : __builtin_nanf("");
       for (int c = 0; c < C; ++c)
         dunit[b * C + c] = (S)((expf((float)row[c] - m) * inv - (c == y ? 1.f : 0.f)) * scale);
     }
@@ -47,9 +67,9 @@ __global__ __launch_bounds__(SINGLE ? 1024 : 256) void ce_fwd_k(const S* __restr
     float total = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) total += red[k];
     if (SINGLE)
-      loss[0] = total / (float)B;
+      loss[0] = total / n_valid;   // (no row counted: 0 / 0 = NaN, as torch)
     else
-      atomicAdd(loss, total / (float)B);
+      atomicAdd(loss, total / n_valid);
   }
 }
 
@@ -57,7 +77,8 @@ template <typename S>
 __global__ __launch_bounds__(256) void ce_bwd_k(const S* __restrict__ logits, const long long* __restrict__ labels,
                                                 const float* __restrict__ dloss, S* __restrict__ dlogits, long long B,
                                                 int C) {
-  const float scale = dloss[0] / (float)B;
+  __shared__ float red[16];
+  const float scale = dloss[0] / ce_count_valid(labels, B, red);
   for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
     const S* row = logits + b * C;
     float m = -INFINITY;
@@ -66,7 +87,7 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const S* __restrict__ logits, co
     for (int c = 0; c < C; ++c) s += expf((float)row[c] - m);
     const float inv = 1.f / s;
     const long long y = labels[b];
-    const float rs = (y >= 0 && y < C) ? scale : __builtin_nanf("");   // invalid label: NaN row, as in the forward
+    const float rs = y == DCTN_CE_IGNORE ? 0.f : (y >= 0 && y < C) ? scale : __builtin_nanf("");   // ignored: zero row; invalid: NaN row
     for (int c = 0; c < C; ++c) {
       const float p = expf((float)row[c] - m) * inv;
       dlogits[b * C + c] = (S)((p - (c == y ? 1.f : 0.f)) * rs);

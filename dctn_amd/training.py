@@ -222,10 +222,10 @@ class _FusedCrossEntropy(torch.autograd.Function):
 
 
 def fused_cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
-    """Mean cross-entropy of (batch, classes) logits (float32 or bfloat16) as a float32 scalar.
-    Every label must lie in [0, classes): unlike `F.cross_entropy` there is NO ignore_index - a label outside the range
-    (including torch's default ignore value -100) makes the loss and the gradient NaN instead of being skipped silently
-    (the reference's loaders never produce one: dctn/dataset_loading.py:282-286)."""
+    """Mean cross-entropy of (batch, classes) logits (float32 or bfloat16) as a float32 scalar, with
+    `F.cross_entropy`'s defaults: rows labelled -100 (its ignore_index) add nothing, get a zero gradient and do not count
+    in the mean.  Any other label outside [0, classes) makes the loss and that row's gradient NaN (torch raises there;
+    the reference's loaders never produce one: dctn/dataset_loading.py:282-286)."""
     return L.on_device(_FusedCrossEntropy.apply, logits, labels)
 
 

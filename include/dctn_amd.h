@@ -339,11 +339,13 @@ int dctn_phi_expand(const void* images, void* x, int64_t n_pixels, float scale, 
  *                      update; their sum is the regulariser's value / its coefficient (stored, not
  *                      accumulated: no fill launch and no atomics in the iteration).
  *                      momentum_buf is float32 whatever the parameter dtype.
- * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.  A label outside [0, C) makes the loss and
- * that sample's gradient row NaN (F.cross_entropy raises on it; there is no ignore_index here).
+ * logits (B, C) contiguous, labels int64; dtypes DCTN_F32 / DCTN_BF16.  Rows labelled -100 (F.cross_entropy's default
+ * ignore_index) add nothing to the loss, get a zero gradient row and do not count in the mean (n = the other rows; n = 0:
+ * NaN, as torch).  Any other label outside [0, C) makes the loss and that sample's gradient row NaN (F.cross_entropy
+ * raises on it).
  * ------------------------------------------------------------------------------------------ */
 int dctn_ce_loss_fwd(const void* logits, const void* labels, void* loss, int64_t B, int C, int dtype, void* stream);
-/* forward that also leaves dlogits_unit = (softmax - onehot) / B (logits' dtype): the backward for an incoming gradient of 1,
+/* forward that also leaves dlogits_unit = (softmax - onehot) / n (logits' dtype): the backward for an incoming gradient of 1,
  * so that a caller who knows its gradient seed is 1 needs no second kernel */
 int dctn_ce_loss_fwd_grad(const void* logits, const void* labels, void* loss, void* dlogits_unit,
                           int64_t B, int C, int dtype, void* stream);

@@ -1212,6 +1212,23 @@ def test_fused_training_tail_matches_torch(dtype):
         tol2 = 1e-6 if dtype == torch.float32 else 2e-2 * float(rl.grad.abs().max())
         assert float((lg.grad.float() - rl.grad).abs().max()) <= tol2
 
+    # rows labelled -100 (F.cross_entropy's default ignore_index): skipped, zero gradient rows, not counted in the mean -
+    # in the one-workgroup form and in the several-workgroups form; all rows ignored: NaN, as torch
+    for rows in (50, 9000):
+        lg = (torch.randn(rows, 10) * 3).to(dtype).to(DEV).requires_grad_(True)
+        lb = torch.randint(0, 10, (rows,), device=DEV)
+        lb[::3] = -100
+        ls = fused_cross_entropy(lg, lb)
+        (ls * 0.5).backward()
+        rl = lg.detach().float().requires_grad_(True)
+        rf = torch.nn.functional.cross_entropy(rl, lb)
+        (rf * 0.5).backward()
+        assert abs(float(ls.detach()) - float(rf.detach())) < 2e-5 * max(1.0, abs(float(rf.detach())))
+        tol3 = 1e-6 if dtype == torch.float32 else 2e-2 * float(rl.grad.abs().max())
+        assert float((lg.grad.float() - rl.grad).abs().max()) <= tol3
+        assert float(lg.grad[::3].abs().max()) == 0.0
+    assert torch.isnan(fused_cross_entropy(lg.detach()[:4], torch.full((4,), -100, device=DEV)))
+
     if dtype == torch.bfloat16:
         return   # the optimizer comparison below needs float32 weights on the torch side
     a = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, dtype, image_size=10)
