@@ -233,7 +233,10 @@ def _sbs_layout_worker(rank, world, port, q):
     red = ddp.FlatGradAllReducer(model.parameters(), average=True)
     assert red._contiguous_flat([p.grad for p in model.parameters()]) is None
     red()
-    q.put((rank, flats, [torch.cat([c.grad.reshape(-1) for c in s.cores]) for s in strings]))
+    # by value (numpy): a tensor travels as a shared-memory handle the parent fetches from THIS process, which may have
+    # exited by then (ConnectionResetError in the parent's q.get)
+    q.put((rank, [f.numpy().copy() for f in flats],
+           [torch.cat([c.grad.reshape(-1) for c in s.cores]).numpy().copy() for s in strings]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -245,7 +248,7 @@ def test_convsbs_classifier_gradient_buckets_world2():
     procs = [ctx.Process(target=_sbs_layout_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {r: (f, g) for r, f, g in (q.get(timeout=120) for _ in range(2))}
+    got = {r: ([torch.from_numpy(a) for a in f], [torch.from_numpy(a) for a in g]) for r, f, g in (q.get(timeout=120) for _ in range(2))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

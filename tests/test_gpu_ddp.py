@@ -64,7 +64,8 @@ def _worker(rank, world, port, q):
     x32 = x.float()
     cores = make_epses_composition_unit_empirical_output_std(((2, 3), (2, 4)), ddp.shard_batch(x32, rank, world), dev,
                                                              torch.float32, batch_size=8)
-    q.put((rank, [p.detach().float().cpu() for p in model.parameters()] + [c.cpu() for c in cores]))
+    # by value (numpy): a tensor in the queue is a shared-memory handle the parent must fetch from this process
+    q.put((rank, [p.detach().float().cpu().numpy() for p in model.parameters()] + [c.float().cpu().numpy() for c in cores]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,7 +79,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_iteration():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(2))
+    got = {r: [torch.from_numpy(a) for a in arrs] for r, arrs in (q.get(timeout=300) for _ in range(2))}
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
