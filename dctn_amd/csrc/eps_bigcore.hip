@@ -71,6 +71,18 @@ constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
 
 enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
 
+#if defined(DCTN_STAMPS) && BC_PART == 1
+// diagnostic build only (make EXTRA=-DDCTN_STAMPS, tools/stamp_bigcore.py): where a workgroup's wave 0 spends its cycles
+// (s_memtime): slot 0 total, 1 prologue, 2 waiting at the stage barrier, 3 core-tile fetch issue, 4 generated-operand +
+// MFMA blocks, 5 core-tile commit, 6 epilogue of the row tiles, 7 first-stage fetch + commit of the row tiles
+__device__ unsigned long long bc_stamps[16384 * 8];
+#define BC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define BC_ACC(slot, a, b) do { if (threadIdx.x == 0) bc_acc[slot] += (b) - (a); } while (0)
+#else
+#define BC_T(var) do { } while (0)
+#define BC_ACC(slot, a, b) do { } while (0)
+#endif
+
 using dctn_bc::BigP;
 
 __device__ __forceinline__ float half_sum(float v) {
@@ -162,6 +174,10 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   float* gxs = stage + 2 * BC_KSTG * 2 * BC_SROW;     // G modes: [rhalf_n*Q][64*BC_WAVES*BC_NT]
   const int tid = threadIdx.x, lane = tid & 63, wl32 = lane & 31, h = lane >> 5, wv = tid >> 6;
   const long long w_block = (long long)blockIdx.x * BC_WPB;
+#if defined(DCTN_STAMPS) && BC_PART == 1
+  unsigned long long bc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  BC_T(t_start);
 
   // ---- window features (and dY rows) of the block's windows -> LDS
   for (int e = tid; e < BC_WPB * p.N; e += 64 * BC_WAVES) {
@@ -288,6 +304,8 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     }
   };
 
+  BC_T(t_pro);
+  BC_ACC(1, t_start, t_pro);
   const int mt_begin = blockIdx.y * p.mt_per_rg;
   const int mt_end = mt_begin + p.mt_per_rg < mtiles ? mt_begin + p.mt_per_rg : mtiles;
   for (int mt = mt_begin; mt < mt_end; ++mt) {
@@ -297,9 +315,12 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[nt][v] = 0.f;
 
+    BC_T(t_f0);
     stage_fetch(mt, 0);
     __syncthreads();  // previous tile's readers are done with both buffers
     stage_commit(0);
+    BC_T(t_f1);
+    BC_ACC(7, t_f0, t_f1);
     // hi product of block hb (xo, G modes: times dY[w, o] of the block's o)
     auto hi_of = [&](int hb, int nt) {
       const int wl = (wv * BC_NT + nt) * 32 + wl32;
@@ -314,8 +335,13 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
 #pragma unroll
     for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hi_of(0, nt);
     for (int st = 0; st < nstage; ++st) {
+      BC_T(t_b0);
       __syncthreads();  // stage st visible; buffer (st+1)&1 free
+      BC_T(t_b1);
+      BC_ACC(2, t_b0, t_b1);
       if (st + 1 < nstage) stage_fetch(mt, st + 1);
+      BC_T(t_b2);
+      BC_ACC(3, t_b1, t_b2);
       const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW + h * BC_SROW + wl32;
       int nhb_here = p.nhb - st * hb_per_stage;
       if (nhb_here > hb_per_stage) nhb_here = hb_per_stage;
@@ -359,8 +385,13 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
 #pragma unroll
         for (int t = 0; t < BC_TBL; ++t) av[t] = avn[t];
       }
+      BC_T(t_m1);
+      BC_ACC(4, t_b2, t_m1);
       if (st + 1 < nstage) stage_commit((st + 1) & 1);
+      BC_T(t_c1);
+      BC_ACC(5, t_m1, t_c1);
     }
+    BC_T(t_e0);
 
     if (MODE == MODE_FWD && p.zsave) {
       // accumulator register 4j + i of lane (wl32, h) is row mt*32 + 8j + 4h + i: row quad mt*8 + 2j + h
@@ -450,8 +481,17 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
         }
       }
     }
+    { BC_T(t_e1); BC_ACC(6, t_e0, t_e1); }
   }
 
+#if defined(DCTN_STAMPS) && BC_PART == 1
+  if (threadIdx.x == 0) {
+    bc_acc[0] = __builtin_amdgcn_s_memtime() - t_start;
+    const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 16384)
+      for (int i = 0; i < 8; ++i) bc_stamps[wg * 8 + i] = bc_acc[i];
+  }
+#endif
   // ---- results (slice blockIdx.y of the output: row groups are summed by a fixed-order reduce)
   if (MODE == MODE_FWD) {
     out += (long long)blockIdx.y * p.Wn * p.O;
@@ -1050,6 +1090,11 @@ int launch_fwd(const void* x, const void* core, void* out, const BigP& b, size_t
 }  // namespace
 
 #if BC_PART == 1
+#ifdef DCTN_STAMPS
+extern "C" int dctn_debug_read_bc_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bc_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 int dctn_bc::launch_fwd_hi(const void* x, const void* core, void* out, const BigP& b, size_t lds, hipStream_t st) {
   switch (b.LOGO) {
     case 3: return launch_fwd<3>(x, core, out, b, lds, st);

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs a library built with -DDCTN_STAMPS: `make -C dctn_amd/csrc clean && make -C dctn_amd/csrc EXTRA=-DDCTN_STAMPS`;
+never the shipped one): where wave 0 of every workgroup of the large-core forward kernel spends its cycles.
+    python tools/stamp_bigcore.py [B]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np   # noqa: E402
+import torch   # noqa: E402
+
+import dctn_amd   # noqa: E402
+from dctn_amd import _lib as L   # noqa: E402
+from dctn_amd.eps import eps   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev = torch.device("cuda")
+K, Q, O = 3, 4, 6
+core = torch.randn(*(Q,) * (K * K), O, device=dev) * Q ** (-4.5)
+x = torch.rand(1, B, 25, 25, Q, device=dev) + 0.1
+with torch.no_grad():
+    for _ in range(3):
+        y = eps(core, x)
+torch.cuda.synchronize()
+n = 16384 * 8
+buf = (ctypes.c_ulonglong * n)()
+lib = L.lib()
+lib.dctn_debug_read_bc_stamps.restype = ctypes.c_int
+rc = lib.dctn_debug_read_bc_stamps(buf, n)
+assert rc == 0, rc
+a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+a = a[a[:, 0] > 0]
+names = ["total", "prologue", "waiting at the stage barrier", "core-tile fetch issue", "operand + MFMA blocks", "core-tile commit",
+         "row-tile epilogues", "first-stage fetch + commit"]
+print(dctn_amd.last_kernel(), "workgroups with stamps:", len(a))
+tot = np.median(a[:, 0])
+for i, nm in enumerate(names):
+    print("  %-32s median %9.0f cycles  (%5.1f %% of total)   min %9.0f  max %9.0f" % (nm, np.median(a[:, i]), 100 * np.median(a[:, i]) / tot, a[:, i].min(), a[:, i].max()))
