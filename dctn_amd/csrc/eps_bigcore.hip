@@ -547,6 +547,13 @@ constexpr int DC_WR = 2, DC_WC2 = 4;  // waves per workgroup along rows / column
                                       // per table build instead of 128 x 256)
 constexpr int DC_THREADS = 64 * DC_WR * DC_WC2;
 constexpr int DC_WC = 128;            // windows per LDS chunk
+// The factor tables of a chunk are entry-major: row e holds entry e of every window of the chunk, the even windows
+// (lane half 0's k-steps) first, then the odd ones; the rows are 2 floats longer than the chunk so that consecutive
+// entries start 2 banks apart (one ds_read_b64 = an entry of two consecutive k-steps, conflict-free over the lanes'
+// consecutive entries).  A lane's 10 row addresses are then constant over the chunk and the k-step is an immediate
+// offset: no address arithmetic in the MFMA loop (every VALU instruction there costs ~9 cycles of the matrix pipe).
+constexpr int DC_ROW = DC_WC + 2;
+__device__ __forceinline__ int dc_pos(int wl) { return (wl & 1) * (DC_WC / 2) + (wl >> 1); }
 
 struct DcoreP {
   int C, B, H, W, K, O, Q, LQ, N, n0, n1, Ho, Wo, OP, LOGO;
@@ -555,7 +562,7 @@ struct DcoreP {
   int A, BN, cols;                 // cols = BN * O: column (b, o) = memory order of the core row
   int lb0, lb1;                    // bits of the lo tables of half 0 / half 1 (multiples of LQ)
   int nlo0, nhi0, nlo1, nhi1;      // table sizes
-  int tstride;                     // floats per window in the table image (odd: conflict-free)
+  int tstride;                     // table entries per window (T0lo | T0hi | T1lo | T1hi | dy | one always-zero entry)
   long long win_per_block;
   float* part;                     // per window-chunk slices [gridDim.y][A * cols] (plain stores, summed in a fixed order), or
                                    // NULL: float atomics into the zero-filled dCore
@@ -563,6 +570,20 @@ struct DcoreP {
 
 // PERX / PERY: register slots of the chunk prefetch (x features / dY values per thread): NQ <= 4 PERX,
 // O <= 4 PERY.
+#if defined(DCTN_STAMPS) && BC_PART == 0
+// diagnostic build only (tools/stamp_bigcore.py dcore): cycles of wave 0 per phase: 0 total, 1 stage commit (+ barrier wait
+// before it), 2 next chunk's fetch issue, 3 table build, 4 barrier after the build, 5 MFMA loop, 6 result store
+__device__ unsigned long long dc_stamps[16384 * 8];
+#define DC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DC_ACC(slot, a, b) do { if (threadIdx.x == 0) dc_acc[slot] += (b) - (a); } while (0)
+extern "C" int dctn_debug_read_dc_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dc_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#else
+#define DC_T(var) do { } while (0)
+#define DC_ACC(slot, a, b) do { } while (0)
+#endif
+
 template <int PERX, int PERY>
 __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* __restrict__ x,
                                                            const float* __restrict__ dY,
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NQ = p.N * p.Q;
   float* xs = smem;                         // [DC_WC][NQ + 1]
-  float* tb = xs + DC_WC * (NQ + 1);        // [DC_WC][tstride]: T0lo | T0hi | T1lo | T1hi | dy
+  float* tb = xs + DC_WC * (NQ + 1);        // [tstride][DC_ROW]: entries T0lo | T0hi | T1lo | T1hi | dy | 0, see DC_ROW
   const int o_t0lo = 0, o_t0hi = p.nlo0, o_t1lo = o_t0hi + p.nhi0, o_t1hi = o_t1lo + p.nlo1,
             o_dy = o_t1hi + p.nhi1;
   const int tid = threadIdx.x, lane = tid & 63, il = lane & 31, kk = lane >> 5, wv = tid >> 6;
@@ -656,24 +677,46 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
   for (int bt = 0; bt < DC_BT; ++bt)
     if (!c_ok[bt]) { offb_lo[bt] = o_zero; offb_hi[bt] = o_zero; offb_dy[bt] = o_zero; }
 
+  // the lane's table rows, at its half's first k-step
+  const float *ba_lo[DC_AT], *ba_hi[DC_AT], *bb_lo[DC_BT], *bb_hi[DC_BT], *bb_dy[DC_BT];
+#pragma unroll
+  for (int at = 0; at < DC_AT; ++at) {
+    ba_lo[at] = tb + offa_lo[at] * DC_ROW + kk * (DC_WC / 2);
+    ba_hi[at] = tb + offa_hi[at] * DC_ROW + kk * (DC_WC / 2);
+  }
+#pragma unroll
+  for (int bt = 0; bt < DC_BT; ++bt) {
+    bb_lo[bt] = tb + offb_lo[bt] * DC_ROW + kk * (DC_WC / 2);
+    bb_hi[bt] = tb + offb_hi[bt] * DC_ROW + kk * (DC_WC / 2);
+    bb_dy[bt] = tb + offb_dy[bt] * DC_ROW + kk * (DC_WC / 2);
+  }
+#if defined(DCTN_STAMPS) && BC_PART == 0
+  unsigned long long dc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DC_T(t_start);
   fetch_chunk(w_begin);
   for (long long w0 = w_begin; w0 < w_end; w0 += DC_WC) {
+    DC_T(t_a);
     __syncthreads();   // the previous chunk's MFMA loop is done with xs / tb
     {
       float* xw = xs + wl_s * (NQ + 1);
-      float* tw = tb + wl_s * p.tstride;
+      float* tw = tb + dc_pos(wl_s);
 #pragma unroll
       for (int i = 0; i < PERX; ++i)
         if ((okx >> i) & 1u) xw[role + ROLES * i] = prex[i];
 #pragma unroll
       for (int i = 0; i < PERY; ++i) {
         const int o = role + ROLES * i;
-        if (o < p.OP) tw[o_dy + o] = prey[i];
+        if (o < p.OP) tw[(o_dy + o) * DC_ROW] = prey[i];
       }
-      if (role == 0) tw[o_zero] = 0.f;
+      if (role == 0) tw[o_zero * DC_ROW] = 0.f;
     }
     __syncthreads();
+    DC_T(t_b);
+    DC_ACC(1, t_a, t_b);
     if (w0 + DC_WC < w_end) fetch_chunk(w0 + DC_WC);   // in flight during the table build and the MFMA loop
+    DC_T(t_c);
+    DC_ACC(2, t_b, t_c);
     {
       // factored Khatri-Rao table `role` of window wl_s, built by doubling in place (most significant
       // digit first): Q + Q^2 + ... multiplies instead of (digits - 1) per entry plus index arithmetic
@@ -682,39 +725,71 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
       else if (role == 1) { nf = p.n0 - p.lb0 / p.LQ; first = 0; off = o_t0hi; }
       else if (role == 2) { nf = p.lb1 / p.LQ; first = p.N - nf; off = o_t1lo; }
       else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; off = o_t1hi; }
-      float* T = tb + wl_s * p.tstride + off;
+      float* T = tb + off * DC_ROW + dc_pos(wl_s);   // entry j of this window's table: T[j * DC_ROW]
       const float* xw = xs + wl_s * (NQ + 1) + first * p.Q;
       if (nf == 0) {
         T[0] = 1.f;
       } else {
-        for (int q = 0; q < p.Q; ++q) T[q] = xw[q];
+        for (int q = 0; q < p.Q; ++q) T[q * DC_ROW] = xw[q];
         int S = p.Q;
         for (int d = 1; d < nf; ++d) {
           const float* xd = xw + d * p.Q;
           for (int j = S - 1; j >= 0; --j) {
-            const float old = T[j];
-            for (int q = p.Q - 1; q >= 0; --q) T[j * p.Q + q] = old * xd[q];
+            const float old = T[j * DC_ROW];
+            for (int q = p.Q - 1; q >= 0; --q) T[(j * p.Q + q) * DC_ROW] = old * xd[q];
           }
           S *= p.Q;
         }
       }
     }
+    DC_T(t_d);
+    DC_ACC(3, t_c, t_d);
     __syncthreads();
-    const float* tw = tb + kk * p.tstride;
-#pragma unroll 2
-    for (int ks = 0; ks < DC_WC / 2; ++ks, tw += 2 * p.tstride) {
-      float pa[DC_AT], pz[DC_BT];
+    DC_T(t_e);
+    DC_ACC(4, t_d, t_e);
+    // Two k-steps per turn: their factors are one ds_read_b64 per table entry and the products packed multiplies.
+    // The reads of the next turn are issued before this turn's 16 MFMAs (a wave sits in their issue for ~1000
+    // cycles; reads issued only after them would arrive with the pipe idle), its products stay behind them.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 ra[DC_AT][2], rz[DC_BT][3];
+    auto read_factors = [&](int ks) {
 #pragma unroll
-      for (int at = 0; at < DC_AT; ++at) pa[at] = tw[offa_lo[at]] * tw[offa_hi[at]];
+      for (int at = 0; at < DC_AT; ++at) {
+        ra[at][0] = *reinterpret_cast<const f32x2*>(ba_lo[at] + ks);
+        ra[at][1] = *reinterpret_cast<const f32x2*>(ba_hi[at] + ks);
+      }
 #pragma unroll
-      for (int bt = 0; bt < DC_BT; ++bt) pz[bt] = tw[offb_lo[bt]] * tw[offb_hi[bt]] * tw[offb_dy[bt]];
+      for (int bt = 0; bt < DC_BT; ++bt) {
+        rz[bt][0] = *reinterpret_cast<const f32x2*>(bb_lo[bt] + ks);
+        rz[bt][1] = *reinterpret_cast<const f32x2*>(bb_hi[bt] + ks);
+        rz[bt][2] = *reinterpret_cast<const f32x2*>(bb_dy[bt] + ks);
+      }
+    };
+    read_factors(0);
 #pragma unroll
-      for (int at = 0; at < DC_AT; ++at)
+    for (int ks = 0; ks < DC_WC / 2; ks += 2) {
+      f32x2 pa[DC_AT], pz[DC_BT];
 #pragma unroll
-        for (int bt = 0; bt < DC_BT; ++bt)
-          acc[at][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[at], pz[bt], acc[at][bt], 0, 0, 0);
+      for (int at = 0; at < DC_AT; ++at) pa[at] = ra[at][0] * ra[at][1];
+#pragma unroll
+      for (int bt = 0; bt < DC_BT; ++bt) pz[bt] = rz[bt][0] * rz[bt][1] * rz[bt][2];
+#ifndef DCTN_EXP_NOREAD
+      if (ks + 2 < DC_WC / 2) read_factors(ks + 2);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int at = 0; at < DC_AT; ++at)
+#pragma unroll
+          for (int bt = 0; bt < DC_BT; ++bt)
+            acc[at][bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[at][g], pz[bt][g], acc[at][bt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    DC_T(t_f);
+    DC_ACC(5, t_e, t_f);
   }
+  DC_T(t_g);
 
   // accumulate into dCore (zero-initialised by the launcher): one register = two 128-byte row segments
 #pragma unroll
@@ -734,6 +809,16 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
         }
       }
     }
+#if defined(DCTN_STAMPS) && BC_PART == 0
+  if (threadIdx.x == 0) {
+    const unsigned long long t_h = __builtin_amdgcn_s_memtime();
+    dc_acc[6] = t_h - t_g;
+    dc_acc[0] = t_h - t_start;
+    const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 16384)
+      for (int i = 0; i < 8; ++i) dc_stamps[wg * 8 + i] = dc_acc[i];
+  }
+#endif
 }
 
 int ilog2i(int v) {
@@ -1325,10 +1410,9 @@ static bool dcore_plan(const EpsP& p, int dtype, int precision, DcoreP& d, long 
   d.lb0 = lo_bits(d.n0); d.lb1 = lo_bits(d.n1);
   d.nlo0 = 1 << d.lb0; d.nhi0 = d.A >> d.lb0; d.nlo1 = 1 << d.lb1; d.nhi1 = d.BN >> d.lb1;
   if (p.N * p.Q > 80 || d.OP > 32) return false;   // register staging plan of the kernel
-  int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP + 1;   // + the always-zero entry
-  if (tstride % 2 == 0) ++tstride;
+  const int tstride = d.nlo0 + d.nhi0 + d.nlo1 + d.nhi1 + d.OP + 1;   // + the always-zero entry
   d.tstride = tstride;
-  lds = ((size_t)DC_WC * (p.N * p.Q + 1) + (size_t)DC_WC * tstride) * sizeof(float);
+  lds = ((size_t)(DC_WC * (p.N * p.Q + 1) + 1) / 2 * 2 + (size_t)DC_ROW * tstride) * sizeof(float);
   if (lds > DCTN_LDS_BUDGET) return false;
   const int ntile_a = (d.A + DC_WR * DC_AT * 32 - 1) / (DC_WR * DC_AT * 32);
   const int ntile_c = (d.cols + DC_WC2 * DC_BT * 32 - 1) / (DC_WC2 * DC_BT * 32);

@@ -15,24 +15,36 @@ from dctn_amd import _lib as L   # noqa: E402
 from dctn_amd.eps import eps   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+WHAT = sys.argv[2] if len(sys.argv) > 2 else "fwd"   # "fwd": eps_bigcore_k forward; "dcore": eps_bigcore_dcore_k
 dev = torch.device("cuda")
 K, Q, O = 3, 4, 6
 core = torch.randn(*(Q,) * (K * K), O, device=dev) * Q ** (-4.5)
 x = torch.rand(1, B, 25, 25, Q, device=dev) + 0.1
-with torch.no_grad():
-    for _ in range(3):
-        y = eps(core, x)
-torch.cuda.synchronize()
 n = 16384 * 8
 buf = (ctypes.c_ulonglong * n)()
 lib = L.lib()
-lib.dctn_debug_read_bc_stamps.restype = ctypes.c_int
-rc = lib.dctn_debug_read_bc_stamps(buf, n)
+if WHAT == "fwd":
+    with torch.no_grad():
+        for _ in range(3):
+            y = eps(core, x)
+    torch.cuda.synchronize()
+    lib.dctn_debug_read_bc_stamps.restype = ctypes.c_int
+    rc = lib.dctn_debug_read_bc_stamps(buf, n)
+    names = ["total", "prologue", "waiting at the stage barrier", "core-tile fetch issue", "operand + MFMA blocks", "core-tile commit",
+             "row-tile epilogues", "first-stage fetch + commit"]
+else:
+    core.requires_grad_(True)
+    for _ in range(2):
+        y = eps(core, x)
+        y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    lib.dctn_debug_read_dc_stamps.restype = ctypes.c_int
+    rc = lib.dctn_debug_read_dc_stamps(buf, n)
+    names = ["total", "chunk commit (+ barrier before it)", "next chunk's fetch issue", "table build", "barrier after the build",
+             "MFMA loop", "result store", "-"]
 assert rc == 0, rc
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 a = a[a[:, 0] > 0]
-names = ["total", "prologue", "waiting at the stage barrier", "core-tile fetch issue", "operand + MFMA blocks", "core-tile commit",
-         "row-tile epilogues", "first-stage fetch + commit"]
 print(dctn_amd.last_kernel(), "workgroups with stamps:", len(a))
 tot = np.median(a[:, 0])
 for i, nm in enumerate(names):
