@@ -71,7 +71,7 @@ constexpr int BC_KSTG = 64;     // k-steps (of 2) per LDS stage
 
 enum { MODE_FWD = 0, MODE_G0 = 1, MODE_G1 = 2 };
 
-#if defined(DCTN_STAMPS) && BC_PART == 1
+#if defined(DCTN_STAMPS) && BC_PART != 0
 // diagnostic build only (make EXTRA=-DDCTN_STAMPS, tools/stamp_bigcore.py): where a workgroup's wave 0 spends its cycles
 // (s_memtime): slot 0 total, 1 prologue, 2 waiting at the stage barrier, 3 core-tile fetch issue, 4 generated-operand +
 // MFMA blocks, 5 core-tile commit, 6 epilogue of the row tiles, 7 first-stage fetch + commit of the row tiles
@@ -84,6 +84,7 @@ __device__ unsigned long long bc_stamps[16384 * 8];
 #endif
 
 using dctn_bc::BigP;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float half_sum(float v) {
   const int iv = __float_as_int(v);
@@ -157,11 +158,43 @@ __device__ __forceinline__ float kr_exact(const float* xs, const BigP& p, int fi
   return v;
 }
 
+// the pair (wl, wl + 32): the two column tiles of a forward wave in one ds_read2_b32 per digit and packed multiplies
+template <int WPB, int ND>
+__device__ __forceinline__ f32x2 kr_exact2(const float* xs, const BigP& p, int first, int idx, int wl) {
+  f32x2 f[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const int dg = (idx >> ((ND - 1 - d) * p.LQ)) & (p.Q - 1);
+    const float* r = xs + ((first + d) * p.Q + dg) * WPB + wl;
+    f[d] = f32x2{r[0], r[32]};
+  }
+  f32x2 v = f[0];
+#pragma unroll
+  for (int d = 1; d < ND; ++d) v *= f[d];
+  return v;
+}
+
+// a * {b.x, b.x} and a * {b.y, b.y} as one packed multiply each (the compiler forms them only now and then)
+__device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_hi(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // LOGO_T: log2 of the padded out size (compile time for FWD, whose epilogue selects output slots
 // statically); ignored (0) by the G modes.
 // ND: number of hi digits of the generated operand (khalf_n - mk) when in 1..4, else -1 (generic).
 template <int MODE, int BC_NT, int LOGO_T, int BC_TBL, int ND>
-__global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __restrict__ x,
+// Two workgroups share a CU (one wave of each per SIMD): told to the compiler, which otherwise plans for one wave per
+// SIMD and spreads over 280-300 registers (accumulators in AGPRs, 16 more as spill space); within 256 all variants but
+// the widest (out sizes 16 / 32 with 16-entry tables or generic digit counts) fit without spills - those keep the default.
+__global__ __launch_bounds__(64 * BC_WAVES)
+__attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1 : 2))) void eps_bigcore_k(const float* __restrict__ x,
                                                                 const float* __restrict__ core,
                                                                 const float* __restrict__ dY,
                                                                 float* __restrict__ out, BigP p) {
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   float* gxs = stage + 2 * BC_KSTG * 2 * BC_SROW;     // G modes: [rhalf_n*Q][64*BC_WAVES*BC_NT]
   const int tid = threadIdx.x, lane = tid & 63, wl32 = lane & 31, h = lane >> 5, wv = tid >> 6;
   const long long w_block = (long long)blockIdx.x * BC_WPB;
-#if defined(DCTN_STAMPS) && BC_PART == 1
+#if defined(DCTN_STAMPS) && BC_PART != 0
   unsigned long long bc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   BC_T(t_start);
@@ -207,21 +240,23 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
   __syncthreads();
 
   // ---- per-lane table of the low part of the generated operand: entry t <-> inner k = 2t + h
-  float tab[BC_NT][BC_TBL];
+  f32x2 tab[BC_NT][BC_TBL / 2];   // entry t = tab[nt][t / 2][t & 1]: pairs of k-steps, one packed multiply each
 #pragma unroll
   for (int nt = 0; nt < BC_NT; ++nt) {
     const int wl = (wv * BC_NT + nt) * 32 + wl32;
 #pragma unroll
     for (int t = 0; t < BC_TBL; ++t) {
       const int kin = 2 * t + h;
+      float tv;
       if (MODE == MODE_FWD) {
-        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
+        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
       } else if (p.xo) {
-        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
+        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
       } else {
-        tab[nt][t] = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
-                     dys[(kin & (p.OP - 1)) * BC_WPB + wl];
+        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
+             dys[(kin & (p.OP - 1)) * BC_WPB + wl];
       }
+      tab[nt][t / 2][t & 1] = tv;
     }
   }
 
@@ -331,9 +366,18 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
       if (MODE != MODE_FWD && p.xo) v *= dys[(hb >> p.lnhbo) * BC_WPB + wl];
       return v;
     };
-    float hi[BC_NT];
-#pragma unroll
-    for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hi_of(0, nt);
+    // the hi products of both column tiles as a pair ({hi, hi} with one tile)
+    auto hi_pair = [&](int hb) {
+      if constexpr (MODE == MODE_FWD && BC_NT == 2 && ND > 0) {
+        return kr_exact2<BC_WPB, ND>(xs, p, p.khalf_first, hb, wv * BC_NT * 32 + wl32);
+      } else {
+        f32x2 r;
+        r.x = hi_of(hb, 0);
+        r.y = BC_NT == 2 ? hi_of(hb, BC_NT - 1) : r.x;
+        return r;
+      }
+    };
+    f32x2 hi = hi_pair(0);
     for (int st = 0; st < nstage; ++st) {
       BC_T(t_b0);
       __syncthreads();  // stage st visible; buffer (st+1)&1 free
@@ -345,45 +389,55 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
       const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW + h * BC_SROW + wl32;
       int nhb_here = p.nhb - st * hb_per_stage;
       if (nhb_here > hb_per_stage) nhb_here = hb_per_stage;
-      float av[BC_TBL];  // matrix-operand values of the current hi block
+      float av[BC_TBL], avn[BC_TBL];  // matrix-operand values of the current / next hi block
+      f32x2 hin;
 #pragma unroll
       for (int t = 0; t < BC_TBL; ++t) av[t] = sb[2 * t * BC_SROW];
-      for (int hb = 0; hb < nhb_here; ++hb) {
+      // One hi block: software pipeline - the NEXT block's hi products and operand values (into hi_n / av_n) are
+      // fetched while this block's MFMAs execute (LDS latency hidden behind the matrix pipe).  The generated operands
+      // of a BATCH of MFMAs come first (8: 4 k-steps x 2 column tiles, packed multiplies of two k-steps), then the
+      // batch back to back: every VALU instruction between MFMAs costs the matrix pipe ~9 cycles
+      // (tools/probes/mfma_f32_rate.hip: a v_mul in front of every MFMA holds it at 0.85, batches of 8 at 0.93).
+      constexpr int BT = BC_TBL / 2 < 4 ? BC_TBL / 2 : 4;   // k-steps per batch
+      auto hi_block = [&](int hb, const float (&av_c)[BC_TBL], const f32x2& hi_c, float (&av_n)[BC_TBL], f32x2& hi_n) {
         const int hbi = st * hb_per_stage + hb;       // global hi-block index
-        // software pipeline: the NEXT block's hi products and operand values are fetched while
-        // this block's MFMAs execute (LDS latency hidden behind the matrix pipe)
-        float hin[BC_NT], avn[BC_TBL];
         const int hbn = hbi + 1 < p.nhb ? hbi + 1 : hbi;
         const int hbl = hb + 1 < nhb_here ? hb + 1 : hb;
-        // the generated operands of a BATCH of MFMAs first (8: 4 k-steps x 2 column tiles), then the batch back to back: a
-        // v_mul directly in front of every MFMA holds the matrix pipe at 0.85 of its rate with two waves per SIMD
-        // (tools/probes/mfma_f32_rate.hip), batches of 8 at 0.93
-        constexpr int BT = BC_TBL / 2 < 4 ? BC_TBL / 2 : 4;   // k-steps per batch
         auto mfma_batch = [&](int t0) {
-          float bop[BC_NT][BT];
+          f32x2 bop[BC_NT][BT / 2];
 #pragma unroll
-          for (int t = 0; t < BT; ++t)
+          for (int t = 0; t < BT; t += 2)
 #pragma unroll
-            for (int nt = 0; nt < BC_NT; ++nt) bop[nt][t] = hi[nt] * tab[nt][t0 + t];
+            for (int nt = 0; nt < BC_NT; ++nt)
+              bop[nt][t / 2] = nt == 0 ? pk_mul_lo(tab[nt][(t0 + t) / 2], hi_c) : pk_mul_hi(tab[nt][(t0 + t) / 2], hi_c);
+          // An MFMA may read a VALU result 2 wait states after it at the earliest, and the compiler does not see through
+          // the inline-asm multiplies: the gap is put in by hand, tied to the last product (with a 4-k-step table and one
+          // column tile that multiply is the only one, right in front of its MFMA).
+          asm volatile("s_nop 1" : "+v"(bop[BC_NT - 1][BT / 2 - 1]));
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < BT; ++t)
 #pragma unroll
             for (int nt = 0; nt < BC_NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t0 + t], bop[nt][t], acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_c[t0 + t], bop[nt][t / 2][t & 1], acc[nt], 0, 0, 0);
         };
 #pragma unroll
         for (int t0 = 0; t0 < BC_TBL / 2; t0 += BT) mfma_batch(t0);
+        hi_n = hi_pair(hbn);
 #pragma unroll
-        for (int nt = 0; nt < BC_NT; ++nt) hin[nt] = hi_of(hbn, nt);
-#pragma unroll
-        for (int t = 0; t < BC_TBL; ++t) avn[t] = sb[2 * (hbl * BC_TBL + t) * BC_SROW];
+        for (int t = 0; t < BC_TBL; ++t) av_n[t] = sb[2 * (hbl * BC_TBL + t) * BC_SROW];
 #pragma unroll
         for (int t0 = BC_TBL / 2; t0 < BC_TBL; t0 += BT) mfma_batch(t0);
-#pragma unroll
-        for (int nt = 0; nt < BC_NT; ++nt) hi[nt] = hin[nt];
-#pragma unroll
-        for (int t = 0; t < BC_TBL; ++t) av[t] = avn[t];
+      };
+      // two blocks per turn, the register sets swapping roles: no copies of the next block's values
+      int hb = 0;
+      for (; hb + 1 < nhb_here; hb += 2) {
+        hi_block(hb, av, hi, avn, hin);
+        hi_block(hb + 1, avn, hin, av, hi);
+      }
+      if (hb < nhb_here) {
+        hi_block(hb, av, hi, avn, hin);
+        hi = hin;   // (av is reloaded at the next stage's start)
       }
       BC_T(t_m1);
       BC_ACC(4, t_b2, t_m1);
@@ -484,7 +538,7 @@ __global__ __launch_bounds__(64 * BC_WAVES) void eps_bigcore_k(const float* __re
     { BC_T(t_e1); BC_ACC(6, t_e0, t_e1); }
   }
 
-#if defined(DCTN_STAMPS) && BC_PART == 1
+#if defined(DCTN_STAMPS) && BC_PART != 0
   if (threadIdx.x == 0) {
     bc_acc[0] = __builtin_amdgcn_s_memtime() - t_start;
     const long long wg = (long long)blockIdx.y * gridDim.x + blockIdx.x;
@@ -1189,6 +1243,11 @@ int dctn_bc::launch_fwd_hi(const void* x, const void* core, void* out, const Big
   return DCTN_ERR_UNSUPPORTED;
 }
 #elif BC_PART == 2
+#ifdef DCTN_STAMPS
+extern "C" int dctn_debug_read_bc_stamps_g(unsigned long long* host, int n) {   // the transposed (dX) launches' stamps
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bc_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 int dctn_bc::launch_g(int mode, const void* x, const void* core, const void* dY, void* out, const BigP& b,
                       size_t lds, hipStream_t st) {
   if (mode == MODE_G0) return launch_tbl<MODE_G0, BC_NT_G, 0>(x, core, dY, out, b, lds, st);

@@ -15,7 +15,7 @@ from dctn_amd import _lib as L   # noqa: E402
 from dctn_amd.eps import eps   # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-WHAT = sys.argv[2] if len(sys.argv) > 2 else "fwd"   # "fwd": eps_bigcore_k forward; "dcore": eps_bigcore_dcore_k
+WHAT = sys.argv[2] if len(sys.argv) > 2 else "fwd"   # "fwd": eps_bigcore_k forward; "dx": its transposed (dX) launches; "dcore": eps_bigcore_dcore_k
 dev = torch.device("cuda")
 K, Q, O = 3, 4, 6
 core = torch.randn(*(Q,) * (K * K), O, device=dev) * Q ** (-4.5)
@@ -27,9 +27,25 @@ if WHAT == "fwd":
     with torch.no_grad():
         for _ in range(3):
             y = eps(core, x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = eps(core, x)
+        e1.record()
     torch.cuda.synchronize()
+    call_ms = e0.elapsed_time(e1)
     lib.dctn_debug_read_bc_stamps.restype = ctypes.c_int
     rc = lib.dctn_debug_read_bc_stamps(buf, n)
+    names = ["total", "prologue", "waiting at the stage barrier", "core-tile fetch issue", "operand + MFMA blocks", "core-tile commit",
+             "row-tile epilogues", "first-stage fetch + commit"]
+elif WHAT == "dx":
+    x.requires_grad_(True)
+    for _ in range(2):
+        y = eps(core, x)
+        y.backward(torch.ones_like(y))
+    torch.cuda.synchronize()
+    lib.dctn_debug_read_bc_stamps_g.restype = ctypes.c_int
+    rc = lib.dctn_debug_read_bc_stamps_g(buf, n)
     names = ["total", "prologue", "waiting at the stage barrier", "core-tile fetch issue", "operand + MFMA blocks", "core-tile commit",
              "row-tile epilogues", "first-stage fetch + commit"]
 else:
@@ -49,3 +65,7 @@ print(dctn_amd.last_kernel(), "workgroups with stamps:", len(a))
 tot = np.median(a[:, 0])
 for i, nm in enumerate(names):
     print("  %-32s median %9.0f cycles  (%5.1f %% of total)   min %9.0f  max %9.0f" % (nm, np.median(a[:, i]), 100 * np.median(a[:, i]) / tot, a[:, i].min(), a[:, i].max()))
+if WHAT == "fwd":
+    # workgroups resident per CU on average: the workgroups' lifetimes over the call's duration (s_memtime ticks at 100 MHz)
+    print("  call %.3f ms; sum of workgroup lifetimes / (call x 256 CUs) = %.2f workgroups per CU (ticks taken as %.0f MHz)" % (
+        call_ms, a[:, 0].sum() / (call_ms * 1e-3 * 100e6 * 256), 100.0))
