@@ -693,7 +693,7 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
   // ---- staging plan of this thread (constant over the kernel): window slot wl_s of every chunk,
   // elements nq = role + 4 i of its NQ features; role r also owns table r of that window
   constexpr int ROLES = DC_THREADS / DC_WC;      // 4
-  const int wl_s = tid % DC_WC, role = tid / DC_WC;
+  const int wl_s = tid % DC_WC, role = __builtin_amdgcn_readfirstlane(tid / DC_WC);   // a wave has one role: scalar
   int foff[PERX];
   unsigned okx = 0;   // bit i: element i exists
 #pragma unroll
@@ -731,6 +731,13 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
   for (int bt = 0; bt < DC_BT; ++bt)
     if (!c_ok[bt]) { offb_lo[bt] = o_zero; offb_hi[bt] = o_zero; offb_dy[bt] = o_zero; }
 
+  // entries of the hi tables that this workgroup's rows / columns index
+  const int hi0_lo = __builtin_amdgcn_readfirstlane((bt_a * DC_WR * DC_AT * 32) >> p.lb0);
+  int hi0_hi = __builtin_amdgcn_readfirstlane((bt_a * DC_WR * DC_AT * 32 + DC_WR * DC_AT * 32 - 1) >> p.lb0);
+  if (hi0_hi > p.nhi0 - 1) hi0_hi = p.nhi0 - 1;
+  const int hi1_lo = __builtin_amdgcn_readfirstlane(((bt_c * DC_WC2 * DC_BT * 32) / p.O) >> p.lb1);
+  int hi1_hi = __builtin_amdgcn_readfirstlane(((bt_c * DC_WC2 * DC_BT * 32 + DC_WC2 * DC_BT * 32 - 1) / p.O) >> p.lb1);
+  if (hi1_hi > p.nhi1 - 1) hi1_hi = p.nhi1 - 1;
   // the lane's table rows, at its half's first k-step
   const float *ba_lo[DC_AT], *ba_hi[DC_AT], *bb_lo[DC_BT], *bb_hi[DC_BT], *bb_dy[DC_BT];
 #pragma unroll
@@ -772,27 +779,37 @@ __global__ __launch_bounds__(DC_THREADS) void eps_bigcore_dcore_k(const float* _
     DC_T(t_c);
     DC_ACC(2, t_b, t_c);
     {
-      // factored Khatri-Rao table `role` of window wl_s, built by doubling in place (most significant
-      // digit first): Q + Q^2 + ... multiplies instead of (digits - 1) per entry plus index arithmetic
-      int first, nf, off;
-      if (role == 0) { nf = p.lb0 / p.LQ; first = p.n0 - nf; off = o_t0lo; }
-      else if (role == 1) { nf = p.n0 - p.lb0 / p.LQ; first = 0; off = o_t0hi; }
-      else if (role == 2) { nf = p.lb1 / p.LQ; first = p.N - nf; off = o_t1lo; }
-      else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; off = o_t1hi; }
-      float* T = tb + off * DC_ROW + dc_pos(wl_s);   // entry j of this window's table: T[j * DC_ROW]
-      const float* xw = xs + wl_s * (NQ + 1) + first * p.Q;
-      if (nf == 0) {
-        T[0] = 1.f;
-      } else {
-        for (int q = 0; q < p.Q; ++q) T[q * DC_ROW] = xw[q];
-        int S = p.Q;
-        for (int d = 1; d < nf; ++d) {
-          const float* xd = xw + d * p.Q;
-          for (int j = S - 1; j >= 0; --j) {
-            const float old = T[j * DC_ROW];
-            for (int q = p.Q - 1; q >= 0; --q) T[(j * p.Q + q) * DC_ROW] = old * xd[q];
+      // The four factored Khatri-Rao tables of window wl_s - of the two hi tables only the entries this workgroup's 128
+      // rows / 512 columns index (8 of 64 and 6 of 16 for the 4^9 x 6 core) - dealt round-robin to the window's four
+      // threads (role is wave-uniform: digits and loop bounds are scalar).  Every entry is the direct product of its
+      // digits' features, U entries in flight: independent LDS reads and the same work for every wave (one table per
+      // thread, doubled in place, left three of four wave pairs waiting for the one with the 64-entry table).
+      const float* xw = xs + wl_s * (NQ + 1);
+      float* tw = tb + dc_pos(wl_s);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int first, nf, off, e_lo, e_hi;   // entries [e_lo, e_hi] are needed
+        if (t == 0) { nf = p.lb0 / p.LQ; first = p.n0 - nf; off = o_t0lo; e_lo = 0; e_hi = p.nlo0 - 1; }
+        else if (t == 1) { nf = p.n0 - p.lb0 / p.LQ; first = 0; off = o_t0hi; e_lo = hi0_lo; e_hi = hi0_hi; }
+        else if (t == 2) { nf = p.lb1 / p.LQ; first = p.N - nf; off = o_t1lo; e_lo = 0; e_hi = p.nlo1 - 1; }
+        else { nf = p.n1 - p.lb1 / p.LQ; first = p.n0; off = o_t1hi; e_lo = hi1_lo; e_hi = hi1_hi; }
+        constexpr int U = 4;
+        for (int e0 = e_lo + role; e0 <= e_hi; e0 += ROLES * U) {
+          float v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) v[u] = 1.f;
+          for (int d = 0; d < nf; ++d) {
+            const int sh = (nf - 1 - d) * p.LQ;
+            const float* xd = xw + (first + d) * p.Q;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int e = e0 + u * ROLES <= e_hi ? e0 + u * ROLES : e0;   // past the range: entry e0 again, not stored
+              v[u] *= xd[(e >> sh) & (p.Q - 1)];
+            }
           }
-          S *= p.Q;
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (e0 + u * ROLES <= e_hi) tw[(off + e0 + u * ROLES) * DC_ROW] = v[u];
         }
       }
     }
