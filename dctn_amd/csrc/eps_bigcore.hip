@@ -307,6 +307,9 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
   // 128 MFMAs of work, in both workgroups of a CU at the same time).
   const unsigned core_bytes = (unsigned)(((long long)1 << (p.N * p.LQ)) * p.O * 4);   // < 2^31 (fill_big)
   const __amdgpu_buffer_rsrc_t rs_core = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(core), 0, (int)core_bytes, 0x00020000);
+  unsigned voff[PER];   // byte offset of element i, or past the core's end where its padded output index is not real
+#pragma unroll
+  for (int i = 0; i < PER; ++i) voff[i] = ((okmask >> i) & 1u) ? coff[i] * 4u : core_bytes;
   auto stage_fetch = [&](int mt, int st) {
     unsigned u;
     if (p.xo) {
@@ -320,6 +323,15 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
     else u = (unsigned)st * (128 >> p.LOGO) * p.BnO + (unsigned)mt * 32u * p.O;
     const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane((int)(u * 4u));
     const int kleft = p.kdim - st * BC_KSTG * 2, rleft = p.rows - mt * 32;   // valid k-values / rows from this stage / tile on
+    if (kleft >= BC_KSTG * 2 && rleft >= 32) {
+      // a whole stage of a whole row tile (all but the last of either): the byte offsets were masked once, at kernel start -
+      // 16 loads and nothing else (the per-element validity below is ~5 instructions an element, and a VALU-heavy phase
+      // crawls while the co-resident workgroup keeps the SIMD's issue busy with MFMAs)
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_core, voff[i], ub, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = tid + 64 * BC_WAVES * i;
@@ -329,14 +341,14 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
       pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_core, ok ? coff[i] * 4u : core_bytes, ub, 0));
     }
   };
+  // element i of a thread sits a constant step behind element i - 1 in the stage image (rows 2 i further on for G0, k-values
+  // 8 i for the others): one address and 16 immediate offsets
+  float* const commit0 = stage + (MODE == MODE_G0 ? (tid & 127) * BC_SROW + (tid >> 7) : (tid >> 5) * BC_SROW + (tid & 31));
+  constexpr int commit_step = MODE == MODE_G0 ? 64 * BC_WAVES / 128 : (64 * BC_WAVES / 32) * BC_SROW;
   auto stage_commit = [&](int buf) {
+    float* dst = commit0 + buf * BC_KSTG * 2 * BC_SROW;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + 64 * BC_WAVES * i;
-      const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
-      const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
-      stage[buf * BC_KSTG * 2 * BC_SROW + kl * BC_SROW + row] = pre[i];
-    }
+    for (int i = 0; i < PER; ++i) dst[i * commit_step] = pre[i];
   };
 
   BC_T(t_pro);
