@@ -1545,7 +1545,10 @@ static bool dcore_plan(const EpsP& p, int dtype, int precision, DcoreP& d, long 
   const int ntile_a = (d.A + DC_WR * DC_AT * 32 - 1) / (DC_WR * DC_AT * 32);
   const int ntile_c = (d.cols + DC_WC2 * DC_BT * 32 - 1) / (DC_WC2 * DC_BT * 32);
   tiles = (long long)ntile_a * ntile_c;
-  chunks = 1024 / tiles;
+  // one workgroup per CU (the kernel's LDS admits one): a workgroup's prologue, result store (128 accumulator values per
+  // lane, one 64-bit address each) and its slice of the partial-sum pass are paid once per window chunk - with four rounds
+  // of workgroups (1024 / tiles chunks) cfg3b's step took 2.39 ms, with one 2.12 ms (cfg3a 7.34 -> 7.08 ms)
+  chunks = 256 / tiles;
   if (chunks < 1) chunks = 1;
   const long long max_chunks = (p.Wn + DC_WC - 1) / DC_WC;
   if (chunks > max_chunks) chunks = max_chunks;
