@@ -501,8 +501,17 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           if (v % STEPV == 0) {
-            const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
-            p1 = R < p.rows ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, R >> LOGO_T, wl) : 0.f;
+            // b = R >> LOGO_T of the lane's row R = mt*32 + (v & 3) + 4 h + 8 (v >> 2) is the same for both lane halves from
+            // OP = 8 on: written from the tile index, so that the digits (and the whole address but the window) are
+            // SCALAR - 2 VALU instructions per digit instead of 6 (8 binary digits per product in a first layer's 4 x 4
+            // window, 8 products per row tile)
+            if constexpr (LOGO_T >= 3) {
+              const int b0 = (mt * 32 + (v & 3) + 8 * (v >> 2)) >> LOGO_T;
+              p1 = b0 < (p.rows >> LOGO_T) ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, b0, wl) : 0.f;
+            } else {   // (both candidates from scalar digits and a select: measured no faster than the per-lane digits)
+              const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
+              p1 = R < p.rows ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, R >> LOGO_T, wl) : 0.f;
+            }
           }
           constexpr int dummy = 0;
           (void)dummy;
