@@ -505,12 +505,20 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
             // OP = 8 on: written from the tile index, so that the digits (and the whole address but the window) are
             // SCALAR - 2 VALU instructions per digit instead of 6 (8 binary digits per product in a first layer's 4 x 4
             // window, 8 products per row tile)
+            // more than 4 digits (first layers: 8 binary digits): all reads ahead of the first multiply - digit by digit
+            // the product is a chain of 8 LDS round trips, ~1 000 cycles, 8 times per row tile of ~16 000
+            const bool flat = p.rhalf_n > 4;
             if constexpr (LOGO_T >= 3) {
               const int b0 = (mt * 32 + (v & 3) + 8 * (v >> 2)) >> LOGO_T;
-              p1 = b0 < (p.rows >> LOGO_T) ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, b0, wl) : 0.f;
+              if (b0 >= (p.rows >> LOGO_T)) p1 = 0.f;
+              else if (flat) p1 = kr_flat<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, b0, wl, NQ);
+              else p1 = kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, b0, wl);
             } else {   // (both candidates from scalar digits and a select: measured no faster than the per-lane digits)
               const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
-              p1 = R < p.rows ? kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, R >> LOGO_T, wl) : 0.f;
+              const int Rc = R < p.rows ? R : 0;
+              const float pv = flat ? kr_flat<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, Rc >> LOGO_T, wl, NQ)
+                                    : kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, Rc >> LOGO_T, wl);
+              p1 = R < p.rows ? pv : 0.f;
             }
           }
           constexpr int dummy = 0;
