@@ -141,6 +141,23 @@ __device__ __forceinline__ float kr_flat(const float* xs, const BigP& p, int fir
   return ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
 }
 
+// kr_flat for an index whose lowest bit is the lane half: `idx` is the UNIFORM part (even; the digits and row numbers
+// are then scalar arithmetic) and the last factor is read one feature row further on in the upper half (`wl_last` =
+// wl + h * WPB): 1 VALU instruction per digit where the per-lane index takes 5.
+template <int WPB>
+__device__ __forceinline__ float kr_flat_half(const float* xs, const BigP& p, int first, int nf, int idx, int wl,
+                                              int wl_last, int one_row) {
+  float f[BC_MAXD];
+#pragma unroll
+  for (int d = 0; d < BC_MAXD; ++d) {
+    const int sh = d < nf ? (nf - 1 - d) * p.LQ : 0;
+    const int dg = (idx >> sh) & (p.Q - 1);
+    const int rowi = d < nf ? (first + d) * p.Q + dg : one_row;
+    f[d] = xs[rowi * WPB + (d == nf - 1 ? wl_last : wl)];
+  }
+  return ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
+}
+
 // The same with the number of factors at compile time (ND = 1..4, chosen by the launcher: no control
 // flow in the main loop): no reads of the ones row and no index arithmetic for absent digits, which
 // were 2/3 of the VALU instructions of the main loop.
@@ -213,8 +230,14 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
   BC_T(t_start);
 
   // ---- window features (and dY rows) of the block's windows -> LDS
-  for (int e = tid; e < BC_WPB * p.N; e += 64 * BC_WAVES) {
-    const int wl = e % BC_WPB, n = e / BC_WPB;
+  {
+    // a thread stages factors n = tid / WPB, + threads / WPB, ... of ONE window (the thread count is a multiple of the
+    // block's windows): its (image, row, column) is found once, and four factors x four features = up to 16 loads are in
+    // flight (one after the other, a first layer's 32 loads and its per-lane table digits made a prologue of 86 k cycles =
+    // 22 % of a workgroup's life)
+    static_assert((64 * BC_WAVES) % BC_WPB == 0, "one window per thread");
+    constexpr int NSTEP = 64 * BC_WAVES / BC_WPB;   // factor stride of a thread
+    const int wl = tid % BC_WPB;
     const long long w = w_block + wl;
     const bool valid = w < p.Wn;
     const long long ww = valid ? w : 0;
@@ -222,11 +245,41 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
     const long long bb = ww / hw;
     const int rem = (int)(ww - bb * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    const int pos = n / p.C, ch = n - pos * p.C;
-    const int dh = pos / p.K, dw = pos - dh * p.K;
-    const float* px = x + ch * p.s[0] + bb * p.s[1] + (long long)(ho + dh) * p.s[2] +
-                      (long long)(wo + dw) * p.s[3];
-    for (int q = 0; q < p.Q; ++q) xs[(n * p.Q + q) * BC_WPB + wl] = valid ? px[q * p.s[4]] : 0.f;
+    const float* pw = x + bb * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
+    // factor n = (window row dh, column dw, channel ch): scalar counters stepped along with n (a wave's threads stage the
+    // same factors), no division per factor
+    const int n_first = __builtin_amdgcn_readfirstlane(tid / BC_WPB);
+    int f_ch = n_first % p.C, f_dw = (n_first / p.C) % p.K, f_dh = n_first / p.C / p.K;
+    auto factor_ptr_next = [&]() {   // the current factor's features, then on by NSTEP factors
+      const float* r = pw + f_ch * p.s[0] + (long long)f_dh * p.s[2] + (long long)f_dw * p.s[3];
+      f_ch += NSTEP;
+      while (f_ch >= p.C) {
+        f_ch -= p.C;
+        if (++f_dw == p.K) { f_dw = 0; ++f_dh; }
+      }
+      return r;
+    };
+    constexpr int FB = 4;   // factors per batch: FB x 4 features = up to 16 loads in flight
+    for (int n = n_first; n < p.N; n += FB * NSTEP) {
+      const float* px[FB];
+#pragma unroll
+      for (int f = 0; f < FB; ++f) px[f] = factor_ptr_next();   // (past the last factor: computed, not read)
+      for (int q0 = 0; q0 < p.Q; q0 += 4) {
+        float a[FB][4];
+#pragma unroll
+        for (int f = 0; f < FB; ++f)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool ok = valid && q0 + u < p.Q && n + f * NSTEP < p.N;
+            a[f][u] = ok ? px[f][(long long)(q0 + u) * p.s[4]] : 0.f;
+          }
+#pragma unroll
+        for (int f = 0; f < FB; ++f)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (q0 + u < p.Q && n + f * NSTEP < p.N) xs[((n + f * NSTEP) * p.Q + q0 + u) * BC_WPB + wl] = a[f][u];
+      }
+    }
   }
   for (int e = tid; e < BC_WPB; e += 64 * BC_WAVES) xs[NQ * BC_WPB + e] = 1.f;
   if (MODE != MODE_FWD) {
@@ -247,13 +300,14 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
 #pragma unroll
     for (int t = 0; t < BC_TBL; ++t) {
       const int kin = 2 * t + h;
+      // kin = 2 t + h: everything but the lane half is compile-time / scalar - the digits of the even part are SALU work
+      // and the lane half moves the last factor's read one feature row on; all reads of a product ahead of its multiplies
+      // (per-lane digits and a chain of LDS round trips per product made a first layer's prologue 22 % of a workgroup's life)
       float tv;
-      if (MODE == MODE_FWD) {
-        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
-      } else if (p.xo) {
-        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin, wl);
-      } else {
-        tv = kr<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, kin >> p.LOGO, wl) *
+      if (MODE == MODE_FWD || p.xo) {
+        tv = kr_flat_half<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, 2 * t, wl, wl + h * BC_WPB, NQ);
+      } else {   // the lane half is part of o (LOGO >= 1)
+        tv = kr_flat_half<BC_WPB>(xs, p, p.khalf_first + p.khalf_n - p.mk, p.mk, (2 * t) >> p.LOGO, wl, wl, NQ) *
              dys[(kin & (p.OP - 1)) * BC_WPB + wl];
       }
       tab[nt][t / 2][t & 1] = tv;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (needs a library built with -DDCTN_STAMPS: `make -C dctn_amd/csrc clean && make -C dctn_amd/csrc EXTRA=-DDCTN_STAMPS`;
 never the shipped one): where wave 0 of every workgroup of the large-core forward kernel spends its cycles.
-    python tools/stamp_bigcore.py [B]"""
+    python tools/stamp_bigcore.py [B] [fwd|dx|dcore] [K Q O H]"""
 import ctypes
 import os
 import sys
@@ -17,9 +17,10 @@ from dctn_amd.eps import eps   # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 WHAT = sys.argv[2] if len(sys.argv) > 2 else "fwd"   # "fwd": eps_bigcore_k forward; "dx": its transposed (dX) launches; "dcore": eps_bigcore_dcore_k
 dev = torch.device("cuda")
-K, Q, O = 3, 4, 6
-core = torch.randn(*(Q,) * (K * K), O, device=dev) * Q ** (-4.5)
-x = torch.rand(1, B, 25, 25, Q, device=dev) + 0.1
+# layer shape: K Q O H (default: cfg3a layer 2 - 3 4 6 on 25 x 25; cfg3b layer 1 is 4 2 8 28)
+K, Q, O, H = (int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (3, 4, 6, 25)
+core = torch.randn(*(Q,) * (K * K), O, device=dev) * Q ** (-K * K / 4)
+x = torch.rand(1, B, H, H, Q, device=dev) + 0.1
 n = 16384 * 8
 buf = (ctypes.c_ulonglong * n)()
 lib = L.lib()
