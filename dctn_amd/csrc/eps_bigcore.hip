@@ -364,7 +364,7 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
   unsigned voff[PER];   // byte offset of element i, or past the core's end where its padded output index is not real
 #pragma unroll
   for (int i = 0; i < PER; ++i) voff[i] = ((okmask >> i) & 1u) ? coff[i] * 4u : core_bytes;
-  auto stage_fetch = [&](int mt, int st, int i0 = 0, int i1 = PER) {   // elements [i0, i1) of the thread's 16
+  auto stage_fetch = [&](int mt, int st) {
     unsigned u;
     if (p.xo) {
       // k0 = 128 st = o0 * Kh + kh0 (128 and Kh are powers of two: no carry into the per-thread part)
@@ -383,13 +383,11 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
       // crawls while the co-resident workgroup keeps the SIMD's issue busy with MFMAs)
 #pragma unroll
       for (int i = 0; i < PER; ++i)
-        if (i >= i0 && i < i1)
-          pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_core, voff[i], ub, 0));
+        pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_core, voff[i], ub, 0));
       return;
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      if (i < i0 || i >= i1) continue;
       const int e = tid + 64 * BC_WAVES * i;
       const int row = MODE == MODE_G0 ? e >> 7 : e & 31;
       const int kl = MODE == MODE_G0 ? e & 127 : e >> 5;
@@ -451,7 +449,7 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
       __syncthreads();  // stage st visible; buffer (st+1)&1 free
       BC_T(t_b1);
       BC_ACC(2, t_b0, t_b1);
-      const bool fetch_next = st + 1 < nstage;   // (then this stage is a whole one: all its hi blocks run)
+      if (st + 1 < nstage) stage_fetch(mt, st + 1);
       BC_T(t_b2);
       BC_ACC(3, t_b1, t_b2);
       const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW + h * BC_SROW + wl32;
@@ -497,23 +495,16 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
 #pragma unroll
         for (int t0 = BC_TBL / 2; t0 < BC_TBL; t0 += BT) mfma_batch(t0);
       };
-      // Two blocks per turn, the register sets swapping roles: no copies of the next block's values.  The next stage's 16
-      // loads go out a few per hi block: issued together they fill the CU's vector-memory queue and the wave stands in their
-      // issue (the transposed kernel's k = (o, b) order makes every load a stride-O gather of 64 cache-line pieces: 1.3 k
-      // cycles per stage, 10 % of a workgroup's life).
-      constexpr int LPB = PER / hb_per_stage > 0 ? PER / hb_per_stage : 1;   // loads per hi block
-#pragma unroll
-      for (int hb = 0; hb < hb_per_stage; hb += 2) {
-        if (hb < nhb_here) {
-          if (fetch_next && hb * LPB < PER) stage_fetch(mt, st + 1, hb * LPB, (hb + 1) * LPB);
-          hi_block(hb, av, hi, avn, hin);
-        }
-        if (hb + 1 < nhb_here) {
-          if (fetch_next && (hb + 1) * LPB < PER) stage_fetch(mt, st + 1, (hb + 1) * LPB, (hb + 2) * LPB);
-          hi_block(hb + 1, avn, hin, av, hi);
-        }
+      // two blocks per turn, the register sets swapping roles: no copies of the next block's values
+      int hb = 0;
+      for (; hb + 1 < nhb_here; hb += 2) {
+        hi_block(hb, av, hi, avn, hin);
+        hi_block(hb + 1, avn, hin, av, hi);
       }
-      if (nhb_here & 1) hi = hin;   // an odd count leaves the current products in the other set (av is reloaded per stage)
+      if (hb < nhb_here) {
+        hi_block(hb, av, hi, avn, hin);
+        hi = hin;   // (av is reloaded at the next stage's start)
+      }
       BC_T(t_m1);
       BC_ACC(4, t_b2, t_m1);
       if (st + 1 < nstage) stage_commit((st + 1) & 1);
