@@ -536,13 +536,23 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
 #pragma unroll
       for (int nt = 0; nt < BC_NT; ++nt) {
         const int wl = (wv * BC_NT + nt) * 32 + wl32;
+        // the rows of an accumulator quad are consecutive (R0 .. R0 + 3, O >= 3: at most one step from b to b + 1 inside it):
+        // one division and the row-half products of b and b + 1 per quad, not one of each per row
+        const int bmax = (p.rows - 1) / p.O;   // (uniform) b + 1 past the last b is never a real row's
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int R = mt * 32 + (v & 3) + 4 * h + 8 * (v >> 2);
-          const int bq = (int)__umulhi((unsigned)R, p.odiv_m), oq = R - bq * p.O;
-          const float val = R < p.rows ? acc[nt][v] * kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, bq, wl) : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int R0 = mt * 32 + 4 * h + 8 * j;
+          const int bq = (int)__umulhi((unsigned)R0, p.odiv_m), oq0 = R0 - bq * p.O;
+          const float pa = kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, bq < bmax ? bq : bmax, wl);
+          const float pb = kr<BC_WPB>(xs, p, p.rhalf_first, p.rhalf_n, bq + 1 < bmax ? bq + 1 : bmax, wl);
 #pragma unroll
-          for (int oo = 0; oo < OPT; ++oo) oacc[nt][oo] += oo == oq ? val : 0.f;
+          for (int i = 0; i < 4; ++i) {
+            const bool wrap = oq0 + i >= p.O;
+            const int oq = wrap ? oq0 + i - p.O : oq0 + i;
+            const float val = R0 + i < p.rows ? acc[nt][4 * j + i] * (wrap ? pb : pa) : 0.f;
+#pragma unroll
+            for (int oo = 0; oo < OPT; ++oo) oacc[nt][oo] += oo == oq ? val : 0.f;
+          }
         }
       }
     } else if (MODE == MODE_FWD) {
