@@ -49,11 +49,6 @@ struct BigP {
   //   generated operand keeps a power-of-two table over the low digits of kh and the hi product
   //   of block hb is dY[w, o = hb >> lnhbo] * KR(high digits, hb & (2^lnhbo - 1)).
   int xo, lkh, lnhbo;
-  // xo3 (G0, out size 6, 16-value tables): a stage = ONE run of 16 values of kh with all six outputs, k = o * 16 + (kh & 15):
-  // the 96 floats (b, o) of a row and stage are contiguous in the core (three 16-byte loads a thread, fully coalesced; the
-  // o-outermost order makes every load a stride-O gather), and the commit restores the (o, kh) order the operand tables
-  // need.  Six hi blocks a stage instead of eight; kdim / nhb count the stage's 128 k slots.
-  int xo3;
   unsigned odiv_m;            // ceil(2^32 / O)
   // FWD, training: the GEMM result Z = T[(b,o), w] is kept for the backward (the reference's autograd saves it too,
   // dctn/eps.py:25-30 step (0,1)), in row-quad-major order Z[R / 4][w][R % 4] - a lane's four accumulator registers
@@ -370,16 +365,6 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
 #pragma unroll
   for (int i = 0; i < PER; ++i) voff[i] = ((okmask >> i) & 1u) ? coff[i] * 4u : core_bytes;
   auto stage_fetch = [&](int mt, int st) {
-    if (MODE == MODE_G0 && p.xo3) {
-      // thread = (row tid >> 3, piece tid & 7): floats [12 piece, 12 piece + 12) of the row's 96-float run (b = 16 st .. + 15, o)
-      const float* src = core + ((long long)mt * 32 + (tid >> 3)) * p.BnO + (long long)st * 96 + (tid & 7) * 12;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
-        pre[4 * i] = v[0]; pre[4 * i + 1] = v[1]; pre[4 * i + 2] = v[2]; pre[4 * i + 3] = v[3];
-      }
-      return;
-    }
     unsigned u;
     if (p.xo) {
       // k0 = 128 st = o0 * Kh + kh0 (128 and Kh are powers of two: no carry into the per-thread part)
@@ -415,12 +400,6 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
   float* const commit0 = stage + (MODE == MODE_G0 ? (tid & 127) * BC_SROW + (tid >> 7) : (tid >> 5) * BC_SROW + (tid & 31));
   constexpr int commit_step = MODE == MODE_G0 ? 64 * BC_WAVES / 128 : (64 * BC_WAVES / 32) * BC_SROW;
   auto stage_commit = [&](int buf) {
-    if (MODE == MODE_G0 && p.xo3) {   // float q of the thread: (b & 15) = 2 piece + q / 6, o = q % 6 -> k row o * 16 + (b & 15)
-      float* dst3 = stage + buf * BC_KSTG * 2 * BC_SROW + 2 * (tid & 7) * BC_SROW + (tid >> 3);
-#pragma unroll
-      for (int q = 0; q < 12; ++q) dst3[((q % 6) * 16 + q / 6) * BC_SROW] = pre[q];
-      return;
-    }
     float* dst = commit0 + buf * BC_KSTG * 2 * BC_SROW;
 #pragma unroll
     for (int i = 0; i < PER; ++i) dst[i * commit_step] = pre[i];
@@ -446,12 +425,6 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
     // hi product of block hb (xo, G modes: times dY[w, o] of the block's o)
     auto hi_of = [&](int hb, int nt) {
       const int wl = (wv * BC_NT + nt) * 32 + wl32;
-      if (MODE == MODE_G0 && p.xo3) {   // block hb = (stage hb / 8 = the run of kh, j = hb % 8 = the output)
-        float v3;
-        if constexpr (ND > 0) v3 = kr_exact<BC_WPB, ND>(xs, p, p.khalf_first, hb / hb_per_stage, wl);
-        else v3 = kr_flat<BC_WPB>(xs, p, p.khalf_first, p.khalf_n - p.mk, hb / hb_per_stage, wl, NQ);
-        return v3 * dys[(hb % hb_per_stage) * BC_WPB + wl];
-      }
       const int hidx = (MODE != MODE_FWD && p.xo) ? (hb & ((1 << p.lnhbo) - 1)) : hb;
       float v;
       if constexpr (ND > 0) v = kr_exact<BC_WPB, ND>(xs, p, p.khalf_first, hidx, wl);
@@ -482,7 +455,6 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
       const float* sb = stage + (st & 1) * BC_KSTG * 2 * BC_SROW + h * BC_SROW + wl32;
       int nhb_here = p.nhb - st * hb_per_stage;
       if (nhb_here > hb_per_stage) nhb_here = hb_per_stage;
-      if (MODE == MODE_G0 && p.xo3) nhb_here = 6;   // the six outputs of the stage's run of kh
       float av[BC_TBL], avn[BC_TBL];  // matrix-operand values of the current / next hi block
       f32x2 hin;
 #pragma unroll
@@ -495,9 +467,7 @@ __attribute__((amdgpu_waves_per_eu((LOGO_T >= 4 && (BC_TBL == 16 || ND < 0)) ? 1
       constexpr int BT = BC_TBL / 2 < 4 ? BC_TBL / 2 : 4;   // k-steps per batch
       auto hi_block = [&](int hb, const float (&av_c)[BC_TBL], const f32x2& hi_c, float (&av_n)[BC_TBL], f32x2& hi_n) {
         const int hbi = st * hb_per_stage + hb;       // global hi-block index
-        int hbn = hbi + 1 < p.nhb ? hbi + 1 : hbi;
-        if (MODE == MODE_G0 && p.xo3 && hb + 1 >= nhb_here)   // the stage's last used block: on to the next stage's first
-          hbn = (st + 1) * hb_per_stage < p.nhb ? (st + 1) * hb_per_stage : hbi;
+        const int hbn = hbi + 1 < p.nhb ? hbi + 1 : hbi;
         const int hbl = hb + 1 < nhb_here ? hb + 1 : hb;
         auto mfma_batch = [&](int t0) {
           f32x2 bop[BC_NT][BT / 2];
@@ -1082,7 +1052,6 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   b.xo = (p.O >= 3 && (p.O & (p.O - 1)) != 0 && p.O <= 16) ? 1 : 0;
   b.odiv_m = (unsigned)(((1ull << 32) + p.O - 1) / p.O);
   b.lkh = 0; b.lnhbo = 0;
-  b.xo3 = 0;
   int khalf_bits;
   if (b.xo) {
     if (mode == MODE_FWD) {
@@ -1116,10 +1085,6 @@ bool fill_big(BigP& b, const EpsP& p, int mode) {
   if (b.ID < 2 || b.ID / 2 > BC_TBL_MAX) return false;
   b.tbl = b.ID / 2;
   if (b.tbl != 4 && b.tbl != 8 && b.tbl != 16) return false;
-  if (b.xo && mode == MODE_G0 && p.O == 6 && b.tbl == 8 && BN >= 16 && A % 32 == 0) {
-    b.xo3 = 1;
-    b.kdim = (BN / 16) * 128;   // BN / 16 stages of 128 k slots (96 used)
-  }
   b.nhb = b.kdim / b.ID;
   if (b.xo && mode != MODE_FWD) {
     if ((1 << b.lkh) < 128 && (128 % (1 << b.lkh)) != 0) return false;
@@ -1150,7 +1115,7 @@ void choose_row_groups(BigP& b, int nt, int max_rg, size_t lds_bytes) {
   // rough cycle model: a row tile = kdim/2 k-steps x nt column tiles x 64 cycles at ~60 % matrix-pipe
   // efficiency; per workgroup ~8k cycles to stage the window features; per slice one write + read of
   // the partial result at ~1.2 KB/cycle
-  const double tile = (double)((b.xo3 ? b.kdim * 3 / 4 : b.kdim) / 2) * nt * 64.0 / 0.6;   // (xo3: 96 of a stage's 128 k slots)
+  const double tile = (double)(b.kdim / 2) * nt * 64.0 / 0.6;
   const double ovh = 8000.0;
   const double slice_bytes = b.mode == MODE_FWD ? (double)b.Wn * b.O * 4.0 : (double)b.Wn * b.N * b.Q * 4.0;
   const double slice = 2.0 * slice_bytes / 1200.0;
