@@ -48,8 +48,11 @@ WORKLOADS = {
     "cfg3a_bf16": (((4, 4), (3, 6)), 28, 2, torch.bfloat16),   # two-halves GEMMs on the bf16 matrix cores
     "cfg3b": (((4, 8), (2, 8)), 28, 2, torch.float32),
     "cfg3b_bf16": (((4, 8), (2, 8)), 28, 2, torch.bfloat16),
+    # what the directory BASELINE configs[3] names really launches (check_super_small_model.sh:1-12: new_runner.py
+    # --ds-type cifar10_ycbcr --epses-specs '(3,6)' --add-constant-channel): one EPS K=3 on 32x32, Q0 = 3 colour values + 1
+    "cfg4_eps36": (((3, 6),), 32, 4, torch.float32),
 }
-EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
 # --workload also takes the two BASELINE configs that are not EPS models (configs[3] "ConvSBS ... DDP over 8xMI355X",
 # configs[4] "logmatmulexp ... 8xMI355X"): the same sharding, timing protocol and JSON line as the EPS workloads
 SIDE_WORKLOADS = ("cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg5")
@@ -66,6 +69,9 @@ def synthetic_input(batch, image_size, q0, dtype, device, seed):
     u = torch.rand(1, batch, image_size, image_size, generator=g)
     if q0 == 2:  # dataset_loading.py:33-36,63 feature map with nu = 1
         x = torch.stack((torch.sin(u * torch.pi / 2) ** 2, torch.cos(u * torch.pi / 2) ** 2), dim=-1)
+    elif q0 == 4:  # dataset_loading.py:349-364: three colour values (standardised) + the constant-1 channel
+        x = torch.cat((torch.randn(1, batch, image_size, image_size, 3, generator=g),
+                       torch.ones(1, batch, image_size, image_size, 1)), dim=-1)
     else:
         x = torch.randn(1, batch, image_size, image_size, q0, generator=g)
     return x.to(dtype).to(device)
@@ -209,31 +215,64 @@ def device_time(fn, dev, iters, graph=True, blocks=3):
 
 
 _TRAFFIC = None
+TRAFFIC_FILE = "r04_pmc_traffic.json"   # the current round's passes only (tools/profile_round.sh + condense_round.py)
 
 
-def pmc_traffic(key):
-    """HBM-side bytes per launch from the committed PMC passes (profiles/r03_pmc_traffic.json, produced by
-    tools/pmc_traffic.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script); None when the
-    kernel has not been profiled."""
+def library_sha256():
+    """sha256 of the kernel library this process loads (dctn_amd/libdctn_amd.so): what ties the committed PMC passes to
+    the code that runs (the passes' `_meta.so_sha256` is taken on the GPU box from the library they profiled)."""
+    import hashlib
+
+    path = os.path.join(ROOT, "dctn_amd", "libdctn_amd.so")
+    try:
+        h = hashlib.sha256()
+        with open(path, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
+def traffic_table():
+    """The committed PMC table, or {} when it was taken on ANOTHER build of the library than the one loaded now (then
+    every `roofline.traffic` is null: a number that nothing ties to the running code is not reported)."""
     global _TRAFFIC
     if _TRAFFIC is None:
         _TRAFFIC = {}
-        for name in ("r03_pmc_traffic.json",):   # the current round's passes only (tools/profile_round.sh + condense_round.py)
-            path = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(path):
-                try:
-                    _TRAFFIC.update(json.load(open(path)))
-                except Exception:
-                    pass
-    if ":" in key and key.split(":", 1)[0] in _TRAFFIC and isinstance(_TRAFFIC[key.split(":", 1)[0]], list):
+        path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if os.path.exists(path):
+            try:
+                table = json.load(open(path))
+            except Exception:
+                table = {}
+            meta = table.get("_meta", {}) if isinstance(table.get("_meta"), dict) else {}
+            match = bool(meta.get("so_sha256")) and meta.get("so_sha256") == library_sha256()
+            _TRAFFIC = table if match else {"_meta": meta}
+            _TRAFFIC["_match"] = match
+    return _TRAFFIC
+
+
+def traffic_stamp():
+    """(git head the passes were taken on, whether they were taken on the library that is loaded now)"""
+    t = traffic_table()
+    return t.get("_meta", {}).get("head"), bool(t.get("_match"))
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per launch from the committed PMC passes (profiles/<round>_pmc_traffic.json, produced by
+    tools/condense_round.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script); None when the
+    kernel has not been profiled or the passes belong to another build of the library."""
+    table = traffic_table()
+    if ":" in key and key.split(":", 1)[0] in table and isinstance(table[key.split(":", 1)[0]], list):
         # side config: "<cfg>:<kernel substring>" -> the longest-running instantiation of that kernel in the config's profile
         cfg, sub = key.split(":", 1)
-        hits = [e for e in _TRAFFIC[cfg] if sub in e["kernel"] and e.get("avg_us")]
+        hits = [e for e in table[cfg] if sub in e["kernel"] and e.get("avg_us")]
         if not hits:
             return None
         return int(max(hits, key=lambda e: e["avg_us"])["traffic_bytes"])
-    v = _TRAFFIC.get(key)
-    return int(v) if isinstance(v, (int, float)) else None
+    v = table.get(key)
+    return int(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else None
 
 
 def roofline_entry(bound, kernel, call, seconds, flops, nbytes, dtype, traffic_key=None, **extra):
@@ -244,8 +283,10 @@ def roofline_entry(bound, kernel, call, seconds, flops, nbytes, dtype, traffic_k
         achieved, unit = flops / seconds / 1e12, "TFLOP/s"
     else:
         peak, achieved, unit = HBM_PEAK_GBS, nbytes / seconds / 1e9, "GB/s"
+    head, match = traffic_stamp()
     entry = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
-             "traffic": pmc_traffic(traffic_key) if traffic_key else None, "kernel": kernel, "call": call,
+             "traffic": pmc_traffic(traffic_key) if traffic_key else None, "traffic_head": head,
+             "traffic_on_this_library": match, "kernel": kernel, "call": call,
              "launch_us": seconds * 1e6, "algorithmic_flops": int(flops), "algorithmic_bytes": int(nbytes),
              "hbm_gbs": nbytes / seconds / 1e9}
     entry.update(extra)
@@ -473,10 +514,11 @@ def extra_eps_model(name, dev, iters):
                      l["_nb"] * l["windows"] * t["gemm_flops"],
                      t["bytes_x"] * l["_nb"] + t["bytes_y"] + t["bytes_core"] * 2))
     us, what, call, fam, fl, by = max(cand)
-    kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k", "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k",
+    kernel = {"eps_fwd_mfma_bigcore_f32": "eps_bigcore_k",
+              "eps_bwd_mfma_bigcore_f32": "eps_bigcore_k (G0, G1) + eps_bigcore_dcore_k" if "L1" not in what else "eps_bigcore_dcore_k",
               "eps_bwd_mfma_bigcore_f32_savedz": "eps_bigcore_k (G0) + eps_bigcore_dp1_k (saved Z) + eps_bigcore_dcore_k"}.get(fam, fam)
     roof = roofline_entry("mfma", kernel, f"{call} ({what})", us * 1e-6, fl, by, dtype, traffic_key=f"{name}:eps_bigcore_k",
-                          traffic_scope=("longest eps_bigcore_k instantiation of the profiled config (profiles/r03_pmc_traffic.json)"
+                          traffic_scope=("longest eps_bigcore_k instantiation of the profiled config (profiles/" + TRAFFIC_FILE + ")"
                                          if dtype == torch.float32 else "not collected for this config"),
                           step_tflops=step_flops / t_fb / 1e12, step_frac=step_flops / t_fb / 1e12 / MFMA_PEAK_TFLOPS[str(dtype).replace("torch.", "")],
                           step_algorithmic_flops=int(step_flops))
@@ -484,7 +526,9 @@ def extra_eps_model(name, dev, iters):
         del l["_t"], l["_nb"]
     arith = ("f32" if dtype == torch.float32 else
              "bf16 storage, bf16 matrix cores with float32 accumulation (not a BASELINE config: the cfg3a model under the bf16 policy)")
-    return {"workload": f"{name}: EPSesPlusLinear({specs}) {arith} on MNIST-shaped 28x28 Q0=2, fwd + bwd(out_grad), batch {batch}",
+    layout = ("CIFAR YCbCr + constant channel layout 32x32 Q0=4 (check_super_small_model.sh:1-12)" if q0 == 4
+              else f"MNIST-shaped {image_size}x{image_size} Q0={q0}")
+    return {"workload": f"{name}: EPSesPlusLinear({specs}) {arith} on {layout}, fwd + bwd(out_grad), batch {batch}",
             "dtype": DTYPE_NAME[dtype], "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
             "value": windows / t_fb, "unit": "windows/s", "layers": layers, "roofline": roof,
             "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, torch.float32 if dtype == torch.bfloat16 else dtype,
@@ -679,10 +723,28 @@ def extra_cfg5(dev, iters):
                                        f"{Wc} of {Wn} windows, {it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
 
 
+def side_scalars(name, e):
+    """One side configuration's entry flattened into scalar `config` keys."""
+    if "value" not in e:
+        return {f"side_{name}_error": str(e.get("error", "failed"))[:120]}
+    roof = e.get("roofline", {})
+    out = {f"side_{name}_ms": round(e["ms_per_step"], 5), f"side_{name}_wps": round(e["value"]),
+           f"side_{name}_frac": round(roof.get("frac", 0.0), 4), f"side_{name}_bound": roof.get("bound")}
+    if roof.get("step_frac") is not None:
+        out[f"side_{name}_step_frac"] = round(roof["step_frac"], 4)
+    if roof.get("fwd_frac") is not None:
+        out[f"side_{name}_fwd_frac"] = round(roof["fwd_frac"], 4)
+    if roof.get("traffic") is not None and roof.get("algorithmic_bytes"):
+        out[f"side_{name}_traffic_x"] = round(roof["traffic"] / roof["algorithmic_bytes"], 2)
+    if "cpu_baseline" in e:
+        out[f"side_{name}_cpu_wps"] = round(e["cpu_baseline"]["value"])
+    return out
+
+
 def run_extra(name, dev):
     if name == "cfg1":
         return extra_cfg1(dev, 20)
-    if name in ("cfg3a", "cfg3b", "cfg3a_bf16", "cfg3b_bf16"):
+    if name in ("cfg3a", "cfg3b", "cfg3a_bf16", "cfg3b_bf16", "cfg4_eps36"):
         return extra_eps_model(name, dev, 10 if name == "cfg3a" else 20)
     if name.startswith("cfg4_r"):
         return extra_cfg4(int(name[6:]), dev, 30)
@@ -708,6 +770,34 @@ def run_extra_in_child(name, no_cpu_baseline, timeout=420.0, device_index=0):
         return json.loads(res.stdout.strip().splitlines()[-1])["configs"][0]
     except Exception as e:   # noqa: BLE001
         return {"workload": name, "error": f"unparsable child output ({type(e).__name__}: {e})"}
+
+
+def launch_ranks(n, argv, timeout=1500.0):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` as a CHILD process of a parent
+    that has made no GPU call: stdout (rank 0's one JSON line) is relayed, stderr passes through; returns the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:   # a free rendezvous port on the loopback address
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log(f"--gpus {n} without WORLD_SIZE: starting the ranks with torch.distributed.run on port {port}")
+    child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+    try:
+        out, _ = child.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()   # this exact child, by handle
+        out, _ = child.communicate()
+        log(f"the {n}-rank run did not finish within {timeout:.0f} s")
+        return 124
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return child.returncode
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -743,6 +833,11 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + "
                     "DCTN_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a single GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.skip_headline:
+        # `python bench.py --gpus N` started as ONE process: start the N ranks as a child (before anything here touches
+        # the GPU; this process never re-executes itself), relay rank 0's JSON line and leave with the child's code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from dctn_amd import ddp
     from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
@@ -1068,14 +1163,14 @@ def main():
                 entries.append(run_extra_in_child(name, args.no_cpu_baseline))
                 entries[-1]["bench_seconds"] = round(time.perf_counter() - t0, 1)
             line["configs"] = entries
-            # the same numbers in compact form INSIDE `config` (a driver that keeps the contract's keys only keeps these):
-            # cfg -> [ms_per_step, windows_per_s, fraction of its roofline (dominant call), cpu oracle windows_per_s]
-            line["config"]["side"] = {
-                name: ([round(e["ms_per_step"], 5), round(e["value"]), round(e["roofline"]["frac"], 4),
-                        round(e["cpu_baseline"]["value"]) if "cpu_baseline" in e else None] if "value" in e
-                       else [None, None, None, e.get("error", "failed")])
-                for name, e in zip(names, entries)}
-            line["config"]["side_legend"] = "cfg: [ms_per_step, windows_per_s, roofline.frac of the dominant call, cpu_baseline windows_per_s]"
+            # the same numbers as SCALAR keys of `config` (a driver that keeps the contract's keys keeps scalars only:
+            # round 3's dict-valued `config.side` was dropped): side_<cfg>_ms = ms per fwd+bwd step, _wps = windows/s,
+            # _frac = fraction of the stated roofline reached by the dominant call, _bound = which roofline,
+            # _step_frac = the same for the whole step where defined, _cpu_wps = the CPU oracle's windows/s
+            for name, e in zip(names, entries):
+                line["config"].update(side_scalars(name, e))
+            line["config"]["side_legend"] = ("side_<cfg>_ms: ms per fwd+bwd step; _wps: windows/s; _frac: dominant call's fraction of its "
+                                             "roofline (_bound: hbm | mfma); _step_frac: whole step; _cpu_wps: CPU oracle windows/s")
         print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():

@@ -219,6 +219,8 @@ class _ManyConvSBSFunction(torch.autograd.Function):
             return False
         C, B, H, W, q = x.shape
         plans = [_plan(sp) for sp in specs]
+        if any(C != p.C or q != p.q for p in plans):   # the single-string path raises the reference's AssertionError for it
+            return False
         key = (B, H, W)
         cache = plans[0].many_ok
         tag = (key, tuple(id(p) for p in plans[1:]))
@@ -234,6 +236,7 @@ class _ManyConvSBSFunction(torch.autograd.Function):
         C, B, H, W, q = x.shape
         plans = [_plan(sp) for sp in specs]
         ns, n = len(plans), plans[0].n
+        assert all(C == p.C and q == p.q for p in plans)   # (the library derives q^C from x: never index cores of another size)
         cores_c = [c.contiguous() for c in cores]
         for core, shape in zip(cores_c, [t for p in plans for t in p.shape_tuples]):
             assert tuple(core.shape) == shape

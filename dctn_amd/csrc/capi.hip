@@ -120,7 +120,11 @@ static int eps_fwd_impl(const void* x, const int64_t x_strides[5], const void* c
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
   {
-    const size_t hb = saved ? eps_halves_saved_bytes(p, dtype) : 0;
+    // the two-halves family may keep the buffer only where the backward will read it as ITS layout (P0 | P1 | Z): the
+    // same routing as dctn_eps_saved_bytes and eps_bwd_impl.  A shape the large-core family claims but then declines
+    // falls through to here with nothing kept (its backward would read the buffer as row-quad-major Z).
+    const bool halves_route = dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision) || f32_prefers_halves(p, dtype);
+    const size_t hb = (saved && halves_route) ? eps_halves_saved_bytes(p, dtype) : 0;
     const bool keep = hb > 0 && saved_bytes >= hb;
     rc = eps_fwd_halves(x, core, out, workspace, workspace_bytes, p, dtype, st, keep ? saved : nullptr);
     if (rc == DCTN_OK && keep && kept) *kept = 1;

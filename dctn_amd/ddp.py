@@ -37,9 +37,24 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
     return rank, local_rank, world
 
 
+def _probe_child_device(local_rank: Optional[int] = None) -> int:
+    """GPU index the probe's child opens: the explicit argument, else the launcher's LOCAL_RANK, else - only when this
+    process has ALREADY initialised the GPU (it then has a current device that means something) - that device, else 0.
+    Never touches the GPU itself: the probe runs before `set_device` (bench.py), where `current_device()` is 0 on every
+    rank and asking would create a HIP context on GPU 0 in every process."""
+    if local_rank is not None:
+        return int(local_rank)
+    if os.environ.get("LOCAL_RANK") is not None:
+        return int(os.environ["LOCAL_RANK"])
+    if torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    return 0
+
+
 def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: torch.dtype = torch.bfloat16,
                             port_offset: int = 53, rank: Optional[int] = None, world_size: Optional[int] = None,
-                            master_addr: Optional[str] = None, master_port: Optional[int] = None) -> bool:
+                            master_addr: Optional[str] = None, master_port: Optional[int] = None,
+                            local_rank: Optional[int] = None) -> bool:
     """Whether an RCCL all-reduce can be captured into a HIP graph on this machine with this world size, found
     out in CHILD processes (`dctn_amd._probe_allreduce_capture`): every rank calls this at the same point, each
     starts one child on its own GPU, the children form a process group of their own on master_port + port_offset,
@@ -49,7 +64,8 @@ def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: t
 
     The children must form a group of the SAME size as the parent's: rank / world size come from the arguments, else
     from the parent's initialised process group, else from RANK / WORLD_SIZE; the rendezvous address from the arguments,
-    else MASTER_ADDR / MASTER_PORT.  A world of more than one rank without a known rendezvous address (mp.spawn with an
+    else MASTER_ADDR / MASTER_PORT; the child's GPU from `local_rank`, else LOCAL_RANK, else the current device of
+    an already initialised GPU runtime (`_probe_child_device`).  A world of more than one rank without a known rendezvous address (mp.spawn with an
     explicit init_method and no environment) cannot be probed: False, i.e. the collective stays outside the graph."""
     import subprocess
     import sys
@@ -68,7 +84,7 @@ def probe_allreduce_capture(timeout: float = 240.0, numel: int = 29098, dtype: t
         master_addr = "127.0.0.1"
     if master_port is None:
         master_port = 29500
-    local_rank = torch.cuda.current_device() if torch.cuda.is_available() else int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = _probe_child_device(local_rank)
     # the children rendezvous among themselves: under torchrun the parent's environment says "use the agent's store"
     # (TORCHELASTIC_USE_AGENT_STORE), which on another port would wait for a server nobody starts
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "TORCH_NCCL_ASYNC_ERROR_HANDLING"}

@@ -58,14 +58,18 @@ class _EpsFunction(torch.autograd.Function):
             )
             if rc != L.SAVED:   # the forward says whether it wrote the buffer; an untouched one never reaches the backward
                 saved = None
-        ctx.save_for_backward(core_c, input)
-        ctx.saved_gemm = saved
+        # the kept GEMM result (up to 416 MB at cfg3a layer 2) is an autograd-managed saved tensor: freed when the
+        # backward has run (not when the last reference to the graph dies), visible to saved_tensors_hooks / checkpointing
+        if saved is None:
+            ctx.save_for_backward(core_c, input)
+        else:
+            ctx.save_for_backward(core_c, input, saved)
         ctx.dims = (C, B, H, W, Q, K, O, prec)
         return out
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
-        core_c, input = ctx.saved_tensors
+        core_c, input, *kept = ctx.saved_tensors
         C, B, H, W, Q, K, O, prec = ctx.dims
         need_dcore, need_dx = ctx.needs_input_grad[:2]
         dev = input.device
@@ -75,7 +79,7 @@ class _EpsFunction(torch.autograd.Function):
         code = L.dtype_code(input)
         nbytes = L.lib().dctn_eps_bwd_workspace_bytes(C, B, H, W, Q, K, O, code, prec, int(need_dx), int(need_dcore))
         ws = L.workspace(nbytes, dev)
-        saved = ctx.saved_gemm
+        saved = kept[0] if kept else None
         common = (None if d_x is None else d_x.data_ptr(), None if d_core is None else d_core.data_ptr(),
                   ws.data_ptr(), ws.numel(), C, B, H, W, Q, K, O, code, prec, L.stream_ptr(dev))
         if saved is not None and need_dx:

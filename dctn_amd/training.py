@@ -92,7 +92,7 @@ class GraphedTrainStep:
             if dist.is_initialized() and dist.get_backend() == "nccl":
                 some = next(p for p in model.parameters() if p.requires_grad)
                 ok = ddp.probe_allreduce_capture(numel=sum(p.numel() for p in model.parameters() if p.requires_grad),
-                                                 dtype=some.dtype)
+                                                 dtype=some.dtype, local_rank=dev.index)
                 graph_allreduce = ddp.all_ranks_agree(ok, dev)
         graph_allreduce = bool(graph_allreduce) and reduces
         split = reduces

@@ -256,3 +256,25 @@ def test_convsbs_classifier_and_fold_two_ranks_on_one_gpu():
     mats = torch.randn(64, 9, 16, 16, generator=gm).to(dev)
     whole = logmatmulexp_fold(mats).cpu()
     assert torch.allclose(torch.cat([torch.from_numpy(got[0][1]), torch.from_numpy(got[1][1])]), whole, rtol=1e-5, atol=1e-5)
+
+
+def test_bench_gpus_2_starts_itself_without_world_size():
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (one process, no WORLD_SIZE): the parent
+    starts torch.distributed.run itself, before any GPU call of its own, and relays rank 0's one JSON line.  Rehearsed
+    here with both ranks on the one GPU of the test box over gloo (RCCL needs a GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["DCTN_BENCH_ONE_DEVICE"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
+                          "--warmup", "2", "--batch", "64", "--configs", "none", "--no-cpu-baseline"],
+                         cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["config"]["windows_per_step"] == 2 * 64 * 676
+    assert line["config"]["allreduce_bytes"] and line["value"] > 0

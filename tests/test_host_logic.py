@@ -404,6 +404,42 @@ def test_allreduce_capture_probe_says_no_without_a_gpu():
     assert ddp.all_ranks_agree(True) is True and ddp.all_ranks_agree(False) is False
 
 
+def test_allreduce_capture_probe_child_opens_the_launchers_gpu(monkeypatch):
+    """Every rank calls the probe BEFORE `torch.cuda.set_device(local_rank)` (bench.py): the child's GPU must then be the
+    launcher's LOCAL_RANK - not `torch.cuda.current_device()`, which is 0 on every rank at that point (all N children on
+    cuda:0: RCCL refuses the duplicate GPU and the multi-GPU run silently loses the graphed collective) - and asking
+    must not create a GPU context in the parent."""
+    import subprocess
+
+    from dctn_amd import ddp
+
+    seen = {}
+
+    class _Child:
+        def wait(self, timeout=None):
+            return 0
+
+    def fake_popen(cmd, cwd=None, env=None, **kw):
+        seen.update(env)
+        return _Child()
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    for rank in (0, 1, 5):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("LOCAL_RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "8")
+        monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+        monkeypatch.setenv("MASTER_PORT", "29511")
+        assert ddp.probe_allreduce_capture(timeout=1.0) is True
+        assert seen["LOCAL_RANK"] == str(rank) and seen["RANK"] == str(rank) and seen["WORLD_SIZE"] == "8"
+        assert seen["MASTER_PORT"] == str(29511 + 53)
+    assert ddp.probe_allreduce_capture(timeout=1.0, local_rank=3) is True and seen["LOCAL_RANK"] == "3"
+    monkeypatch.delenv("LOCAL_RANK")
+    assert ddp._probe_child_device() == (torch.cuda.current_device() if torch.cuda.is_initialized() else 0)
+    if not torch.cuda.is_available():
+        assert not torch.cuda.is_initialized()
+
+
 def test_eps_plus_linear_model_is_picklable_and_refreshes_p_on_load():
     """The dropout gate's host copy of `p` is refreshed by a module-level load_state_dict hook (a lambda stored on the
     module made `torch.save(model)` / spawn arguments fail)."""

@@ -18,7 +18,7 @@ import json
 import os
 import sys
 
-CONFIGS = ("headline", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r16", "cfg5")
+CONFIGS = ("headline", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
 HEADLINE_KEYS = ("eps_fwd_head_q2reg_k", "eps_fwd_q2reg_k", "eps_bwd_dcore_q2reg_k", "eps_head_reduce_k", "eps_bwd_dcore_reduce_k",
                  "head_fwd_k")
 
@@ -50,7 +50,7 @@ def ours(name):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
     dst = sys.argv[3] if len(sys.argv) > 3 else "profiles"
     traffic, lines = {"_note": "HBM-side bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is "
@@ -93,6 +93,22 @@ def main():
                 for key in HEADLINE_KEYS:
                     if key + "<" in e["kernel"] or key + "(" in e["kernel"] or ("N_1" in e["kernel"] and key in e["kernel"]):
                         traffic.setdefault(f"{key}:B1024", e["traffic_bytes"])
+    # what ties these passes to a build: the sha256 of the library the profiled processes loaded (taken on the GPU box by
+    # profile_round.sh) and the git head of the tree it was built from (bench.py nulls `roofline.traffic` on a mismatch)
+    meta = {}
+    stamp = os.path.join(src, "stamp.json")
+    if os.path.exists(stamp):
+        meta.update(json.load(open(stamp)))
+    try:
+        import subprocess
+
+        meta["head"] = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "dctn_amd", "include"], capture_output=True, text=True).stdout.strip()
+        meta["head_note"] = ("library sources differ from this head (uncommitted changes at condense time)" if dirty
+                             else "dctn_amd/ and include/ clean at this head when the passes were condensed")
+    except Exception:
+        pass
+    traffic["_meta"] = meta
     json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
     json.dump(lines, open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w"), indent=1)
     sq = {}
@@ -119,7 +135,7 @@ def main():
                             "summed over waves; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs")
             json.dump(per, open(os.path.join(dst, f"{rnd}_sq_{cfg}.json"), "w"), indent=1)
     print(json.dumps({k: (v if not isinstance(v, list) else [(e["kernel"][:60], e["avg_us"], e["traffic_bytes"]) for e in v[:4]])
-                      for k, v in traffic.items() if k != "_note"}, indent=1))
+                      for k, v in traffic.items() if k not in ("_note", "_meta")}, indent=1))
 
 
 if __name__ == "__main__":
