@@ -643,15 +643,22 @@ def extra_cfg4(r, dev, iters):
     n_par = sum(p.numel() for p in many.parameters())
     by_fwd = x.numel() * 4 + y.numel() * 4 + n_par * 4
     by_fb = 3 * x.numel() * 4 + 2 * y.numel() * 4 + 3 * n_par * 4     # + read x again, read dY, write dX, cores + dCores
-    if r >= 16:   # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
-        roof = roofline_entry("mfma", "convsbs_bwd_mfma_k" if "mfma" in fam else "convsbs_bwd_regu_k (+ convsbs_regu_tail_k)", "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)" if "mfma" in fam else "dctn_convsbs_bwd (register-resident sweep: nothing kept by the forward)", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:" + ("convsbs_bwd_mfma" if "mfma" in fam else "convsbs_bwd_reg"), fwd_us=t_f * 1e6,
-                              fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
+    if "band" in fam:
+        kname, call, tkey = ("convsbs_bwd_band_k (+ convsbs_band_tail_k)",
+                             "dctn_convsbs_bwd (band-owning backward: chain recomputed in registers, nothing kept by the forward)",
+                             "convsbs_bwd_band")
+    elif "mfma" in fam:
+        kname, call, tkey = "convsbs_bwd_mfma16_k", "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)", "convsbs_bwd_mfma"
+    else:
+        kname, call, tkey = ("convsbs_bwd_regu_k (+ convsbs_regu_tail_k)",
+                             "dctn_convsbs_bwd (register-resident sweep: nothing kept by the forward)", "convsbs_bwd_reg")
+    if r >= 8:    # compute bound: the shared-core GEMMs of the sweep on the f32 matrix cores
+        roof = roofline_entry("mfma", kname, call, t_b, 2 * flops_fwd, by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:{tkey}",
+                              fwd_us=t_f * 1e6, fwd_tflops=flops_fwd / t_f / 1e12, step_tflops=3 * flops_fwd / t_fb / 1e12,
                               step_frac=3 * flops_fwd / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float32"], family=fam)
     else:         # HBM / launch-latency bound: bytes of the fused ideal against the HBM peak
-        roof = roofline_entry("hbm", "convsbs_bwd_mfma_k" if "mfma" in fam else "convsbs_bwd_regu_k (+ convsbs_regu_tail_k)", "dctn_convsbs_bwd_saved (forward states from dctn_convsbs_fwd)" if "mfma" in fam else "dctn_convsbs_bwd (register-resident sweep: nothing kept by the forward)", t_b, 2 * flops_fwd,
-                              by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:" + ("convsbs_bwd_mfma" if "mfma" in fam else "convsbs_bwd_reg"), fwd_us=t_f * 1e6,
-                              fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
+        roof = roofline_entry("hbm", kname, call, t_b, 2 * flops_fwd, by_fb - by_fwd, torch.float32, traffic_key=f"cfg4_r{r}:{tkey}",
+                              fwd_us=t_f * 1e6, fwd_gbs=by_fwd / t_f / 1e9, step_gbs=by_fb / t_fb / 1e9,
                               step_frac=by_fb / t_fb / 1e9 / HBM_PEAK_GBS, family=fam)
     cores_n = usable_cores()
     torch.set_num_threads(cores_n)

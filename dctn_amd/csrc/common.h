@@ -128,6 +128,16 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                      int q, int dtype, hipStream_t st, float* partials = nullptr, size_t partial_bytes = 0,
                      const float* saved_states = nullptr);
+// Band-owning backward for bonds 9..16 (two roles per SIMD, nothing kept by the forward) - convsbs_band.hip.  Strings it
+// covers keep no forward states (convsbs_saved_states_bytes returns 0 for them); `ws` holds the per-workgroup dCore
+// records and the partial sums of the pixel rows two bands share (convsbs_band_bwd_workspace; 0 = outside the family).
+bool convsbs_band_covers(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B,
+                         int H, int W, int q, int dtype);
+size_t convsbs_band_bwd_workspace(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C,
+                                  int B, int H, int W, int q, int dtype);
+int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
+                     float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);
 // room for the per-workgroup partial-gradient records of the MFMA backward (deterministic dCore)
 constexpr int SBS_MAX_PARTIAL_RECORDS = 2048;
 

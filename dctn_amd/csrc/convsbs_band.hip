@@ -1,0 +1,721 @@
+// ConvSBS backward for LARGE bonds (8 < largest bond <= 16) on the f32 matrix cores, one launch + one tail:
+// float32 open chains of at most nine cores (the snakes of mnist.py:189-223), at most two output values, both on one
+// middle core, q^C <= 4 - BASELINE cfg4 at r = 16.
+//
+// Replaces torch autograd through dctn/conv_sbs.py:258-304 for these strings, and the round-2 backward of
+// convsbs_mfma.hip (convsbs_bwd_mfma16_k: forward states through HBM - 81 MB written by the forward and read back -,
+// per-window feature gradients through HBM, four helper launches, one wave per SIMD with 415 registers).  Here:
+//   * a workgroup owns a BAND of window rows of ONE image.  It keeps the per-window feature gradients of the band in
+//     LDS and writes the band's dX itself, in a fixed order; the max_h pixel rows two bands share go to a small side
+//     buffer as two partial sums that the tail kernel adds.  No per-window gradient tensor, no zero-fill, no gather.
+//   * nothing is kept by the forward: the chain is recomputed per 16-window tile and the input state of every core
+//     stays in REGISTERS until the way back (4 registers per state: 64 for nine cores).
+//   * TWO ROLES, one wave of each per SIMD (waves w and w + 4 of a 512-thread workgroup share a SIMD):
+//       chain waves (0-3): forward sweep, adjoint sweep, d/d(features) - everything that is a dependent chain;
+//       gradient waves (4-7): dCore += G^T (f v) with the WINDOWS on the k index; they own the dCore accumulators
+//       (8 slots x q^C tiles x 4 registers) across the whole band.  The chain wave hands over G and v of a tile
+//       through LDS (two buffers, one workgroup barrier per hand-over): the gradient wave's MFMAs fill the matrix
+//       pipe while the chain wave is in an epilogue, and the chain wave is free of the 128-160 accumulator registers
+//       that held the old kernel at one wave per SIMD.
+//   * tiles per feature value instead of rows padded to four: U_qq[r', w] = sum_l core[o, l, r', qq] v[l, w] is one
+//       16x16 tile per qq (v_mfma_f32_16x16x4_f32, K = l), so q = 3 costs 12 MFMAs per product, not 16, and q = 2 costs 8.
+//       State layout: register s of lane (w, g) holds l = 4 g + s; the accumulator's register r of lane (w, g) is row
+//       4 g + r, so  v'[r'] = sum_qq f[qq] U_qq[r']  lands in state layout: the chain never leaves registers.
+//       Adjoint: W_qq[l, w] = sum_r' core[o, l, r', qq] G[r', w] from a second pack with the bond legs exchanged;
+//       dv[l] = sum_qq f[qq] W_qq[l] (state layout again), df[qq] = sum_l v[l] W_qq[l].
+//   * per-workgroup dCore records in the cores' natural layout, summed in a fixed order by the tail kernel:
+//     bit-reproducible gradients.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float bd_f4;
+typedef __attribute__((ext_vector_type(2))) int bd_i2;
+
+namespace {
+
+constexpr int BD_NC = 9;          // cores per string (compile-time unrolled; shorter strings run too)
+constexpr int BD_NPK = BD_NC - 1; // packs / accumulator slots: middle core c -> slot c - 1, the second output value -> slot 7
+constexpr int BD_TS = 24;         // floats per row of a transposed hand-over tile (b128 reads conflict-free, b32 writes 2-way)
+constexpr int BD_TILE = 16 * BD_TS;      // one hand-over tile (G or v): [row][window]
+constexpr int BD_FS = BD_NC * 16 * 4;    // feature products of a 16-window tile: [core][window][4]
+constexpr int BD_THREADS = 512;
+
+struct BdP {
+  const float* x;
+  const float* dY;
+  float* dX;            // (C, B, H, W, q) contiguous, or NULL
+  float* records;       // [workgroup][core_off[n]] partial core gradients, or NULL (no core gradient wanted)
+  float* side;          // partial sums of the pixel rows two bands share: [image][boundary][part][max_h][W][C q]
+  const float* core[BD_NC];
+  long long xs[5];
+  int n, C, q, qc, B, H, W, Ho, Wo, Otot, max_h;
+  int o[BD_NC], bl[BD_NC], br[BD_NC], ph[BD_NC], pw[BD_NC];
+  int nin[BD_NC];       // input states of core c (1, or 2 behind the two-valued core)
+  int c2;               // the core with two output values, or -1
+  int nb, band_rows;    // bands per image, window rows per band (the last band of an image may be shorter)
+  int iters;            // tiles per chain wave
+  int core_off[BD_NC + 1];
+  int packF_off, packA_off, first_off, last_off, fs_off, raw_off, gv_off, rows_off;   // LDS plan (float offsets)
+};
+
+struct BdTailP {
+  float* dcore[BD_NC];
+  int core_off[BD_NC + 1];
+  int n, nrec, total;
+  int last_stride, qc;
+  const float* records;
+  const float* side;
+  float* dX;
+  int B, H, W, Cq, C, q, nb, band_rows, max_h;
+  long long nshared;    // shared pixel-row elements: B (nb - 1) max_h W C q
+};
+
+__device__ __forceinline__ float bd_group_sum(float v) {   // sum over the four k groups (lanes w, w+16, w+32, w+48), in every lane
+  const int iv = __float_as_int(v);
+  const bd_i2 r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  const float t = __int_as_float(r[0]) + __int_as_float(r[1]);
+  const int it = __float_as_int(t);
+  const bd_i2 r2 = __builtin_amdgcn_permlane32_swap(it, it, false, false);
+  return __int_as_float(r2[0]) + __int_as_float(r2[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float bd_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float bd_row_sum16(float v) {   // sum over the 16 lanes of a row (the tile's windows), in every lane
+  v = bd_dpp_add<0x128>(v);
+  v = bd_dpp_add<0x124>(v);
+  v = bd_dpp_add<0x122>(v);
+  return bd_dpp_add<0x121>(v);
+}
+__device__ __forceinline__ void bd_wave_lds_sync() {   // LDS written by some lanes of this wave, read by others
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One fragment element of pack `pk` (middle core c, output o): FWD  A[row r' = i][k: l = 4 g + s],
+//                                                                ADJ  A[row l = i][k: r' = 4 g + s]
+template <int QT>
+__device__ __forceinline__ float bd_pack_element(const BdP& p, int e, bool adj) {
+  const int s = e & 3, ln = (e >> 2) & 63, rest = e >> 8;
+  const int qq = rest % QT, pk = rest / QT;
+  const int c = pk < BD_NPK - 1 ? pk + 1 : p.c2, o = pk < BD_NPK - 1 ? 0 : 1;
+  if (c < 1 || c + 1 >= p.n || o >= p.o[c]) return 0.f;
+  const int i = ln & 15, gg = ln >> 4;
+  const int l = adj ? i : 4 * gg + s, r = adj ? 4 * gg + s : i;
+  if (l >= p.bl[c] || r >= p.br[c] || qq >= p.qc) return 0.f;
+  return p.core[c][(long long)((o * p.bl[c] + l) * p.br[c] + r) * p.qc + qq];
+}
+
+// QT: feature values per core (q^C, 2..4) = 16x16 tiles per product.  CH: 1 = one channel (the products ARE the pixel's
+// values), 2 = two channels of two values (QT = 4; the deeper layers of the reference's classifier).
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
+  constexpr int RK = CH == 2 ? 4 : QT;   // gradient values per core and window in the band's LDS rows
+  const int img = (int)blockIdx.x / p.nb, kb = (int)blockIdx.x - img * p.nb;
+  const int r0 = kb * p.band_rows, r1 = r0 + p.band_rows < p.Ho ? r0 + p.band_rows : p.Ho;
+  const int nwin = (r1 - r0) * p.Wo;
+
+  // ---- the packs: every global load first, then the LDS stores (one round trip for the whole string)
+  {
+    constexpr int PER = (BD_NPK * QT * 256) / BD_THREADS;
+    float va[PER], vb[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      va[j] = bd_pack_element<QT>(p, tid + BD_THREADS * j, false);
+      vb[j] = bd_pack_element<QT>(p, tid + BD_THREADS * j, true);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      lds[p.packF_off + tid + BD_THREADS * j] = va[j];
+      lds[p.packA_off + tid + BD_THREADS * j] = vb[j];
+    }
+    // first core (1, 1, r', qc) as [r'][4]; last core (1, l, 1, qc) as [l][4]; zero beyond the real extents
+    if (tid < 64) {
+      const int rr = tid >> 2, qq = tid & 3;
+      lds[p.first_off + tid] = (qq < p.qc && rr < p.br[0]) ? p.core[0][rr * p.qc + qq] : 0.f;
+      lds[p.last_off + tid] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][rr * p.qc + qq] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  if (wv < 4) {
+    // =============================================================================== chain wave
+    float* fsb = lds + p.fs_off + wv * 2 * BD_FS;
+    float* rawb = lds + p.raw_off + wv * BD_FS;          // CH == 2: the pixels' raw values [core][window][4]
+    float* gvb = lds + p.gv_off + wv * 4 * BD_TILE;      // two buffers of (G tile, v tile)
+    float* rows = lds + p.rows_off;
+    float dfirst[4][QT], dlast[4][QT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) { dfirst[s][qq] = 0.f; dlast[s][qq] = 0.f; }
+    int gs = 0;
+    // prefetch registers: the pixels of cores g, g + 4, g + 8 of the lane's window, and the window's dY
+    float pre[3][4], pdy[2];
+    auto issue_loads = [&](int it) {
+      const int wb = (it * 4 + wv) * 16 + wl;
+      const bool valid = wb < nwin;
+      const int wbb = valid ? wb : 0;
+      const int hr = wbb / p.Wo, wo = wbb - hr * p.Wo, ho = r0 + hr;
+      const float* win = p.x + (long long)img * p.xs[1] + (long long)ho * p.xs[2] + (long long)wo * p.xs[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = g + 4 * k;
+        const int cc = c < p.n ? c : 0;
+        const float* px = win + (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
+        if constexpr (CH == 2) {
+          pre[k][0] = valid ? px[0] : 0.f;
+          pre[k][1] = valid ? px[p.xs[4]] : 0.f;
+          pre[k][2] = valid ? px[p.xs[0]] : 0.f;
+          pre[k][3] = valid ? px[p.xs[0] + p.xs[4]] : 0.f;
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) pre[k][d] = (valid && d < QT) ? px[(d < QT ? d : 0) * p.xs[4]] : 0.f;
+        }
+      }
+      const long long wglob = ((long long)img * p.Ho + ho) * p.Wo + wo;
+      pdy[0] = valid ? p.dY[wglob * p.Otot] : 0.f;
+      pdy[1] = (valid && p.Otot > 1) ? p.dY[wglob * p.Otot + 1] : 0.f;
+    };
+    auto commit = [&](int it) {
+      float* fs = fsb + (it & 1) * BD_FS;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = g + 4 * k;
+        if (c < p.n) {
+          if constexpr (CH == 2) {   // f[2 d + e] = x0[d] x1[e]  (channel 0 most significant)
+            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) =
+                bd_f4{pre[k][0] * pre[k][2], pre[k][0] * pre[k][3], pre[k][1] * pre[k][2], pre[k][1] * pre[k][3]};
+            *reinterpret_cast<bd_f4*>(rawb + (c * 16 + wl) * 4) = bd_f4{pre[k][0], pre[k][1], pre[k][2], pre[k][3]};
+          } else {
+            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{pre[k][0], pre[k][1], pre[k][2], pre[k][3]};
+          }
+        }
+      }
+    };
+    issue_loads(0);
+
+    for (int it = 0; it < p.iters; ++it) {
+      const float* fs = fsb + (it & 1) * BD_FS;
+      commit(it);
+      const float dy0 = pdy[0], dy1 = pdy[1];
+      const int wb = (it * 4 + wv) * 16 + wl;
+      const bool valid = wb < nwin;
+      bd_wave_lds_sync();
+
+      // ---------------------------------------------------------------- forward sweep, input states kept
+      float Sin0[BD_NC][4], Sin1[BD_NC][4];   // input states of cores 1 .. n-1 (slot c); two behind the two-valued core
+      float v0[4], v1[4];
+      {
+        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.first_off + (4 * g + s) * 4);
+          float a = cp[0] * f[0] + cp[1] * f[1];
+          if (QT > 2) a += cp[2] * f[2];
+          if (QT > 3) a += cp[3] * f[3];
+          v0[s] = a;
+          v1[s] = 0.f;
+        }
+      }
+      // U_qq = A_qq x vin (K = l): the whole A operand of a pack is QT b128 reads; k-step outermost so that the QT
+      // accumulators form independent chains
+      auto product = [&](int off, int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
+        bd_f4 a[QT];
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) {
+          a[qq] = *reinterpret_cast<const bd_f4*>(lds + off + ((pk * QT + qq) * 64 + lane) * 4);
+          D[qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
+      };
+#pragma unroll
+      for (int c = 1; c < BD_NC - 1; ++c) {
+        if (c + 1 < p.n) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { Sin0[c][s] = v0[s]; Sin1[c][s] = v1[s]; }
+          const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
+          float n0[4], n1[4];
+          bd_f4 D[QT];
+          product(p.packF_off, c - 1, v0, D);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float a = f[0] * D[0][r] + f[1] * D[1][r];
+            if (QT > 2) a += f[2] * D[2 % QT][r];
+            if (QT > 3) a += f[3] * D[3 % QT][r];
+            n0[r] = a;
+            n1[r] = 0.f;
+          }
+          if (p.o[c] > 1) {
+            product(p.packF_off, BD_NPK - 1, v0, D);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float a = f[0] * D[0][r] + f[1] * D[1][r];
+              if (QT > 2) a += f[2] * D[2 % QT][r];
+              if (QT > 3) a += f[3] * D[3 % QT][r];
+              n1[r] = a;
+            }
+          } else if (p.nin[c] > 1) {
+            product(p.packF_off, c - 1, v1, D);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float a = f[0] * D[0][r] + f[1] * D[1][r];
+              if (QT > 2) a += f[2] * D[2 % QT][r];
+              if (QT > 3) a += f[3] * D[3 % QT][r];
+              n1[r] = a;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v0[r] = n0[r]; v1[r] = n1[r]; }
+        }
+      }
+      // the next tile's pixels and dY travel during the way back
+      if (it + 1 < p.iters) issue_loads(it + 1);
+
+      // ---------------------------------------------------------------- way back
+      // per-window feature gradient of core c -> the band's LDS row (one lane per window: the k groups hold the same sum)
+      auto put_row = [&](int c, const float (&df)[QT]) {
+        if (p.dX == nullptr) return;
+        float t[QT];
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) t[qq] = bd_group_sum(df[qq]);
+        if (g == 0 && valid) {
+          float* dst = rows + ((size_t)wb * p.n + c) * RK;
+          if constexpr (CH == 2) {   // d/d(products) -> d/d(pixel values): raw = (x0[0], x0[1], x1[0], x1[1])
+            const bd_f4 xr = *reinterpret_cast<const bd_f4*>(rawb + (c * 16 + wl) * 4);
+            dst[0] = t[0] * xr[2] + t[1] * xr[3];   // channel 0, value 0
+            dst[1] = t[2] * xr[2] + t[3] * xr[3];   // channel 0, value 1
+            dst[2] = t[0] * xr[0] + t[2] * xr[1];   // channel 1, value 0
+            dst[3] = t[1] * xr[0] + t[3] * xr[1];   // channel 1, value 1
+          } else {
+#pragma unroll
+            for (int qq = 0; qq < QT; ++qq) dst[qq] = t[qq];
+          }
+        }
+      };
+      float G0[4], G1[4];
+      {   // last core: out[a] = sum_l v_a[l] tl[l],  tl[l] = sum_qq coreL[l][qq] f[qq]
+        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + ((p.n - 1) * 16 + wl) * 4);
+        float df[QT];
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.last_off + (4 * g + s) * 4);
+          float tl = cp[0] * f[0] + cp[1] * f[1];
+          if (QT > 2) tl += cp[2] * f[2];
+          if (QT > 3) tl += cp[3] * f[3];
+          G0[s] = dy0 * tl;
+          G1[s] = dy1 * tl;
+          const float u = dy0 * v0[s] + dy1 * v1[s];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) {
+            df[qq] += u * cp[qq];
+            dlast[s][qq] += u * f[qq];
+          }
+        }
+        put_row(p.n - 1, df);
+      }
+      // one (input state, output value) pair of a middle core: adjoint + feature gradient, then G and v of the tile go
+      // to the gradient wave (transposed tiles [row][window], buffer gs & 1) and the workgroup meets at the barrier
+      auto pair_step = [&](int c, int pk, const float (&Gs)[4], const float (&vin)[4], const bd_f4& f, float (&d)[4],
+                           float (&df)[QT]) {
+        bd_f4 Wt[QT];
+        product(p.packA_off, pk, Gs, Wt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = f[0] * Wt[0][r] + f[1] * Wt[1][r];
+          if (QT > 2) a += f[2] * Wt[2 % QT][r];
+          if (QT > 3) a += f[3] * Wt[3 % QT][r];
+          d[r] += a;
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) df[qq] += vin[r] * Wt[qq][r];
+        }
+        float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          gt[(4 * g + s) * BD_TS + wl] = Gs[s];
+          gt[BD_TILE + (4 * g + s) * BD_TS + wl] = vin[s];
+        }
+        __syncthreads();
+        ++gs;
+      };
+#pragma unroll
+      for (int c = BD_NC - 2; c >= 1; --c) {
+        if (c + 1 < p.n) {
+          const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
+          float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, df[QT];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
+          pair_step(c, c - 1, G0, Sin0[c], f, d0, df);
+          if (p.o[c] > 1) pair_step(c, BD_NPK - 1, G1, Sin0[c], f, d0, df);
+          else if (p.nin[c] > 1) pair_step(c, c - 1, G1, Sin1[c], f, d1, df);
+          put_row(c, df);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { G0[s] = d0[s]; G1[s] = d1[s]; }
+        }
+      }
+      {   // first core: v[r'] = sum_qq core0[r'][qq] f[qq]
+        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
+        float df[QT];
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.first_off + (4 * g + s) * 4);
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) {
+            df[qq] += G0[s] * cp[qq];
+            dfirst[s][qq] += G0[s] * f[qq];
+          }
+        }
+        put_row(0, df);
+      }
+    }
+
+    // ---- first / last core gradients: sum over the tile's 16 window lanes; lane (0, g) then holds entries l = 4 g + s.
+    // They go to the staging area behind the barrier below (the packs are dead by then).
+    __syncthreads();   // (A) every chain step is done; the gradient waves have consumed the last hand-over
+    float* stage = lds + p.packF_off;   // [slot 0..7][qq][reg][64] tiles, then first / last [16][4] each
+    float* fl = stage + BD_NPK * QT * 256;
+    for (int turn = 0; turn < 4; ++turn) {
+      if (wv == turn) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) {
+            const float a = bd_row_sum16(dfirst[s][qq]), b = bd_row_sum16(dlast[s][qq]);
+            if (wl == 0) {
+              const int e = (4 * g + s) * 4 + qq;
+              fl[e] = (turn == 0 ? 0.f : fl[e]) + a;
+              fl[64 + e] = (turn == 0 ? 0.f : fl[64 + e]) + b;
+            }
+          }
+      }
+      __syncthreads();   // (B turn)
+    }
+  } else {
+    // =============================================================================== gradient wave
+    const int wp = wv - 4;
+    const float* fsb = lds + p.fs_off + wp * 2 * BD_FS;
+    const float* gvb = lds + p.gv_off + wp * 4 * BD_TILE;
+    bd_f4 acc[BD_NPK][QT];
+#pragma unroll
+    for (int i = 0; i < BD_NPK; ++i)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) acc[i][qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
+    int gs = 0;
+    for (int it = 0; it < p.iters; ++it) {
+      const float* fs = fsb + (it & 1) * BD_FS;
+      // T_qq[r'][l] += sum_w G[r', w] f_qq[w] v[l, w]: k-step ks of lane group g is window 4 g + ks
+      auto take = [&](int c, bd_f4 (&A)[QT]) {
+        __syncthreads();
+        const float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+        ++gs;
+        const bd_f4 ga = *reinterpret_cast<const bd_f4*>(gt + wl * BD_TS + 4 * g);             // G[r' = wl][w = 4 g ..]
+        const bd_f4 vb = *reinterpret_cast<const bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g);   // v[l = wl][w = 4 g ..]
+        bd_f4 fw[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fw[ks] = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + 4 * g + ks) * 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq)
+            A[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], vb[ks] * fw[ks][qq], A[qq], 0, 0, 0);
+      };
+#pragma unroll
+      for (int c = BD_NC - 2; c >= 1; --c) {
+        if (c + 1 < p.n) {
+          take(c, acc[c - 1]);
+          if (p.o[c] > 1) take(c, acc[BD_NPK - 1]);
+          else if (p.nin[c] > 1) take(c, acc[c - 1]);
+        }
+      }
+    }
+    __syncthreads();   // (A)
+    // ---- the four gradient waves' tiles join in LDS, one wave after the other (fixed order: bit-reproducible)
+    float* stage = lds + p.packF_off;
+    for (int turn = 0; turn < 4; ++turn) {
+      if (wp == turn) {
+#pragma unroll
+        for (int i = 0; i < BD_NPK; ++i)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* dst = stage + ((i * QT + qq) * 4 + r) * 64 + lane;
+              *dst = (turn == 0 ? 0.f : *dst) + acc[i][qq][r];
+            }
+      }
+      __syncthreads();   // (B turn)
+    }
+  }
+
+  // ---- the workgroup's record: the cores' natural layouts back to back (core_off)
+  if (p.records != nullptr) {
+    const float* stage = lds + p.packF_off;
+    const float* fl = stage + BD_NPK * QT * 256;
+    float* rec = p.records + (size_t)blockIdx.x * p.core_off[p.n];
+    for (int e = tid; e < BD_NPK * QT * 256; e += BD_THREADS) {
+      const int ln = e & 63, r = (e >> 6) & 3, rest = e >> 8;
+      const int qq = rest % QT, i = rest / QT;
+      const int c = i < BD_NPK - 1 ? i + 1 : p.c2, o = i < BD_NPK - 1 ? 0 : 1;
+      if (c < 1 || c + 1 >= p.n || o >= p.o[c]) continue;
+      const int l = ln & 15, rp = 4 * (ln >> 4) + r;   // lane (col l, group) register r is row r' = 4 group + r
+      if (l < p.bl[c] && rp < p.br[c] && qq < p.qc)
+        rec[p.core_off[c] + ((o * p.bl[c] + l) * p.br[c] + rp) * p.qc + qq] = stage[e];
+    }
+    if (tid < 64) {
+      const int rr = tid >> 2, qq = tid & 3;
+      if (qq < p.qc && rr < p.br[0]) rec[p.core_off[0] + rr * p.qc + qq] = fl[tid];
+      if (qq < p.qc && rr < p.bl[p.n - 1]) rec[p.core_off[p.n - 1] + rr * p.qc + qq] = fl[64 + tid];
+    }
+  }
+
+  // ---- dX of the band: every pixel value sums the windows of this band that cover it, in core order; rows shared
+  // with the band above / below go to the side buffer as this band's partial sum
+  if (p.dX != nullptr) {
+    const float* rows = lds + p.rows_off;
+    const int Cq = p.C * p.q;
+    const int y0 = r0, y1 = (r1 + p.max_h < p.H) ? r1 + p.max_h : p.H;
+    const int npix = (y1 - y0) * p.W * p.C;
+    for (int e = tid; e < npix; e += BD_THREADS) {
+      const int ch = e / ((y1 - y0) * p.W), r2 = e - ch * (y1 - y0) * p.W;
+      const int yr = r2 / p.W, xc = r2 - yr * p.W;
+      const int y = y0 + yr;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < BD_NC; ++c) {
+        if (c < p.n) {
+          const int ho = y - p.ph[c], wo = xc - p.pw[c];
+          if (ho >= r0 && ho < r1 && wo >= 0 && wo < p.Wo) {
+            const float* d = rows + ((size_t)((ho - r0) * p.Wo + wo) * p.n + c) * RK + (CH == 2 ? ch * 2 : 0);
+#pragma unroll
+            for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) a[k] += d[k];
+          }
+        }
+      }
+      const bool with_above = kb > 0 && y < r0 + p.max_h;
+      const bool with_below = kb + 1 < p.nb && y >= r1;
+      float* dst;
+      if (with_above || with_below) {
+        const int bnd = with_above ? kb - 1 : kb, part = with_above ? 1 : 0;
+        const int yb = y - (bnd + 1) * p.band_rows;
+        dst = p.side + ((((size_t)img * (p.nb - 1) + bnd) * 2 + part) * p.max_h + yb) * p.W * Cq + (size_t)xc * Cq + ch * p.q;
+      } else {
+        dst = p.dX + ((((size_t)ch * p.B + img) * p.H + y) * p.W + xc) * p.q;
+      }
+#pragma unroll
+      for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) dst[k] = a[k];
+    }
+  }
+}
+
+// dCore_c[e] = sum over the workgroups' records in a fixed order; the pixel rows two bands share = the sum of their two
+// partial sums.  64 elements per workgroup, 4 record subsets, LDS join (as convsbs_dcore_reduce_k).
+__global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
+  __shared__ float red[4][64];
+  const int nblk_core = p.records ? (p.total + 63) / 64 : 0;
+  if ((int)blockIdx.x < nblk_core) {
+    const int e = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < p.total) {
+      int r = sub;
+      for (; r + 12 < p.nrec; r += 16) {
+        a0 += p.records[(size_t)r * p.total + e];
+        a1 += p.records[(size_t)(r + 4) * p.total + e];
+        a2 += p.records[(size_t)(r + 8) * p.total + e];
+        a3 += p.records[(size_t)(r + 12) * p.total + e];
+      }
+      for (; r < p.nrec; r += 4) a0 += p.records[(size_t)r * p.total + e];
+    }
+    red[sub][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sub == 0 && e < p.total) {
+      const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      int c = 0;
+      while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
+      p.dcore[c][e - p.core_off[c]] = v;
+    }
+    return;
+  }
+  // shared rows: element = (image, boundary, row, column, channel, value)
+  const long long e = ((long long)blockIdx.x - nblk_core) * 256 + threadIdx.x;
+  if (e >= p.nshared) return;
+  const int rowlen = p.W * p.Cq;
+  const long long per_b = (long long)p.max_h * rowlen;
+  const long long bi = e / per_b;                 // image * (nb - 1) + boundary
+  const int rem = (int)(e - bi * per_b);
+  const int yb = rem / rowlen, r2 = rem - yb * rowlen;
+  const int xc = r2 / p.Cq, k = r2 - xc * p.Cq;
+  const int img = (int)(bi / (p.nb - 1)), bnd = (int)(bi - (long long)img * (p.nb - 1));
+  const int y = (bnd + 1) * p.band_rows + yb;
+  if (y >= p.H) return;
+  const int ch = k / p.q, d = k - ch * p.q;
+  const float* s0 = p.side + ((size_t)bi * 2 * p.max_h + yb) * rowlen + r2;
+  const float v = s0[0] + s0[(size_t)p.max_h * rowlen];
+  p.dX[((((size_t)ch * p.B + img) * p.H + y) * p.W + xc) * p.q + d] = v;
+}
+
+// family check + the launch plan; DCTN_ERR_UNSUPPORTED outside the family
+struct BdPlan {
+  BdP p;
+  int lds_bytes, nwg, QT, CH;
+  size_t records_bytes, side_bytes;
+};
+
+int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, const int* out_sizes, const int* bond_sizes,
+            const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype) {
+  if (dtype != DCTN_F32 || n < 3 || n > BD_NC || bond_sizes[0] != 1) return DCTN_ERR_UNSUPPORTED;
+  int Ra = 0;
+  for (int c = 1; c < n; ++c) {
+    if (bond_sizes[c] < 1) return DCTN_ERR_UNSUPPORTED;
+    Ra = bond_sizes[c] > Ra ? bond_sizes[c] : Ra;
+  }
+  if (Ra <= 8 || Ra > 16) return DCTN_ERR_UNSUPPORTED;   // (smaller bonds: a quarter-full tile; convsbs_reg / convsbs_mfma take them)
+  int qc = 1;
+  for (int c = 0; c < C; ++c) qc *= q;
+  if (!((C == 1 && q >= 2 && q <= 4) || (C == 2 && q == 2))) return DCTN_ERR_UNSUPPORTED;
+  BdP& p = pl.p;
+  p.c2 = -1;
+  int otot = 1;
+  for (int c = 0; c < n; ++c) {
+    if (out_sizes[c] < 1 || out_sizes[c] > 2) return DCTN_ERR_UNSUPPORTED;
+    if (out_sizes[c] == 2) {
+      if (p.c2 >= 0 || c == 0 || c == n - 1) return DCTN_ERR_UNSUPPORTED;
+      p.c2 = c;
+    }
+    otot *= out_sizes[c];
+  }
+  pl.QT = qc;
+  pl.CH = C == 2 ? 2 : 1;
+  p.n = n; p.C = C; p.q = q; p.qc = qc; p.B = B; p.H = H; p.W = W; p.Otot = otot;
+  int max_h = 0, max_w = 0, nin = 1;
+  p.core_off[0] = 0;
+  for (int c = 0; c < BD_NC; ++c) {
+    const int cc = c < n ? c : n - 1;
+    p.o[c] = out_sizes[cc];
+    p.bl[c] = cc == 0 ? 1 : bond_sizes[cc];
+    p.br[c] = cc == n - 1 ? 1 : bond_sizes[cc + 1];
+    p.ph[c] = pos_h[cc];
+    p.pw[c] = pos_w[cc];
+    p.core[c] = cores ? (const float*)cores[cc] : nullptr;
+    if (c < n) {
+      p.nin[c] = nin;
+      nin *= out_sizes[c];
+      p.core_off[c + 1] = p.core_off[c] + p.o[c] * p.bl[c] * p.br[c] * qc;
+      max_h = pos_h[c] > max_h ? pos_h[c] : max_h;
+      max_w = pos_w[c] > max_w ? pos_w[c] : max_w;
+    } else {
+      p.nin[c] = 1;
+      p.core_off[c + 1] = p.core_off[c];
+    }
+  }
+  p.max_h = max_h;
+  p.Ho = H - max_h; p.Wo = W - max_w;
+  if (p.Ho < 1 || p.Wo < 1) return DCTN_ERR_BAD_SHAPE;
+  for (int i = 0; i < 5; ++i) p.xs[i] = xs ? xs[i] : 0;
+  // LDS plan: packs, tables, per chain wave two feature buffers (+ raw values), two hand-over buffers; the band's rows
+  int off = 0;
+  p.packF_off = off; off += BD_NPK * pl.QT * 256;
+  p.packA_off = off; off += BD_NPK * pl.QT * 256;
+  p.first_off = off; off += 64;
+  p.last_off = off; off += 64;
+  p.fs_off = off; off += 4 * 2 * BD_FS;
+  p.raw_off = off; off += pl.CH == 2 ? 4 * BD_FS : 0;
+  p.gv_off = off; off += 4 * 4 * BD_TILE;
+  p.rows_off = off;
+  // the staging area of the final join lies over the forward packs: slots + first / last tables must fit
+  if (BD_NPK * pl.QT * 256 + 128 > 2 * BD_NPK * pl.QT * 256) return DCTN_ERR_UNSUPPORTED;
+  const int RK = pl.CH == 2 ? 4 : pl.QT;
+  const int min_rows = max_h > 1 ? max_h : 1;
+  // bands per image: enough workgroups for the chip, every band at least max_h rows, the band's gradient rows in LDS
+  int nb = (256 + B - 1) / B;
+  if (nb < 1) nb = 1;
+  if (nb > p.Ho / min_rows) nb = p.Ho / min_rows;
+  if (nb < 1) return DCTN_ERR_UNSUPPORTED;
+  for (;;) {
+    const int rows = (p.Ho + nb - 1) / nb;
+    const long long rows_floats = (long long)rows * p.Wo * n * RK;
+    if ((long long)(off + rows_floats) * 4 <= DCTN_LDS_BUDGET) {
+      p.band_rows = rows;
+      break;
+    }
+    ++nb;
+    if ((p.Ho + nb - 1) / nb < min_rows || nb > p.Ho) return DCTN_ERR_UNSUPPORTED;
+  }
+  p.nb = (p.Ho + p.band_rows - 1) / p.band_rows;   // (the rounding can leave fewer bands than asked for)
+  const int tiles = (p.band_rows * p.Wo + 15) / 16;
+  p.iters = (tiles + 3) / 4;
+  pl.lds_bytes = (off + p.band_rows * p.Wo * n * RK) * 4;
+  pl.nwg = B * p.nb;
+  pl.records_bytes = (size_t)pl.nwg * p.core_off[n] * sizeof(float);
+  pl.side_bytes = (size_t)B * (p.nb - 1) * 2 * max_h * W * C * q * sizeof(float);
+  return DCTN_OK;
+}
+
+size_t bd_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+bool convsbs_band_covers(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B,
+                         int H, int W, int q, int dtype) {
+  BdPlan pl;
+  return bd_plan(pl, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype) == DCTN_OK;
+}
+
+size_t convsbs_band_bwd_workspace(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C,
+                                  int B, int H, int W, int q, int dtype) {
+  BdPlan pl;
+  if (bd_plan(pl, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype) != DCTN_OK) return 0;
+  return bd_align256(pl.records_bytes) + bd_align256(pl.side_bytes) + 256;
+}
+
+int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
+                     float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes) {
+  BdPlan pl;
+  const int rc = bd_plan(pl, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  if (rc != DCTN_OK) return rc;
+  if (!dX && !dcores) return DCTN_OK;
+  const size_t need = bd_align256(pl.records_bytes) + bd_align256(pl.side_bytes);
+  if (!ws || ws_bytes < need) return DCTN_ERR_WORKSPACE;
+  BdP& p = pl.p;
+  p.x = (const float*)x;
+  p.dY = (const float*)dY;
+  p.dX = (float*)dX;
+  p.records = dcores ? (float*)ws : nullptr;
+  p.side = (float*)((unsigned char*)ws + bd_align256(pl.records_bytes));
+#define BD_LAUNCH(QTV, CHV)                                                                                     \
+  do {                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              pl.lds_bytes);                                                                    \
+    hipLaunchKernelGGL((convsbs_bwd_band_k<QTV, CHV>), dim3((unsigned)pl.nwg), dim3(BD_THREADS), pl.lds_bytes, st, p); \
+  } while (0)
+  if (pl.CH == 2) BD_LAUNCH(4, 2);
+  else if (pl.QT == 2) BD_LAUNCH(2, 1);
+  else if (pl.QT == 3) BD_LAUNCH(3, 1);
+  else BD_LAUNCH(4, 1);
+#undef BD_LAUNCH
+  DCTN_CHECK_LAUNCH();
+  BdTailP t;
+  t.n = n; t.nrec = pl.nwg; t.total = p.core_off[n]; t.qc = p.qc; t.last_stride = p.qc;
+  for (int c = 0; c <= BD_NC; ++c) t.core_off[c] = p.core_off[c];
+  for (int c = 0; c < BD_NC; ++c) t.dcore[c] = (dcores && c < n) ? dcores[c] : nullptr;
+  t.records = p.records; t.side = p.side; t.dX = p.dX;
+  t.B = B; t.H = H; t.W = W; t.C = C; t.q = q; t.Cq = C * q; t.nb = p.nb; t.band_rows = p.band_rows; t.max_h = p.max_h;
+  t.nshared = p.dX ? (long long)B * (p.nb - 1) * p.max_h * W * C * q : 0;
+  const long long blocks = (p.records ? (t.total + 63) / 64 : 0) + (t.nshared + 255) / 256;
+  if (blocks > 0) {
+    hipLaunchKernelGGL(convsbs_band_tail_k, dim3((unsigned)blocks), dim3(256), 0, st, t);
+    DCTN_CHECK_LAUNCH();
+  }
+  dctn_set_last_kernel("convsbs_bwd_band_f32");
+  return DCTN_OK;
+}

@@ -513,7 +513,9 @@ size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int
     return 0;
   if (!backward) return 256;
   const size_t a = bwd_ws(p, dtype), b = convsbs_reg_bwd_workspace(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
-  return (a > b ? a : b) + 256;
+  const size_t c = convsbs_band_bwd_workspace(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  const size_t m = a > b ? a : b;
+  return (m > c ? m : c) + 256;
 }
 
 size_t dctn_convsbs_saved_states_bytes(int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B, int H,
@@ -602,6 +604,13 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
       if (!dCores[c]) return DCTN_ERR_NULL;
     rc = convsbs_bwd_reg(x, x_strides, cores, dY, dX, (float* const*)dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
                          W, q, dtype, st, workspace, workspace_bytes);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
+  if (dtype == DCTN_F32) {   // bonds 9..16: the band-owning backward (recomputes the chain; no saved states, no helper launches)
+    for (int c = 0; dCores && c < n_cores; ++c)
+      if (!dCores[c]) return DCTN_ERR_NULL;
+    rc = convsbs_bwd_band(x, x_strides, cores, dY, dX, (float* const*)dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
+                          W, q, dtype, st, workspace, workspace_bytes);
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
   switch (dtype) {

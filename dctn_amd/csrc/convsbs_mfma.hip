@@ -1505,6 +1505,8 @@ size_t convsbs_saved_states_bytes(int n, const int* out_sizes, const int* bond_s
                                   int C, int B, int H, int W, int q, int dtype) {
   if (dtype != DCTN_F32 || n < 3 || n > SBSM_MAXC) return 0;
   if (!sbsm_whole(n, out_sizes, bond_sizes)) return 0;
+  // strings the band-owning backward takes (convsbs_band.hip) recompute the chain in registers: nothing to keep
+  if (convsbs_band_covers(n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return 0;
   SbsMP p;
   int R, off;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};

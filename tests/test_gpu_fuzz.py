@@ -472,6 +472,16 @@ def sbs_reg_family_takes(pos, bonds, outs, C, q):
             and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2)))
 
 
+def sbs_band_family_takes(pos, bonds, outs, C, q):
+    """Strings whose BACKWARD runs on the band-owning kernels (convsbs_band.hip): float32 open chains of at most 9 cores,
+    largest bond 9..16, at most one two-valued core - a middle one -, q^C <= 4."""
+    prod = 1
+    for o in outs:
+        prod *= o
+    return (3 <= len(pos) <= 9 and bonds[0] == 1 and 8 < max(bonds[1:]) <= 16 and all(o in (1, 2) for o in outs) and prod <= 2
+            and outs[0] == 1 and outs[-1] == 1 and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2)))
+
+
 @pytest.mark.parametrize("family", ["default", "matrix_cores"])
 @pytest.mark.parametrize("case", sbs_mfma_cases(), ids=lambda c: "n%d_r%s_o%s_C%dq%d" % (
     len(c[0]), c[1][1] if len(set(c[1][1:])) == 1 else "".join("%x" % b for b in c[1]), "".join(map(str, c[2])), c[3], c[4]))
@@ -502,7 +512,7 @@ def _convsbs_family_case(case, fam):
     check(y, want, torch.float32, "forward")
     dy = torch.randn_like(y)
     y.backward(dy)
-    assert dctn_amd.last_kernel() == f"convsbs_bwd_{fam}_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_bwd_{'band' if sbs_band_family_takes(*case) else fam}_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     check(x.grad, gr[0], torch.float32, "dX")
     for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
@@ -561,6 +571,68 @@ def test_convsbs_reg_family_shapes(case):
     dy = torch.randn_like(y)
     y.backward(dy)
     assert dctn_amd.last_kernel() == "convsbs_bwd_reg_f32"
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x0.double()] + cores64, dy.cpu().double())
+    if x_grad:
+        check(x.grad, gr[0], torch.float32, "dX")
+    else:
+        assert x.grad is None
+    for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
+        if core_grad:
+            check(c.grad, gc, torch.float32, f"dCore{i}")
+        else:
+            assert c.grad is None
+    first = ([c.grad.clone() for c in m.cores] if core_grad else []) + ([x.grad.clone()] if x_grad else [])
+    for c in m.cores:
+        c.grad = None
+    x.grad = None
+    m(x).backward(dy)
+    again = ([c.grad for c in m.cores] if core_grad else []) + ([x.grad] if x_grad else [])
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+
+
+BAND_CASES = [
+    # pos, bonds, outs, C, q, B, H, W, x needs grad, cores need grad, strided x
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 2, 32, 32, True, True, False),   # BASELINE cfg4 r = 16 geometry, two images
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 130, 8, 9, True, True, False),   # more images than CUs: one band per image
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 2, 2, 3, 14, 13, True, True, False),   # the classifier's second layer: two channels
+    (SNAKE9, (1,) + (16,) * 8, (1,) * 9, 1, 2, 2, 9, 40, True, True, True),                         # one output, q = 2, strided x, wide rows
+    (SNAKE9, (1,) + (16,) * 8, (1, 2, 1, 1, 1, 1, 1, 1, 1), 1, 4, 1, 11, 7, True, True, False),    # two states from the second core on, q = 4
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 1, 1, 1, 2, 1), 1, 3, 5, 7, 7, True, True, False),     # the two-valued core next to the end
+    (SNAKE9, (1, 9, 16, 11, 12, 10, 16, 13, 15), (1, 1, 1, 2, 1, 1, 1, 1, 1), 1, 3, 3, 10, 12, True, True, False),   # unequal bonds
+    (SNAKE9[:4], (1, 12, 16, 9), (1, 1, 2, 1), 2, 2, 4, 6, 9, True, True, False),                   # four cores
+    (((0, 0), (0, 1), (0, 2)), (1, 16, 16), (1, 2, 1), 1, 3, 7, 5, 21, True, True, False),          # one row of pixels: no shared rows
+    (((0, 0), (1, 0), (2, 0), (3, 0), (4, 0)), (1, 10, 10, 10, 10), (1,) * 5, 1, 2, 2, 23, 6, True, True, False),   # a column: four shared rows per boundary
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 1, 3, 3, 10, 10, False, True, False),  # x without gradient
+    (SNAKE9, (1,) + (16,) * 8, (1, 1, 1, 1, 2, 1, 1, 1, 1), 2, 2, 3, 10, 10, True, False, False),  # cores without gradient
+]
+
+
+@pytest.mark.parametrize("case", BAND_CASES, ids=lambda c: "n%d_b%s_o%s_C%dq%d_B%d_%dx%d%s%s%s" % (
+    len(c[0]), max(c[1]), "".join(map(str, c[2])), c[3], c[4], c[5], c[6], c[7], "" if c[8] else "_nodx", "" if c[9] else "_nodcore",
+    "_strided" if c[10] else ""))
+def test_convsbs_band_family_shapes(case):
+    """Bonds 9..16, backward by band-owning workgroups with two roles per SIMD (chain waves and gradient waves): bands of
+    one image and the pixel rows they share, ragged tiles, chain waves without a tile, every position of the two-valued
+    core, unequal bonds (zero-padded packs), both channel modes, every q - against the oracle, and bit-reproducible."""
+    pos, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided = case
+    assert sbs_band_family_takes(pos, bonds, outs, C, q)
+    torch.manual_seed(B + H + W)
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
+    m = ConvSBS(spec, DumbNormalInitialization((q ** C * max(bonds)) ** -0.5 * 1.2)).to(DEV)
+    for c in m.cores:
+        c.requires_grad_(core_grad)
+    x0 = torch.randn(C, B, H, W, q)
+    x = x0.to(DEV)
+    if strided:
+        x = x.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    x.requires_grad_(x_grad)
+    y = m(x)
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, list(pos), x0.double())
+    check(y, want, torch.float32, "forward")
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert dctn_amd.last_kernel() == "convsbs_bwd_band_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x0.double()] + cores64, dy.cpu().double())
     if x_grad:
         check(x.grad, gr[0], torch.float32, "dX")
