@@ -30,12 +30,25 @@
 typedef __attribute__((ext_vector_type(4))) float bd_f4;
 typedef __attribute__((ext_vector_type(2))) int bd_i2;
 
+// diagnostic build only (make EXTRA=-DDCTN_STAMPS, tools/stamp_band.py): wave 0 (chain) and wave 4 (gradient) of every
+// workgroup leave the shader-clock value of each phase boundary behind the side buffers in the workspace
+#ifdef DCTN_STAMPS
+#define BD_STAMP(k)                                                                                              \
+  do {                                                                                                           \
+    if (lane == 0 && (wv & 3) == 0 && p.stamps)                                                                  \
+      p.stamps[((size_t)blockIdx.x * 2 + (wv >> 2)) * 32 + (k)] = (long long)__builtin_readcyclecounter();       \
+  } while (0)
+#else
+#define BD_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BD_NC = 9;          // cores per string (compile-time unrolled; shorter strings run too)
 constexpr int BD_NPK = BD_NC - 1; // packs / accumulator slots: middle core c -> slot c - 1, the second output value -> slot 7
-constexpr int BD_TS = 24;         // floats per row of a transposed hand-over tile (b128 reads conflict-free, b32 writes 2-way)
-constexpr int BD_TILE = 16 * BD_TS;      // one hand-over tile (G or v): [row][window]
+constexpr int BD_TS = 20;         // floats per row of a hand-over tile [window][16]: the chain wave's b128 row writes and the
+                                  // gradient wave's transposed b32 reads (rows 4 apart: 80 floats = 16 banks) are conflict-free
+constexpr int BD_TILE = 16 * BD_TS;      // one hand-over tile (G or v)
 constexpr int BD_FS = BD_NC * 16 * 4;    // feature products of a 16-window tile: [core][window][4]
 constexpr int BD_THREADS = 512;
 
@@ -55,13 +68,15 @@ struct BdP {
   int iters;            // tiles per chain wave
   int core_off[BD_NC + 1];
   int packF_off, packA_off, first_off, last_off, fs_off, raw_off, gv_off, rows_off;   // LDS plan (float offsets)
+  long long* stamps;    // diagnostic build only
 };
 
 struct BdTailP {
   float* dcore[BD_NC];
   int core_off[BD_NC + 1];
-  int n, nrec, total;
-  int last_stride, qc;
+  int n, nrec, total, rec_len;
+  int bl[BD_NC], br[BD_NC];
+  int qc;
   const float* records;
   const float* side;
   float* dX;
@@ -93,20 +108,6 @@ __device__ __forceinline__ void bd_wave_lds_sync() {   // LDS written by some la
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One fragment element of pack `pk` (middle core c, output o): FWD  A[row r' = i][k: l = 4 g + s],
-//                                                                ADJ  A[row l = i][k: r' = 4 g + s]
-template <int QT>
-__device__ __forceinline__ float bd_pack_element(const BdP& p, int e, bool adj) {
-  const int s = e & 3, ln = (e >> 2) & 63, rest = e >> 8;
-  const int qq = rest % QT, pk = rest / QT;
-  const int c = pk < BD_NPK - 1 ? pk + 1 : p.c2, o = pk < BD_NPK - 1 ? 0 : 1;
-  if (c < 1 || c + 1 >= p.n || o >= p.o[c]) return 0.f;
-  const int i = ln & 15, gg = ln >> 4;
-  const int l = adj ? i : 4 * gg + s, r = adj ? 4 * gg + s : i;
-  if (l >= p.bl[c] || r >= p.br[c] || qq >= p.qc) return 0.f;
-  return p.core[c][(long long)((o * p.bl[c] + l) * p.br[c] + r) * p.qc + qq];
-}
-
 // QT: feature values per core (q^C, 2..4) = 16x16 tiles per product.  CH: 1 = one channel (the products ARE the pixel's
 // values), 2 = two channels of two values (QT = 4; the deeper layers of the reference's classifier).
 template <int QT, int CH>
@@ -114,39 +115,115 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
   constexpr int RK = CH == 2 ? 4 : QT;   // gradient values per core and window in the band's LDS rows
+  constexpr int BD_CPT = BD_NPK * QT * 256;   // the gradient tiles of a workgroup, in accumulator layout (one copy of the join area)
+  // the LDS plan as compile-time offsets (floats; bd_plan lays out the same): 16-byte accesses need provable alignment
+  constexpr int PACKF = 0, PACKA = BD_CPT, FIRST = 2 * BD_CPT, LAST = FIRST + 64, FSO = LAST + 64;
+  constexpr int RAWO = FSO + 4 * 2 * BD_FS, GVO = RAWO + (CH == 2 ? 4 * BD_FS : 0), ROWSO = GVO + 4 * 4 * BD_TILE;
   const int img = (int)blockIdx.x / p.nb, kb = (int)blockIdx.x - img * p.nb;
   const int r0 = kb * p.band_rows, r1 = r0 + p.band_rows < p.Ho ? r0 + p.band_rows : p.Ho;
   const int nwin = (r1 - r0) * p.Wo;
+  BD_STAMP(0);
 
-  // ---- the packs: every global load first, then the LDS stores (one round trip for the whole string)
+  // ---- the packs.  Both are permutations of the middle cores' 6-8 K elements: every thread takes elements of the cores'
+  // own (contiguous) layout - coalesced loads, all in flight before the first LDS store - and scatters each to its place
+  // in the forward and in the adjoint pack (the gather form, 2 x 24 four-byte loads at computed addresses per thread, took
+  // 21 k cycles of a 273 k-cycle kernel).  The packs are zero beyond a core's own bonds: zero-filled first.
   {
-    constexpr int PER = (BD_NPK * QT * 256) / BD_THREADS;
-    float va[PER], vb[PER];
+    constexpr int CHUNKS = (2 * BD_NPK * QT * 256) / 4 / BD_THREADS;   // 16-byte chunks per thread (the packs are contiguous)
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      va[j] = bd_pack_element<QT>(p, tid + BD_THREADS * j, false);
-      vb[j] = bd_pack_element<QT>(p, tid + BD_THREADS * j, true);
+    for (int j = 0; j < CHUNKS; ++j)
+      *reinterpret_cast<bd_f4*>(lds + PACKF + (tid + BD_THREADS * j) * 4) = bd_f4{0.f, 0.f, 0.f, 0.f};
+    float va[BD_NC - 2][3];   // a core has at most 2 * 16 * 16 * 4 = 2048 elements... of which 512 threads take 3 rounds (q^C <= 3) or 4
+    float vb[BD_NC - 2];      // (fourth round: only two-valued cores with four feature values)
+#pragma unroll
+    for (int c = 1; c < BD_NC - 1; ++c) {
+      const int cnt = c + 1 < p.n ? p.o[c] * p.bl[c] * p.br[c] * QT : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) va[c - 1][j] = tid + BD_THREADS * j < cnt ? p.core[c][tid + BD_THREADS * j] : 0.f;
+      vb[c - 1] = (QT == 4 && tid + BD_THREADS * 3 < cnt) ? p.core[c][tid + BD_THREADS * 3] : 0.f;
     }
+    __syncthreads();   // the zero fill is complete
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      lds[p.packF_off + tid + BD_THREADS * j] = va[j];
-      lds[p.packA_off + tid + BD_THREADS * j] = vb[j];
+    for (int c = 1; c < BD_NC - 1; ++c) {
+      if (c + 1 < p.n) {
+        const int bl = p.bl[c], br = p.br[c];
+        const int cnt = p.o[c] * bl * br * QT;
+        const float ibr = 1.0f / (float)br, ibl = 1.0f / (float)bl;
+#pragma unroll
+        for (int j = 0; j < (QT == 4 ? 4 : 3); ++j) {
+          const int e = tid + BD_THREADS * j;
+          if (e < cnt) {
+            const int qq = e % QT, t = e / QT;                      // element (o, l, r, qq) of the core's [o][l][r][qq] layout
+            const int t1 = (int)(((float)t + 0.5f) * ibr);           // t / br  (exact: t < 2048)
+            const int r = t - t1 * br;
+            const int o = (int)(((float)t1 + 0.5f) * ibl);           // t1 / bl
+            const int l = t1 - o * bl;
+            const int pk = o == 0 ? c - 1 : BD_NPK - 1;
+            const float val = j < 3 ? va[c - 1][j < 3 ? j : 0] : vb[c - 1];
+            lds[PACKF + ((pk * QT + qq) * 64 + r + 16 * (l >> 2)) * 4 + (l & 3)] = val;   // A[row r'][k: l = 4 g + s]
+            lds[PACKA + ((pk * QT + qq) * 64 + l + 16 * (r >> 2)) * 4 + (r & 3)] = val;   // A[row l][k: r' = 4 g + s]
+          }
+        }
+      }
     }
     // first core (1, 1, r', qc) as [r'][4]; last core (1, l, 1, qc) as [l][4]; zero beyond the real extents
     if (tid < 64) {
       const int rr = tid >> 2, qq = tid & 3;
-      lds[p.first_off + tid] = (qq < p.qc && rr < p.br[0]) ? p.core[0][rr * p.qc + qq] : 0.f;
-      lds[p.last_off + tid] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][rr * p.qc + qq] : 0.f;
+      lds[FIRST + tid] = (qq < p.qc && rr < p.br[0]) ? p.core[0][rr * p.qc + qq] : 0.f;
+      lds[LAST + tid] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][rr * p.qc + qq] : 0.f;
     }
   }
   __syncthreads();
+  BD_STAMP(1);
+
+  // ---- dX of the band (run by every thread behind barrier (A)): every pixel value sums the windows of this band that
+  // cover it, in core order; rows shared with the band above / below go to the side buffer as this band's partial sum
+  auto write_dx = [&](int t0, int nt) {
+    if (p.dX == nullptr) return;
+    const float* rows = lds + ROWSO;
+    const int Cq = p.C * p.q;
+    const int y0 = r0, y1 = (r1 + p.max_h < p.H) ? r1 + p.max_h : p.H;
+    const int npix = (y1 - y0) * p.W * p.C;
+    for (int e = t0; e < npix; e += nt) {
+      const int ch = e / ((y1 - y0) * p.W), r2 = e - ch * (y1 - y0) * p.W;
+      const int yr = r2 / p.W, xc = r2 - yr * p.W;
+      const int y = y0 + yr;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < BD_NC; ++c) {
+        if (c < p.n) {
+          const int ho = y - p.ph[c], wo = xc - p.pw[c];
+          if (ho >= r0 && ho < r1 && wo >= 0 && wo < p.Wo) {
+            const float* d = rows + ((size_t)((ho - r0) * p.Wo + wo) * p.n + c) * RK + (CH == 2 ? ch * 2 : 0);
+#pragma unroll
+            for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) a[k] += d[k];
+          }
+        }
+      }
+      const bool with_above = kb > 0 && y < r0 + p.max_h;
+      const bool with_below = kb + 1 < p.nb && y >= r1;
+      float* dst;
+      if (with_above || with_below) {
+        const int bnd = with_above ? kb - 1 : kb, part = with_above ? 1 : 0;
+        const int yb = y - (bnd + 1) * p.band_rows;
+        dst = p.side + ((((size_t)img * (p.nb - 1) + bnd) * 2 + part) * p.max_h + yb) * p.W * Cq + (size_t)xc * Cq + ch * p.q;
+      } else {
+        dst = p.dX + ((((size_t)ch * p.B + img) * p.H + y) * p.W + xc) * p.q;
+      }
+#pragma unroll
+      for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) dst[k] = a[k];
+    }
+  };
 
   if (wv < 4) {
     // =============================================================================== chain wave
-    float* fsb = lds + p.fs_off + wv * 2 * BD_FS;
-    float* rawb = lds + p.raw_off + wv * BD_FS;          // CH == 2: the pixels' raw values [core][window][4]
-    float* gvb = lds + p.gv_off + wv * 4 * BD_TILE;      // two buffers of (G tile, v tile)
-    float* rows = lds + p.rows_off;
+    // the chain is the critical path: its instructions go first on the SIMD it shares with a gradient wave, whose MFMAs
+    // then fill the pipe during the chain's epilogues instead of competing with its products
+    __builtin_amdgcn_s_setprio(2);
+    float* fsb = lds + FSO + wv * 2 * BD_FS;
+    float* rawb = lds + RAWO + wv * BD_FS;          // CH == 2: the pixels' raw values [core][window][4]
+    float* gvb = lds + GVO + wv * 4 * BD_TILE;      // two buffers of (G tile, v tile)
+    float* rows = lds + ROWSO;
     float dfirst[4][QT], dlast[4][QT];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -200,11 +277,13 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
 
     for (int it = 0; it < p.iters; ++it) {
       const float* fs = fsb + (it & 1) * BD_FS;
+      if (it == 1) BD_STAMP(2);
       commit(it);
       const float dy0 = pdy[0], dy1 = pdy[1];
       const int wb = (it * 4 + wv) * 16 + wl;
       const bool valid = wb < nwin;
       bd_wave_lds_sync();
+      if (it == 1) BD_STAMP(3);
 
       // ---------------------------------------------------------------- forward sweep, input states kept
       float Sin0[BD_NC][4], Sin1[BD_NC][4];   // input states of cores 1 .. n-1 (slot c); two behind the two-valued core
@@ -213,7 +292,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.first_off + (4 * g + s) * 4);
+          float cp[4];   // (4-byte reads: the 16 window lanes of a k group read the same entry)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) cp[qq] = qq < QT ? lds[FIRST + (4 * g + s) * 4 + qq] : 0.f;
           float a = cp[0] * f[0] + cp[1] * f[1];
           if (QT > 2) a += cp[2] * f[2];
           if (QT > 3) a += cp[3] * f[3];
@@ -230,6 +311,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           a[qq] = *reinterpret_cast<const bd_f4*>(lds + off + ((pk * QT + qq) * 64 + lane) * 4);
           D[qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
         }
+        __builtin_amdgcn_sched_barrier(0);   // (the whole A operand is in flight before the first MFMA waits for a part of it)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -243,7 +325,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
           float n0[4], n1[4];
           bd_f4 D[QT];
-          product(p.packF_off, c - 1, v0, D);
+          product(PACKF, c - 1, v0, D);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float a = f[0] * D[0][r] + f[1] * D[1][r];
@@ -253,7 +335,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
             n1[r] = 0.f;
           }
           if (p.o[c] > 1) {
-            product(p.packF_off, BD_NPK - 1, v0, D);
+            product(PACKF, BD_NPK - 1, v0, D);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float a = f[0] * D[0][r] + f[1] * D[1][r];
@@ -262,7 +344,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
               n1[r] = a;
             }
           } else if (p.nin[c] > 1) {
-            product(p.packF_off, c - 1, v1, D);
+            product(PACKF, c - 1, v1, D);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float a = f[0] * D[0][r] + f[1] * D[1][r];
@@ -275,6 +357,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           for (int r = 0; r < 4; ++r) { v0[r] = n0[r]; v1[r] = n1[r]; }
         }
       }
+      if (it == 1) BD_STAMP(4);
       // the next tile's pixels and dY travel during the way back
       if (it + 1 < p.iters) issue_loads(it + 1);
 
@@ -307,7 +390,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.last_off + (4 * g + s) * 4);
+          float cp[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) cp[qq] = qq < QT ? lds[LAST + (4 * g + s) * 4 + qq] : 0.f;
           float tl = cp[0] * f[0] + cp[1] * f[1];
           if (QT > 2) tl += cp[2] * f[2];
           if (QT > 3) tl += cp[3] * f[3];
@@ -322,12 +407,15 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         }
         put_row(p.n - 1, df);
       }
+      if (it == 1) BD_STAMP(5);
       // one (input state, output value) pair of a middle core: adjoint + feature gradient, then G and v of the tile go
       // to the gradient wave (transposed tiles [row][window], buffer gs & 1) and the workgroup meets at the barrier
       auto pair_step = [&](int c, int pk, const float (&Gs)[4], const float (&vin)[4], const bd_f4& f, float (&d)[4],
                            float (&df)[QT]) {
+        if (it == 1 && c == 3) BD_STAMP(19);
         bd_f4 Wt[QT];
-        product(p.packA_off, pk, Gs, Wt);
+        product(PACKA, pk, Gs, Wt);
+        if (it == 1 && c == 3) BD_STAMP(20);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float a = f[0] * Wt[0][r] + f[1] * Wt[1][r];
@@ -337,13 +425,13 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) df[qq] += vin[r] * Wt[qq][r];
         }
+        if (it == 1 && c == 3) BD_STAMP(21);
         float* gt = gvb + (gs & 1) * 2 * BD_TILE;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          gt[(4 * g + s) * BD_TS + wl] = Gs[s];
-          gt[BD_TILE + (4 * g + s) * BD_TS + wl] = vin[s];
-        }
+        *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};              // G[w][r' = 4 g ..]
+        *reinterpret_cast<bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g) = bd_f4{vin[0], vin[1], vin[2], vin[3]};  // v[w][l = 4 g ..]
+        if (it == 1 && c == 3) BD_STAMP(22);
         __syncthreads();
+        if (it == 1 && c == 3) BD_STAMP(23);
         ++gs;
       };
 #pragma unroll
@@ -359,6 +447,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           put_row(c, df);
 #pragma unroll
           for (int s = 0; s < 4; ++s) { G0[s] = d0[s]; G1[s] = d1[s]; }
+          if (it == 1) BD_STAMP(5 + (BD_NC - 1 - c));   // 6 (core 7) .. 12 (core 1)
         }
       }
       {   // first core: v[r'] = sum_qq core0[r'][qq] f[qq]
@@ -368,7 +457,9 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bd_f4 cp = *reinterpret_cast<const bd_f4*>(lds + p.first_off + (4 * g + s) * 4);
+          float cp[QT];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) cp[qq] = lds[FIRST + (4 * g + s) * 4 + qq];
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) {
             df[qq] += G0[s] * cp[qq];
@@ -377,34 +468,37 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         }
         put_row(0, df);
       }
+      if (it == 1) BD_STAMP(13);
     }
+    BD_STAMP(14);
 
-    // ---- first / last core gradients: sum over the tile's 16 window lanes; lane (0, g) then holds entries l = 4 g + s.
-    // They go to the staging area behind the barrier below (the packs are dead by then).
-    __syncthreads();   // (A) every chain step is done; the gradient waves have consumed the last hand-over
-    float* stage = lds + p.packF_off;   // [slot 0..7][qq][reg][64] tiles, then first / last [16][4] each
-    float* fl = stage + BD_NPK * QT * 256;
-    for (int turn = 0; turn < 4; ++turn) {
-      if (wv == turn) {
+    // ---- barrier (A): every chain step is done and the gradient waves have consumed the last hand-over.  The chain waves
+    // then write the band's dX (they hold nothing else; the gradient waves meanwhile join their accumulators in the part of
+    // the LDS in front of the band's rows), and behind (B1) leave the partial sums of their first / last core gradients
+    __syncthreads();   // (A)
+    BD_STAMP(15);
+    write_dx(tid, BD_THREADS / 2);
+    __syncthreads();   // (B1)
+    BD_STAMP(16);
+    {
+      float* fl = lds + 2 * BD_CPT + wv * 128;   // first [16][4], last [16][4] of this wave
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int qq = 0; qq < QT; ++qq) {
-            const float a = bd_row_sum16(dfirst[s][qq]), b = bd_row_sum16(dlast[s][qq]);
-            if (wl == 0) {
-              const int e = (4 * g + s) * 4 + qq;
-              fl[e] = (turn == 0 ? 0.f : fl[e]) + a;
-              fl[64 + e] = (turn == 0 ? 0.f : fl[64 + e]) + b;
-            }
+        for (int qq = 0; qq < 4; ++qq) {
+          const float a = qq < QT ? bd_row_sum16(dfirst[s][qq < QT ? qq : 0]) : 0.f;
+          const float b = qq < QT ? bd_row_sum16(dlast[s][qq < QT ? qq : 0]) : 0.f;
+          if (wl == 0) {   // lane (0, g) holds the sum over the tile's 16 window lanes of entries l = 4 g + s
+            fl[(4 * g + s) * 4 + qq] = a;
+            fl[64 + (4 * g + s) * 4 + qq] = b;
           }
-      }
-      __syncthreads();   // (B turn)
+        }
     }
   } else {
     // =============================================================================== gradient wave
     const int wp = wv - 4;
-    const float* fsb = lds + p.fs_off + wp * 2 * BD_FS;
-    const float* gvb = lds + p.gv_off + wp * 4 * BD_TILE;
+    const float* fsb = lds + FSO + wp * 2 * BD_FS;
+    const float* gvb = lds + GVO + wp * 4 * BD_TILE;
     bd_f4 acc[BD_NPK][QT];
 #pragma unroll
     for (int i = 0; i < BD_NPK; ++i)
@@ -413,21 +507,41 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
     int gs = 0;
     for (int it = 0; it < p.iters; ++it) {
       const float* fs = fsb + (it & 1) * BD_FS;
+      if (it == 1) BD_STAMP(2);
       // T_qq[r'][l] += sum_w G[r', w] f_qq[w] v[l, w]: k-step ks of lane group g is window 4 g + ks
       auto take = [&](int c, bd_f4 (&A)[QT]) {
+        if (it == 1 && c == 3) BD_STAMP(19);
         __syncthreads();
+        if (it == 1 && c == 3) BD_STAMP(20);
         const float* gt = gvb + (gs & 1) * 2 * BD_TILE;
         ++gs;
-        const bd_f4 ga = *reinterpret_cast<const bd_f4*>(gt + wl * BD_TS + 4 * g);             // G[r' = wl][w = 4 g ..]
-        const bd_f4 vb = *reinterpret_cast<const bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g);   // v[l = wl][w = 4 g ..]
-        bd_f4 fw[4];
+        float ga[4], vb[4];   // k-step ks of lane group g is window 4 g + ks: G[w][r' = wl], v[w][l = wl]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fw[ks] = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + 4 * g + ks) * 4);
+        for (int ks = 0; ks < 4; ++ks) {
+          ga[ks] = gt[(4 * g + ks) * BD_TS + wl];
+          vb[ks] = gt[BD_TILE + (4 * g + ks) * BD_TS + wl];
+        }
+        // (the 16 lanes of a k group want the same four windows' values: 4-byte reads broadcast, 16-byte reads of one
+        // address by several lanes of a group are served one lane after the other - SQ_LDS_BANK_CONFLICT was 56 % of the
+        // LDS cycles with b128 here)
+        float fw[4][QT];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int qq = 0; qq < QT; ++qq)
-            A[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], vb[ks] * fw[ks][qq], A[qq], 0, 0, 0);
+          for (int qq = 0; qq < QT; ++qq) fw[ks][qq] = fs[(c * 16 + 4 * g + ks) * 4 + qq];
+        // every read is in flight before the first product (left alone the scheduler, short of registers next to 96-128
+        // accumulators, issued them in five dependent batches: 1 500 cycles per hand-over)
+        __builtin_amdgcn_sched_barrier(0);
+        float bq[4][QT];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) bq[ks][qq] = vb[ks] * fw[ks][qq];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) A[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bq[ks][qq], A[qq], 0, 0, 0);
+        if (it == 1 && c == 3) BD_STAMP(21);
       };
 #pragma unroll
       for (int c = BD_NC - 2; c >= 1; --c) {
@@ -435,86 +549,52 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           take(c, acc[c - 1]);
           if (p.o[c] > 1) take(c, acc[BD_NPK - 1]);
           else if (p.nin[c] > 1) take(c, acc[c - 1]);
+          if (it == 1) BD_STAMP(5 + (BD_NC - 1 - c));
         }
       }
     }
+    BD_STAMP(14);
     __syncthreads();   // (A)
-    // ---- the four gradient waves' tiles join in LDS, one wave after the other (fixed order: bit-reproducible)
-    float* stage = lds + p.packF_off;
-    for (int turn = 0; turn < 4; ++turn) {
-      if (wp == turn) {
+    BD_STAMP(15);
+    // ---- the four waves' tiles join in two copies, in accumulator layout [slot][qq][register][lane]: waves 0, 1 store,
+    // behind (B1) waves 2, 3 add theirs (fixed pairing: bit-reproducible)
+    {
+      float* cp = lds + (wp & 1) * BD_CPT + lane;
+      if (wp < 2) {
 #pragma unroll
         for (int i = 0; i < BD_NPK; ++i)
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* dst = stage + ((i * QT + qq) * 4 + r) * 64 + lane;
-              *dst = (turn == 0 ? 0.f : *dst) + acc[i][qq][r];
-            }
+            for (int r = 0; r < 4; ++r) cp[((i * QT + qq) * 4 + r) * 64] = acc[i][qq][r];
       }
-      __syncthreads();   // (B turn)
+      __syncthreads();   // (B1)
+      BD_STAMP(16);
+      if (wp >= 2) {
+#pragma unroll
+        for (int i = 0; i < BD_NPK; ++i)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[((i * QT + qq) * 4 + r) * 64] += acc[i][qq][r];
+      }
     }
   }
-
-  // ---- the workgroup's record: the cores' natural layouts back to back (core_off)
+  __syncthreads();   // (D)
+  BD_STAMP(17);
+  // ---- the workgroup's record = the sum of the two copies (and of the four first / last partial sums), in the join area's
+  // own layout (the tail kernel, which reads every record anyway, puts the entries into the cores' layouts)
   if (p.records != nullptr) {
-    const float* stage = lds + p.packF_off;
-    const float* fl = stage + BD_NPK * QT * 256;
-    float* rec = p.records + (size_t)blockIdx.x * p.core_off[p.n];
-    for (int e = tid; e < BD_NPK * QT * 256; e += BD_THREADS) {
-      const int ln = e & 63, r = (e >> 6) & 3, rest = e >> 8;
-      const int qq = rest % QT, i = rest / QT;
-      const int c = i < BD_NPK - 1 ? i + 1 : p.c2, o = i < BD_NPK - 1 ? 0 : 1;
-      if (c < 1 || c + 1 >= p.n || o >= p.o[c]) continue;
-      const int l = ln & 15, rp = 4 * (ln >> 4) + r;   // lane (col l, group) register r is row r' = 4 group + r
-      if (l < p.bl[c] && rp < p.br[c] && qq < p.qc)
-        rec[p.core_off[c] + ((o * p.bl[c] + l) * p.br[c] + rp) * p.qc + qq] = stage[e];
-    }
-    if (tid < 64) {
-      const int rr = tid >> 2, qq = tid & 3;
-      if (qq < p.qc && rr < p.br[0]) rec[p.core_off[0] + rr * p.qc + qq] = fl[tid];
-      if (qq < p.qc && rr < p.bl[p.n - 1]) rec[p.core_off[p.n - 1] + rr * p.qc + qq] = fl[64 + tid];
+    bd_f4* rec = reinterpret_cast<bd_f4*>(p.records + (size_t)blockIdx.x * (BD_CPT + 128));
+    for (int e = tid; e < BD_CPT / 4; e += BD_THREADS)
+      rec[e] = *reinterpret_cast<const bd_f4*>(lds + e * 4) + *reinterpret_cast<const bd_f4*>(lds + BD_CPT + e * 4);
+    if (tid < 32) {
+      const float* fl = lds + 2 * BD_CPT + tid * 4;
+      rec[BD_CPT / 4 + tid] = (*reinterpret_cast<const bd_f4*>(fl) + *reinterpret_cast<const bd_f4*>(fl + 128)) +
+                              (*reinterpret_cast<const bd_f4*>(fl + 256) + *reinterpret_cast<const bd_f4*>(fl + 384));
     }
   }
-
-  // ---- dX of the band: every pixel value sums the windows of this band that cover it, in core order; rows shared
-  // with the band above / below go to the side buffer as this band's partial sum
-  if (p.dX != nullptr) {
-    const float* rows = lds + p.rows_off;
-    const int Cq = p.C * p.q;
-    const int y0 = r0, y1 = (r1 + p.max_h < p.H) ? r1 + p.max_h : p.H;
-    const int npix = (y1 - y0) * p.W * p.C;
-    for (int e = tid; e < npix; e += BD_THREADS) {
-      const int ch = e / ((y1 - y0) * p.W), r2 = e - ch * (y1 - y0) * p.W;
-      const int yr = r2 / p.W, xc = r2 - yr * p.W;
-      const int y = y0 + yr;
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < BD_NC; ++c) {
-        if (c < p.n) {
-          const int ho = y - p.ph[c], wo = xc - p.pw[c];
-          if (ho >= r0 && ho < r1 && wo >= 0 && wo < p.Wo) {
-            const float* d = rows + ((size_t)((ho - r0) * p.Wo + wo) * p.n + c) * RK + (CH == 2 ? ch * 2 : 0);
-#pragma unroll
-            for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) a[k] += d[k];
-          }
-        }
-      }
-      const bool with_above = kb > 0 && y < r0 + p.max_h;
-      const bool with_below = kb + 1 < p.nb && y >= r1;
-      float* dst;
-      if (with_above || with_below) {
-        const int bnd = with_above ? kb - 1 : kb, part = with_above ? 1 : 0;
-        const int yb = y - (bnd + 1) * p.band_rows;
-        dst = p.side + ((((size_t)img * (p.nb - 1) + bnd) * 2 + part) * p.max_h + yb) * p.W * Cq + (size_t)xc * Cq + ch * p.q;
-      } else {
-        dst = p.dX + ((((size_t)ch * p.B + img) * p.H + y) * p.W + xc) * p.q;
-      }
-#pragma unroll
-      for (int k = 0; k < (CH == 2 ? 2 : QT); ++k) dst[k] = a[k];
-    }
-  }
+  BD_STAMP(18);
 }
 
 // dCore_c[e] = sum over the workgroups' records in a fixed order; the pixel rows two bands share = the sum of their two
@@ -523,26 +603,38 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
   __shared__ float red[4][64];
   const int nblk_core = p.records ? (p.total + 63) / 64 : 0;
   if ((int)blockIdx.x < nblk_core) {
+    // output element e of the cores' layouts back to back -> its position in a record (the join area's layout: middle cores
+    // as accumulator tiles [slot][qq][register = r' & 3][lane = l + 16 (r' >> 2)], then the first and the last core [16][4])
     const int e = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    int c = 0, pos = 0;
+    if (e < p.total) {
+      while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
+      const int idx = e - p.core_off[c];
+      if (c == 0 || c == p.n - 1) {
+        pos = BD_NPK * p.qc * 256 + (c == 0 ? 0 : 64) + (idx / p.qc) * 4 + idx % p.qc;
+      } else {
+        const int qq = idx % p.qc, t = idx / p.qc;
+        const int r = t % p.br[c], t1 = t / p.br[c];
+        const int l = t1 % p.bl[c], o = t1 / p.bl[c];
+        const int slot = o == 0 ? c - 1 : BD_NPK - 1;
+        pos = ((slot * p.qc + qq) * 4 + (r & 3)) * 64 + l + 16 * (r >> 2);
+      }
+    }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (e < p.total) {
       int r = sub;
       for (; r + 12 < p.nrec; r += 16) {
-        a0 += p.records[(size_t)r * p.total + e];
-        a1 += p.records[(size_t)(r + 4) * p.total + e];
-        a2 += p.records[(size_t)(r + 8) * p.total + e];
-        a3 += p.records[(size_t)(r + 12) * p.total + e];
+        a0 += p.records[(size_t)r * p.rec_len + pos];
+        a1 += p.records[(size_t)(r + 4) * p.rec_len + pos];
+        a2 += p.records[(size_t)(r + 8) * p.rec_len + pos];
+        a3 += p.records[(size_t)(r + 12) * p.rec_len + pos];
       }
-      for (; r < p.nrec; r += 4) a0 += p.records[(size_t)r * p.total + e];
+      for (; r < p.nrec; r += 4) a0 += p.records[(size_t)r * p.rec_len + pos];
     }
     red[sub][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (sub == 0 && e < p.total) {
-      const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-      int c = 0;
-      while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
-      p.dcore[c][e - p.core_off[c]] = v;
-    }
+    if (sub == 0 && e < p.total)
+      p.dcore[c][e - p.core_off[c]] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     return;
   }
   // shared rows: element = (image, boundary, row, column, channel, value)
@@ -566,7 +658,7 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
 // family check + the launch plan; DCTN_ERR_UNSUPPORTED outside the family
 struct BdPlan {
   BdP p;
-  int lds_bytes, nwg, QT, CH;
+  int lds_bytes, nwg, QT, CH, rec_len;
   size_t records_bytes, side_bytes;
 };
 
@@ -630,9 +722,7 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
   p.fs_off = off; off += 4 * 2 * BD_FS;
   p.raw_off = off; off += pl.CH == 2 ? 4 * BD_FS : 0;
   p.gv_off = off; off += 4 * 4 * BD_TILE;
-  p.rows_off = off;
-  // the staging area of the final join lies over the forward packs: slots + first / last tables must fit
-  if (BD_NPK * pl.QT * 256 + 128 > 2 * BD_NPK * pl.QT * 256) return DCTN_ERR_UNSUPPORTED;
+  p.rows_off = off;   // (the kernel computes the same offsets at compile time)
   const int RK = pl.CH == 2 ? 4 : pl.QT;
   const int min_rows = max_h > 1 ? max_h : 1;
   // bands per image: enough workgroups for the chip, every band at least max_h rows, the band's gradient rows in LDS
@@ -654,8 +744,11 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
   const int tiles = (p.band_rows * p.Wo + 15) / 16;
   p.iters = (tiles + 3) / 4;
   pl.lds_bytes = (off + p.band_rows * p.Wo * n * RK) * 4;
+  pl.rec_len = BD_NPK * pl.QT * 256 + 128;
+  // (the join area - two copies of the tiles + four first / last partial sums - lies in front of the band's rows: the packs
+  // alone are as large as the two copies)
   pl.nwg = B * p.nb;
-  pl.records_bytes = (size_t)pl.nwg * p.core_off[n] * sizeof(float);
+  pl.records_bytes = (size_t)pl.nwg * pl.rec_len * sizeof(float);
   pl.side_bytes = (size_t)B * (p.nb - 1) * 2 * max_h * W * C * q * sizeof(float);
   return DCTN_OK;
 }
@@ -674,7 +767,11 @@ size_t convsbs_band_bwd_workspace(int n, const int* out_sizes, const int* bond_s
                                   int B, int H, int W, int q, int dtype) {
   BdPlan pl;
   if (bd_plan(pl, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype) != DCTN_OK) return 0;
-  return bd_align256(pl.records_bytes) + bd_align256(pl.side_bytes) + 256;
+  size_t extra = 0;
+#ifdef DCTN_STAMPS
+  extra = (size_t)pl.nwg * 2 * 32 * sizeof(long long);
+#endif
+  return bd_align256(pl.records_bytes) + bd_align256(pl.side_bytes) + 256 + extra;
 }
 
 int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
@@ -692,6 +789,10 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
   p.dX = (float*)dX;
   p.records = dcores ? (float*)ws : nullptr;
   p.side = (float*)((unsigned char*)ws + bd_align256(pl.records_bytes));
+  p.stamps = nullptr;
+#ifdef DCTN_STAMPS
+  if (ws_bytes >= need + (size_t)pl.nwg * 2 * 32 * sizeof(long long)) p.stamps = (long long*)((unsigned char*)ws + need);
+#endif
 #define BD_LAUNCH(QTV, CHV)                                                                                     \
   do {                                                                                                          \
     (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -705,8 +806,9 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
 #undef BD_LAUNCH
   DCTN_CHECK_LAUNCH();
   BdTailP t;
-  t.n = n; t.nrec = pl.nwg; t.total = p.core_off[n]; t.qc = p.qc; t.last_stride = p.qc;
+  t.n = n; t.nrec = pl.nwg; t.total = p.core_off[n]; t.qc = p.qc; t.rec_len = pl.rec_len;
   for (int c = 0; c <= BD_NC; ++c) t.core_off[c] = p.core_off[c];
+  for (int c = 0; c < BD_NC; ++c) { t.bl[c] = p.bl[c]; t.br[c] = p.br[c]; }
   for (int c = 0; c < BD_NC; ++c) t.dcore[c] = (dcores && c < n) ? dcores[c] : nullptr;
   t.records = p.records; t.side = p.side; t.dX = p.dX;
   t.B = B; t.H = H; t.W = W; t.C = C; t.q = q; t.Cq = C * q; t.nb = p.nb; t.band_rows = p.band_rows; t.max_h = p.max_h;

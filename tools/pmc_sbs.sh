@@ -11,7 +11,7 @@ for t in "abc":
     if not f: print(t,"no file"); continue
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
-        if "mfma16" in r["Kernel_Name"]: acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "convsbs" in r["Kernel_Name"]: acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,cs in acc.items():
         print(k, {c: round(sum(v)/len(v)) for c,v in cs.items()}, len(next(iter(cs.values()))))
 PY
