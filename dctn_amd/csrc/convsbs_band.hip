@@ -13,18 +13,23 @@
 //   * TWO ROLES, one wave of each per SIMD (waves w and w + 4 of a 512-thread workgroup share a SIMD):
 //       chain waves (0-3): forward sweep, adjoint sweep, d/d(features) - everything that is a dependent chain;
 //       gradient waves (4-7): dCore += G^T (f v) with the WINDOWS on the k index; they own the dCore accumulators
-//       (8 slots x q^C tiles x 4 registers) across the whole band.  The chain wave hands over G and v of a tile
-//       through LDS (two buffers, one workgroup barrier per hand-over): the gradient wave's MFMAs fill the matrix
-//       pipe while the chain wave is in an epilogue, and the chain wave is free of the 128-160 accumulator registers
-//       that held the old kernel at one wave per SIMD.
+//       (8 slots x q^C tiles x 4 registers + one tile each for the first / last core) across the whole band, and they
+//       stage their chain wave's tiles (pixels, dY) two tiles ahead.  The chain wave hands over G and v of a pair through
+//       LDS (two buffers, one workgroup barrier per hand-over, stored BEFORE the pair's product so that the barrier waits
+//       while the matrix pipe works); the gradient wave runs one hand-over behind (operands of hand-over k fetched while
+//       hand-over k - 1 is multiplied), and the chain wave is free of the 128-160 accumulator registers that held the old
+//       kernel at one wave per SIMD.
 //   * tiles per feature value instead of rows padded to four: U_qq[r', w] = sum_l core[o, l, r', qq] v[l, w] is one
 //       16x16 tile per qq (v_mfma_f32_16x16x4_f32, K = l), so q = 3 costs 12 MFMAs per product, not 16, and q = 2 costs 8.
 //       State layout: register s of lane (w, g) holds l = 4 g + s; the accumulator's register r of lane (w, g) is row
 //       4 g + r, so  v'[r'] = sum_qq f[qq] U_qq[r']  lands in state layout: the chain never leaves registers.
 //       Adjoint: W_qq[l, w] = sum_r' core[o, l, r', qq] G[r', w] from a second pack with the bond legs exchanged;
 //       dv[l] = sum_qq f[qq] W_qq[l] (state layout again), df[qq] = sum_l v[l] W_qq[l].
-//   * per-workgroup dCore records in the cores' natural layout, summed in a fixed order by the tail kernel:
-//     bit-reproducible gradients.
+//   * per-workgroup dCore records (the accumulator layout as it stands, 16-byte stores), summed in a fixed order and put
+//     into the cores' layouts by the tail kernel: bit-reproducible gradients.
+// Measured at BASELINE cfg4 r = 16 (115 200 windows): 108 us + 7 us tail (round 3: 161 us + 17 us of helpers; forward 50 -> 41 us
+// without the state stores).  In-kernel stamps (tools/stamp_band.py): a 16-window tile takes a chain wave ~25 k cycles of
+// which its MFMAs are 8.4 k and the gradient wave's 4.4 k; what was tried on that gap is in NOTEBOOK.md.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float bd_f4;
@@ -49,8 +54,11 @@ constexpr int BD_NPK = BD_NC - 1; // packs / accumulator slots: middle core c ->
 constexpr int BD_TS = 20;         // floats per row of a hand-over tile [window][16]: the chain wave's b128 row writes and the
                                   // gradient wave's transposed b32 reads (rows 4 apart: 80 floats = 16 banks) are conflict-free
 constexpr int BD_TILE = 16 * BD_TS;      // one hand-over tile (G or v)
-constexpr int BD_FS = BD_NC * 16 * 4;    // feature products of a 16-window tile: [core][window][4]
+constexpr int BD_FS = (BD_NC + 1) * 16 * 4;   // feature products of a 16-window tile: [core][window][4]; row 9: the windows' dY
+constexpr int BD_LDS_BUDGET = 160 * 1024;      // the whole LDS of a CU: one workgroup per CU
 constexpr int BD_THREADS = 512;
+constexpr int BD_NFS = 3;         // feature buffers per chain wave: the tile on its way back, the next one, the one the gradient
+                                  // wave may still be reading right behind the last barrier of the previous tile
 
 struct BdP {
   const float* x;
@@ -108,6 +116,10 @@ __device__ __forceinline__ void bd_wave_lds_sync() {   // LDS written by some la
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ void bd_barrier() {   // workgroup barrier that orders LDS only: vector-memory loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // QT: feature values per core (q^C, 2..4) = 16x16 tiles per product.  CH: 1 = one channel (the products ARE the pixel's
 // values), 2 = two channels of two values (QT = 4; the deeper layers of the reference's classifier).
 template <int QT, int CH>
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
   constexpr int BD_CPT = BD_NPK * QT * 256;   // the gradient tiles of a workgroup, in accumulator layout (one copy of the join area)
   // the LDS plan as compile-time offsets (floats; bd_plan lays out the same): 16-byte accesses need provable alignment
   constexpr int PACKF = 0, PACKA = BD_CPT, FIRST = 2 * BD_CPT, LAST = FIRST + 64, FSO = LAST + 64;
-  constexpr int RAWO = FSO + 4 * 2 * BD_FS, GVO = RAWO + (CH == 2 ? 4 * BD_FS : 0), ROWSO = GVO + 4 * 4 * BD_TILE;
+  constexpr int RAWO = FSO + 4 * BD_NFS * BD_FS, GVO = RAWO + (CH == 2 ? 4 * BD_NFS * BD_FS : 0), ROWSO = GVO + 4 * 4 * BD_TILE;
   const int img = (int)blockIdx.x / p.nb, kb = (int)blockIdx.x - img * p.nb;
   const int r0 = kb * p.band_rows, r1 = r0 + p.band_rows < p.Ho ? r0 + p.band_rows : p.Ho;
   const int nwin = (r1 - r0) * p.Wo;
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
 #pragma unroll
     for (int j = 0; j < CHUNKS; ++j)
       *reinterpret_cast<bd_f4*>(lds + PACKF + (tid + BD_THREADS * j) * 4) = bd_f4{0.f, 0.f, 0.f, 0.f};
-    float va[BD_NC - 2][3];   // a core has at most 2 * 16 * 16 * 4 = 2048 elements... of which 512 threads take 3 rounds (q^C <= 3) or 4
+    float va[BD_NC - 2][3];   // a core has at most 2 * 16 * 16 * 4 = 2048 elements: three rounds of 512 threads (q^C <= 3) or four
     float vb[BD_NC - 2];      // (fourth round: only two-valued cores with four feature values)
 #pragma unroll
     for (int c = 1; c < BD_NC - 1; ++c) {
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
       for (int j = 0; j < 3; ++j) va[c - 1][j] = tid + BD_THREADS * j < cnt ? p.core[c][tid + BD_THREADS * j] : 0.f;
       vb[c - 1] = (QT == 4 && tid + BD_THREADS * 3 < cnt) ? p.core[c][tid + BD_THREADS * 3] : 0.f;
     }
-    __syncthreads();   // the zero fill is complete
+    bd_barrier();   // the zero fill is complete
 #pragma unroll
     for (int c = 1; c < BD_NC - 1; ++c) {
       if (c + 1 < p.n) {
@@ -173,11 +185,11 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
       lds[LAST + tid] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][rr * p.qc + qq] : 0.f;
     }
   }
-  __syncthreads();
+  bd_barrier();
   BD_STAMP(1);
 
-  // ---- dX of the band (run by every thread behind barrier (A)): every pixel value sums the windows of this band that
-  // cover it, in core order; rows shared with the band above / below go to the side buffer as this band's partial sum
+  // ---- dX of the band (run behind barrier (A)): every pixel value sums the windows of this band that cover it, in core
+  // order; rows shared with the band above / below go to the side buffer as this band's partial sum
   auto write_dx = [&](int t0, int nt) {
     if (p.dX == nullptr) return;
     const float* rows = lds + ROWSO;
@@ -217,151 +229,123 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
 
   if (wv < 4) {
     // =============================================================================== chain wave
-    // the chain is the critical path: its instructions go first on the SIMD it shares with a gradient wave, whose MFMAs
-    // then fill the pipe during the chain's epilogues instead of competing with its products
-    __builtin_amdgcn_s_setprio(2);
-    float* fsb = lds + FSO + wv * 2 * BD_FS;
-    float* rawb = lds + RAWO + wv * BD_FS;          // CH == 2: the pixels' raw values [core][window][4]
-    float* gvb = lds + GVO + wv * 4 * BD_TILE;      // two buffers of (G tile, v tile)
+    // (s_setprio for either role changed nothing: 110.4 / 110.5 / 114.8 us for priorities chain:gradient 0:0 / 2:0 / 0:2)
+    const float* fsb = lds + FSO + wv * BD_NFS * BD_FS;     // feature products (and dY) of three tiles: [tile % 3][row][window][4],
+    const float* rawb = lds + RAWO + wv * BD_NFS * BD_FS;   // CH == 2: the pixels' raw values - both staged by the gradient wave
+    float* gvb = lds + GVO + wv * 4 * BD_TILE;              // two buffers of (G tile, v tile)
     float* rows = lds + ROWSO;
-    float dfirst[4][QT], dlast[4][QT];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int qq = 0; qq < QT; ++qq) { dfirst[s][qq] = 0.f; dlast[s][qq] = 0.f; }
     int gs = 0;
-    // prefetch registers: the pixels of cores g, g + 4, g + 8 of the lane's window, and the window's dY
-    float pre[3][4], pdy[2];
-    auto issue_loads = [&](int it) {
-      const int wb = (it * 4 + wv) * 16 + wl;
-      const bool valid = wb < nwin;
-      const int wbb = valid ? wb : 0;
-      const int hr = wbb / p.Wo, wo = wbb - hr * p.Wo, ho = r0 + hr;
-      const float* win = p.x + (long long)img * p.xs[1] + (long long)ho * p.xs[2] + (long long)wo * p.xs[3];
+
+    // U_qq = A_qq x vin (K = l or r'): the whole A operand of a pack is QT b128 reads, all in flight before the first MFMA
+    // waits for a part of it; k-step outermost so that the QT accumulators form independent chains
+    auto product = [&](int off, int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
+      bd_f4 a[QT];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int c = g + 4 * k;
-        const int cc = c < p.n ? c : 0;
-        const float* px = win + (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
-        if constexpr (CH == 2) {
-          pre[k][0] = valid ? px[0] : 0.f;
-          pre[k][1] = valid ? px[p.xs[4]] : 0.f;
-          pre[k][2] = valid ? px[p.xs[0]] : 0.f;
-          pre[k][3] = valid ? px[p.xs[0] + p.xs[4]] : 0.f;
-        } else {
-#pragma unroll
-          for (int d = 0; d < 4; ++d) pre[k][d] = (valid && d < QT) ? px[(d < QT ? d : 0) * p.xs[4]] : 0.f;
-        }
+      for (int qq = 0; qq < QT; ++qq) {
+        a[qq] = *reinterpret_cast<const bd_f4*>(lds + off + ((pk * QT + qq) * 64 + lane) * 4);
+        D[qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
       }
-      const long long wglob = ((long long)img * p.Ho + ho) * p.Wo + wo;
-      pdy[0] = valid ? p.dY[wglob * p.Otot] : 0.f;
-      pdy[1] = (valid && p.Otot > 1) ? p.dY[wglob * p.Otot + 1] : 0.f;
-    };
-    auto commit = [&](int it) {
-      float* fs = fsb + (it & 1) * BD_FS;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int c = g + 4 * k;
-        if (c < p.n) {
-          if constexpr (CH == 2) {   // f[2 d + e] = x0[d] x1[e]  (channel 0 most significant)
-            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) =
-                bd_f4{pre[k][0] * pre[k][2], pre[k][0] * pre[k][3], pre[k][1] * pre[k][2], pre[k][1] * pre[k][3]};
-            *reinterpret_cast<bd_f4*>(rawb + (c * 16 + wl) * 4) = bd_f4{pre[k][0], pre[k][1], pre[k][2], pre[k][3]};
-          } else {
-            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{pre[k][0], pre[k][1], pre[k][2], pre[k][3]};
-          }
-        }
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
+    };
+    auto fwd_epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[4]) {   // v'[r'] = sum_qq f[qq] U_qq[r']
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = f[0] * D[0][r] + f[1] * D[1][r];
+        if (QT > 2) a += f[2] * D[2 % QT][r];
+        if (QT > 3) a += f[3] * D[3 % QT][r];
+        out[r] = a;
       }
     };
-    issue_loads(0);
-
-    for (int it = 0; it < p.iters; ++it) {
-      const float* fs = fsb + (it & 1) * BD_FS;
-      if (it == 1) BD_STAMP(2);
-      commit(it);
-      const float dy0 = pdy[0], dy1 = pdy[1];
-      const int wb = (it * 4 + wv) * 16 + wl;
-      const bool valid = wb < nwin;
-      bd_wave_lds_sync();
-      if (it == 1) BD_STAMP(3);
-
-      // ---------------------------------------------------------------- forward sweep, input states kept
-      float Sin0[BD_NC][4], Sin1[BD_NC][4];   // input states of cores 1 .. n-1 (slot c); two behind the two-valued core
-      float v0[4], v1[4];
-      {
-        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
+    auto bwd_epi = [&](const bd_f4 (&Wt)[QT], const bd_f4& f, const float (&vin)[4], float (&dv)[4], float (&df)[QT]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float cp[4];   // (4-byte reads: the 16 window lanes of a k group read the same entry)
+      for (int r = 0; r < 4; ++r) {   // dv[l] = sum_qq f[qq] W_qq[l];  df[qq] += sum_l v[l] W_qq[l]
+        float a = f[0] * Wt[0][r] + f[1] * Wt[1][r];
+        if (QT > 2) a += f[2] * Wt[2 % QT][r];
+        if (QT > 3) a += f[3] * Wt[3 % QT][r];
+        dv[r] = a;
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) cp[qq] = qq < QT ? lds[FIRST + (4 * g + s) * 4 + qq] : 0.f;
-          float a = cp[0] * f[0] + cp[1] * f[1];
-          if (QT > 2) a += cp[2] * f[2];
-          if (QT > 3) a += cp[3] * f[3];
-          v0[s] = a;
-          v1[s] = 0.f;
-        }
+        for (int qq = 0; qq < QT; ++qq) df[qq] += vin[r] * Wt[qq][r];
       }
-      // U_qq = A_qq x vin (K = l): the whole A operand of a pack is QT b128 reads; k-step outermost so that the QT
-      // accumulators form independent chains
-      auto product = [&](int off, int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
-        bd_f4 a[QT];
+    };
+    // G and v of the tile for the gradient wave (rows = windows, buffer gs & 1); meet(): the hand-over's barrier
+    auto store_tiles = [&](const float (&Gs)[4], const float (&vin)[4]) {
+      float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+      *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};              // G[w][r' = 4 g ..]
+      *reinterpret_cast<bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g) = bd_f4{vin[0], vin[1], vin[2], vin[3]};  // v[w][l = 4 g ..]
+    };
+    auto meet = [&]() {
+      bd_barrier();
+      ++gs;
+    };
+    auto handover_g = [&](const float (&Gs)[4]) {   // the first / last core's gradient needs no second operand
+      float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+      *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};
+      meet();
+    };
+    auto first_core = [&](const float* fs, float (&w0)[4]) {   // v[r'] = sum_qq core0[r'][qq] f[qq]
+      const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
 #pragma unroll
-        for (int qq = 0; qq < QT; ++qq) {
-          a[qq] = *reinterpret_cast<const bd_f4*>(lds + off + ((pk * QT + qq) * 64 + lane) * 4);
-          D[qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
-        }
-        __builtin_amdgcn_sched_barrier(0);   // (the whole A operand is in flight before the first MFMA waits for a part of it)
+      for (int s = 0; s < 4; ++s) {
+        float a = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (4 * g + s) * 4 + qq] * f[qq];   // (4-byte reads: 16 lanes read one entry)
+        w0[s] = a;
+      }
+    };
+    // forward through middle core c: (w0, w1) -> (w0, w1)
+    auto fwd_core = [&](int c, const float* fs, float (&w0)[4], float (&w1)[4]) {
+      const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
+      float n0[4], n1[4] = {0.f, 0.f, 0.f, 0.f};
+      bd_f4 D[QT];
+      product(PACKF, c - 1, w0, D);
+      fwd_epi(D, f, n0);
+      if (p.o[c] > 1 || p.nin[c] > 1) {
+        const bool second_out = p.o[c] > 1;   // (o = 1 from state 0) or (o = 0 from state 1): wave-uniform
+        float vin[4];
 #pragma unroll
-          for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
-      };
+        for (int s = 0; s < 4; ++s) vin[s] = second_out ? w0[s] : w1[s];
+        product(PACKF, second_out ? BD_NPK - 1 : c - 1, vin, D);
+        fwd_epi(D, f, n1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
+    };
+
+    float Sin0[BD_NC][4], Sin1[BD_NC][4];   // input states of the middle cores of the tile on its way back (slot c)
+    float v0[4], v1[4];                     // input states of its last core
+    // ---- barrier (P): the gradient wave has staged the first tile's features
+    bd_barrier();
+    auto forward_sweep = [&](const float* fs) {
+      first_core(fs, v0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v1[s] = 0.f;
 #pragma unroll
       for (int c = 1; c < BD_NC - 1; ++c) {
         if (c + 1 < p.n) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) { Sin0[c][s] = v0[s]; Sin1[c][s] = v1[s]; }
-          const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
-          float n0[4], n1[4];
-          bd_f4 D[QT];
-          product(PACKF, c - 1, v0, D);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float a = f[0] * D[0][r] + f[1] * D[1][r];
-            if (QT > 2) a += f[2] * D[2 % QT][r];
-            if (QT > 3) a += f[3] * D[3 % QT][r];
-            n0[r] = a;
-            n1[r] = 0.f;
-          }
-          if (p.o[c] > 1) {
-            product(PACKF, BD_NPK - 1, v0, D);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float a = f[0] * D[0][r] + f[1] * D[1][r];
-              if (QT > 2) a += f[2] * D[2 % QT][r];
-              if (QT > 3) a += f[3] * D[3 % QT][r];
-              n1[r] = a;
-            }
-          } else if (p.nin[c] > 1) {
-            product(PACKF, c - 1, v1, D);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float a = f[0] * D[0][r] + f[1] * D[1][r];
-              if (QT > 2) a += f[2] * D[2 % QT][r];
-              if (QT > 3) a += f[3] * D[3 % QT][r];
-              n1[r] = a;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { v0[r] = n0[r]; v1[r] = n1[r]; }
+          fwd_core(c, fs, v0, v1);
         }
       }
-      if (it == 1) BD_STAMP(4);
-      // the next tile's pixels and dY travel during the way back
-      if (it + 1 < p.iters) issue_loads(it + 1);
+    };
+    bd_barrier();   // (P2): the second tile's features are staged
 
-      // ---------------------------------------------------------------- way back
+    for (int it = 0; it < p.iters; ++it) {
+      const float* fs = fsb + (it % BD_NFS) * BD_FS;
+      if (it == 1) BD_STAMP(2);
+      const float* raw = rawb + (it % BD_NFS) * BD_FS;
+      (void)raw;
+      forward_sweep(fs);
+      if (it == 1) BD_STAMP(3);
+      const float dy0 = fs[(BD_NC * 16 + wl) * 4], dy1 = fs[(BD_NC * 16 + wl) * 4 + 1];
+      const int wb = (it * 4 + wv) * 16 + wl;
+      const bool valid = wb < nwin;
+      if (it == 1) BD_STAMP(4);
+
       // per-window feature gradient of core c -> the band's LDS row (one lane per window: the k groups hold the same sum)
       auto put_row = [&](int c, const float (&df)[QT]) {
         if (p.dX == nullptr) return;
@@ -371,7 +355,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
         if (g == 0 && valid) {
           float* dst = rows + ((size_t)wb * p.n + c) * RK;
           if constexpr (CH == 2) {   // d/d(products) -> d/d(pixel values): raw = (x0[0], x0[1], x1[0], x1[1])
-            const bd_f4 xr = *reinterpret_cast<const bd_f4*>(rawb + (c * 16 + wl) * 4);
+            const bd_f4 xr = *reinterpret_cast<const bd_f4*>(raw + (c * 16 + wl) * 4);
             dst[0] = t[0] * xr[2] + t[1] * xr[3];   // channel 0, value 0
             dst[1] = t[2] * xr[2] + t[3] * xr[3];   // channel 0, value 1
             dst[2] = t[0] * xr[0] + t[2] * xr[1];   // channel 1, value 0
@@ -382,91 +366,85 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
           }
         }
       };
+
+      // ---------------------------------------------------------------- way back
       float G0[4], G1[4];
       {   // last core: out[a] = sum_l v_a[l] tl[l],  tl[l] = sum_qq coreL[l][qq] f[qq]
         const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + ((p.n - 1) * 16 + wl) * 4);
-        float df[QT];
+        float df[QT], u[4];
 #pragma unroll
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          float cp[4];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) cp[qq] = qq < QT ? lds[LAST + (4 * g + s) * 4 + qq] : 0.f;
-          float tl = cp[0] * f[0] + cp[1] * f[1];
-          if (QT > 2) tl += cp[2] * f[2];
-          if (QT > 3) tl += cp[3] * f[3];
-          G0[s] = dy0 * tl;
-          G1[s] = dy1 * tl;
-          const float u = dy0 * v0[s] + dy1 * v1[s];
+          float cp[QT], tl = 0.f;
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) {
-            df[qq] += u * cp[qq];
-            dlast[s][qq] += u * f[qq];
+            cp[qq] = lds[LAST + (4 * g + s) * 4 + qq];
+            tl += cp[qq] * f[qq];
           }
+          G0[s] = dy0 * tl;
+          G1[s] = dy1 * tl;
+          u[s] = dy0 * v0[s] + dy1 * v1[s];
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) df[qq] += u[s] * cp[qq];
         }
         put_row(p.n - 1, df);
+        handover_g(u);   // dCoreL[l][qq] = sum_w u[l, w] f[qq, w]: four MFMAs of the gradient wave
       }
       if (it == 1) BD_STAMP(5);
-      // one (input state, output value) pair of a middle core: adjoint + feature gradient, then G and v of the tile go
-      // to the gradient wave (transposed tiles [row][window], buffer gs & 1) and the workgroup meets at the barrier
-      auto pair_step = [&](int c, int pk, const float (&Gs)[4], const float (&vin)[4], const bd_f4& f, float (&d)[4],
-                           float (&df)[QT]) {
-        if (it == 1 && c == 3) BD_STAMP(19);
-        bd_f4 Wt[QT];
-        product(PACKA, pk, Gs, Wt);
-        if (it == 1 && c == 3) BD_STAMP(20);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float a = f[0] * Wt[0][r] + f[1] * Wt[1][r];
-          if (QT > 2) a += f[2] * Wt[2 % QT][r];
-          if (QT > 3) a += f[3] * Wt[3 % QT][r];
-          d[r] += a;
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) df[qq] += vin[r] * Wt[qq][r];
-        }
-        if (it == 1 && c == 3) BD_STAMP(21);
-        float* gt = gvb + (gs & 1) * 2 * BD_TILE;
-        *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};              // G[w][r' = 4 g ..]
-        *reinterpret_cast<bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g) = bd_f4{vin[0], vin[1], vin[2], vin[3]};  // v[w][l = 4 g ..]
-        if (it == 1 && c == 3) BD_STAMP(22);
-        __syncthreads();
-        if (it == 1 && c == 3) BD_STAMP(23);
-        ++gs;
-      };
+      // One (input state, output value) pair of a middle core.  What the gradient wave needs - the adjoint G the pair starts
+      // from and the input state v - is known BEFORE the pair's product: it is stored first, the product's MFMAs are issued,
+      // and only then the workgroup meets at the barrier - the wait runs while the matrix pipe works on this wave's product,
+      // the gradient wave's MFMAs take the pipe during this wave's epilogue.  (Barrier behind the epilogue: 1 250 cycles a pair.)
 #pragma unroll
       for (int c = BD_NC - 2; c >= 1; --c) {
         if (c + 1 < p.n) {
           const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
-          float d0[4] = {0.f, 0.f, 0.f, 0.f}, d1[4] = {0.f, 0.f, 0.f, 0.f}, df[QT];
+          float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, df[QT];
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
-          pair_step(c, c - 1, G0, Sin0[c], f, d0, df);
-          if (p.o[c] > 1) pair_step(c, BD_NPK - 1, G1, Sin0[c], f, d0, df);
-          else if (p.nin[c] > 1) pair_step(c, c - 1, G1, Sin1[c], f, d1, df);
+          bd_f4 Wt[QT];
+          if (it == 1 && c == 3) BD_STAMP(19);
+          store_tiles(G0, Sin0[c]);
+          product(PACKA, c - 1, G0, Wt);
+          if (it == 1 && c == 3) BD_STAMP(20);
+          meet();
+          if (it == 1 && c == 3) BD_STAMP(21);
+          bwd_epi(Wt, f, Sin0[c], d0, df);
+          if (it == 1 && c == 3) BD_STAMP(22);
+          if (p.o[c] > 1 || p.nin[c] > 1) {   // a second pair: (o = 1, state 0) or (o = 0, state 1)
+            const bool b_out = p.o[c] > 1;
+            float vin2[4], dt[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) vin2[s] = b_out ? Sin0[c][s] : Sin1[c][s];
+            store_tiles(G1, vin2);
+            product(PACKA, b_out ? BD_NPK - 1 : c - 1, G1, Wt);
+            meet();
+            bwd_epi(Wt, f, vin2, dt, df);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              d0[r] += b_out ? dt[r] : 0.f;
+              d1[r] = b_out ? 0.f : dt[r];
+            }
+          }
           put_row(c, df);
+          if (it == 1 && c == 3) BD_STAMP(23);
 #pragma unroll
           for (int s = 0; s < 4; ++s) { G0[s] = d0[s]; G1[s] = d1[s]; }
           if (it == 1) BD_STAMP(5 + (BD_NC - 1 - c));   // 6 (core 7) .. 12 (core 1)
         }
       }
       {   // first core: v[r'] = sum_qq core0[r'][qq] f[qq]
-        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
         float df[QT];
 #pragma unroll
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          float cp[QT];
 #pragma unroll
-          for (int qq = 0; qq < QT; ++qq) cp[qq] = lds[FIRST + (4 * g + s) * 4 + qq];
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) {
-            df[qq] += G0[s] * cp[qq];
-            dfirst[s][qq] += G0[s] * f[qq];
-          }
+          for (int qq = 0; qq < QT; ++qq) df[qq] += G0[s] * lds[FIRST + (4 * g + s) * 4 + qq];
         }
         put_row(0, df);
+        handover_g(G0);   // dCore0[r'][qq] = sum_w G0[r', w] f[qq, w]
       }
       if (it == 1) BD_STAMP(13);
     }
@@ -475,89 +453,216 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
     // ---- barrier (A): every chain step is done and the gradient waves have consumed the last hand-over.  The chain waves
     // then write the band's dX (they hold nothing else; the gradient waves meanwhile join their accumulators in the part of
     // the LDS in front of the band's rows), and behind (B1) leave the partial sums of their first / last core gradients
-    __syncthreads();   // (A)
+    bd_barrier();   // (A)
     BD_STAMP(15);
     write_dx(tid, BD_THREADS / 2);
-    __syncthreads();   // (B1)
+    bd_barrier();   // (B1)
     BD_STAMP(16);
-    {
-      float* fl = lds + 2 * BD_CPT + wv * 128;   // first [16][4], last [16][4] of this wave
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const float a = qq < QT ? bd_row_sum16(dfirst[s][qq < QT ? qq : 0]) : 0.f;
-          const float b = qq < QT ? bd_row_sum16(dlast[s][qq < QT ? qq : 0]) : 0.f;
-          if (wl == 0) {   // lane (0, g) holds the sum over the tile's 16 window lanes of entries l = 4 g + s
-            fl[(4 * g + s) * 4 + qq] = a;
-            fl[64 + (4 * g + s) * 4 + qq] = b;
-          }
-        }
-    }
   } else {
     // =============================================================================== gradient wave
     const int wp = wv - 4;
-    const float* fsb = lds + FSO + wp * 2 * BD_FS;
+    float* fsb = lds + FSO + wp * BD_NFS * BD_FS;
+    float* rawb = lds + RAWO + wp * BD_NFS * BD_FS;
     const float* gvb = lds + GVO + wp * 4 * BD_TILE;
-    bd_f4 acc[BD_NPK][QT];
+    (void)rawb;
+    // ---- it also stages its chain wave's tiles, two tiles ahead: the pixels of cores g, g + 4, g + 8 of the lane's window
+    // (lane group 1, which has no third core: the window's dY) travel during one tile and go to LDS as feature products
+    float pre[3][4];
+    // (the lane's window advances by 64 per tile: its (row, column) and the pixel addresses are carried along instead of
+    // being divided out of the window index every tile - the wave yields the issue port to its chain wave)
+    int ld_wb = wp * 16 + wl, ld_hr = ld_wb / p.Wo, ld_wo = ld_wb - ld_hr * p.Wo;
+    long long poff[3];   // element offsets of the lane's three pixels inside a window
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = g + 4 * k, cc = c < p.n ? c : 0;
+      poff[k] = (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
+    }
+    const float* ximg = p.x + (long long)img * p.xs[1] + (long long)r0 * p.xs[2];
+    const float* dyimg = p.dY + ((long long)img * p.Ho + r0) * p.Wo * p.Otot;
+    // Loads are UNCONDITIONAL (a lane without a window reads window 0 of the band) and nothing is done with their values
+    // here: a select on a just-loaded value makes the wave wait for the load on the spot (the staging then took 2 600
+    // cycles of every tile, at a barrier its chain wave waits at); validity is applied when the values go to LDS.
+    auto issue_loads = [&](int it) {   // tiles in order: it = 0, 1, 2, ...
+      (void)it;
+      const bool valid = ld_wb < nwin;
+      const float* win = ximg + (valid ? (long long)ld_hr * p.xs[2] + (long long)ld_wo * p.xs[3] : 0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* px = win + poff[k];
+        if constexpr (CH == 2) {
+          pre[k][0] = px[0];
+          pre[k][1] = px[p.xs[4]];
+          pre[k][2] = px[p.xs[0]];
+          pre[k][3] = px[p.xs[0] + p.xs[4]];
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) pre[k][d] = px[(d < QT ? d : 0) * p.xs[4]];
+        }
+      }
+      if (g == 1) {   // (cores 1 and 5 only: the third slot carries dY)
+        const float* dyp = dyimg + (long long)(valid ? ld_wb : 0) * p.Otot;
+        pre[2][0] = dyp[0];
+        pre[2][1] = dyp[p.Otot > 1 ? 1 : 0];
+      }
+      ld_wb += 64;
+      ld_wo += 64;
+      while (ld_wo >= p.Wo) { ld_wo -= p.Wo; ++ld_hr; }
+    };
+    auto commit = [&](int it) {
+      float* fs = fsb + (it % BD_NFS) * BD_FS;
+      const bool valid = (it * 4 + wp) * 16 + wl < nwin;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = g + 4 * k;
+        if (c < p.n && !(k == 2 && g == 1)) {
+          float v[4];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) v[d] = (valid && (CH == 2 || d < QT)) ? pre[k][d] : 0.f;
+          if constexpr (CH == 2) {   // f[2 d + e] = x0[d] x1[e]  (channel 0 most significant); the raw values beside them
+            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{v[0] * v[2], v[0] * v[3], v[1] * v[2], v[1] * v[3]};
+            *reinterpret_cast<bd_f4*>(rawb + (it % BD_NFS) * BD_FS + (c * 16 + wl) * 4) = bd_f4{v[0], v[1], v[2], v[3]};
+          } else {
+            *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{v[0], v[1], v[2], v[3]};
+          }
+        }
+      }
+      if (g == 1)
+        *reinterpret_cast<bd_f4*>(fs + (BD_NC * 16 + wl) * 4) =
+            bd_f4{valid ? pre[2][0] : 0.f, (valid && p.Otot > 1) ? pre[2][1] : 0.f, 0.f, 0.f};
+    };
+    issue_loads(0);
+    commit(0);
+    if (p.iters > 1) issue_loads(1);
+    bd_barrier();   // (P)
+    if (p.iters > 1) commit(1);
+    if (p.iters > 2) issue_loads(2);
+    bd_barrier();   // (P2)
+
+    bd_f4 acc[BD_NPK][QT], accL = bd_f4{0.f, 0.f, 0.f, 0.f}, accF = bd_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < BD_NPK; ++i)
 #pragma unroll
       for (int qq = 0; qq < QT; ++qq) acc[i][qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
     int gs = 0;
+    // The wave runs ONE hand-over behind: behind barrier k it fetches the operands of hand-over k (LDS -> registers) and,
+    // while those reads fly, multiplies hand-over k - 1 from the registers it fetched a step ago.
+    // Middle cores: T_qq[r'][l] += sum_w G[r', w] f_qq[w] v[l, w]; k-step ks of lane group g is window 4 g + ks.
+    // First / last core: T[r'][qq] += sum_w G[r', w] f[qq, w] - ONE tile, its columns the feature values (lanes wl < 4).
+    float ga[4], vb[4], fw[4][QT], b4[4];   // the pending hand-over
+    bool have = false, pend7 = false;       // (wave-uniform) one is pending; it belongs to the two-valued core's second output
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ga[ks] = 0.f; vb[ks] = 0.f; b4[ks] = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) fw[ks][qq] = 0.f;
+    }
+    auto flush_mid = [&](bd_f4 (&A)[QT]) {
+      float bq[4][QT];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) bq[ks][qq] = vb[ks] * fw[ks][qq];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) A[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bq[ks][qq], A[qq], 0, 0, 0);
+    };
+    auto flush_fl = [&](bd_f4& A) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) A = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], b4[ks], A, 0, 0, 0);
+    };
+    // fetch hand-over gs (behind its barrier) into the NEW registers; mid: G, v and the core's features; fl: G and the features as columns
+    auto fetch_mid = [&](int c, const float* fs, float (&ga2)[4], float (&vb2)[4], float (&fw2)[4][QT]) {
+      bd_barrier();
+      const float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+      ++gs;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ga2[ks] = gt[(4 * g + ks) * BD_TS + wl];              // G[w][r' = wl]
+        vb2[ks] = gt[BD_TILE + (4 * g + ks) * BD_TS + wl];    // v[w][l = wl]
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) fw2[ks][qq] = fs[(c * 16 + 4 * g + ks) * 4 + qq];   // (4-byte reads broadcast)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fetch_fl = [&](int c, const float* fs, float (&ga2)[4], float (&b2)[4]) {
+      bd_barrier();
+      const float* gt = gvb + (gs & 1) * 2 * BD_TILE;
+      ++gs;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ga2[ks] = gt[(4 * g + ks) * BD_TS + wl];
+        const float fv = fs[(c * 16 + 4 * g + ks) * 4 + (wl & 3)];
+        b2[ks] = wl < 4 ? fv : 0.f;                            // B[k = window][column = feature value wl]
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
     for (int it = 0; it < p.iters; ++it) {
-      const float* fs = fsb + (it & 1) * BD_FS;
+      const float* fs = fsb + (it % BD_NFS) * BD_FS;
       if (it == 1) BD_STAMP(2);
-      // T_qq[r'][l] += sum_w G[r', w] f_qq[w] v[l, w]: k-step ks of lane group g is window 4 g + ks
-      auto take = [&](int c, bd_f4 (&A)[QT]) {
-        if (it == 1 && c == 3) BD_STAMP(19);
-        __syncthreads();
-        if (it == 1 && c == 3) BD_STAMP(20);
-        const float* gt = gvb + (gs & 1) * 2 * BD_TILE;
-        ++gs;
-        float ga[4], vb[4];   // k-step ks of lane group g is window 4 g + ks: G[w][r' = wl], v[w][l = wl]
+      {   // ---- the last core's hand-over; pending: the first core's of the previous tile
+        float ga2[4], b2[4];
+        fetch_fl(p.n - 1, fs, ga2, b2);
+        if (have) flush_fl(accF);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          ga[ks] = gt[(4 * g + ks) * BD_TS + wl];
-          vb[ks] = gt[BD_TILE + (4 * g + ks) * BD_TS + wl];
-        }
-        // (the 16 lanes of a k group want the same four windows' values: 4-byte reads broadcast, 16-byte reads of one
-        // address by several lanes of a group are served one lane after the other - SQ_LDS_BANK_CONFLICT was 56 % of the
-        // LDS cycles with b128 here)
-        float fw[4][QT];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) fw[ks][qq] = fs[(c * 16 + 4 * g + ks) * 4 + qq];
-        // every read is in flight before the first product (left alone the scheduler, short of registers next to 96-128
-        // accumulators, issued them in five dependent batches: 1 500 cycles per hand-over)
-        __builtin_amdgcn_sched_barrier(0);
-        float bq[4][QT];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) bq[ks][qq] = vb[ks] * fw[ks][qq];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) A[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks], bq[ks][qq], A[qq], 0, 0, 0);
-        if (it == 1 && c == 3) BD_STAMP(21);
-      };
+        for (int ks = 0; ks < 4; ++ks) { ga[ks] = ga2[ks]; b4[ks] = b2[ks]; }
+        have = true;
+      }
 #pragma unroll
       for (int c = BD_NC - 2; c >= 1; --c) {
         if (c + 1 < p.n) {
-          take(c, acc[c - 1]);
-          if (p.o[c] > 1) take(c, acc[BD_NPK - 1]);
-          else if (p.nin[c] > 1) take(c, acc[c - 1]);
+          {   // ---- first pair of core c; pending: the last core's hand-over (top core) or the last pair of core c + 1
+            float ga2[4], vb2[4], fw2[4][QT];
+            if (it == 1 && c == 3) BD_STAMP(19);
+            fetch_mid(c, fs, ga2, vb2, fw2);
+            if (it == 1 && c == 3) BD_STAMP(20);
+            if (c + 2 == p.n) flush_fl(accL);
+            else if (pend7) flush_mid(acc[BD_NPK - 1]);
+            else flush_mid(acc[c < BD_NC - 2 ? c : 0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              ga[ks] = ga2[ks]; vb[ks] = vb2[ks];
+#pragma unroll
+              for (int qq = 0; qq < QT; ++qq) fw[ks][qq] = fw2[ks][qq];
+            }
+            pend7 = false;
+            if (it == 1 && c == 3) BD_STAMP(21);
+          }
+          if (p.o[c] > 1 || p.nin[c] > 1) {   // ---- second pair of core c; pending: its first pair (slot c - 1)
+            float ga2[4], vb2[4], fw2[4][QT];
+            fetch_mid(c, fs, ga2, vb2, fw2);
+            flush_mid(acc[c - 1]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              ga[ks] = ga2[ks]; vb[ks] = vb2[ks];
+#pragma unroll
+              for (int qq = 0; qq < QT; ++qq) fw[ks][qq] = fw2[ks][qq];
+            }
+            pend7 = p.o[c] > 1;
+          }
+          if (c == 4) {   // the tile after next: its pixels have arrived during this tile; the one after that sets out
+            if (it + 2 < p.iters) commit(it + 2);
+            if (it + 3 < p.iters) issue_loads(it + 3);
+          }
           if (it == 1) BD_STAMP(5 + (BD_NC - 1 - c));
         }
       }
+      {   // ---- the first core's hand-over; pending: the last pair of core 1 (slot 0, or 7)
+        float ga2[4], b2[4];
+        fetch_fl(0, fs, ga2, b2);
+        if (pend7) flush_mid(acc[BD_NPK - 1]); else flush_mid(acc[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { ga[ks] = ga2[ks]; b4[ks] = b2[ks]; }
+        pend7 = false;
+      }
     }
+    if (have) flush_fl(accF);   // the last tile's first-core hand-over
     BD_STAMP(14);
-    __syncthreads();   // (A)
+    bd_barrier();   // (A)
     BD_STAMP(15);
     // ---- the four waves' tiles join in two copies, in accumulator layout [slot][qq][register][lane]: waves 0, 1 store,
-    // behind (B1) waves 2, 3 add theirs (fixed pairing: bit-reproducible)
+    // behind (B1) waves 2, 3 add theirs (fixed pairing: bit-reproducible); the first / last core tiles (columns = feature
+    // values, lanes wl < 4) go to the wave's own [16][4] tables
     {
       float* cp = lds + (wp & 1) * BD_CPT + lane;
       if (wp < 2) {
@@ -568,7 +673,15 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cp[((i * QT + qq) * 4 + r) * 64] = acc[i][qq][r];
       }
-      __syncthreads();   // (B1)
+      if (wl < 4) {
+        float* fl = lds + 2 * BD_CPT + wp * 128;   // first [16][4], last [16][4] of this wave
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          fl[(4 * g + r) * 4 + wl] = accF[r];
+          fl[64 + (4 * g + r) * 4 + wl] = accL[r];
+        }
+      }
+      bd_barrier();   // (B1)
       BD_STAMP(16);
       if (wp >= 2) {
 #pragma unroll
@@ -580,7 +693,7 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
       }
     }
   }
-  __syncthreads();   // (D)
+  bd_barrier();   // (D)
   BD_STAMP(17);
   // ---- the workgroup's record = the sum of the two copies (and of the four first / last partial sums), in the join area's
   // own layout (the tail kernel, which reads every record anyway, puts the entries into the cores' layouts)
@@ -719,8 +832,8 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
   p.packA_off = off; off += BD_NPK * pl.QT * 256;
   p.first_off = off; off += 64;
   p.last_off = off; off += 64;
-  p.fs_off = off; off += 4 * 2 * BD_FS;
-  p.raw_off = off; off += pl.CH == 2 ? 4 * BD_FS : 0;
+  p.fs_off = off; off += 4 * BD_NFS * BD_FS;
+  p.raw_off = off; off += pl.CH == 2 ? 4 * BD_NFS * BD_FS : 0;
   p.gv_off = off; off += 4 * 4 * BD_TILE;
   p.rows_off = off;   // (the kernel computes the same offsets at compile time)
   const int RK = pl.CH == 2 ? 4 : pl.QT;
@@ -733,7 +846,7 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
   for (;;) {
     const int rows = (p.Ho + nb - 1) / nb;
     const long long rows_floats = (long long)rows * p.Wo * n * RK;
-    if ((long long)(off + rows_floats) * 4 <= DCTN_LDS_BUDGET) {
+    if ((long long)(off + rows_floats) * 4 <= BD_LDS_BUDGET) {
       p.band_rows = rows;
       break;
     }

@@ -81,9 +81,9 @@ for role, nm in ((0, "chain wave 0"), (1, "gradient wave 4")):
         d = s[:, k] - s[:, prev]
         print(f"   {k:2d} {names.get(k, ''):18s} median {float(d.median()):8.0f}   max {float(d.max()):8.0f}   min {float(d.min()):8.0f}")
         prev = k
-    fine = {0: ["19 core 3 pair step starts", "20 A operand read, 12 MFMAs issued", "21 epilogue (dv, df) done", "22 hand-over stored",
-                "23 barrier passed"],
-            1: ["19 arrives at the barrier of core 3's hand-over", "20 barrier passed", "21 operands read, 12 MFMAs issued"]}[role]
+    fine = {0: ["19 core 3 starts", "20 hand-over stored, A operand read, 12 MFMAs issued", "21 barrier passed", "22 epilogue (dv, df) done",
+                "23 feature gradient summed over the k groups and put in its row"],
+            1: ["19 arrives at the barrier of core 3's hand-over", "20 barrier passed, operands of this hand-over read", "21 pending hand-over multiplied (12 MFMAs issued)"]}[role]
     for k in range(20, 19 + len(fine)):
         d = s[:, k] - s[:, k - 1]
         print(f"      {fine[k - 19]:45s} median {float(d.median()):7.0f}   max {float(d.max()):7.0f}")
