@@ -135,6 +135,9 @@ bool convsbs_band_covers(int n, const int* out_sizes, const int* bond_sizes, con
                          int H, int W, int q, int dtype);
 size_t convsbs_band_bwd_workspace(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C,
                                   int B, int H, int W, int q, int dtype);
+int convsbs_fwd_band(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n, const int* out_sizes,
+                     const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype,
+                     hipStream_t st);
 int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* dY, void* dX,
                      float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
                      const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);

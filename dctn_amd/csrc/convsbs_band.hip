@@ -710,6 +710,198 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
   BD_STAMP(18);
 }
 
+// ------------------------------------------------------------------------------------------------ forward
+// The same chain, forwards only: no accumulators, no states to keep - 8 identical waves per workgroup, each with its own
+// 16-window tiles (flat over all windows of the batch), at most 128 registers so that FOUR waves share a SIMD and cover
+// each other's dependent product -> epilogue -> product chain (the round-2 forward, convsbs_fwd_mfma_k: two waves per
+// SIMD, rows padded to four feature values, one LDS round trip per k-step: 41 us at the cfg4 shape, matrix pipe 29 % busy).
+// The next tile's pixels travel while the current one is swept.
+struct BdFwdP {
+  const float* x;
+  float* out;
+  const float* core[BD_NC];
+  long long xs[5];
+  int n, C, q, qc, B, H, W, Ho, Wo, Otot;
+  int o[BD_NC], bl[BD_NC], br[BD_NC], ph[BD_NC], pw[BD_NC], nin[BD_NC];
+  long long Wn, ntiles;
+};
+
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
+  constexpr int CPT = BD_NPK * QT * 256;
+  constexpr int PACKF = 0, FIRST = CPT, LAST = FIRST + 64, FSO = LAST + 64;   // then per wave two feature buffers [core][window][4]
+  constexpr int FS = BD_NC * 16 * 4;
+  // ---- the forward pack (as in the backward: coalesced loads of the cores' own layouts, scattered into fragment order)
+  {
+    constexpr int CHUNKS = CPT / 4 / BD_THREADS;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) *reinterpret_cast<bd_f4*>(lds + PACKF + (tid + BD_THREADS * j) * 4) = bd_f4{0.f, 0.f, 0.f, 0.f};
+    float va[BD_NC - 2][4];
+#pragma unroll
+    for (int c = 1; c < BD_NC - 1; ++c) {
+      const int cnt = c + 1 < p.n ? p.o[c] * p.bl[c] * p.br[c] * QT : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        va[c - 1][j] = ((QT == 4 || j < 3) && tid + BD_THREADS * j < cnt) ? p.core[c][tid + BD_THREADS * j] : 0.f;
+    }
+    bd_barrier();
+#pragma unroll
+    for (int c = 1; c < BD_NC - 1; ++c) {
+      if (c + 1 < p.n) {
+        const int bl = p.bl[c], br = p.br[c];
+        const int cnt = p.o[c] * bl * br * QT;
+        const float ibr = 1.0f / (float)br, ibl = 1.0f / (float)bl;
+#pragma unroll
+        for (int j = 0; j < (QT == 4 ? 4 : 3); ++j) {
+          const int e = tid + BD_THREADS * j;
+          if (e < cnt) {
+            const int qq = e % QT, t = e / QT;
+            const int t1 = (int)(((float)t + 0.5f) * ibr);
+            const int r = t - t1 * br;
+            const int o = (int)(((float)t1 + 0.5f) * ibl);
+            const int l = t1 - o * bl;
+            const int pk = o == 0 ? c - 1 : BD_NPK - 1;
+            lds[PACKF + ((pk * QT + qq) * 64 + r + 16 * (l >> 2)) * 4 + (l & 3)] = va[c - 1][j];
+          }
+        }
+      }
+    }
+    if (tid < 64) {
+      const int rr = tid >> 2, qq = tid & 3;
+      lds[FIRST + tid] = (qq < p.qc && rr < p.br[0]) ? p.core[0][rr * p.qc + qq] : 0.f;
+      lds[LAST + tid] = (qq < p.qc && rr < p.bl[p.n - 1]) ? p.core[p.n - 1][rr * p.qc + qq] : 0.f;
+    }
+  }
+  bd_barrier();
+
+  float* fsb = lds + FSO + wv * 2 * FS;
+  const long long wave = (long long)blockIdx.x * 8 + wv, nwaves = (long long)gridDim.x * 8;
+  const int hw = p.Ho * p.Wo;
+  // prefetch registers: the pixels of cores g, g + 4, g + 8 of the lane's window (unconditional loads; validity at commit)
+  float pre[3][4];
+  auto issue_loads = [&](long long tile) {
+    const long long w = tile * 16 + wl;
+    const long long ww = w < p.Wn ? w : 0;
+    const long long b = ww / hw;
+    const int rem = (int)(ww - b * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const float* win = p.x + b * p.xs[1] + (long long)ho * p.xs[2] + (long long)wo * p.xs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = g + 4 * k, cc = c < p.n ? c : 0;
+      const float* px = win + (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
+      if constexpr (CH == 2) {
+        pre[k][0] = px[0];
+        pre[k][1] = px[p.xs[4]];
+        pre[k][2] = px[p.xs[0]];
+        pre[k][3] = px[p.xs[0] + p.xs[4]];
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) pre[k][d] = px[(d < QT ? d : 0) * p.xs[4]];
+      }
+    }
+  };
+  auto commit = [&](long long tile, float* fs) {
+    const bool valid = tile * 16 + wl < p.Wn;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = g + 4 * k;
+      if (c < p.n) {
+        float v[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v[d] = (valid && (CH == 2 || d < QT)) ? pre[k][d] : 0.f;
+        if constexpr (CH == 2) *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{v[0] * v[2], v[0] * v[3], v[1] * v[2], v[1] * v[3]};
+        else *reinterpret_cast<bd_f4*>(fs + (c * 16 + wl) * 4) = bd_f4{v[0], v[1], v[2], v[3]};
+      }
+    }
+  };
+  auto product = [&](int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
+    bd_f4 a[QT];
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      a[qq] = *reinterpret_cast<const bd_f4*>(lds + PACKF + ((pk * QT + qq) * 64 + lane) * 4);
+      D[qq] = bd_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
+  };
+  auto epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = f[0] * D[0][r] + f[1] * D[1][r];
+      if (QT > 2) a += f[2] * D[2 % QT][r];
+      if (QT > 3) a += f[3] * D[3 % QT][r];
+      out[r] = a;
+    }
+  };
+
+  long long tile = wave;
+  if (tile < p.ntiles) issue_loads(tile);
+  int buf = 0;
+  for (; tile < p.ntiles; tile += nwaves) {
+    float* fs = fsb + buf * FS;
+    buf ^= 1;
+    commit(tile, fs);
+    if (tile + nwaves < p.ntiles) issue_loads(tile + nwaves);
+    bd_wave_lds_sync();
+    float w0[4], w1[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (4 * g + s) * 4 + qq] * f[qq];
+        w0[s] = a;
+      }
+    }
+#pragma unroll
+    for (int c = 1; c < BD_NC - 1; ++c) {
+      if (c + 1 < p.n) {
+        const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
+        float n0[4], n1[4] = {0.f, 0.f, 0.f, 0.f};
+        bd_f4 D[QT];
+        product(c - 1, w0, D);
+        epi(D, f, n0);
+        if (p.o[c] > 1 || p.nin[c] > 1) {
+          const bool second_out = p.o[c] > 1;
+          float vin[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vin[s] = second_out ? w0[s] : w1[s];
+          product(second_out ? BD_NPK - 1 : c - 1, vin, D);
+          epi(D, f, n1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
+      }
+    }
+    {   // last core: out[a] = sum_l v_a[l] sum_qq coreL[l][qq] f[qq]
+      const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + ((p.n - 1) * 16 + wl) * 4);
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float tl = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) tl += lds[LAST + (4 * g + s) * 4 + qq] * f[qq];
+        r0 += w0[s] * tl;
+        r1 += w1[s] * tl;
+      }
+      r0 = bd_group_sum(r0);
+      r1 = bd_group_sum(r1);
+      const long long w = tile * 16 + wl;
+      if (g == 0 && w < p.Wn) {
+        p.out[w * p.Otot] = r0;
+        if (p.Otot > 1) p.out[w * p.Otot + 1] = r1;
+      }
+    }
+  }
+}
+
 // dCore_c[e] = sum over the workgroups' records in a fixed order; the pixel rows two bands share = the sum of their two
 // partial sums.  64 elements per workgroup, 4 record subsets, LDS join (as convsbs_dcore_reduce_k).
 __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
@@ -932,5 +1124,41 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
     DCTN_CHECK_LAUNCH();
   }
   dctn_set_last_kernel("convsbs_bwd_band_f32");
+  return DCTN_OK;
+}
+
+int convsbs_fwd_band(const void* x, const int64_t xs[5], const void* const* cores, void* out, int n, const int* out_sizes,
+                     const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype,
+                     hipStream_t st) {
+  BdPlan pl;
+  const int rc = bd_plan(pl, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  if (rc != DCTN_OK) return rc;
+  const BdP& b = pl.p;
+  BdFwdP p;
+  p.x = (const float*)x; p.out = (float*)out;
+  for (int c = 0; c < BD_NC; ++c) {
+    p.core[c] = b.core[c]; p.o[c] = b.o[c]; p.bl[c] = b.bl[c]; p.br[c] = b.br[c]; p.ph[c] = b.ph[c]; p.pw[c] = b.pw[c]; p.nin[c] = b.nin[c];
+  }
+  for (int i = 0; i < 5; ++i) p.xs[i] = b.xs[i];
+  p.n = n; p.C = C; p.q = q; p.qc = b.qc; p.B = B; p.H = H; p.W = W; p.Ho = b.Ho; p.Wo = b.Wo; p.Otot = b.Otot;
+  p.Wn = (long long)B * b.Ho * b.Wo;
+  p.ntiles = (p.Wn + 15) / 16;
+  const int lds_bytes = (BD_NPK * pl.QT * 256 + 128 + 8 * 2 * BD_NC * 16 * 4) * 4;   // pack + tables + 8 waves x 2 feature buffers
+  long long blocks = (p.ntiles + 7) / 8;
+  const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;   // 128 registers: two workgroups (four waves per SIMD) per CU
+  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+#define BD_FLAUNCH(QTV, CHV)                                                                                    \
+  do {                                                                                                          \
+    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              lds_bytes);                                                                       \
+    hipLaunchKernelGGL((convsbs_fwd_band_k<QTV, CHV>), dim3((unsigned)blocks), dim3(BD_THREADS), lds_bytes, st, p); \
+  } while (0)
+  if (pl.CH == 2) BD_FLAUNCH(4, 2);
+  else if (pl.QT == 2) BD_FLAUNCH(2, 1);
+  else if (pl.QT == 3) BD_FLAUNCH(3, 1);
+  else BD_FLAUNCH(4, 1);
+#undef BD_FLAUNCH
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("convsbs_fwd_band_f32");
   return DCTN_OK;
 }

@@ -549,6 +549,9 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
     rc = convsbs_fwd_reg(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
+  // bonds 9..16: the band family's forward (nothing kept: its backward recomputes the chain in registers)
+  rc = convsbs_fwd_band(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   float* save = (sb > 0 && workspace && workspace_bytes >= sb) ? (float*)workspace : nullptr;
   rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,

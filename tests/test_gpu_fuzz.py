@@ -506,13 +506,15 @@ def _convsbs_family_case(case, fam):
     B, H, W = 3, spec.max_height_pos + 6, spec.max_width_pos + 7      # 126 windows: three full groups and a ragged one
     x = torch.randn(C, B, H, W, q, device=DEV, requires_grad=True)
     y = m(x)
+    if sbs_band_family_takes(*case):
+        fam = "band"   # bonds 9..16: forward and backward of convsbs_band.hip
     assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, list(pos), x.detach().cpu().double())
     check(y, want, torch.float32, "forward")
     dy = torch.randn_like(y)
     y.backward(dy)
-    assert dctn_amd.last_kernel() == f"convsbs_bwd_{'band' if sbs_band_family_takes(*case) else fam}_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_bwd_{fam}_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     check(x.grad, gr[0], torch.float32, "dX")
     for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
@@ -627,6 +629,7 @@ def test_convsbs_band_family_shapes(case):
         x = x.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
     x.requires_grad_(x_grad)
     y = m(x)
+    assert dctn_amd.last_kernel() == "convsbs_fwd_band_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, list(pos), x0.double())
     check(y, want, torch.float32, "forward")

@@ -296,15 +296,15 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
     m = many.strings[0].to(DEV)
     x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
     (y,) = many(x)
-    fam = "reg" if r <= 4 else "mfma"   # bond <= 4: lane-per-window register sweep; above: the matrix-core sweep
+    # bond <= 4: lane-per-window register sweep; 5..8: the matrix-core sweep; 9..16: the band family (convsbs_band.hip)
+    fam = "reg" if r <= 4 else "mfma" if r <= 8 else "band"
     assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, snake, x.detach().cpu().double())
     assert close(y, want, torch.float32)
     dy = torch.randn_like(y)
     y.backward(dy)
-    # bonds 9..16: the band-owning backward (convsbs_band.hip: chain recomputed in registers, nothing kept by the forward)
-    assert dctn_amd.last_kernel() == f"convsbs_bwd_{'band' if r > 8 else fam}_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_bwd_{fam}_f32"
     gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, snake, xx), [x.detach().cpu().double()] + cores64, dy.cpu().double())
     assert close(x.grad, gr[0], torch.float32)
     for c, gc in zip(m.cores, gr[1:]):
