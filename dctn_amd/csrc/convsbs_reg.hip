@@ -66,6 +66,8 @@ struct SrP {
   int slot[SR_MAXC];       // core c's pixel = slot-th pixel of the FIRST string (all strings cover the same window positions):
                            // where its feature gradient goes in the per-window LDS row that the dX writer sums
   int tot_all;             // elements of all strings' cores together (coff is absolute inside that record)
+  // a string with ONE many-valued core (the ten-label final string of the reference's classifier, mnist.py:213-223)
+  int mv, O;               // index of that core (-1: none) and its output count (3..16); every other core has one value
 };
 
 constexpr int SR_MAXS = 2;        // strings per launch
@@ -921,6 +923,337 @@ __global__ __launch_bounds__(256) void convsbs_regu_tail_k(const float* __restri
   }
 }
 
+// ================================================================================================ one many-valued core
+// The final string of the reference's ConvSBS classifier (mnist.py:213-223): nine cores, the centre one with NUM_LABELS = 10
+// outputs.  Every output shares the prefix state v (cores before m) and the SUFFIX vector s (cores behind m, applied right
+// to left: s_c = T_c s_(c+1)), so
+//     out[o] = sum_(l,r,qq) core_m[o][l][r][qq] v[l] s[r] f_m[qq]
+// is one short dot product per output and window, and the way back is
+//     dz[l][r][qq] = sum_o dY[o] core_m[o][l][r][qq],   dCore_m[o] += dY[o] (v x s x f)   (lane sums as for the other cores),
+// then dv, ds, df_m from dz and ONE adjoint pass through the prefix and through the suffix - the work of a one-valued
+// string plus O dot products, where the matrix-core sweep ran the whole chain once per pair of outputs (five launches
+// each way, 0.39 ms of the classifier's 0.57 ms step).
+// LDS pack: cores c != m as one [R][R][QC] slice at c * E, the many-valued core's O slices behind them at (NC + o) * E.
+template <int R, int QC>
+__device__ __forceinline__ void sm_fill_pack(float* pack, const SrP& p, int ncores, int tid, int nthreads) {
+  constexpr int E = R * R * QC;
+  for (int e = tid; e < (ncores + p.O) * E; e += nthreads) {
+    const int sl = e / E, rem = e - sl * E;
+    const int c = sl < ncores ? sl : p.mv, o = sl < ncores ? 0 : sl - ncores;
+    const int l = rem / (R * QC), r3 = rem - l * (R * QC);
+    const int r = r3 / QC, qq = r3 - r * QC;
+    float v = 0.f;
+    if (c < p.n && (sl >= ncores || c != p.mv) && l < p.bl[c] && r < p.br[c]) v = p.core[c][((o * p.bl[c] + l) * p.br[c] + r) * QC + qq];
+    pack[e] = v;
+  }
+}
+
+// prefix state and suffix vector of a window: v = e0 T_0 .. T_(m-1),  s = T_(m+1) .. T_(n-1) e0
+template <int R, int QC, int NC>
+__device__ __forceinline__ void sm_prefix_suffix(const float* pack, const SrP& p, const float (*f)[QC], float (*vs)[R], float (*ss)[R]) {
+  constexpr int E = R * R * QC;
+  // vs[c] = the state entering core c (c <= m); ss[c] = the vector leaving core c - 1 to the right, i.e. s_c (c > m)
+#pragma unroll
+  for (int r = 0; r < R; ++r) { vs[0][r] = r == 0 ? 1.f : 0.f; ss[NC][r] = r == 0 ? 1.f : 0.f; }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c < p.mv) {
+      float T[R][R];
+      sr_tmat<R, QC>(pack + c * E, f[c], T);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int l = 0; l < R; ++l) a = fmaf(vs[c][l], T[l][r], a);
+        vs[c + 1][r] = a;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) vs[c + 1][r] = vs[c][r];
+    }
+  }
+#pragma unroll
+  for (int c = NC - 1; c >= 0; --c) {
+    if (c > p.mv && c < p.n) {
+      float T[R][R];
+      sr_tmat<R, QC>(pack + c * E, f[c], T);
+#pragma unroll
+      for (int l = 0; l < R; ++l) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) a = fmaf(T[l][r], ss[c + 1][r], a);
+        ss[c][l] = a;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) ss[c][r] = ss[c + 1][r];
+    }
+  }
+}
+
+template <int R, int QC, bool TWOCH>
+__global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regmv_k(SrP p, float* __restrict__ out) {
+  constexpr int NC = SR_MAXC, E = R * R * QC;
+  extern __shared__ __align__(16) float smem[];
+  float* pack = smem;
+  const int tid = threadIdx.x;
+  sm_fill_pack<R, QC>(pack, p, NC, tid, SR_FWD_THREADS);
+  __syncthreads();
+  const int hw = p.Ho * p.Wo;
+  for (long long w = (long long)blockIdx.x * SR_FWD_THREADS + tid; w < p.Wn; w += (long long)gridDim.x * SR_FWD_THREADS) {
+    const long long b = w / hw;
+    const int rem = (int)(w - b * hw);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    float f[NC][QC], xr[4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c < p.n) sr_features<QC, TWOCH>(p, c, b, ho, wo, f[c], xr);
+      else
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) f[c][qq] = 0.f;
+    }
+    float vs[NC + 1][R], ss[NC + 1][R];
+    sm_prefix_suffix<R, QC, NC>(pack, p, f, vs, ss);
+    float fm[QC];
+#pragma unroll
+    for (int qq = 0; qq < QC; ++qq) fm[qq] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (c == p.mv)
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) fm[qq] = f[c][qq];
+    float z[E];   // v[l] s[r] f_m[qq]
+#pragma unroll
+    for (int l = 0; l < R; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float vsr = vs[NC][l] * ss[0][r];   // (vs is constant from m on, ss from m + 1 down: the ends hold v_m and s_(m+1))
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) z[(l * R + r) * QC + qq] = vsr * fm[qq];
+      }
+    float* op = out + w * p.O;
+#pragma unroll 1
+    for (int o = 0; o < p.O; ++o) {
+      const float* pk = pack + (NC + o) * E;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; e += 2) { a0 = fmaf(pk[e], z[e], a0); a1 = fmaf(pk[e + 1], z[e + 1], a1); }
+      op[o] = a0 + a1;
+    }
+  }
+}
+
+template <int R, int QC, bool TWOCH, int NC>
+__global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
+  constexpr int E = R * R * QC;
+  constexpr int NWAVES = SR_BWD_THREADS / 64;
+  extern __shared__ __align__(16) float smem[];
+  const int PK = (NC + p.O) * E;
+  float* pack = smem;                 // [PK]
+  float* wacc = pack + PK;            // [NWAVES][PK]: per-wave dCore sums
+  float* dfl = wacc + NWAVES * PK;    // [windows of the band][n * C * q]: d/d(pixel values) per window
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cq = p.C * p.q, NCq = p.n * Cq;
+  const int img = blockIdx.x / p.bands, band = blockIdx.x - img * p.bands;
+  const int r0 = band * p.band_rows, r1 = min(p.H, r0 + p.band_rows);
+  const int wr0 = max(0, r0 - p.max_h), wr1 = min(p.Ho, r1);
+  const int nwin = wr1 > wr0 ? (wr1 - wr0) * p.Wo : 0;
+  sm_fill_pack<R, QC>(pack, p, NC, tid, SR_BWD_THREADS);
+  for (int e = tid; e < NWAVES * PK; e += SR_BWD_THREADS) wacc[e] = 0.f;
+  __syncthreads();
+  float* wmine = wacc + wave * PK;
+
+  for (int base = wave * 64; base < nwin; base += SR_BWD_THREADS) {   // (uniform per wave: the lane sums need every lane)
+    const int i = base + lane;
+    const bool valid = i < nwin;
+    const int ic = valid ? i : nwin - 1;
+    const int hrow = ic / p.Wo;
+    const int ho = wr0 + hrow, wo = ic - hrow * p.Wo;
+    const long long w = ((long long)img * p.Ho + ho) * p.Wo + wo;
+    const bool owner = valid && ho >= r0 && p.part != nullptr;   // dCore counts a window in the band of its top-left pixel
+    const bool first = base == wave * 64;
+
+    float f[NC][QC], xr[4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c < p.n) sr_features<QC, TWOCH>(p, c, img, ho, wo, f[c], xr);
+      else
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) f[c][qq] = 0.f;
+    }
+    float vs[NC + 1][R], ss[NC + 1][R];
+    sm_prefix_suffix<R, QC, NC>(pack, p, f, vs, ss);
+    float fm[QC];
+#pragma unroll
+    for (int qq = 0; qq < QC; ++qq) fm[qq] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (c == p.mv)
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) fm[qq] = f[c][qq];
+    float vsr[R][R];
+#pragma unroll
+    for (int l = 0; l < R; ++l)
+#pragma unroll
+      for (int r = 0; r < R; ++r) vsr[l][r] = vs[NC][l] * ss[0][r];
+
+    // d/d(pixel values) of this window and core c from d/d(feature products)
+    auto put_row = [&](int c, const float (&dF)[QC]) {
+      if (!valid || p.dX == nullptr) return;
+      float* d = dfl + (size_t)i * NCq + c * Cq;
+      if constexpr (TWOCH) {
+        float fc[QC], xv[4];
+        sr_features<QC, TWOCH>(p, c, img, ho, wo, fc, xv);   // (the raw values again: a cache hit, not 36 registers held)
+        d[0] = dF[0] * xv[2] + dF[1] * xv[3];
+        d[1] = dF[2] * xv[2] + dF[3] * xv[3];
+        d[2] = dF[0] * xv[0] + dF[2] * xv[1];
+        d[3] = dF[1] * xv[0] + dF[3] * xv[1];
+      } else {
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) d[qq] = dF[qq];
+      }
+    };
+
+    // ---- the many-valued core, pass A: dCore_m[o] += dY[o] (v x s x f) - O lane sums of E products
+    const float* dyp = p.dY + w * p.O;
+    if (p.part != nullptr) {
+#pragma unroll 1
+      for (int o = 0; o < p.O; ++o) {
+        const float g = owner ? dyp[o] : 0.f;
+        float prod[E];
+#pragma unroll
+        for (int l = 0; l < R; ++l)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float gv = g * vsr[l][r];
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) prod[(l * R + r) * QC + qq] = gv * fm[qq];
+          }
+        sr_wave_reduce_add<E>(prod, wmine + (NC + o) * E, lane, first);
+      }
+    }
+    // ---- pass B: dz = sum_o dY[o] core_m[o], then its three contractions
+    float dv[R], ds[R], dFm[QC];
+    {
+      float dz[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) dz[e] = 0.f;
+#pragma unroll 1
+      for (int o = 0; o < p.O; ++o) {
+        const float g = valid ? dyp[o] : 0.f;
+        const float* pk = pack + (NC + o) * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) dz[e] = fmaf(g, pk[e], dz[e]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) { dv[r] = 0.f; ds[r] = 0.f; }
+#pragma unroll
+      for (int qq = 0; qq < QC; ++qq) dFm[qq] = 0.f;
+#pragma unroll
+      for (int l = 0; l < R; ++l)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float zf = 0.f;   // sum_qq dz f_m[qq]
+#pragma unroll
+          for (int qq = 0; qq < QC; ++qq) {
+            zf = fmaf(dz[(l * R + r) * QC + qq], fm[qq], zf);
+            dFm[qq] = fmaf(dz[(l * R + r) * QC + qq], vsr[l][r], dFm[qq]);
+          }
+          dv[l] = fmaf(zf, ss[0][r], dv[l]);
+          ds[r] = fmaf(zf, vs[NC][l], ds[r]);
+        }
+    }
+    // ---- the cores behind m, left to right: s_c = T_c s_(c+1);  d/ds_c is known -> dT_c = ds_c x s_(c+1), ds_(c+1) = T_c^T ds_c
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c == p.mv) put_row(c, dFm);
+      if (c > p.mv && c < p.n) {
+        const float* pkc = pack + c * E;
+        float T[R][R], dF[QC], nds[R], prod[E];
+        sr_tmat<R, QC>(pkc, f[c], T);
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) dF[qq] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nds[r] = 0.f;
+#pragma unroll
+        for (int l = 0; l < R; ++l)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float dT = ds[l] * ss[c + 1][r];
+            nds[r] = fmaf(T[l][r], ds[l], nds[r]);
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) {
+              dF[qq] = fmaf(dT, pkc[(l * R + r) * QC + qq], dF[qq]);
+              prod[(l * R + r) * QC + qq] = owner ? dT * f[c][qq] : 0.f;
+            }
+          }
+        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wmine + c * E, lane, first);
+#pragma unroll
+        for (int r = 0; r < R; ++r) ds[r] = nds[r];
+        put_row(c, dF);
+      }
+    }
+    // ---- the cores in front of m, right to left: G = d/d(state leaving core c)
+#pragma unroll
+    for (int c = NC - 1; c >= 0; --c) {
+      if (c < p.mv) {
+        const float* pkc = pack + c * E;
+        float T[R][R], dF[QC], Gin[R], prod[E];
+        sr_tmat<R, QC>(pkc, f[c], T);
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) dF[qq] = 0.f;
+#pragma unroll
+        for (int l = 0; l < R; ++l) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float vg = vs[c][l] * dv[r];
+            a = fmaf(T[l][r], dv[r], a);
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) {
+              dF[qq] = fmaf(vg, pkc[(l * R + r) * QC + qq], dF[qq]);
+              prod[(l * R + r) * QC + qq] = owner ? vg * f[c][qq] : 0.f;
+            }
+          }
+          Gin[l] = a;
+        }
+        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wmine + c * E, lane, first);
+#pragma unroll
+        for (int r = 0; r < R; ++r) dv[r] = Gin[r];
+        put_row(c, dF);
+      }
+    }
+  }
+  __syncthreads();
+  if (p.dX != nullptr) sr_write_dx_band<NC, (TWOCH ? 2 : QC)>(p, dfl, p.n, img, r0, r1, wr0, tid, SR_BWD_THREADS);
+  if (p.part != nullptr) {
+    for (int e = tid; e < PK; e += SR_BWD_THREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NWAVES; ++wv) s += wacc[wv * PK + e];
+      p.part[(long long)e * p.nrec + blockIdx.x] = s;
+    }
+  }
+}
+
+// dCore of a string with a many-valued core: padded entry (slice, l, r, qq) -> its place
+template <int R, int QC>
+__global__ __launch_bounds__(256) void convsbs_regmv_tail_k(const float* __restrict__ part, SrTailP t, int mv, int O) {
+  constexpr int E = R * R * QC;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (SR_MAXC + O) * E) return;
+  const int sl = e / E, rem = e - sl * E;
+  const int c = sl < SR_MAXC ? sl : mv, o = sl < SR_MAXC ? 0 : sl - SR_MAXC;
+  const int l = rem / (R * QC), r3 = rem - l * (R * QC);
+  const int r = r3 / QC, qq = r3 - r * QC;
+  if (c >= t.n || (sl < SR_MAXC && c == mv) || l >= t.bl[c] || r >= t.br[c]) return;   // padding (wave-uniform)
+  float s = 0.f;
+  for (int k = lane; k < t.nrec; k += 64) s += part[(long long)e * t.nrec + k];
+  s = wave_reduce_sum(s);
+  if (lane == 0) t.dcore[c][((o * t.bl[c] + l) * t.br[c] + r) * QC + qq] = s;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct SrPlan {
   int R, QC, twoch;
@@ -958,6 +1291,7 @@ bool sr_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void*
   p.n = n; p.C = C; p.q = q; p.B = B; p.H = H; p.W = W; p.Ho = H - max_h; p.Wo = W - max_w; p.Otot = otot; p.max_h = max_h;
   p.Wn = (long long)B * p.Ho * p.Wo;
   p.dY = nullptr; p.dX = nullptr; p.part = nullptr;
+  p.mv = -1; p.O = 0;
   pl.R = maxb <= 2 ? 2 : 4;
   pl.QC = qc;
   pl.twoch = C == 2;
@@ -1001,6 +1335,75 @@ bool sr_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void*
   return true;
 }
 
+
+// the same for a string with ONE many-valued core (3..16 values; every other core one value)
+bool sm_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void* const* cores, int n, const int* out_sizes,
+             const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype) {
+  if (dtype != DCTN_F32 || n < 2 || n > SR_MAXC || bond_sizes[0] != 1) return false;
+  int qc = 1;
+  for (int c = 0; c < C; ++c) qc *= q;
+  if (!((C == 1 && q >= 2 && q <= 4) || (C == 2 && q == 2))) return false;
+  int maxb = 1, max_h = 0, max_w = 0, mv = -1;
+  for (int c = 0; c < n; ++c) {
+    const int bl = bond_sizes[c], br = bond_sizes[(c + 1) % n];
+    if (bl < 1 || br < 1 || bl > 4 || br > 4) return false;
+    if (out_sizes[c] != 1) {
+      if (mv >= 0 || out_sizes[c] < 3 || out_sizes[c] > 16) return false;
+      mv = c;
+    }
+    maxb = bl > maxb ? bl : maxb;
+    maxb = br > maxb ? br : maxb;
+    max_h = pos_h[c] > max_h ? pos_h[c] : max_h;
+    max_w = pos_w[c] > max_w ? pos_w[c] : max_w;
+    p.core[c] = cores ? (const float*)cores[c] : nullptr;
+    p.o[c] = out_sizes[c]; p.bl[c] = bl; p.br[c] = br; p.ph[c] = pos_h[c]; p.pw[c] = pos_w[c];
+  }
+  if (mv < 0 || maxb < 2) return false;
+  for (int c = n; c < SR_MAXC; ++c) { p.core[c] = nullptr; p.o[c] = 1; p.bl[c] = 1; p.br[c] = 1; p.ph[c] = 0; p.pw[c] = 0; }
+  if (H <= max_h || W <= max_w) return false;
+  p.x = (const float*)x;
+  for (int i = 0; i < 5; ++i) p.xs[i] = xs ? xs[i] : 0;
+  p.n = n; p.C = C; p.q = q; p.B = B; p.H = H; p.W = W; p.Ho = H - max_h; p.Wo = W - max_w; p.max_h = max_h;
+  p.mv = mv; p.O = out_sizes[mv]; p.Otot = p.O;
+  p.Wn = (long long)B * p.Ho * p.Wo;
+  p.dY = nullptr; p.dX = nullptr; p.part = nullptr; p.out = nullptr;
+  pl.R = maxb <= 2 ? 2 : 4;
+  pl.QC = qc;
+  pl.twoch = C == 2;
+  pl.uniform = 0;
+  p.coff[0] = 0;
+  for (int c = 0; c < SR_MAXC; ++c) p.coff[c + 1] = p.coff[c] + (c < n ? p.o[c] * p.bl[c] * p.br[c] * qc : 0);
+  pl.tot = p.coff[SR_MAXC];
+  p.tot_all = pl.tot;
+  for (int c = 0; c < SR_MAXC; ++c) p.slot[c] = c;
+  const int NCq = n * C * q;
+  const size_t PK = (size_t)(SR_MAXC + p.O) * pl.R * pl.R * pl.QC;
+  const size_t fixed = PK * (1 + SR_BWD_THREADS / 64);
+  int best = -1;
+  for (int nb = 1; nb <= H; ++nb) {
+    const int br = (H + nb - 1) / nb;
+    const int bands = (H + br - 1) / br;
+    int maxwin = 0;
+    for (int b2 = 0; b2 < bands; ++b2) {
+      const int r0 = b2 * br, r1 = r0 + br < H ? r0 + br : H;
+      const int wr0 = r0 - max_h > 0 ? r0 - max_h : 0, wr1 = r1 < p.Ho ? r1 : p.Ho;
+      const int nw = wr1 > wr0 ? (wr1 - wr0) * p.Wo : 0;
+      maxwin = nw > maxwin ? nw : maxwin;
+    }
+    const size_t lds = (fixed + (size_t)maxwin * NCq) * sizeof(float);
+    if (lds > DCTN_LDS_BUDGET) continue;
+    best = br; pl.max_w_in_band = maxwin; pl.lds_bwd = lds;
+    if (maxwin <= SR_BWD_THREADS && (long long)B * bands >= 256) break;
+    if (maxwin <= SR_BWD_THREADS / 2) break;
+  }
+  if (best < 0) return false;
+  pl.band_rows = best;
+  pl.bands = (H + best - 1) / best;
+  pl.nrec = B * pl.bands;
+  p.band_rows = pl.band_rows; p.bands = pl.bands; p.nrec = pl.nrec;
+  return true;
+}
+
 }  // namespace
 
 // room for the per-workgroup dCore records of the register-resident backward (0: the string is not in the family)
@@ -1008,7 +1411,10 @@ size_t convsbs_reg_bwd_workspace(int n, const int* out_sizes, const int* bond_si
                                  int C, int B, int H, int W, int q, int dtype) {
   SrP p;
   SrPlan pl;
-  if (!sr_fill(p, pl, nullptr, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return 0;
+  if (!sr_fill(p, pl, nullptr, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) {
+    if (!sm_fill(p, pl, nullptr, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return 0;
+    return (size_t)(SR_MAXC + p.O) * pl.R * pl.R * pl.QC * pl.nrec * sizeof(float) + 256;
+  }
   const size_t ent = pl.uniform ? (size_t)pl.tot : (size_t)SR_MAXC * 2 * pl.R * pl.R * pl.QC;
   return ent * pl.nrec * sizeof(float) + 256;
 }
@@ -1018,7 +1424,30 @@ int convsbs_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores
                     hipStream_t st) {
   SrP p;
   SrPlan pl;
-  if (!sr_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (!sr_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) {
+    // one many-valued core (the classifier's ten-label string): prefix state, suffix vector, one dot product per output
+    if (!sm_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+    long long blocks = (p.Wn + SR_FWD_THREADS - 1) / SR_FWD_THREADS;
+    if (blocks > 2048) blocks = 2048;
+    const size_t lds = (size_t)(SR_MAXC + p.O) * pl.R * pl.R * pl.QC * sizeof(float);
+#define SM_FWD(RR, QQ, TC)                                                                                          \
+  hipLaunchKernelGGL((convsbs_fwd_regmv_k<RR, QQ, TC>), dim3((unsigned)blocks), dim3(SR_FWD_THREADS), lds, st, p, (float*)out)
+    if (pl.R == 2) {
+      if (pl.twoch) SM_FWD(2, 4, true);
+      else if (pl.QC == 2) SM_FWD(2, 2, false);
+      else if (pl.QC == 3) SM_FWD(2, 3, false);
+      else SM_FWD(2, 4, false);
+    } else {
+      if (pl.twoch) SM_FWD(4, 4, true);
+      else if (pl.QC == 2) SM_FWD(4, 2, false);
+      else if (pl.QC == 3) SM_FWD(4, 3, false);
+      else SM_FWD(4, 4, false);
+    }
+#undef SM_FWD
+    DCTN_CHECK_LAUNCH();
+    dctn_set_last_kernel("convsbs_fwd_reg_f32");
+    return DCTN_OK;
+  }
   long long blocks = (p.Wn + SR_FWD_THREADS - 1) / SR_FWD_THREADS;
   if (blocks > 2048) blocks = 2048;
   p.out = (float*)out;
@@ -1059,7 +1488,44 @@ int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores
                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes) {
   SrP p;
   SrPlan pl;
-  if (!sr_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+  if (!sr_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) {
+    if (!sm_fill(p, pl, x, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype)) return DCTN_ERR_UNSUPPORTED;
+    const int ent = (SR_MAXC + p.O) * pl.R * pl.R * pl.QC;
+    if (dcores && (!ws || ws_bytes < (size_t)ent * pl.nrec * sizeof(float))) return DCTN_ERR_WORKSPACE;
+    if ((uintptr_t)ws % 16) return DCTN_ERR_WORKSPACE;
+    p.dY = (const float*)dY;
+    p.dX = (float*)dX;
+    p.part = dcores ? (float*)ws : nullptr;
+    SrTailP t;
+    for (int c = 0; c < SR_MAXS * SR_MAXC; ++c) t.dcore[c] = (dcores && c < n) ? dcores[c] : nullptr;
+    for (int c = 0; c < SR_MAXC; ++c) { t.o[c] = p.o[c]; t.bl[c] = p.bl[c]; t.br[c] = p.br[c]; }
+    t.n = n; t.nrec = pl.nrec;
+    for (int c = 0; c <= SR_MAXS * SR_MAXC; ++c) t.coff[c] = c <= SR_MAXC ? p.coff[c] : p.coff[SR_MAXC];
+#define SM_BWD(RR, QQ, TC)                                                                                            \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_regmv_k<RR, QQ, TC, SR_MAXC>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bwd);                           \
+    hipLaunchKernelGGL((convsbs_bwd_regmv_k<RR, QQ, TC, SR_MAXC>), dim3((unsigned)pl.nrec), dim3(SR_BWD_THREADS), pl.lds_bwd, st, p); \
+    if (dcores)                                                                                                       \
+      hipLaunchKernelGGL((convsbs_regmv_tail_k<RR, QQ>), dim3((unsigned)((ent + 3) / 4)), dim3(256), 0, st, (const float*)ws, t, \
+                         p.mv, p.O);                                                                                  \
+  } while (0)
+    if (pl.R == 2) {
+      if (pl.twoch) SM_BWD(2, 4, true);
+      else if (pl.QC == 2) SM_BWD(2, 2, false);
+      else if (pl.QC == 3) SM_BWD(2, 3, false);
+      else SM_BWD(2, 4, false);
+    } else {
+      if (pl.twoch) SM_BWD(4, 4, true);
+      else if (pl.QC == 2) SM_BWD(4, 2, false);
+      else if (pl.QC == 3) SM_BWD(4, 3, false);
+      else SM_BWD(4, 4, false);
+    }
+#undef SM_BWD
+    DCTN_CHECK_LAUNCH();
+    dctn_set_last_kernel("convsbs_bwd_reg_f32");
+    return DCTN_OK;
+  }
   const size_t ent = pl.uniform ? (size_t)pl.tot : (size_t)SR_MAXC * 2 * pl.R * pl.R * pl.QC;
   const size_t need = ent * pl.nrec * sizeof(float);
   if (dcores && (!ws || ws_bytes < need)) return DCTN_ERR_WORKSPACE;

@@ -464,12 +464,14 @@ def sbs_mfma_cases():
 
 def sbs_reg_family_takes(pos, bonds, outs, C, q):
     """Strings the register-resident small-bond sweep (convsbs_reg.hip) takes by default: float32 open chains of at most
-    9 cores, every bond <= 4, at most one two-valued core, q^C <= 4."""
+    9 cores, every bond <= 4, at most one two-valued core or exactly one many-valued core, q^C <= 4."""
     prod = 1
     for o in outs:
         prod *= o
-    return (len(pos) <= 9 and bonds[0] == 1 and 2 <= max(bonds) <= 4 and all(o in (1, 2) for o in outs) and prod <= 2
-            and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2)))
+    many = [o for o in outs if o != 1]
+    shape_ok = len(pos) <= 9 and bonds[0] == 1 and 2 <= max(bonds) <= 4 and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2))
+    # at most one two-valued core - or exactly one many-valued core (3..16 values: the classifier's ten-label string)
+    return shape_ok and ((all(o in (1, 2) for o in outs) and prod <= 2) or (len(many) == 1 and 3 <= many[0] <= 16))
 
 
 def sbs_band_family_takes(pos, bonds, outs, C, q):
@@ -553,6 +555,66 @@ def test_convsbs_reg_family_shapes(case):
     """Lane = window, chain state and every core's input state in registers, dX written by the kernel that owns the
     band of pixel rows, dCore through per-workgroup records: bands, halo rows, ragged waves, looping lanes, unequal
     bonds, both channel modes - against the oracle, and bit-reproducible."""
+    pos, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided = case
+    assert sbs_reg_family_takes(pos, bonds, outs, C, q)
+    torch.manual_seed(B + H + W)
+    spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
+    m = ConvSBS(spec, DumbNormalInitialization((q ** C * max(bonds)) ** -0.5 * 1.2)).to(DEV)
+    for c in m.cores:
+        c.requires_grad_(core_grad)
+    x0 = torch.randn(C, B, H, W, q)
+    x = x0.to(DEV)
+    if strided:
+        x = x.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    x.requires_grad_(x_grad)
+    y = m(x)
+    assert dctn_amd.last_kernel() == "convsbs_fwd_reg_f32"
+    cores64 = [c.detach().cpu().double() for c in m.cores]
+    want = R.convsbs_forward(cores64, list(pos), x0.double())
+    check(y, want, torch.float32, "forward")
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert dctn_amd.last_kernel() == "convsbs_bwd_reg_f32"
+    gr = R.grads(lambda xx, *cc: R.convsbs_forward(cc, list(pos), xx), [x0.double()] + cores64, dy.cpu().double())
+    if x_grad:
+        check(x.grad, gr[0], torch.float32, "dX")
+    else:
+        assert x.grad is None
+    for i, (c, gc) in enumerate(zip(m.cores, gr[1:])):
+        if core_grad:
+            check(c.grad, gc, torch.float32, f"dCore{i}")
+        else:
+            assert c.grad is None
+    first = ([c.grad.clone() for c in m.cores] if core_grad else []) + ([x.grad.clone()] if x_grad else [])
+    for c in m.cores:
+        c.grad = None
+    x.grad = None
+    m(x).backward(dy)
+    again = ([c.grad for c in m.cores] if core_grad else []) + ([x.grad] if x_grad else [])
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+
+
+MV_CASES = [
+    # pos, bonds, outs, C, q, B, H, W, x needs grad, cores need grad, strided x
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 10, 1, 1, 1, 1), 2, 2, 3, 10, 10, True, True, False),   # the classifier's final string, bond 4
+    (SNAKE9, (1,) + (2,) * 8, (1, 1, 1, 1, 10, 1, 1, 1, 1), 2, 2, 130, 8, 8, True, True, False),   # ... at the reference's default bond, many images
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 10, 1, 1, 1, 1), 1, 3, 2, 12, 40, True, True, True),    # one channel, q = 3, wide rows, strided x
+    (SNAKE9, (1,) + (3,) * 8, (16, 1, 1, 1, 1, 1, 1, 1, 1), 1, 2, 2, 7, 9, True, True, False),     # the many-valued core first (no prefix)
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 1, 1, 1, 1, 3), 1, 4, 2, 6, 6, True, True, False),      # ... last (no suffix), q = 4
+    (SNAKE9, (1, 2, 4, 3, 4, 2, 4, 3, 4), (1, 1, 5, 1, 1, 1, 1, 1, 1), 2, 2, 3, 9, 8, True, True, False),   # unequal bonds
+    (((0, 0), (0, 1), (1, 1), (1, 0)), (1, 4, 4, 4), (1, 7, 1, 1), 1, 3, 6, 6, 5, True, True, False),       # four cores
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 10, 1, 1, 1, 1), 2, 2, 3, 10, 10, False, True, False),  # x without gradient
+    (SNAKE9, (1,) + (4,) * 8, (1, 1, 1, 1, 10, 1, 1, 1, 1), 2, 2, 3, 10, 10, True, False, False),  # cores without gradient
+]
+
+
+@pytest.mark.parametrize("case", MV_CASES, ids=lambda c: "n%d_b%s_o%s_C%dq%d_B%d_%dx%d%s%s%s" % (
+    len(c[0]), max(c[1]), "x".join(map(str, c[2])), c[3], c[4], c[5], c[6], c[7], "" if c[8] else "_nodx", "" if c[9] else "_nodcore",
+    "_strided" if c[10] else ""))
+def test_convsbs_reg_family_many_valued_core(case):
+    """One many-valued core (the ten-label final string of the reference's classifier, mnist.py:213-223) on the register
+    sweep: prefix state, suffix vector, one dot product per output; the many-valued core at either end and in the
+    middle, both channel modes, unequal bonds, bands - against the oracle, and bit-reproducible."""
     pos, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided = case
     assert sbs_reg_family_takes(pos, bonds, outs, C, q)
     torch.manual_seed(B + H + W)

@@ -1105,8 +1105,8 @@ def test_graphed_train_step_matches_eager():
 @pytest.mark.parametrize("bond,ring", [(4, False), (4, True), (2, False)])
 def test_convsbs_classifier_step_eager_and_graphed(bond, ring):
     """The reference's ConvSBS classifier (mnist.py:170-262: two-string layers, a final string with ten labels on its
-    middle core): every string runs on the MFMA sweep (slices of the many-valued core, ring slices, bond 2 zero-padded
-    to the 4-wide tiles); the whole training iteration is capturable (no synchronisation, no host read-back on
+    middle core): open chains run on the register sweep - the ten-label string too -, rings on the matrix-core sweep (ring
+    slices, slices of the many-valued core); the whole training iteration is capturable (no synchronisation, no host read-back on
     the path) and the graphed iteration leaves the parameters where the eager one leaves them."""
     import copy
 
@@ -1154,7 +1154,9 @@ def test_convsbs_classifier_step_eager_and_graphed(bond, ring):
     a.calibrate(xs[0])
     b = copy.deepcopy(a)
     y0 = a(xs[0])
-    want_family = "convsbs_fwd_mfma_f32"   # (bond 2: zero-padded to the 4-wide tiles)
+    # the last string to run is the ten-label one: open chains of bond <= 4 take it on the register sweep (prefix state,
+    # suffix vector, one dot product per label: convsbs_reg.hip); rings run as slices of the matrix-core sweep
+    want_family = "convsbs_fwd_mfma_f32" if ring else "convsbs_fwd_reg_f32"
     assert dctn_amd.last_kernel() == want_family and y0.shape == (8, 10)
     assert 1e-3 < float(y0.detach().abs().median()) < 1e3, float(y0.detach().abs().median())   # a live model
     # (a small step: the gradients of a 27-core product are large and an unnormalised ring model diverges quickly; the
