@@ -310,122 +310,6 @@ __device__ __forceinline__ void sr_wave_reduce_add(const float* prod, float* wac
   }
 }
 
-// ---- the same lane sums on the matrix core.  dCore[l][r][qq] += sum over the wave's 64 windows of vg[l][r] f[qq] is a
-// GEMM with the WINDOWS on k:  A[i = (l, r)][k = window] = vg,  B[k = window][j = qq] = f  (v_mfma_f32_16x16x4_f32, 16
-// k-steps).  Lane = window, so both operands go through a per-wave LDS tile [window][16] / [window][4] (16-byte row
-// writes, transposed 4-byte reads; the 16-byte slot of a row is XORed with bits 1..2 of the row: both conflict-free) -
-// 5 stores + 32 loads + 16 MFMAs per slice where the swap / DPP tree (sr_wave_reduce_add) issues ~2.5 vector
-// instructions per entry on top of the E products (64 entries: ~220 instructions; SQ counters of round 3: the tree was
-// a third of the backward's 4 600 vector instructions per wave).
-typedef __attribute__((ext_vector_type(4))) float sr_f4;
-constexpr int SR_TILE = 64 * 16 + 64 * 4;   // floats of one wave's transposition tile
-
-__device__ __forceinline__ void sr_wave_lds_order() {   // LDS written by lanes of this wave, read by others of the same wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// vg: RR = R*R values per lane (index l * R + r); fo: the lane's QC feature values (zero for windows another band owns);
-// dst: this wave's sums of the slice, [l][r][qq]
-template <int RR, int QC>
-__device__ __forceinline__ void sr_outer_add(const float* vg, const float* fo, float* tile, float* dst, int lane, bool first) {
-  float* tv = tile;
-  float* tf = tile + 64 * 16;
-  const int sw = (lane >> 1) & 3;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    *reinterpret_cast<sr_f4*>(tv + lane * 16 + 4 * (k ^ sw)) =
-        sr_f4{4 * k < RR ? vg[4 * k < RR ? 4 * k : 0] : 0.f, 4 * k + 1 < RR ? vg[4 * k + 1 < RR ? 4 * k + 1 : 0] : 0.f,
-              4 * k + 2 < RR ? vg[4 * k + 2 < RR ? 4 * k + 2 : 0] : 0.f, 4 * k + 3 < RR ? vg[4 * k + 3 < RR ? 4 * k + 3 : 0] : 0.f};
-  *reinterpret_cast<sr_f4*>(tf + lane * 4) = sr_f4{fo[0], QC > 1 ? fo[QC > 1 ? 1 : 0] : 0.f, QC > 2 ? fo[QC > 2 ? 2 : 0] : 0.f,
-                                                     QC > 3 ? fo[QC > 3 ? 3 : 0] : 0.f};
-  sr_wave_lds_order();
-  const int i = lane & 15, g = lane >> 4;
-  float a[16], b[16];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const int w = 4 * ks + g;                                   // k-step ks of lane group g is window 4 ks + g
-    a[ks] = tv[w * 16 + 4 * ((i >> 2) ^ ((w >> 1) & 3)) + (i & 3)];
-    b[ks] = tf[w * 4 + (i & 3)];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  sr_f4 acc = sr_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], i < 4 ? b[ks] : 0.f, acc, 0, 0, 0);
-  if (i < QC) {   // lane (column qq = i, group g): register t is row (l, r) = 4 g + t
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int e = 4 * g + t;
-      if (e < RR) {
-        if (first) dst[e * QC + i] = acc[t]; else dst[e * QC + i] += acc[t];
-      }
-    }
-  }
-  sr_wave_lds_order();
-}
-
-// three factors: dCore_m[o][lr][qq] += sum_w dY[w][o] vsr[w][lr] f[w][qq]  (the many-valued core: O <= 16 rows o, RR <= 16
-// columns lr, one product chain per qq).  dy16: the lane's O values of dY (zero beyond O, and for windows of another band)
-template <int RR, int QC>
-__device__ __forceinline__ void sr_outer3_add(const float* dy16, const float* vsr, const float* f, float* tile, float* dst, int O,
-                                              int lane, bool first) {
-  float* tv = tile;             // dY rows [window][16] (swizzled) - read as the A operand
-  float* tf = tile + 64 * 16;   // f rows [window][4]
-  const int sw = (lane >> 1) & 3;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    *reinterpret_cast<sr_f4*>(tv + lane * 16 + 4 * (k ^ sw)) = sr_f4{dy16[4 * k], dy16[4 * k + 1], dy16[4 * k + 2], dy16[4 * k + 3]};
-  *reinterpret_cast<sr_f4*>(tf + lane * 4) = sr_f4{f[0], QC > 1 ? f[QC > 1 ? 1 : 0] : 0.f, QC > 2 ? f[QC > 2 ? 2 : 0] : 0.f,
-                                                     QC > 3 ? f[QC > 3 ? 3 : 0] : 0.f};
-  sr_wave_lds_order();
-  const int i = lane & 15, g = lane >> 4;
-  float a[16];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const int w = 4 * ks + g;
-    a[ks] = tv[w * 16 + 4 * ((i >> 2) ^ ((w >> 1) & 3)) + (i & 3)];
-  }
-  sr_wave_lds_order();
-  // second use of the tile's first part: vsr rows [window][16] (the B operand's column factor)
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    *reinterpret_cast<sr_f4*>(tv + lane * 16 + 4 * (k ^ sw)) =
-        sr_f4{4 * k < RR ? vsr[4 * k < RR ? 4 * k : 0] : 0.f, 4 * k + 1 < RR ? vsr[4 * k + 1 < RR ? 4 * k + 1 : 0] : 0.f,
-              4 * k + 2 < RR ? vsr[4 * k + 2 < RR ? 4 * k + 2 : 0] : 0.f, 4 * k + 3 < RR ? vsr[4 * k + 3 < RR ? 4 * k + 3 : 0] : 0.f};
-  sr_wave_lds_order();
-  float bv[16], bf[16][QC];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const int w = 4 * ks + g;
-    bv[ks] = tv[w * 16 + 4 * ((i >> 2) ^ ((w >> 1) & 3)) + (i & 3)];   // vsr[w][lr = i]
-#pragma unroll
-    for (int qq = 0; qq < QC; ++qq) bf[ks][qq] = tf[w * 4 + qq];           // f[w][qq] (one address per lane group: broadcast)
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  sr_f4 acc[QC];
-#pragma unroll
-  for (int qq = 0; qq < QC; ++qq) acc[qq] = sr_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-    for (int qq = 0; qq < QC; ++qq) acc[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks] * bf[ks][qq], acc[qq], 0, 0, 0);
-  if (i < RR) {   // lane (column lr = i, group g): register t is row o = 4 g + t
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int o = 4 * g + t;
-      if (o < O) {
-#pragma unroll
-        for (int qq = 0; qq < QC; ++qq) {
-          float* d = dst + (o * RR + i) * QC + qq;
-          if (first) *d = acc[qq][t]; else *d += acc[qq][t];
-        }
-      }
-    }
-  }
-  sr_wave_lds_order();
-}
-
 template <int R, int QC, bool TWOCH, int NC>
 __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_reg_k(SrP p) {
   constexpr int PKC = 2 * R * R * QC, PK = NC * PKC, E = R * R * QC;
@@ -783,8 +667,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP pa, SrP
   const SrP& p = pa;                  // geometry, x, dX, records: common to the strings
   const int tot = pa.tot_all;
   float* wacc = smem;                 // [NWAVES][tot]: per-wave dCore sums, natural layout
-  float* tiles = wacc + ((NWAVES * tot + 3) & ~3);   // [NWAVES][SR_TILE]: per-wave transposition tiles of the middle cores' lane sums
-  float* dfl = tiles + NWAVES * SR_TILE;             // [windows of the band][NC * C * q]
+  float* dfl = wacc + NWAVES * tot;   // [windows of the band][NC * C * q]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Cq = p.C * p.q, NCq = NC * Cq;
   const int img = blockIdx.x / p.bands, band = blockIdx.x - img * p.bands;
@@ -961,14 +844,17 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regu_k(SrP pa, SrP
             }
           }
         }
+        float prod[EM];
 #pragma unroll
         for (int l = 0; l < R; ++l)
 #pragma unroll
           for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int qq = 0; qq < QC; ++qq) dF[qq] = fmaf(vg[l][r], ks[(l * R + r) * QC + qq], dF[qq]);
-        // the slice's dCore sums over the wave's windows: on the matrix core (sr_outer_add)
-        if (want_dcore) sr_outer_add<R * R, QC>(&vg[0][0], fo, tiles + wave * SR_TILE, wa + p.coff[c] + SL * EM, lane, first);
+            for (int qq = 0; qq < QC; ++qq) {
+              dF[qq] = fmaf(vg[l][r], ks[(l * R + r) * QC + qq], dF[qq]);
+              prod[(l * R + r) * QC + qq] = vg[l][r] * fo[qq];
+            }
+        if (want_dcore) sr_wave_reduce_add<EM>(prod, wa + p.coff[c] + SL * EM, lane, first);
       };
       slice(std::integral_constant<int, 0>{});
       if (oc == 2) slice(std::integral_constant<int, 1>{});
@@ -1165,15 +1051,13 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
   const int PK = (NC + p.O) * E;
   float* pack = smem;                 // [PK]
   float* wacc = pack + PK;            // [NWAVES][PK]: per-wave dCore sums
-  float* tiles = wacc + NWAVES * PK;  // [NWAVES][SR_TILE]: per-wave transposition tiles of the lane sums (sr_outer_add)
-  float* dfl = tiles + NWAVES * SR_TILE;   // [windows of the band][n * C * q]: d/d(pixel values) per window
+  float* dfl = wacc + NWAVES * PK;    // [windows of the band][n * C * q]: d/d(pixel values) per window
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Cq = p.C * p.q, NCq = p.n * Cq;
   const int img = blockIdx.x / p.bands, band = blockIdx.x - img * p.bands;
   const int r0 = band * p.band_rows, r1 = min(p.H, r0 + p.band_rows);
   const int wr0 = max(0, r0 - p.max_h), wr1 = min(p.Ho, r1);
   const int nwin = wr1 > wr0 ? (wr1 - wr0) * p.Wo : 0;
-  float* tile = tiles + wave * SR_TILE;
   sm_fill_pack<R, QC>(pack, p, NC, tid, SR_BWD_THREADS);
   for (int e = tid; e < NWAVES * PK; e += SR_BWD_THREADS) wacc[e] = 0.f;
   __syncthreads();
@@ -1230,14 +1114,23 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
       }
     };
 
-    // ---- the many-valued core, pass A: dCore_m[o][lr][qq] += dY[o] vsr[lr] f[qq] summed over the wave's windows: one
-    // three-factor product on the matrix core (rows o, columns lr, a chain per qq)
+    // ---- the many-valued core, pass A: dCore_m[o] += dY[o] (v x s x f) - O lane sums of E products
     const float* dyp = p.dY + w * p.O;
     if (p.part != nullptr) {
-      float dy16[16];
+#pragma unroll 1
+      for (int o = 0; o < p.O; ++o) {
+        const float g = owner ? dyp[o] : 0.f;
+        float prod[E];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) dy16[o] = (owner && o < p.O) ? dyp[o < p.O ? o : 0] : 0.f;
-      sr_outer3_add<R * R, QC>(dy16, &vsr[0][0], fm, tile, wmine + NC * E, p.O, lane, first);
+        for (int l = 0; l < R; ++l)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float gv = g * vsr[l][r];
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) prod[(l * R + r) * QC + qq] = gv * fm[qq];
+          }
+        sr_wave_reduce_add<E>(prod, wmine + (NC + o) * E, lane, first);
+      }
     }
     // ---- pass B: dz = sum_o dY[o] core_m[o], then its three contractions
     float dv[R], ds[R], dFm[QC];
@@ -1276,10 +1169,10 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
       if (c == p.mv) put_row(c, dFm);
       if (c > p.mv && c < p.n) {
         const float* pkc = pack + c * E;
-        float T[R][R], dF[QC], nds[R], dTm[R][R], fo[QC];
+        float T[R][R], dF[QC], nds[R], prod[E];
         sr_tmat<R, QC>(pkc, f[c], T);
 #pragma unroll
-        for (int qq = 0; qq < QC; ++qq) { dF[qq] = 0.f; fo[qq] = owner ? f[c][qq] : 0.f; }
+        for (int qq = 0; qq < QC; ++qq) dF[qq] = 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) nds[r] = 0.f;
 #pragma unroll
@@ -1287,12 +1180,14 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const float dT = ds[l] * ss[c + 1][r];
-            dTm[l][r] = dT;
             nds[r] = fmaf(T[l][r], ds[l], nds[r]);
 #pragma unroll
-            for (int qq = 0; qq < QC; ++qq) dF[qq] = fmaf(dT, pkc[(l * R + r) * QC + qq], dF[qq]);
+            for (int qq = 0; qq < QC; ++qq) {
+              dF[qq] = fmaf(dT, pkc[(l * R + r) * QC + qq], dF[qq]);
+              prod[(l * R + r) * QC + qq] = owner ? dT * f[c][qq] : 0.f;
+            }
           }
-        if (p.part != nullptr) sr_outer_add<R * R, QC>(&dTm[0][0], fo, tile, wmine + c * E, lane, first);
+        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wmine + c * E, lane, first);
 #pragma unroll
         for (int r = 0; r < R; ++r) ds[r] = nds[r];
         put_row(c, dF);
@@ -1303,24 +1198,26 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
     for (int c = NC - 1; c >= 0; --c) {
       if (c < p.mv) {
         const float* pkc = pack + c * E;
-        float T[R][R], dF[QC], Gin[R], vgm[R][R], fo[QC];
+        float T[R][R], dF[QC], Gin[R], prod[E];
         sr_tmat<R, QC>(pkc, f[c], T);
 #pragma unroll
-        for (int qq = 0; qq < QC; ++qq) { dF[qq] = 0.f; fo[qq] = owner ? f[c][qq] : 0.f; }
+        for (int qq = 0; qq < QC; ++qq) dF[qq] = 0.f;
 #pragma unroll
         for (int l = 0; l < R; ++l) {
           float a = 0.f;
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const float vg = vs[c][l] * dv[r];
-            vgm[l][r] = vg;
             a = fmaf(T[l][r], dv[r], a);
 #pragma unroll
-            for (int qq = 0; qq < QC; ++qq) dF[qq] = fmaf(vg, pkc[(l * R + r) * QC + qq], dF[qq]);
+            for (int qq = 0; qq < QC; ++qq) {
+              dF[qq] = fmaf(vg, pkc[(l * R + r) * QC + qq], dF[qq]);
+              prod[(l * R + r) * QC + qq] = owner ? vg * f[c][qq] : 0.f;
+            }
           }
           Gin[l] = a;
         }
-        if (p.part != nullptr) sr_outer_add<R * R, QC>(&vgm[0][0], fo, tile, wmine + c * E, lane, first);
+        if (p.part != nullptr) sr_wave_reduce_add<E>(prod, wmine + c * E, lane, first);
 #pragma unroll
         for (int r = 0; r < R; ++r) dv[r] = Gin[r];
         put_row(c, dF);
@@ -1412,8 +1309,7 @@ bool sr_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void*
   // ~2 workgroups per CU) when the batch is small
   const int NCq = n * C * q;
   const size_t PK = (size_t)SR_MAXC * 2 * pl.R * pl.R * pl.QC;
-  const size_t fixed = pl.uniform ? (((size_t)pl.tot * (SR_BWD_THREADS / 64) + 3) & ~(size_t)3) + (size_t)(SR_BWD_THREADS / 64) * SR_TILE
-                                  : PK * (1 + SR_BWD_THREADS / 64);
+  const size_t fixed = pl.uniform ? (size_t)pl.tot * (SR_BWD_THREADS / 64) : PK * (1 + SR_BWD_THREADS / 64);
   int best = -1;
   for (int nb = 1; nb <= H; ++nb) {
     const int br = (H + nb - 1) / nb;
@@ -1482,7 +1378,7 @@ bool sm_fill(SrP& p, SrPlan& pl, const void* x, const int64_t xs[5], const void*
   for (int c = 0; c < SR_MAXC; ++c) p.slot[c] = c;
   const int NCq = n * C * q;
   const size_t PK = (size_t)(SR_MAXC + p.O) * pl.R * pl.R * pl.QC;
-  const size_t fixed = PK * (1 + SR_BWD_THREADS / 64) + (size_t)(SR_BWD_THREADS / 64) * SR_TILE;
+  const size_t fixed = PK * (1 + SR_BWD_THREADS / 64);
   int best = -1;
   for (int nb = 1; nb <= H; ++nb) {
     const int br = (H + nb - 1) / nb;
@@ -1725,8 +1621,7 @@ bool su_plan_many(SrP* ps, SrPlan& pl, int ns, const void* x, const int64_t xs[5
   }
   for (int s2 = 0; s2 < ns; ++s2) ps[s2].tot_all = base;
   pl.tot = base;
-  pl.lds_bwd = ((((size_t)base * (SR_BWD_THREADS / 64) + 3) & ~(size_t)3) + (size_t)(SR_BWD_THREADS / 64) * SR_TILE +
-                (size_t)pl.max_w_in_band * n * C * q) * sizeof(float);
+  pl.lds_bwd = ((size_t)base * (SR_BWD_THREADS / 64) + (size_t)pl.max_w_in_band * n * C * q) * sizeof(float);
   return pl.lds_bwd <= DCTN_LDS_BUDGET;
 }
 }  // namespace
