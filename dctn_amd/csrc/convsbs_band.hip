@@ -83,8 +83,8 @@ struct BdTailP {
   float* dcore[BD_NC];
   int core_off[BD_NC + 1];
   int n, nrec, total, rec_len;
-  int bl[BD_NC], br[BD_NC];
-  int qc;
+  int bl[BD_NC], br[BD_NC], o[BD_NC];
+  int qc, c2;
   const float* records;
   const float* side;
   float* dX;
@@ -906,27 +906,15 @@ __global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP
 // partial sums.  64 elements per workgroup, 4 record subsets, LDS join (as convsbs_dcore_reduce_k).
 __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
   __shared__ float red[4][64];
-  const int nblk_core = p.records ? (p.total + 63) / 64 : 0;
+  const int nblk_core = p.records ? (p.rec_len + 63) / 64 : 0;
   if ((int)blockIdx.x < nblk_core) {
-    // output element e of the cores' layouts back to back -> its position in a record (the join area's layout: middle cores
-    // as accumulator tiles [slot][qq][register = r' & 3][lane = l + 16 (r' >> 2)], then the first and the last core [16][4])
-    const int e = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    int c = 0, pos = 0;
-    if (e < p.total) {
-      while (c + 1 < p.n && e >= p.core_off[c + 1]) ++c;
-      const int idx = e - p.core_off[c];
-      if (c == 0 || c == p.n - 1) {
-        pos = BD_NPK * p.qc * 256 + (c == 0 ? 0 : 64) + (idx / p.qc) * 4 + idx % p.qc;
-      } else {
-        const int qq = idx % p.qc, t = idx / p.qc;
-        const int r = t % p.br[c], t1 = t / p.br[c];
-        const int l = t1 % p.bl[c], o = t1 / p.bl[c];
-        const int slot = o == 0 ? c - 1 : BD_NPK - 1;
-        pos = ((slot * p.qc + qq) * 4 + (r & 3)) * 64 + l + 16 * (r >> 2);
-      }
-    }
+    // 64 consecutive POSITIONS of the records per workgroup (coalesced: a record is the join area as it stands - middle
+    // cores as accumulator tiles [slot][qq][register = r' & 3][lane = l + 16 (r' >> 2)], then the first and the last core
+    // [16][4]); the sum goes to the element of the cores' layouts that position stands for.  (Element-major reads
+    // gathered one 4-byte word per 64-byte line: 51 MB of traffic for 6.4 MB of records.)
+    const int pos = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < p.total) {
+    if (pos < p.rec_len) {
       int r = sub;
       for (; r + 12 < p.nrec; r += 16) {
         a0 += p.records[(size_t)r * p.rec_len + pos];
@@ -938,8 +926,30 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
     }
     red[sub][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (sub == 0 && e < p.total)
-      p.dcore[c][e - p.core_off[c]] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && pos < p.rec_len) {
+      const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      const int cpt = BD_NPK * p.qc * 256;
+      int c, o = 0, l, r, qq;
+      if (pos >= cpt) {   // first core [r'][4] / last core [l][4]
+        const int e = pos - cpt, last = e >= 64;
+        c = last ? p.n - 1 : 0;
+        const int rr = (e & 63) >> 2;
+        qq = e & 3;
+        l = last ? rr : 0;
+        r = last ? 0 : rr;
+      } else {
+        const int ln = pos & 63, reg = (pos >> 6) & 3, rest = pos >> 8;
+        qq = rest % p.qc;
+        const int slot = rest / p.qc;
+        c = slot < BD_NPK - 1 ? slot + 1 : p.c2;
+        o = slot < BD_NPK - 1 ? 0 : 1;
+        l = ln & 15;
+        r = 4 * (ln >> 4) + reg;
+        if (slot < BD_NPK - 1 && c + 1 >= p.n) c = -1;   // a slot of a core the string does not have
+      }
+      if (c >= 0 && c < p.n && p.dcore[c] != nullptr && qq < p.qc && l < p.bl[c] && r < p.br[c] && o < p.o[c])
+        p.dcore[c][((o * p.bl[c] + l) * p.br[c] + r) * p.qc + qq] = v;
+    }
     return;
   }
   // shared rows: element = (image, boundary, row, column, channel, value)
@@ -1113,12 +1123,13 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
   BdTailP t;
   t.n = n; t.nrec = pl.nwg; t.total = p.core_off[n]; t.qc = p.qc; t.rec_len = pl.rec_len;
   for (int c = 0; c <= BD_NC; ++c) t.core_off[c] = p.core_off[c];
-  for (int c = 0; c < BD_NC; ++c) { t.bl[c] = p.bl[c]; t.br[c] = p.br[c]; }
+  for (int c = 0; c < BD_NC; ++c) { t.bl[c] = p.bl[c]; t.br[c] = p.br[c]; t.o[c] = p.o[c]; }
+  t.c2 = p.c2;
   for (int c = 0; c < BD_NC; ++c) t.dcore[c] = (dcores && c < n) ? dcores[c] : nullptr;
   t.records = p.records; t.side = p.side; t.dX = p.dX;
   t.B = B; t.H = H; t.W = W; t.C = C; t.q = q; t.Cq = C * q; t.nb = p.nb; t.band_rows = p.band_rows; t.max_h = p.max_h;
   t.nshared = p.dX ? (long long)B * (p.nb - 1) * p.max_h * W * C * q : 0;
-  const long long blocks = (p.records ? (t.total + 63) / 64 : 0) + (t.nshared + 255) / 256;
+  const long long blocks = (p.records ? (t.rec_len + 63) / 64 : 0) + (t.nshared + 255) / 256;
   if (blocks > 0) {
     hipLaunchKernelGGL(convsbs_band_tail_k, dim3((unsigned)blocks), dim3(256), 0, st, t);
     DCTN_CHECK_LAUNCH();
