@@ -828,6 +828,10 @@ def main():
                     help="capture the gradient all-reduce into the step's HIP graph.  auto (default): yes over RCCL when a "
                          "child-process probe shows that the capture works on this machine; 1: the same, and fail if it does "
                          "not; 0: replay the fwd+bwd graph and launch the collective eagerly")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "direct"],
+                    help="gradient all-reduce of the step: rccl (default: torch.distributed all_reduce = RCCL ring / tree) or direct "
+                         "(dctn_ar_*: one kernel per step and rank reading every peer's buffer over its own xGMI link, "
+                         "always inside the step's HIP graph); the line carries allreduce_us of both")
     ap.add_argument("--configs", default="all",
                     help="the other BASELINE configs measured into `configs` at N = 1: all (default), none, or a comma list of "
                          + ", ".join(EXTRA_CONFIGS))
@@ -968,8 +972,9 @@ def main():
             x.grad = None
             logmatmulexp_fold(x).backward(out_grad)
 
-    reducer = (ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce)
+    reducer = (ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce, algorithm=args.allreduce)
                if (params and (world > 1 or force_reduce)) else None)
+    direct = reducer is not None and getattr(reducer, "_direct", None) is not None
 
     def fwd_bwd_reduce():
         fwd_bwd()
@@ -991,7 +996,8 @@ def main():
     # of limping on: after a failed capture of a collective, later collectives of this process fail.
     graph, reduce_in_graph = None, False
     if args.graph:
-        want_reduce = reducer is not None and probe_ok is not None and ddp.all_ranks_agree(bool(probe_ok), dev)
+        # (the direct collective is a plain kernel launch: capturable without a probe)
+        want_reduce = reducer is not None and (direct or (probe_ok is not None and ddp.all_ranks_agree(bool(probe_ok), dev)))
         if reducer is not None and args.graph_allreduce == "1" and not want_reduce:
             raise SystemExit("--graph-allreduce 1: the all-reduce capture probe failed (or the backend is not RCCL)")
         if want_reduce:
@@ -1057,7 +1063,7 @@ def main():
 
     # what the collective costs, alone: the same message, replayed from a graph when the step's collective is (device
     # time of back-to-back dependent all-reduces), else launched eagerly as in the step
-    allreduce_us = step_without_allreduce_us = allreduce_bytes = None
+    allreduce_us = step_without_allreduce_us = allreduce_bytes = other_us = None
     if reducer is not None:
         flat = getattr(reducer, "_flat", None)
         msg = flat if flat is not None else reducer.bucket
@@ -1079,10 +1085,29 @@ def main():
             step_without_allreduce_us = device_time(g2.replay, dev, max(1, args.steps // gsteps), graph=False) / gsteps * 1e6
         else:
             step_without_allreduce_us = device_time(fwd_bwd, dev, args.steps, graph=False) * 1e6
+        # the same message through the OTHER algorithm (eager launches; the direct one replayed from a graph too)
+        other_us = None
+        try:
+            if direct:
+                other = ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce, algorithm="rccl")
+                other_us = device_time(lambda: other._reduce(buf), dev, 100, graph=False) * 1e6
+            elif world > 1 and msg.is_cuda:
+                dr = ddp.DirectAllReducer(msg.numel(), msg.dtype, dev, average=True)
+
+                def ten_direct():
+                    for _ in range(10):
+                        dr(buf)
+                other_us = device_time(ten_direct, dev, 20) / 10 * 1e6
+                if dr.status() != 0:
+                    other_us = None
+        except Exception as e:   # noqa: BLE001
+            log(f"timing the other all-reduce algorithm failed ({type(e).__name__}: {e})")
         if world > 1:   # the slowest rank's figures
-            t = torch.tensor([allreduce_us, step_without_allreduce_us], dtype=torch.float64, device=dev)
+            t = torch.tensor([allreduce_us, step_without_allreduce_us, other_us if other_us is not None else -1.0],
+                             dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             allreduce_us, step_without_allreduce_us = float(t[0]), float(t[1])
+            other_us = float(t[2]) if float(t[2]) >= 0 else None
 
     # one step per graph launch beside the default several: what a training loop that feeds fresh data every step gets
     # (GraphedTrainStep replays one iteration per launch); the difference is the command processor's per-launch work
@@ -1128,7 +1153,10 @@ def main():
             "blocks_ms": [b * 1e3 for b in block_s],
             "allreduce_in_graph": reduce_in_graph,
             "allreduce_capture_probe": probe_ok,
+            "allreduce": args.allreduce if reducer is not None else None,
             "allreduce_us": allreduce_us,
+            "allreduce_us_direct": (allreduce_us if direct else other_us) if reducer is not None else None,
+            "allreduce_us_rccl": (other_us if direct else allreduce_us) if reducer is not None else None,
             "allreduce_bytes": allreduce_bytes,
             "step_without_allreduce_us": step_without_allreduce_us,
             "rccl_env": rccl_env,

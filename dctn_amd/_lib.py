@@ -84,6 +84,13 @@ SIGNATURES = {
     "dctn_fiber_gram_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_i64, c_int]),
     "dctn_fiber_gram": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_i64, c_int, c_void]),
     "dctn_logmatmulexp_fold_bwd": (c_int, [c_void, c_void, c_void, c_void, c_size, c_i64, c_int, c_int, c_int, c_void]),
+    "dctn_ar_handle_bytes": (c_size, []),
+    "dctn_ar_create": (c_int, [c_int, c_int, c_size, _PtrP]),
+    "dctn_ar_export": (c_int, [c_void, c_void]),
+    "dctn_ar_connect": (c_int, [c_void, c_void]),
+    "dctn_ar_allreduce": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void]),
+    "dctn_ar_status": (c_int, [c_void]),
+    "dctn_ar_destroy": (c_int, [c_void]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -146,9 +146,14 @@ class FlatGradAllReducer:
     dtype (no conversion kernels); mixed dtypes go through an fp32 bucket.
     """
 
-    def __init__(self, params: Iterable[Tensor], average: bool = True, skip_single_rank: bool = True):
+    def __init__(self, params: Iterable[Tensor], average: bool = True, skip_single_rank: bool = True,
+                 algorithm: str = "rccl"):
+        """algorithm: "rccl" (default: `dist.all_reduce`) or "direct" (`DirectAllReducer`: one kernel per step reading the
+        peers' buffers over all xGMI links at once; ranks of one node, device tensors)."""
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         self.average = average
+        self.algorithm = algorithm
+        self._direct: Optional["DirectAllReducer"] = None
         self.skip_single_rank = skip_single_rank   # False: issue the collective even for one rank (rehearsal)
         self._seen_grads: List[Optional[Tensor]] = []
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -165,10 +170,17 @@ class FlatGradAllReducer:
             off += p.numel()
         backend = dist.get_backend() if dist.is_initialized() else ""
         self.use_avg = average and backend == "nccl"
+        if algorithm == "direct" and self.bucket.is_cuda and self.world > 1:
+            # (created here, eagerly: it allocates, maps its peers' blocks and synchronises - none of which may happen
+            # inside a HIP-graph capture of the step)
+            self._direct = DirectAllReducer(numel, bucket_dtype, ref.device, average=average)
 
     def _reduce(self, buf: Tensor) -> None:
         """In-place sum / mean of ``buf`` over the ranks.  RCCL's AVG is one launch; if the backend or
         the dtype refuses it (raised synchronously at enqueue), fall back to SUM + divide for good."""
+        if self._direct is not None and buf.is_cuda and buf.dtype == self._direct.dtype and buf.numel() <= self._direct.max_numel:
+            self._direct(buf)
+            return
         if self.use_avg:
             try:
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG)
@@ -228,6 +240,61 @@ class FlatGradAllReducer:
                     p.grad = v.to(p.dtype).clone()
                 else:
                     p.grad.copy_(v)
+
+
+class DirectAllReducer:
+    """One-shot direct all-reduce of ONE flat device tensor over peer-mapped buffers (`dctn_ar_*`, SURVEY section 5: the
+    messages are 58 KB .. 7.5 MB, latency-bound; on a fully connected xGMI node every rank reads its peers' buffers over all
+    its links at once instead of paying the 2 (P - 1) hops of a ring).  The ranks must share a node (IPC handles are
+    exchanged through the process group with `all_gather_object`; two ranks on one GPU work too).  `__call__(buf)` enqueues
+    one kernel on the current stream, in place, capturable into a HIP graph; every rank gets bitwise the same mean (or sum).
+    `status()` synchronises and returns 0, or r + 1 when a wait for rank r timed out (~2 s) - that step's values are then
+    invalid and the caller should fall back to the RCCL path."""
+
+    def __init__(self, max_numel: int, dtype: torch.dtype, device: torch.device, average: bool = True):
+        import ctypes
+
+        from . import _lib as L
+
+        assert dist.is_initialized(), "DirectAllReducer needs a process group to exchange its IPC handles"
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.average, self.device, self.dtype = average, device, dtype
+        self._L = L
+        lib = L.lib()
+        nbytes = int(max_numel) * torch.empty((), dtype=dtype).element_size()
+        state = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            L.check(lib.dctn_ar_create(self.world, self.rank, nbytes, ctypes.byref(state)), "direct all-reduce: create")
+            self._state = state
+            hb = int(lib.dctn_ar_handle_bytes())
+            mine = ctypes.create_string_buffer(hb)
+            L.check(lib.dctn_ar_export(state, mine), "direct all-reduce: export")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(mine.raw))
+            packed = ctypes.create_string_buffer(b"".join(handles), hb * self.world)
+            L.check(lib.dctn_ar_connect(state, packed), "direct all-reduce: connect")
+        dist.barrier()   # every rank has mapped every block before the first kernel publishes into one
+        self.max_numel = int(max_numel)
+
+    def __call__(self, buf: Tensor) -> None:
+        assert buf.is_cuda and buf.is_contiguous() and buf.dtype == self.dtype and buf.numel() <= self.max_numel
+        L = self._L
+        L.check(L.lib().dctn_ar_allreduce(self._state, buf.data_ptr(), buf.numel(), L.dtype_code(buf), int(self.average),
+                                           L.stream_ptr(buf.device)), "direct all-reduce")
+
+    def status(self) -> int:
+        return int(self._L.lib().dctn_ar_status(self._state))
+
+    def close(self) -> None:
+        if getattr(self, "_state", None) is not None:
+            self._L.lib().dctn_ar_destroy(self._state)
+            self._state = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 @torch.no_grad()

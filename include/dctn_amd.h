@@ -374,6 +374,28 @@ size_t dctn_fiber_gram_workspace_bytes(int64_t pre, int qa, int qb, int64_t post
 int dctn_fiber_gram(const void* A, const void* B, void* out, void* workspace, size_t workspace_bytes,
                     int64_t pre, int qa, int qb, int64_t post, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Latency-first gradient all-reduce over peer-mapped buffers (the reference has no
+ * collective; the build's one collective is the mean of the parameter gradients, 58 KB .. 7.5 MB: latency-bound).
+ * One-shot direct algorithm for the ranks of ONE node: every rank owns an uncached device block (flag lines + two
+ * staging buffers), exported once as an IPC handle and mapped by every peer; per step ONE kernel per rank copies the
+ * rank's values to its staging buffer, publishes its step number to every peer, waits (bounded, ~2 s) for theirs,
+ * then sums every rank's staging buffer in rank order (float32 / float64 accumulation) and writes the (scaled)
+ * result over `buf` in place: bitwise identical on all ranks.  Replayable from a HIP graph (the step counter lives
+ * in device memory).  dctn_ar_create / _connect / _status / _destroy allocate, map or synchronise and are NOT
+ * capturable; dctn_ar_allreduce only enqueues.  Host-side pairing: dctn_amd/ddp.py `DirectAllReducer`.
+ *   create(world <= 16, rank, max_bytes)  -> opaque state;  export -> dctn_ar_handle_bytes() bytes for the peers;
+ *   connect(handles of ALL ranks, rank-major);  allreduce(buf, n elements, dtype, average);
+ *   status: 0 = every wait completed, r + 1 = a wait for rank r timed out (the results of that step are invalid).
+ * ------------------------------------------------------------------------------------------ */
+size_t dctn_ar_handle_bytes(void);
+int dctn_ar_create(int world, int rank, size_t max_bytes, void** state_out);
+int dctn_ar_export(void* state, void* handle_out);
+int dctn_ar_connect(void* state, const void* handles);
+int dctn_ar_allreduce(void* state, void* buf, int64_t n, int dtype, int average, void* stream);
+int dctn_ar_status(void* state);
+int dctn_ar_destroy(void* state);
+
 #ifdef __cplusplus
 }
 #endif

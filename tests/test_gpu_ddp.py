@@ -258,7 +258,8 @@ def test_convsbs_classifier_and_fold_two_ranks_on_one_gpu():
     assert torch.allclose(torch.cat([torch.from_numpy(got[0][1]), torch.from_numpy(got[1][1])]), whole, rtol=1e-5, atol=1e-5)
 
 
-def test_bench_gpus_2_starts_itself_without_world_size():
+@pytest.mark.parametrize("algorithm", ["rccl", "direct"])
+def test_bench_gpus_2_starts_itself_without_world_size(algorithm):
     """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (one process, no WORLD_SIZE): the parent
     starts torch.distributed.run itself, before any GPU call of its own, and relays rank 0's one JSON line.  Rehearsed
     here with both ranks on the one GPU of the test box over gloo (RCCL needs a GPU per rank)."""
@@ -270,11 +271,111 @@ def test_bench_gpus_2_starts_itself_without_world_size():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["DCTN_BENCH_ONE_DEVICE"] = "1"
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
-                          "--warmup", "2", "--batch", "64", "--configs", "none", "--no-cpu-baseline"],
+                          "--warmup", "2", "--batch", "64", "--configs", "none", "--no-cpu-baseline", "--allreduce", algorithm],
                          cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout[-1000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["config"]["windows_per_step"] == 2 * 64 * 676
-    assert line["config"]["allreduce_bytes"] and line["value"] > 0
+    assert line["config"]["allreduce_bytes"] and line["value"] > 0 and line["config"]["allreduce"] == algorithm
+    # both algorithms are timed on the step's message whichever one the step uses (`--backend gloo` stands in for RCCL here)
+    assert line["config"]["allreduce_us_direct"] > 0 and line["config"]["allreduce_us_rccl"] > 0
+    if algorithm == "direct":
+        assert line["config"]["allreduce_in_graph"] is True   # a plain kernel launch: captured without a probe
+
+
+# ------------------------------------------------------------------ the direct (one-shot) all-reduce
+def _direct_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("gloo")
+    out = {"rank": rank}
+    try:
+        for dtype, n in ((torch.float32, 29098), (torch.bfloat16, 29098), (torch.float64, 1000), (torch.float32, 1_900_000)):
+            red = ddp.DirectAllReducer(n, dtype, dev, average=True)
+            g = torch.Generator().manual_seed(100 + rank)
+            worst = 0.0
+            for step in range(5):   # (five steps: both staging buffers, the step counter, flag lines reused)
+                mine = torch.randn(n, generator=g).to(dtype)
+                both = [torch.empty(n, dtype=dtype) for _ in range(world)]
+                dist.all_gather(both, mine)
+                want = (sum(b.double() for b in both) / world)
+                buf = mine.to(dev)
+                red(buf)
+                torch.cuda.synchronize(dev)
+                tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float64: 1e-14}[dtype]
+                worst = max(worst, float((buf.cpu().double() - want).abs().max() / want.abs().max()) / tol)
+                # every rank holds bitwise the same result (same numbers added in the same order)
+                mineb = buf.cpu().view(torch.uint8)
+                allb = [torch.empty_like(mineb) for _ in range(world)]
+                dist.all_gather(allb, mineb)
+                assert all(torch.equal(allb[0], b) for b in allb)
+            out[f"{dtype}_{n}"] = worst
+            out[f"status_{dtype}_{n}"] = red.status()
+            # replayed from a HIP graph: the step counter lives in device memory
+            if n == 29098 and dtype == torch.float32:
+                static = torch.zeros(n, device=dev)
+                side = torch.cuda.Stream(dev)
+                with torch.cuda.stream(side):
+                    static.fill_(float(rank + 1))
+                    red(static)
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                graph = torch.cuda.CUDAGraph()
+                static.fill_(float(rank + 1))
+                torch.cuda.synchronize(dev)
+                with torch.cuda.graph(graph, stream=torch.cuda.Stream(dev), capture_error_mode="thread_local"):
+                    red(static)
+                ok = True
+                for k in range(4):
+                    static.fill_(float(rank + 1 + k))
+                    torch.cuda.synchronize(dev)
+                    dist.barrier()
+                    graph.replay()
+                    torch.cuda.synchronize(dev)
+                    wantv = sum(r + 1 + k for r in range(world)) / world
+                    ok = ok and bool((static == wantv).all())
+                out["graph"] = ok
+                out["status_graph"] = red.status()
+            red.close()
+        # through FlatGradAllReducer(algorithm="direct"): the same mean as the process group's all-reduce
+        params = [torch.nn.Parameter(torch.randn(5, 7, device=dev)), torch.nn.Parameter(torch.randn(11, device=dev))]
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        fr = ddp.FlatGradAllReducer(params, average=True, algorithm="direct")
+        fr()
+        torch.cuda.synchronize(dev)
+        out["flat"] = all(bool((p.grad == (world + 1) / 2).all()) for p in params)
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_allreduce_two_ranks_on_one_gpu():
+    """`dctn_ar_*` / `ddp.DirectAllReducer`: every rank's uncached block is mapped by its peer through an IPC handle; one
+    kernel per step and rank copies, publishes its step number, waits for the peer's, and sums both staging buffers in
+    rank order - here with two ranks sharing the one GPU of the test box (float32 / bfloat16 / float64, a 58 KB and a
+    7.6 MB message, five steps each, a HIP-graph replay, and through `FlatGradAllReducer(algorithm="direct")`)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for o in outs:
+        assert "error" not in o, o
+        statuses = {k: v for k, v in o.items() if k.startswith("status")}
+        assert all(v == 0 for v in statuses.values()), f"a wait timed out (the two ranks' kernels did not overlap?): {statuses}"
+        assert all(v <= 1.0 for k, v in o.items() if k.startswith("torch.")), o
+        assert o["graph"] is True and o["flat"] is True, o
