@@ -622,6 +622,172 @@ __global__ __launch_bounds__(256) void halves_dx_half_k(const S* __restrict__ x,
   }
 }
 
+// ---- cross-lane sums for the butterfly below, on the VALU (DPP / permlane swaps) - ds_bpermute-based shuffles put ~200
+// LDS-crossbar operations on every window and the LDS unit of a CU became the limit (87 us per half at cfg1, as slow as the
+// table form).  A 64-bit value moves as two 32-bit halves.
+typedef __attribute__((ext_vector_type(2))) int hv_i2;
+template <int CTRL>
+__device__ __forceinline__ float hv_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double hv_dpp(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// lanes 0-31: a summed over (lane, lane + 32); lanes 32-63: b likewise
+__device__ __forceinline__ float hv_pair32(float a, float b) {
+  const hv_i2 r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ double hv_pair32(double a, double b) {
+  const long long x = __double_as_longlong(a), y = __double_as_longlong(b);
+  const hv_i2 lo = __builtin_amdgcn_permlane32_swap((int)x, (int)y, false, false);
+  const hv_i2 hi = __builtin_amdgcn_permlane32_swap((int)(x >> 32), (int)(y >> 32), false, false);
+  return __longlong_as_double(((long long)hi[0] << 32) | (unsigned)lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | (unsigned)lo[1]);
+}
+// even rows of 16 lanes: a summed over the row pair; odd rows: b
+__device__ __forceinline__ float hv_pair16(float a, float b) {
+  const hv_i2 r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ double hv_pair16(double a, double b) {
+  const long long x = __double_as_longlong(a), y = __double_as_longlong(b);
+  const hv_i2 lo = __builtin_amdgcn_permlane16_swap((int)x, (int)y, false, false);
+  const hv_i2 hi = __builtin_amdgcn_permlane16_swap((int)(x >> 32), (int)(y >> 32), false, false);
+  return __longlong_as_double(((long long)hi[0] << 32) | (unsigned)lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | (unsigned)lo[1]);
+}
+// v + (v of the lane across bit BIT), BIT = 0..5
+template <int BIT, typename T>
+__device__ __forceinline__ T hv_xsum(T v) {
+  if constexpr (BIT == 0) return v + hv_dpp<0xB1>(v);                       // quad_perm [1,0,3,2]
+  else if constexpr (BIT == 1) return v + hv_dpp<0x4E>(v);                  // quad_perm [2,3,0,1]
+  else if constexpr (BIT == 2) return v + hv_dpp<0x1B>(hv_dpp<0x141>(v));   // half-row mirror (xor 7), then quad reverse (xor 3)
+  else if constexpr (BIT == 3) return v + hv_dpp<0x141>(hv_dpp<0x140>(v));  // row mirror (xor 15), then half-row mirror (xor 7)
+  else if constexpr (BIT == 4) return hv_pair16(v, v);
+  else return hv_pair32(v, v);
+}
+
+// ---- the same gradient for Q = 2 halves of 6..8 factors, without tables: a wave-level butterfly.
+// F(x_0 .. x_(nd-1)) = sum_e dP[e] prod_f x_f[digit_f(e)] is multilinear; reverse mode over the contraction tree
+//   u_nd = dP,   u_f[prefix] = u_(f+1)[prefix, 0] x_f[0] + u_(f+1)[prefix, 1] x_f[1]      (up-sweep, last factor first)
+//   dF/dx_f[q] = sum_prefix ( prod_(g < f) x_g[prefix_g] ) u_(f+1)[prefix, q]
+// costs ~2 E multiply-adds where the table form above spends 2 nd E (and 3 LDS reads per term).  Lane = the six leading
+// digits (factor 0 = lane bit 5 .. factor 5 = lane bit 0), the remaining nd - 6 factors are the lane's own 1 / 2 / 4 values;
+// the six cross-lane levels exchange one value with the lane across one bit; the 2 nd results are wave sums.
+// One wave per window; everything in registers; cfg1 (two 8-factor halves, float64): 2 x 60 us (the table form: 2 x 88;
+// without its loads or without its stores the kernel takes 56-59 us: f64 vector arithmetic and address work, not memory).
+template <int ND, typename T, typename S>
+__global__ __launch_bounds__(256) void halves_dx_half_q2_k(const S* __restrict__ x, const T* __restrict__ dP,
+                                                        T* __restrict__ gxw, HalfP h, int second, long long w0,
+                                                        long long nw, DxSavedZ sz) {
+  constexpr int NI = ND - 6, VPL = 1 << NI, E = 1 << ND;
+  const EpsP& p = h.p;
+  const int lane = threadIdx.x & 63;
+  const int base = second ? h.n0 : 0;
+  const int hw = p.Ho * p.Wo;
+  const long long wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  for (long long wl = wave0; wl < nw; wl += (long long)gridDim.x * 4) {
+    const long long w = w0 + wl;
+    const long long b = w / hw;
+    const int rem = (int)(w - b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    T xv[ND][2];
+#pragma unroll
+    for (int f = 0; f < ND; ++f) {
+      const int n = base + f;
+      const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
+      const S* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3];
+      xv[f][0] = (T)px[0];
+      xv[f][1] = (T)px[p.s[4]];
+    }
+    T d[VPL];
+    if (sz.mode == 0) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) d[j] = dP[wl * E + lane * VPL + j];
+    } else {
+      const S* zrow = reinterpret_cast<const S*>(sz.z) + wl * (long long)E * sz.O;
+      const S* dyr = reinterpret_cast<const S*>(sz.dy) + wl * sz.O;
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        T acc = 0.0;
+        for (int o = 0; o < sz.O; ++o) acc += (T)dyr[o] * (T)zrow[(long long)(lane * VPL + j) * sz.O + o];
+        d[j] = acc;
+      }
+    }
+    // ---- in-lane levels (factors ND-1 .. 6): u7[i6] and u6 (ND = 8), u6 (ND = 7)
+    T u7[2] = {0, 0}, v;
+    if constexpr (NI == 2) {
+      u7[0] = d[0] * xv[7][0] + d[1] * xv[7][1];
+      u7[1] = d[2] * xv[7][0] + d[3] * xv[7][1];
+      v = u7[0] * xv[6][0] + u7[1] * xv[6][1];
+    } else if constexpr (NI == 1) {
+      v = d[0] * xv[6][0] + d[1] * xv[6][1];
+    } else {
+      v = d[0];
+    }
+    // ---- six cross-lane levels: bit b of the lane is the digit of factor 5 - b
+    T vb[6], wgt[6];
+    auto level = [&](auto bc) {   // contract factor 5 - b: both lanes of a pair add their own term (t + the partner's t)
+      constexpr int bb = decltype(bc)::value;
+      vb[bb] = v;
+      const T t = v * (((lane >> bb) & 1) ? xv[5 - bb][1] : xv[5 - bb][0]);
+      v = hv_xsum<bb>(t);
+    };
+    level(std::integral_constant<int, 0>{});
+    level(std::integral_constant<int, 1>{});
+    level(std::integral_constant<int, 2>{});
+    level(std::integral_constant<int, 3>{});
+    level(std::integral_constant<int, 4>{});
+    level(std::integral_constant<int, 5>{});
+    // ---- the weights of the prefixes: wgt[b] = prod over the lane bits above b of that factor's value
+    T Wp = 1.0;
+#pragma unroll
+    for (int bb = 5; bb >= 0; --bb) {
+      wgt[bb] = Wp;
+      Wp *= ((lane >> bb) & 1) ? xv[5 - bb][1] : xv[5 - bb][0];
+    }
+    // ---- per-lane terms of the 2 ND results, then their wave sums
+    T pg[ND][2];
+#pragma unroll
+    for (int bb = 0; bb < 6; ++bb) {
+      const bool rep = (lane & ((1 << bb) - 1)) == 0;   // one lane per (prefix, digit): the lower bits hold copies
+      const int mine = (lane >> bb) & 1;
+      const T t = rep ? wgt[bb] * vb[bb] : (T)0.0;
+      pg[5 - bb][0] = mine ? (T)0.0 : t;
+      pg[5 - bb][1] = mine ? t : (T)0.0;
+    }
+    if constexpr (NI == 2) {
+      pg[6][0] = Wp * u7[0];
+      pg[6][1] = Wp * u7[1];
+      pg[7][0] = Wp * (xv[6][0] * d[0] + xv[6][1] * d[2]);
+      pg[7][1] = Wp * (xv[6][0] * d[1] + xv[6][1] * d[3]);
+    } else if constexpr (NI == 1) {
+      pg[6][0] = Wp * d[0];
+      pg[6][1] = Wp * d[1];
+    }
+    // the wave sums of the (up to) 16 values k = 2 f + q: two register-halving levels (lane halves take values k / k + 8,
+    // then row pairs k / k + 4), then the 16 lanes of a row: row rho ends with values 8 (rho >> 1) + 4 (rho & 1) + j
+    T vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vals[k] = k < 2 * ND ? pg[k < 2 * ND ? k / 2 : 0][k & 1] : (T)0.0;
+    T t8[8], t4[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t8[j] = hv_pair32(vals[j], vals[j + 8]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = hv_pair16(t8[j], t8[j + 4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = hv_xsum<3>(hv_xsum<2>(hv_xsum<1>(hv_xsum<0>(t4[j]))));
+    if ((lane & 15) == 0) {
+      const int k0 = 8 * (lane >> 5) + 4 * ((lane >> 4) & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + j < 2 * ND) gxw[(long long)(base * 2 + k0 + j) * p.Wn + w] = t4[j];
+    }
+  }
+}
+
 // dCore (+)= sum of the split-k partial products
 template <typename T, typename S = T>
 __global__ __launch_bounds__(256) void halves_sum_partials_k(const T* __restrict__ part, S* __restrict__ dCore,
@@ -693,6 +859,15 @@ int launch_dx_half_q(const S* x, const T* dP, T* gxw, const HalfP& h, int second
 template <typename T, typename S = T>
 int launch_dx_half(const S* x, const T* dP, T* gxw, const HalfP& h, int second, long long w0,
                    long long nw, hipStream_t st, DxSavedZ sz = DxSavedZ{nullptr, nullptr, 0, 0}) {
+  const int ndh = second ? h.n1 : h.n0;
+  if (h.p.Q == 2 && ndh >= 6 && ndh <= 8) {   // binary halves of 6..8 factors: the register butterfly
+    const dim3 g(blocks_for(nw, 4)), b(256);
+    if (ndh == 8) hipLaunchKernelGGL((halves_dx_half_q2_k<8, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
+    else if (ndh == 7) hipLaunchKernelGGL((halves_dx_half_q2_k<7, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
+    else hipLaunchKernelGGL((halves_dx_half_q2_k<6, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
+    DCTN_CHECK_LAUNCH();
+    return DCTN_OK;
+  }
   switch (ilog2_pow2(h.p.Q)) {
     case 1: return launch_dx_half_q<1, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
     case 2: return launch_dx_half_q<2, T, S>(x, dP, gxw, h, second, w0, nw, st, sz);
