@@ -348,8 +348,31 @@ __device__ __forceinline__ void lme_exact_window(const float* __restrict__ base,
   *reinterpret_cast<float4*>(outw + c * 16 + 4 * g) = make_float4(vn[0], vn[1], vn[2], vn[3]);
 }
 
+// 16-byte global accesses of the fold kernels.  NT: the streaming ("nt") policy, for folds whose matrices are far larger
+// than the 256 MiB last-level cache - every byte is used once per pass, so it should not displace anything; measured on
+// the access pattern alone (tools/probes/window_stream2.hip, 692 224 windows of 9 matrices): 4.97 -> 5.39 TB/s.
+typedef float lme_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 lme_ld4(const float* p) {
+  if (NT) {
+    const lme_v4f v = __builtin_nontemporal_load(reinterpret_cast<const lme_v4f*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+  return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void lme_st4(float* p, const float4& q) {
+  if (NT) {
+    const lme_v4f v = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<lme_v4f*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = q;
+  }
+}
+
 // One step of the forward fold on the state (E, a); `last`: the result goes out instead of becoming the next state.
 // Returns false when the step was rejected (uniform over the wave).
+template <bool NT = false>
 __device__ __forceinline__ bool lme_fwd_step(float* scr, int c, int g, const float4& qm, float (&E)[4], float& a, bool last,
                                              float* __restrict__ outp) {
   float mcol[4];
@@ -364,7 +387,7 @@ __device__ __forceinline__ bool lme_fwd_step(float* scr, int c, int g, const flo
     float r[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) r[reg] = (lg2(S[reg]) + a - __shfl(nb, 4 * g + reg, 64)) * LME_LN2;
-    *reinterpret_cast<float4*>(outp) = make_float4(r[0], r[1], r[2], r[3]);
+    lme_st4<NT>(outp, make_float4(r[0], r[1], r[2], r[3]));
   } else {
     a += da;
 #pragma unroll
@@ -376,8 +399,8 @@ __device__ __forceinline__ bool lme_fwd_step(float* scr, int c, int g, const flo
 // L <= LMAX: slot l holds matrix l of the wave's current window until step l has used it and is refilled at once with
 // matrix l of the wave's NEXT window - the steps are unrolled, so every slot is a fixed set of registers (a rotating
 // queue of four cost 12 v_mov per step) and up to LMAX KiB per wave are in flight across the window boundary.
-template <int LMAX>
-__global__ __launch_bounds__(256) void lme_fold16_fwd_slots_k(const float* __restrict__ mats, float* __restrict__ out,
+template <int LMAX, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 9 ? 4 : 1))) void lme_fold16_fwd_slots_k(const float* __restrict__ mats, float* __restrict__ out,
                                                               long long Wn, int L) {
   __shared__ __align__(16) float scratch[4][LME_TILE];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -389,13 +412,13 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_slots_k(const float* __res
   float4 Mq[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l)
-    Mq[l] = *reinterpret_cast<const float4*>(mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
+    Mq[l] = lme_ld4<NT>(mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
   for (long long w = wave; w < Wn; w += nwaves) {
     const float* nbase = mats + (w + nwaves < Wn ? w + nwaves : w) * (long long)L * 256 + gl_off;   // (the last window re-reads itself)
     const float4 v4 = Mq[0];
-    Mq[0] = *reinterpret_cast<const float4*>(nbase);
+    Mq[0] = lme_ld4<NT>(nbase);
     if (L == 1) {   // nothing to fold
-      *reinterpret_cast<float4*>(out + w * 256 + gl_off) = v4;
+      lme_st4<NT>(out + w * 256 + gl_off, v4);
       continue;
     }
     float E[4], a;
@@ -408,8 +431,8 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_slots_k(const float* __res
     for (int l = 1; l < LMAX; ++l) {
       if (l < L) {
         const float4 qm = Mq[l];
-        Mq[l] = *reinterpret_cast<const float4*>(nbase + (long long)l * 256);
-        if (good) good = lme_fwd_step(scr, c, g, qm, E, a, l == L - 1, out + w * 256 + gl_off);
+        Mq[l] = lme_ld4<NT>(nbase + (long long)l * 256);
+        if (good) good = lme_fwd_step<NT>(scr, c, g, qm, E, a, l == L - 1, out + w * 256 + gl_off);
       }
     }
     if (!good) lme_exact_window(mats + w * (long long)L * 256, out + w * 256, L, c, g);
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
 // step the factorisation cannot represent is flagged and left to the exact kernel.
 constexpr int LME_BWD_WAVES = 4;
 
-template <int LMAX>
+template <int LMAX, bool NT>
 __device__ __forceinline__ void lme_fold16_bwd_body(
     const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
     int* __restrict__ flags, long long Wn, int L) {
@@ -489,7 +512,7 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
   // had loads outstanding for a fifth of its time).  Matrix 1, whose slot frees last and is needed first, waits in N1.
   float Mr[LMAX][4], N1[4] = {0.f, 0.f, 0.f, 0.f};
   auto load4 = [&](float (&dst)[4], const float* src) {
-    const float4 q = *reinterpret_cast<const float4*>(src);
+    const float4 q = lme_ld4<NT>(src);
     dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
   };
 #pragma unroll
@@ -556,14 +579,13 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
         f32x4_t T2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) T2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hc[s], EPc[s], T2, 0, 0, 0);
-        *reinterpret_cast<float4*>(dMats + (w * L + l) * 256 + gl_off) =
-            make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]);
+        lme_st4<NT>(dMats + (w * L + l) * 256 + gl_off, make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]));
 #pragma unroll
         for (int s = 0; s < 4; ++s) G[s] = T1[s] * EP[s];
         if (l >= 2) load4(Mr[l], nbase + (long long)l * 256);
       }
     }
-    *reinterpret_cast<float4*>(dMats + (w * L) * 256 + gl_off) = make_float4(G[0], G[1], G[2], G[3]);
+    lme_st4<NT>(dMats + (w * L) * 256 + gl_off, make_float4(G[0], G[1], G[2], G[3]));
 #pragma unroll
     for (int s = 0; s < 4; ++s) Mr[1 < LMAX ? 1 : 0][s] = N1[s];
   }
@@ -578,26 +600,29 @@ long long resident_blocks(const void* fn, int threads) {
   return (long long)per_cu * cus;
 }
 
-template <int LMAX>
+template <int LMAX, bool NT>
 __global__ __launch_bounds__(64 * LME_BWD_WAVES) __attribute__((amdgpu_waves_per_eu(LMAX <= 9 ? 3 : 1))) void lme_fold16_bwd_mfma_k(
     const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
     int* __restrict__ flags, long long Wn, int L) {
-  lme_fold16_bwd_body<LMAX>(mats, dOut, dMats, flags, Wn, L);
+  lme_fold16_bwd_body<LMAX, NT>(mats, dOut, dMats, flags, Wn, L);
 }
 
 // (Round 3: the same body held to 128 registers with amdgpu_waves_per_eu(4, 4) - four waves per SIMD instead of three,
 // 14 spilled registers - measured SLOWER at L = 9: 3.93 against 3.37 ms for 692 224 windows.  The kernel's three pipes
 // are together ~100 % busy (vector 46 %, matrix 29 %, LDS 24 %: profiles/r02_sq_cfg5.json); the spill traffic costs
 // more than the fourth wave's overlap gains.)
-template <int LMAX>
+template <int LMAX, bool NT>
 void fold16_bwd_launch(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, int L,
                        hipStream_t st) {
   long long blocks = (Wn + LME_BWD_WAVES - 1) / LME_BWD_WAVES;
-  const long long cap = resident_blocks((const void*)lme_fold16_bwd_mfma_k<LMAX>, 64 * LME_BWD_WAVES);
+  const long long cap = resident_blocks((const void*)lme_fold16_bwd_mfma_k<LMAX, NT>, 64 * LME_BWD_WAVES);
   if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
-  hipLaunchKernelGGL((lme_fold16_bwd_mfma_k<LMAX>), dim3((unsigned)blocks), dim3(64 * LME_BWD_WAVES), 0, st,
+  hipLaunchKernelGGL((lme_fold16_bwd_mfma_k<LMAX, NT>), dim3((unsigned)blocks), dim3(64 * LME_BWD_WAVES), 0, st,
                      mats, dOut, dMats, flags, Wn, L);
 }
+
+// the fold's matrices do not fit the last-level cache (256 MiB): stream them (lme_ld4<true>)
+static bool lme_streams(long long Wn, int L) { return Wn * (long long)L * 1024 > (512ll << 20); }
 
 unsigned grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
@@ -747,16 +772,18 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
   if (D > 32) return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DCTN_F32 && D == 16 && ((uintptr_t)mats % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
-    const void* fn = L <= 5 ? (const void*)lme_fold16_fwd_slots_k<5> : L <= 9 ? (const void*)lme_fold16_fwd_slots_k<9>
-                     : L <= 16 ? (const void*)lme_fold16_fwd_slots_k<16> : (const void*)lme_fold16_fwd_mfma_k;
+    const bool nt = lme_streams(Wn, L);
     long long blocks = (Wn + 3) / 4;
-    const long long cap = resident_blocks(fn, 256);
-    if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
-    const dim3 g((unsigned)blocks), b(256);
-    if (L <= 5) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<5>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
-    else if (L <= 9) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<9>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
-    else if (L <= 16) hipLaunchKernelGGL(lme_fold16_fwd_slots_k<16>, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
-    else hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, g, b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+    const dim3 b(256);
+    auto slots = [&](auto kern) {
+      const long long cap = resident_blocks((const void*)kern, 256);
+      if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+    };
+    if (L <= 5) nt ? slots(lme_fold16_fwd_slots_k<5, true>) : slots(lme_fold16_fwd_slots_k<5, false>);
+    else if (L <= 9) nt ? slots(lme_fold16_fwd_slots_k<9, true>) : slots(lme_fold16_fwd_slots_k<9, false>);
+    else if (L <= 16) nt ? slots(lme_fold16_fwd_slots_k<16, true>) : slots(lme_fold16_fwd_slots_k<16, false>);
+    else slots(lme_fold16_fwd_mfma_k);
     DCTN_CHECK_LAUNCH();
     dctn_set_last_kernel("logmatmulexp_fold_fwd_mfma16");
     return DCTN_OK;
@@ -784,9 +811,10 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats, 
     const float* m = (const float*)mats;
     const float* dy = (const float*)dOut;
     float* dm = (float*)dMats;
-    if (L <= 5) fold16_bwd_launch<5>(m, dy, dm, flags, Wn, L, st);
-    else if (L <= 9) fold16_bwd_launch<9>(m, dy, dm, flags, Wn, L, st);
-    else fold16_bwd_launch<16>(m, dy, dm, flags, Wn, L, st);
+    const bool nt = lme_streams(Wn, L);
+    if (L <= 5) nt ? fold16_bwd_launch<5, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<5, false>(m, dy, dm, flags, Wn, L, st);
+    else if (L <= 9) nt ? fold16_bwd_launch<9, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<9, false>(m, dy, dm, flags, Wn, L, st);
+    else nt ? fold16_bwd_launch<16, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<16, false>(m, dy, dm, flags, Wn, L, st);
     DCTN_CHECK_LAUNCH();
     const int rc = fold_bwd_launch<float, float>(mats, dOut, dMats, Wn, L, D, st, flags);  // flagged windows only
     if (rc != DCTN_OK) return rc;
