@@ -397,10 +397,11 @@ def headline_roofline(model, x, specs, steps):
         kernels = {}
     # this path is compute bound (MFMA for the core GEMM, VALU for the Khatri-Rao halves);
     # algorithmic flops per window: forward 2*Q^N*O (GEMM) + the two halves and the final dot; dCore the
-    # same GEMM size transposed (+ forming dY and dWeight when the head is fused: 4*Cout*O)
+    # same GEMM size transposed (+ forming dY when the head is fused: 2*Cout*O; dWeight = dLogits^T x features is formed
+    # by the call's second kernel since round 4 and is not counted for this one)
     half = 2 * (Q ** ((N + 1) // 2) + Q ** (N // 2)) + 2 * Q ** (N // 2) * O
     flops = {"eps_fwd": wn * (t["gemm_flops"] + half),
-             "eps_bwd_dcore": wn * (t["gemm_flops"] + half + (4 * cout * O if t["fused"] else 0))}
+             "eps_bwd_dcore": wn * (t["gemm_flops"] + half + (2 * cout * O if t["fused"] else 0))}
     alg = {"eps_fwd": t["bytes_x"] + t["bytes_y"] + t["bytes_core"],
            "eps_bwd_dcore": t["bytes_x"] + t["bytes_y"] + t["bytes_core"]
                             + ((B * cout + 2 * w_head.numel() + cout) * esz if t["fused"] else 0)}

@@ -320,6 +320,8 @@ __device__ __forceinline__ void unpack_row(const RawRow<S, OP>& r, float (&v)[OP
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
+// one value against a pair: a single v_pk_mul_f32 (the broadcast is an operand selector, not an instruction)
+__device__ __forceinline__ f32x2 bmul2(float s, f32x2 v) { return f32x2{s, s} * v; }
 // 8 floats -> one MFMA operand fragment: exactly four v_cvt_pk_bf16_f32 (element-wise casts into a
 // bf16x8 make the compiler convert singly and re-pack with shifts and ors)
 __device__ __forceinline__ bf16x8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6,
@@ -404,22 +406,28 @@ __device__ __forceinline__ WaveJob wave_job(const MfmaP& p, int waves_per_block,
 template <int N0>
 __device__ __forceinline__ void build_p0(const float (*xv)[2], bf16x8 (&X)[(1 << N0) / 16],
                                          bf16x8 (&Y)[(1 << N0) / 16]) {
+  // (packed f32 multiplies - v_pk_mul_f32, one scalar broadcast against a pair - in the same order of factors as the
+  //  scalar form: 24 instead of 54 multiplies for the 32 products, and every result pair is one v_cvt_pk_bf16_f32)
   constexpr int KS = (1 << N0) / 16;
-  float lo8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    lo8[j] = xv[N0 - 3][(j >> 2) & 1] * xv[N0 - 2][(j >> 1) & 1] * xv[N0 - 1][j & 1];
+  const f32x2 x1 = {xv[N0 - 1][0], xv[N0 - 1][1]}, x2 = {xv[N0 - 2][0], xv[N0 - 2][1]};
+  const f32x2 m01 = bmul2(xv[N0 - 3][0], x2), m23 = bmul2(xv[N0 - 3][1], x2);
+  const f32x2 lo[4] = {bmul2(m01[0], x1), bmul2(m01[1], x1), bmul2(m23[0], x1), bmul2(m23[1], x1)};   // a = .. 2 i, 2 i + 1
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     float hi = 1.f;
 #pragma unroll
     for (int t = 0; t < N0 - 4; ++t) hi = t == 0 ? xv[N0 - 5][s & 1] : hi * xv[N0 - 5 - t][(s >> t) & 1];
-    const float h0 = N0 > 4 ? hi * xv[N0 - 4][0] : xv[N0 - 4][0];
-    const float h1 = N0 > 4 ? hi * xv[N0 - 4][1] : xv[N0 - 4][1];
-    X[s] = pack8(h0 * lo8[0], h0 * lo8[1], h0 * lo8[2], h0 * lo8[3], h0 * lo8[4], h0 * lo8[5], h0 * lo8[6],
-                 h0 * lo8[7]);
-    Y[s] = pack8(h1 * lo8[0], h1 * lo8[1], h1 * lo8[2], h1 * lo8[3], h1 * lo8[4], h1 * lo8[5], h1 * lo8[6],
-                 h1 * lo8[7]);
+    const f32x2 x4 = {xv[N0 - 4][0], xv[N0 - 4][1]};
+    const f32x2 h = N0 > 4 ? bmul2(hi, x4) : x4;
+    int4v rx, ry;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 a = bmul2(h[0], lo[i]), b = bmul2(h[1], lo[i]);
+      rx[i] = (int)pack_bf16(a[0], a[1]);
+      ry[i] = (int)pack_bf16(b[0], b[1]);
+    }
+    X[s] = __builtin_bit_cast(bf16x8, rx);
+    Y[s] = __builtin_bit_cast(bf16x8, ry);
   }
 }
 
@@ -800,6 +808,10 @@ constexpr size_t dcore_dyn_lds_bytes(int mt) { return (size_t)BWD_WAVES * (1 + m
 // dW[c, pos*O + o] += dLogits[b, c] * feat[b, pos, o]  (`feat` = the layer's forward output), reduced
 // over the workgroup's 8 sample chunks in LDS and written as one partial tile per chunk block to
 // `dwpart` [ncb][Cout][P*O]; eps_head_reduce_k sums the tiles (and dLogits into dBias).
+// Exception (round 4): the HEADMM shapes (cfg2) leave dW to eps_head_reduce_k altogether - dW = dLogits^T x feat
+// is a plain (Cout x B) x (B x P*O) product that needs nothing of this kernel; formed here it cost 4 of the 12 matrix
+// instructions of a group, 64 accumulator registers, the loads of `feat`, a 1.7 us LDS epilogue and 2.5 MB of partial
+// tiles written and read back (the "1.6x traffic" of rounds 2-3).
 template <typename S, int N0, int N1, int OP, bool XVEC, bool OVEC, int ROWS, int HEADC>
 __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S* __restrict__ x,
                                                              const S* __restrict__ dY,
@@ -847,15 +859,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   constexpr bool HEADMM = HEADC > 0 && HEADC <= 16 && LDST && OVEC && XVEC && sizeof(S) == 2 && OP == 4;
   float hwf[HEADC > 0 && !HEADMM ? HEADC : 1][OP];
   float dwacc[HEADC > 0 && !HEADMM ? HEADC : 1][OP];
-  f32x16 dwm[HEADMM ? OP : 1];   // HEADMM: dW[class v][the lane's position][o] in register v of dwm[o]
 #pragma unroll
   for (int c = 0; c < (HEADC > 0 && !HEADMM ? HEADC : 1); ++c)
 #pragma unroll
     for (int o = 0; o < OP; ++o) dwacc[c][o] = 0.f;
-#pragma unroll
-  for (int o = 0; o < (HEADMM ? OP : 1); ++o)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) dwm[o][v] = 0.f;
   constexpr int DLW = HEADC > 0 ? HEADC / 2 : 1;   // dwords of one row of dLogits (bf16 pairs)
   const unsigned* dl32 = reinterpret_cast<const unsigned*>(dY);
   unsigned dlraw[DLW];
@@ -880,16 +887,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     if constexpr (LDST) {
       bf16x8 X[KS], Y[KS];
       build_p0<N0>(xv, X, Y);
-      float p1[BN];   // built by doubling: 2 + 4 + ... + BN multiplies instead of (N1 - 1) * BN
+      // P1 by doubling, a pair per multiply: (p1[bb], p1[bb | 1 << u]) = p1[bb] * (x[0], x[1]) (b bit u <-> factor N-1-u)
+      float p1[BN];
       p1[0] = xv[N - 1][0];
       p1[1] = xv[N - 1][1];
 #pragma unroll
       for (int u = 1; u < N1; ++u)
 #pragma unroll
         for (int bb = (1 << u) - 1; bb >= 0; --bb) {
-          const float lo = p1[bb];
-          p1[bb | (1 << u)] = lo * xv[N - 1 - u][1];
-          p1[bb] = lo * xv[N - 1 - u][0];
+          const f32x2 pr = bmul2(p1[bb], f32x2{xv[N - 1 - u][0], xv[N - 1 - u][1]});
+          p1[bb] = pr[0];
+          p1[bb | (1 << u)] = pr[1];
         }
       wave_lds_sync();   // the previous step's transposed reads are done
       // the lane's window = its row of every tile; features in natural a order: 16 s + j, 16 s + 8 + j
@@ -904,14 +912,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-          float z[8];
+          int4v zr;   // z[j] = p1[m >> LOGO] * dy[m & (OP - 1)], m = (t << 5) | (c4 << 3) | j: pairs share the p1 factor
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int m = (t << 5) | (c4 << 3) | j;
-            z[j] = p1[m >> LOGO] * dyl[m & (OP - 1)];
+          for (int jp = 0; jp < 4; ++jp) {
+            const int m = (t << 5) | (c4 << 3) | (2 * jp);
+            static_assert(OP >= 2, "a pair of consecutive m shares b = m >> LOGO");
+            const f32x2 zz = bmul2(p1[m >> LOGO], f32x2{dyl[m & (OP - 1)], dyl[(m + 1) & (OP - 1)]});
+            zr[jp] = (int)pack_bf16(zz[0], zz[1]);
           }
-          *reinterpret_cast<bf16x8*>(tiles + (1 + t) * 64 * LROW + trl.wr[c4]) =
-              pack8(z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]);
+          *reinterpret_cast<bf16x8*>(tiles + (1 + t) * 64 * LROW + trl.wr[c4]) = __builtin_bit_cast(bf16x8, zr);
         }
       wave_lds_sync();
 #pragma unroll
@@ -926,14 +935,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     }
   };
   if constexpr (HEADMM) {
-    // Roles of the lane in the two small products of a group of 8 samples (32x32x16 tiles, lane = (r, h)):
+    // Role of the lane in the small product of a group of 8 samples (32x32x16 tiles, lane = (r, h)):
     //   dY[sample][pos] = sum_class dLogits[sample][class] W[class][pos][o]:   A row r <-> sample slot 4 (r >> 3) + (r & 3) of
     //     the lane half (r >> 2) & 1 whose positions the tile holds (rows of the other half are zero), so the two tiles
     //     of an output (positions 0-31 / 32-63 of the wave) add into ONE accumulator and register v of lane (r, h) is
     //     sample v at the lane's own position;
-    //   dW[class][pos] += sum_sample dLogits[sample][class] feat[sample][pos][o]:   A row r <-> class 4 (r >> 3) + (r & 3),
-    //     non-zero only in the k half (= lane half of the B operand = of the positions) equal to (r >> 2) & 1: one tile
-    //     per output, register v of lane (r, h) is class v at the lane's own position.
+    //   (dW = dLogits^T x feat is NOT formed here: eps_head_reduce_k's `gemm` role.)
     // The head-weight operand is the same for the workgroup's 8 waves (same positions): 16 classes x 64 positions x 8 bytes
     // are staged ONCE through LDS (one 16-byte load per thread, behind the tiles) - loaded per wave it was 64 KB per CU
     // through the vector-memory path in front of the first sample.
@@ -944,21 +951,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     const __amdgpu_buffer_rsrc_t rs_dl = make_rsrc(dY, dl_bytes);
     const int slot = 4 * (r >> 3) + (r & 3);
     const bool rlow = ((r >> 2) & 1) == 0;
-    const unsigned voff_t = (rlow == (h == 0) && slot < p.Cout) ? (unsigned)slot * 2u : dl_bytes;
-    // a group's operands: 16 bytes of dLogits per lane, 8 single values of its transpose, the features of the lane's
-    // position for the 8 samples
+    // a group's operand: 16 bytes of dLogits per lane
     u32x4 fa;
-    unsigned ft[8];
-    u32x2 rf[8];
     auto issue_group = [&](int g0) {
       const unsigned voff_a = (r < 16 && g0 + slot < job.b1 && 8 * h < p.Cout) ? (unsigned)slot * dlrow + 16u * h : dl_bytes;
       fa = __builtin_amdgcn_raw_buffer_load_b128(rs_dl, voff_a, (unsigned)g0 * dlrow, 0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        ft[j] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
-            rs_dl, voff_t, g0 + j < job.b1 ? (unsigned)(g0 + j) * dlrow : dl_bytes, 0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rf[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_dy, job.voff_o, (unsigned)(g0 + j) * p.o_s1b, 0);
     };
     u32x4 wv4;
     {
@@ -979,14 +976,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
       // dY of the group's samples and the group's share of dW (formed in front of the group's first sample: inside its
       // step, behind the window's own products, the operands' registers met P0 / P1's and the kernel spilled: 15.3 us)
       auto group_products = [&]() {
-        int4v a0, a1, at;
+        int4v a0, a1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const bool dv = 8 * h + 2 * d < p.Cout;   // classes past Cout: the next sample's row, not zeros
           const int v = (int)(d == 0 ? fa.x : d == 1 ? fa.y : d == 2 ? fa.z : fa.w);
           a0[d] = (dv && rlow) ? v : 0;
           a1[d] = (dv && !rlow) ? v : 0;
-          at[d] = (int)(ft[2 * d] | (ft[2 * d + 1] << 16));
         }
 #pragma unroll
         for (int o = 0; o < OP; ++o) {
@@ -1007,12 +1003,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
                                                            __builtin_bit_cast(bf16x8, bw), dya, 0, 0, 0);
           }
           dyg[o] = __builtin_shufflevector(dya, dya, 0, 1, 2, 3, 4, 5, 6, 7);
-          int4v bf;
-#pragma unroll
-          for (int d = 0; d < 4; ++d)
-            bf[d] = (int)__builtin_amdgcn_perm((o >> 1) ? rf[2 * d + 1].y : rf[2 * d + 1].x, (o >> 1) ? rf[2 * d].y : rf[2 * d].x, sel);
-          dwm[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, at), __builtin_bit_cast(bf16x8, bf),
-                                                            dwm[o], 0, 0, 0);
         }
       };
       group_products();
@@ -1234,7 +1224,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   }
 
   DCTN_STAMP(p, 4);
-  if constexpr (HEADC > 0) {
+  if constexpr (HEADC > 0 && !HEADMM) {
     // head-weight gradient: sum the 8 waves (same positions, different sample chunks) in LDS and store the
     // workgroup's partial tile; LDS index (cc*64 + lane)*OP + o makes the stores run along the feature index.
     // LDST shapes: as many classes per round as the 96 KiB of tiles hold (all 10 of cfg2: one round); others: the
@@ -1257,10 +1247,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
           // static register index: unrolled over every (c0, cc) pair that can occur
           float v = 0.f;
 #pragma unroll
-          for (int c = 0; c < HEADC; ++c) {
-            if constexpr (HEADMM) v = (c == c0 + cc) ? dwm[o][c] : v;
-            else v = (c == c0 + cc) ? dwacc[c][o] : v;
-          }
+          for (int c = 0; c < HEADC; ++c) v = (c == c0 + cc) ? dwacc[c][o] : v;
           red1[wv * SLOT + (cc * 64 + lane) * OP + o] = v;
         }
       __syncthreads();
@@ -1312,13 +1299,88 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 // Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
 // as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
 // (256 consecutive features each), the last one sums dLogits over the batch into dBias.
+// The `gemm` role of eps_head_reduce_k (HEADMM shapes, cfg2): dW[c][f] = sum_b dLogits[b][c] * feat[b][f] for the 64
+// features [64 blk, 64 blk + 64) of one workgroup, on v_mfma_f32_16x16x32_bf16 (rows = classes, columns = features,
+// k = samples).  Wave w takes the samples [w spw, (w + 1) spw) in blocks of 32; lane (n, kg) = (lane % 16, lane / 16)
+// loads, for the 8 samples 8 kg .. 8 kg + 7 of a block, 8 bytes of the feature row (features 4 n .. 4 n + 3 of the
+// slice: a load instruction covers 128 contiguous bytes of 4 rows) and one value of dLogits - the k-contiguous fragments
+// come from 8 loads, never from a transpose; tile j of the wave is the features 4 n + j.  The next block's loads are
+// issued before the current block's products (B = 1024: both blocks of a wave in flight at once - the role is one
+// round trip, like the partial-tile sums it replaces).  The 16 waves' tiles meet in LDS (64 KiB dynamic), thread
+// (slot, lane) sums one element in wave order (deterministic) and stores it.
+// (Tried first: this product as its own kernel on a forked side stream next to the dCore kernel - the two cross-stream
+// dependencies cost more than the kernel: 45.9 us per step in the graph, 30.7 us per eager call.)
+constexpr int DWG_WAVES = 16;
+__device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ dL,
+                                                  bf16_t* __restrict__ dW, int B, int Cout, long long F, int blk,
+                                                  float* __restrict__ lds) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
+  const unsigned f_bytes = (unsigned)((long long)B * F * 2), dl_bytes = (unsigned)B * (unsigned)Cout * 2u;
+  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(feat, f_bytes), rs_dl = make_rsrc(dL, dl_bytes);
+  const long long fcol = (long long)blk * 64 + 4 * n;
+  const bool fok = fcol + 3 < F;   // (F is a multiple of 4: OP == 4)
+  const int spw = (((B + DWG_WAVES - 1) / DWG_WAVES) + 31) / 32 * 32;
+  const int b0 = wv * spw, b1 = b0 + spw < B ? b0 + spw : B;
+  f32x4v acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  u32x2 fr[8], frn[8];
+  unsigned a16[8], a16n[8];
+  auto issue = [&](int kb, u32x2 (&f)[8], unsigned (&a)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = kb + 8 * kg + j;
+      const bool in = b < b1;
+      f[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_f, (in && fok) ? (unsigned)((long long)b * F * 2 + fcol * 2) : f_bytes, 0, 0);
+      a[j] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+          rs_dl, (in && n < Cout) ? (unsigned)b * (unsigned)Cout * 2u + 2u * n : dl_bytes, 0, 0);
+    }
+  };
+  if (b0 < b1) issue(b0, fr, a16);
+  for (int kb = b0; kb < b1; kb += 32) {
+    if (kb + 32 < b1) issue(kb + 32, frn, a16n);
+    __builtin_amdgcn_sched_barrier(0);
+    int4v at;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) at[d] = (int)(a16[2 * d] | (a16[2 * d + 1] << 16));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;   // the odd / even halves of two dwords
+      int4v bf;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        bf[d] = (int)__builtin_amdgcn_perm((j >> 1) ? fr[2 * d + 1].y : fr[2 * d + 1].x, (j >> 1) ? fr[2 * d].y : fr[2 * d].x, sel);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, at), __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fr[j] = frn[j]; a16[j] = a16n[j]; }
+  }
+  // acc[j][i] = dW[class 4 kg + i][feature 64 blk + 4 n + j] of this wave's samples
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds[(wv * 16 + j * 4 + i) * 64 + lane] = acc[j][i];
+  __syncthreads();
+  {
+    const int slot = tid >> 6, j = slot >> 2, i = slot & 3;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < DWG_WAVES; ++w) t += lds[(w * 16 + slot) * 64 + lane];
+    const int c = 4 * kg + i;
+    const long long f = (long long)blk * 64 + 4 * n + j;
+    if (c < Cout && f < F) dW[(long long)c * F + f] = (bf16_t)t;
+  }
+}
+
 __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restrict__ partial,
                                                           bf16_t* __restrict__ dCore, int nblk, int A, int BN,
                                                           int O, int OP, int ACOLS, int n_core,
                                                           const float* __restrict__ dwpart,
                                                           bf16_t* __restrict__ dW, int ncb, long long nW, int n_dw,
                                                           const bf16_t* __restrict__ dL,
-                                                          bf16_t* __restrict__ dBias, int B, int Cout) {
+                                                          bf16_t* __restrict__ dBias, int B, int Cout,
+                                                          const bf16_t* __restrict__ feat, int gemm) {
   // The kernel is a latency chain, not a bandwidth problem: 1024 threads per workgroup so that every
   // partial tile of an element is fetched in ONE round of independent loads.
   __shared__ float red[32][33];
@@ -1351,6 +1413,11 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
   }
   if ((int)blockIdx.x < n_core + n_dw) {
     if (!dW) return;
+    if (gemm) {   // no partial tiles: the product itself (n_dw = ceil(F / 64) workgroups, nW = Cout * F)
+      extern __shared__ __attribute__((aligned(16))) float gemm_lds[];
+      head_dw_gemm_role(feat, dL, dW, B, Cout, nW / Cout, (int)blockIdx.x - n_core, gemm_lds);
+      return;
+    }
     // 4 threads per element, each up to 8 independent loads (ncb <= 32), joined by two lane shuffles
     const long long e = (long long)((int)blockIdx.x - n_core) * 256 + (tid >> 2);
     const int sub = tid & 3;
@@ -1615,10 +1682,16 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
   if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
-  const int n_core = BN * OP * AT, n_dw = (int)((nW + 255) / 256);
-  hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), 0, st, (const float*)ws, (S*)dCore,
+  // the condition under which the kernel above took its HEADMM path and left dW to this one
+  constexpr int MT = BN * OP / 32;
+  const bool gemm = A == 32 && MT <= 2 && OP == 4 && m.vec_ok && (long long)m.B * m.P * OP * 2 < (1LL << 31);
+  const int n_core = BN * OP * AT, n_dw = gemm ? (int)(((long long)m.P * OP + 63) / 64) : (int)((nW + 255) / 256);
+  constexpr size_t GEMM_LDS = (size_t)DWG_WAVES * 16 * 64 * sizeof(float);
+  static_assert(DWG_WAVES * 64 == 1024, "the gemm role is the whole workgroup of eps_head_reduce_k");
+  if (gemm) (void)hipFuncSetAttribute((const void*)eps_head_reduce_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
+  hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), gemm ? GEMM_LDS : 0, st, (const float*)ws, (S*)dCore,
                      grid, A, BN, m.O, OP, AT * 32, n_core, (const float*)dwpart, (S*)dW, m.ncb, nW, n_dw,
-                     (const S*)dL, (S*)dBias, m.B, m.Cout);
+                     (const S*)dL, (S*)dBias, m.B, m.Cout, (const S*)feat, gemm ? 1 : 0);
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("eps_head_bwd_mfma_q2reg");
   return DCTN_OK;
