@@ -174,8 +174,29 @@ struct MfmaP {
   } while (0)
 static unsigned long long* g_stamps = nullptr;
 void dctn_stamps_set(unsigned long long* p) { g_stamps = p; }
+// the finishing kernel has no parameter block: its stamps go through a device global
+__device__ unsigned long long* g_dev_stamps = nullptr;
+void dctn_reduce_stamps_set(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dev_stamps), &p, sizeof(p)); }
+#define DCTN_STAMP_T(P, SLOT, TID)                                                              \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    if ((P).stamps && threadIdx.x == (TID)) (P).stamps[(long long)blockIdx.x * 8 + (SLOT)] = t_;  \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#define DCTN_STAMP_G(SLOT)                                                                       \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    if (g_dev_stamps && threadIdx.x == 0) g_dev_stamps[(long long)blockIdx.x * 8 + (SLOT)] = t_;  \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
 #else
 #define DCTN_STAMP(P, SLOT) do { } while (0)
+#define DCTN_STAMP_T(P, SLOT, TID) do { } while (0)
+#define DCTN_STAMP_G(SLOT) do { } while (0)
 #endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -322,6 +343,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 }
 // one value against a pair: a single v_pk_mul_f32 (the broadcast is an operand selector, not an instruction)
 __device__ __forceinline__ f32x2 bmul2(float s, f32x2 v) { return f32x2{s, s} * v; }
+// (measured per site on one box, 20-step graph: P0 on packed multiplies -0.6 us per step, P1 / Z -0.2, the forward's
+//  P1 halves 0; the forward's epilogue on v_pk_fma_f32 +1.4 us - packed FMAs beside MFMAs cost more than they save)
+// acc + s * v on a pair as two scalar fused multiply-adds (v_pk_fma_f32 here cost 1.4 us per step: 33.4 against 32.0)
+__device__ __forceinline__ f32x2 bfma2(float s, f32x2 v, f32x2 acc) { return f32x2{__builtin_fmaf(s, v[0], acc[0]), __builtin_fmaf(s, v[1], acc[1])}; }
 // 8 floats -> one MFMA operand fragment: exactly four v_cvt_pk_bf16_f32 (element-wise casts into a
 // bf16x8 make the compiler convert singly and re-pack with shifts and ors)
 __device__ __forceinline__ bf16x8 pack8(float f0, float f1, float f2, float f3, float f4, float f5, float f6,
@@ -708,14 +733,15 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
         for (int u = 2; u < N1; ++u)
 #pragma unroll
           for (int bh = (1 << (u - 1)) - 1; bh >= 0; --bh) {
-            const float lo = ph[bh];
-            ph[bh | (1 << (u - 1))] = lo * xv[N - 1 - u][1];
-            ph[bh] = lo * xv[N - 1 - u][0];
+            const f32x2 pr = bmul2(ph[bh], f32x2{xv[N - 1 - u][0], xv[N - 1 - u][1]});
+            ph[bh] = pr[0];
+            ph[bh | (1 << (u - 1))] = pr[1];
           }
 #pragma unroll
         for (int bh = 0; bh < BN / 2; ++bh) {
-          m0[bh] = ph[bh] * xv[N - 1][0];
-          m1[bh] = ph[bh] * xv[N - 1][1];
+          const f32x2 mm = bmul2(ph[bh], f32x2{xv[N - 1][0], xv[N - 1][1]});
+          m0[bh] = mm[0];
+          m1[bh] = mm[1];
           swap_halves(m0[bh], m1[bh]);
         }
       }
@@ -732,12 +758,16 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
 #pragma unroll
           for (int s = 0; s < KS; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s], set ? pf1[s] : pf0[s], acc, 0, 0, 0);
+          // registers v, v + 1 (v even) are the outputs o, o + 1 of one b: a packed fused multiply-add per pair
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
+          for (int v = 0; v < 16; v += 2) {
             const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
             const float mm = set ? m1[code >> LOGO] : m0[code >> LOGO];
-            float& dst = set ? res1[code & (OP - 1)] : res0[code & (OP - 1)];
-            dst = __builtin_fmaf(acc[v], mm, dst);
+            float* dst = set ? res1 : res0;
+            const int o = code & (OP - 1);
+            const f32x2 r = bfma2(mm, f32x2{acc[v], acc[v + 1]}, f32x2{dst[o], dst[o + 1]});
+            dst[o] = r[0];
+            dst[o + 1] = r[1];
           }
         }
       }
@@ -827,6 +857,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
   // removes, per 64 windows, 12 of the 20 MFMAs, the 48 bf16 conversions behind them and all 24
   // lane swaps from a kernel that is bound by VALU + MFMA issue.
   constexpr bool LDST = A == 32 && MT <= 2;
+  // (Round 4, built and dropped: Z through identity products on the matrix core and only P0 through LDS - 12 instead
+  //  of 36 LDS instructions per step, 8 more matrix instructions, 48 more vector ones: 11.4 against 11.2 us.)
   __shared__ float red[BWD_WAVES][32 * 32];
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wv = tid >> 6;
@@ -1186,7 +1218,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void eps_bwd_dcore_q2reg_k(const S*
     // there in ONE round (two barriers) instead of one round per tile through the 32 KiB static buffer
     static_assert(AT == 1 && (size_t)BWD_WAVES * MT * 1024 * 4 <= dcore_dyn_lds_bytes(MT), "dCore tiles must fit");
     float* big = reinterpret_cast<float*>(dsm);
+    DCTN_STAMP_T(p, 6, 64 * (BWD_WAVES - 1));
     __syncthreads();
+    DCTN_STAMP(p, 7);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -1305,11 +1339,17 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 // loads, for the 8 samples 8 kg .. 8 kg + 7 of a block, 8 bytes of the feature row (features 4 n .. 4 n + 3 of the
 // slice: a load instruction covers 128 contiguous bytes of 4 rows) and one value of dLogits - the k-contiguous fragments
 // come from 8 loads, never from a transpose; tile j of the wave is the features 4 n + j.  The next block's loads are
-// issued before the current block's products (B = 1024: both blocks of a wave in flight at once - the role is one
-// round trip, like the partial-tile sums it replaces).  The 16 waves' tiles meet in LDS (64 KiB dynamic), thread
-// (slot, lane) sums one element in wave order (deterministic) and stores it.
-// (Tried first: this product as its own kernel on a forked side stream next to the dCore kernel - the two cross-stream
-// dependencies cost more than the kernel: 45.9 us per step in the graph, 30.7 us per eager call.)
+// issued before the current block's products (B = 1024: both blocks of a wave in flight at once).  The 16 waves' tiles
+// meet in LDS (64 KiB dynamic), thread (slot, lane) sums one element in wave order (deterministic) and stores it.
+// What bounds the role (tools/stamp_cfg2.hip): a workgroup pulls 1024 rows x 128 B through ONE CU's memory path - the
+// first loads are back 2.3 us after the kernel's start, the last wave's after 5.5; the role ends at 6.1 us (the dCore
+// roles next to it at 2.0).  Tried and dropped:
+//  * the product as its own kernel on a forked side stream next to the dCore kernel - the two cross-stream
+//    dependencies cost more than the kernel: 45.9 us per step in the graph, 30.7 us per eager call;
+//  * the samples split 4 ways over 172 workgroups, the 4 KiB partial tiles combined by the last workgroup of a slice
+//    to arrive (write-through stores, an agent-scope counter zeroed by the dCore kernel, agent-scope loads; parity
+//    green): products done after 2.5 us instead of 5.5, but the store-and-count costs 1.3 us and the last arriver's
+//    re-read 1.2 (release / acquire on the counter: 2.5 + 2.5) - the role ends at 6.0 us, no gain for the machinery.
 constexpr int DWG_WAVES = 16;
 __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ dL,
                                                   bf16_t* __restrict__ dW, int B, int Cout, long long F, int blk,
@@ -1337,6 +1377,7 @@ __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ fea
           rs_dl, (in && n < Cout) ? (unsigned)b * (unsigned)Cout * 2u + 2u * n : dl_bytes, 0, 0);
     }
   };
+  DCTN_STAMP_G(0);
   if (b0 < b1) issue(b0, fr, a16);
   for (int kb = b0; kb < b1; kb += 32) {
     if (kb + 32 < b1) issue(kb + 32, frn, a16n);
@@ -1361,7 +1402,9 @@ __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ fea
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) lds[(wv * 16 + j * 4 + i) * 64 + lane] = acc[j][i];
+  DCTN_STAMP_G(1);
   __syncthreads();
+  DCTN_STAMP_G(2);
   {
     const int slot = tid >> 6, j = slot >> 2, i = slot & 3;
     float t = 0.f;
@@ -1371,6 +1414,7 @@ __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ fea
     const long long f = (long long)blk * 64 + 4 * n + j;
     if (c < Cout && f < F) dW[(long long)c * F + f] = (bf16_t)t;
   }
+  DCTN_STAMP_G(4);
 }
 
 __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restrict__ partial,
@@ -1386,6 +1430,7 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
   __shared__ float red[32][33];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < n_core) {
+    DCTN_STAMP_G(0);
     const int c = tid & 31, k32 = tid >> 5;
     const long long stride = (long long)BN * OP * ACOLS;
     const long long e = (long long)blockIdx.x * 32 + c;  // flat (m, a) index
@@ -1409,6 +1454,7 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
       const int b = m / OP, o = m % OP;
       if (a < A && o < O) dCore[((long long)a * BN + b) * O + o] = (bf16_t)t;
     }
+    DCTN_STAMP_G(4);
     return;
   }
   if ((int)blockIdx.x < n_core + n_dw) {
@@ -1666,6 +1712,10 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   if (grid == 0) return DCTN_ERR_UNSUPPORTED;
   float* dwpart = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + core_ws_bytes);
   const long long nW = (long long)m.Cout * m.P * OP;   // dwpart: [ncb][Cout][P*O]
+  // the condition under which the kernel below takes its HEADMM path and leaves dW to eps_head_reduce_k's gemm role
+  constexpr int MT = BN * OP / 32;
+  const bool gemm = A == 32 && MT <= 2 && OP == 4 && m.vec_ok && (long long)m.B * m.P * OP * 2 < (1LL << 31);
+
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;
   constexpr int RW = NN == 9 ? 3 : 4;
@@ -1682,9 +1732,6 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
   if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
-  // the condition under which the kernel above took its HEADMM path and left dW to this one
-  constexpr int MT = BN * OP / 32;
-  const bool gemm = A == 32 && MT <= 2 && OP == 4 && m.vec_ok && (long long)m.B * m.P * OP * 2 < (1LL << 31);
   const int n_core = BN * OP * AT, n_dw = gemm ? (int)(((long long)m.P * OP + 63) / 64) : (int)((nW + 255) / 256);
   constexpr size_t GEMM_LDS = (size_t)DWG_WAVES * 16 * 64 * sizeof(float);
   static_assert(DWG_WAVES * 64 == 1024, "the gemm role is the whole workgroup of eps_head_reduce_k");

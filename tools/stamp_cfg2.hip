@@ -71,7 +71,9 @@ int main(int argc, char** argv) {
   const char* fl[] = {"entry", "core staged, fragments in regs", "first sample done", "loop done", "", "", "", ""};
   const char* hl[] = {"entry", "core staged, fragments in regs", "first sample done", "last group's samples done (wave 0)", "end", "", "", ""};
   const char* bl[] = {"entry", "head-weight slice arrived", "first sample's loads arrived", "loop done", "dCore tile reduced + stored",
-                      "dW tiles reduced + stored (end)", "", ""};
+                      "end", "loop done, last wave", "every wave out of the loop (barrier)"};
+  const char* rl[] = {"entry (dCore roles: blocks 0-63; gemm roles after)", "gemm: products done, tile in LDS", "gemm: barrier passed",
+                      "", "end", "", "", ""};
   for (int rep = 0; rep < 3; ++rep) {   // the last repetition is reported (warm caches, as inside a replayed step)
     dctn_stamps_set(nullptr);
     for (int i = 0; i < 3; ++i) {
@@ -96,7 +98,21 @@ int main(int argc, char** argv) {
     p.opts = 0;
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(hs.data(), stamps, NB * 8 * 8, hipMemcpyDeviceToHost));
-    if (rep == 2) report("eps_bwd_dcore_q2reg_k (fused head)", hs, NB, 6, bl);
+    if (rep == 2) report("eps_bwd_dcore_q2reg_k (fused head)", hs, NB, 8, bl);
+    // the finishing kernel (eager: its own launch, after the dCore kernel has drained)
+    dctn_stamps_set(nullptr);
+    CK(hipMemset(stamps, 0, NB * 8 * 8));
+    dctn_reduce_stamps_set(stamps);
+    if (eps_head_bwd_mfma(x, feat, dl, wgt, dcore, dw, db, ws, wsb, p, Cout, DCTN_BF16, 0, st) != DCTN_OK) return 1;
+    CK(hipStreamSynchronize(st));
+    dctn_reduce_stamps_set(nullptr);
+    CK(hipMemcpy(hs.data(), stamps, NB * 8 * 8, hipMemcpyDeviceToHost));
+    if (rep == 2) {
+      std::vector<unsigned long long> a(hs.begin(), hs.begin() + 64 * 8), b(hs.begin() + 64 * 8, hs.end());
+      // common origin: the earliest entry of either role
+      report("eps_head_reduce_k, all roles", hs, NB, 5, rl);
+      report("eps_head_reduce_k, dCore roles only", a, 64, 5, rl);
+    }
   }
   return 0;
 }
