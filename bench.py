@@ -403,8 +403,10 @@ def headline_roofline(model, x, specs, steps):
     flops = {"eps_fwd": wn * (t["gemm_flops"] + half),
              "eps_bwd_dcore": wn * (t["gemm_flops"] + half + (2 * cout * O if t["fused"] else 0))}
     alg = {"eps_fwd": t["bytes_x"] + t["bytes_y"] + t["bytes_core"],
-           "eps_bwd_dcore": t["bytes_x"] + t["bytes_y"] + t["bytes_core"]
-                            + ((B * cout + 2 * w_head.numel() + cout) * esz if t["fused"] else 0)}
+           # fused: the kernel reads x, dLogits and the head weight and produces dCore; the features are read and
+           # dWeight / dBias written by the call's second kernel since round 4 (not this kernel's bytes any more)
+           "eps_bwd_dcore": (t["bytes_x"] + t["bytes_core"] + (B * cout + w_head.numel()) * esz) if t["fused"]
+                            else t["bytes_x"] + t["bytes_y"] + t["bytes_core"]}
     if q2:
         dom = max(("eps_fwd", "eps_bwd_dcore"), key=lambda k: kernels[{"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[k]])
         kname = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[dom]

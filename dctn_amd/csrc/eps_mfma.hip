@@ -1333,17 +1333,19 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 // Second (and last) kernel of the fused head backward: workgroups [0, n_core) finish dCore exactly
 // as eps_bwd_dcore_reduce_k does, the next n_dw sum the ncb partial tiles of the head-weight gradient
 // (256 consecutive features each), the last one sums dLogits over the batch into dBias.
-// The `gemm` role of eps_head_reduce_k (HEADMM shapes, cfg2): dW[c][f] = sum_b dLogits[b][c] * feat[b][f] for the 64
-// features [64 blk, 64 blk + 64) of one workgroup, on v_mfma_f32_16x16x32_bf16 (rows = classes, columns = features,
+// The `gemm` role of eps_head_reduce_k (HEADMM shapes, cfg2): dW[c][f] = sum_b dLogits[b][c] * feat[b][f] for the
+// DWG_FW features of one workgroup's slice, on v_mfma_f32_16x16x32_bf16 (rows = classes, columns = features,
 // k = samples).  Wave w takes the samples [w spw, (w + 1) spw) in blocks of 32; lane (n, kg) = (lane % 16, lane / 16)
-// loads, for the 8 samples 8 kg .. 8 kg + 7 of a block, 8 bytes of the feature row (features 4 n .. 4 n + 3 of the
-// slice: a load instruction covers 128 contiguous bytes of 4 rows) and one value of dLogits - the k-contiguous fragments
-// come from 8 loads, never from a transpose; tile j of the wave is the features 4 n + j.  The next block's loads are
-// issued before the current block's products (B = 1024: both blocks of a wave in flight at once).  The 16 waves' tiles
-// meet in LDS (64 KiB dynamic), thread (slot, lane) sums one element in wave order (deterministic) and stores it.
-// What bounds the role (tools/stamp_cfg2.hip): a workgroup pulls 1024 rows x 128 B through ONE CU's memory path - the
-// first loads are back 2.3 us after the kernel's start, the last wave's after 5.5; the role ends at 6.1 us (the dCore
-// roles next to it at 2.0).  Tried and dropped:
+// loads, for the 8 samples 8 kg .. 8 kg + 7 of a block, its FL = DWG_FW / 16 features of the row and one value of
+// dLogits - the k-contiguous fragments come from 8 loads, never from a transpose; tile j of the wave is the features
+// FL n + j.  The next block's loads are issued before the current block's products (B = 1024: both blocks of a wave in
+// flight at once).  The 16 waves' tiles meet in LDS (dynamic), thread (slot, lane) sums one element in wave order
+// (deterministic) and stores it.
+// What bounds the role (tools/stamp_cfg2.hip) is the volume ONE CU pulls through its memory path: with 64-feature
+// slices (128-byte pieces of 1024 rows, 43 workgroups) the first loads are back 2.3 us after the kernel's start, the
+// last wave's after 5.5, the role ends at 6.1 us (the dCore roles next to it at 2.0).  32-feature slices (64-byte
+// pieces - the memory path fetches 64-byte sectors, so the volume per CU halves; 85 workgroups) end at 4.8 us;
+// 16-feature slices (32-byte pieces, 169 workgroups) at 5.3: a sector is the least a piece costs.  Tried and dropped:
 //  * the product as its own kernel on a forked side stream next to the dCore kernel - the two cross-stream
 //    dependencies cost more than the kernel: 45.9 us per step in the graph, 30.7 us per eager call;
 //  * the samples split 4 ways over 172 workgroups, the 4 KiB partial tiles combined by the last workgroup of a slice
@@ -1351,28 +1353,40 @@ __global__ __launch_bounds__(256) void eps_bwd_dcore_reduce_k(const float* __res
 //    green): products done after 2.5 us instead of 5.5, but the store-and-count costs 1.3 us and the last arriver's
 //    re-read 1.2 (release / acquire on the counter: 2.5 + 2.5) - the role ends at 6.0 us, no gain for the machinery.
 constexpr int DWG_WAVES = 16;
+constexpr int DWG_FW = 32;   // features of one workgroup's slice (4 bytes of a row per lane: 64-byte pieces of 4 rows per load)
 __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ feat, const bf16_t* __restrict__ dL,
                                                   bf16_t* __restrict__ dW, int B, int Cout, long long F, int blk,
                                                   float* __restrict__ lds) {
   typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  constexpr int FL = DWG_FW / 16;   // features per lane = tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kg = lane >> 4;
   const unsigned f_bytes = (unsigned)((long long)B * F * 2), dl_bytes = (unsigned)B * (unsigned)Cout * 2u;
   const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(feat, f_bytes), rs_dl = make_rsrc(dL, dl_bytes);
-  const long long fcol = (long long)blk * 64 + 4 * n;
-  const bool fok = fcol + 3 < F;   // (F is a multiple of 4: OP == 4)
+  const long long fcol = (long long)blk * DWG_FW + FL * n;
+  const bool fok = fcol + FL - 1 < F;   // (F is a multiple of 4: OP == 4)
   const int spw = (((B + DWG_WAVES - 1) / DWG_WAVES) + 31) / 32 * 32;
   const int b0 = wv * spw, b1 = b0 + spw < B ? b0 + spw : B;
-  f32x4v acc[4];
+  f32x4v acc[FL];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  u32x2 fr[8], frn[8];
+  for (int j = 0; j < FL; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  constexpr int FD = FL >= 2 ? FL / 2 : 1;   // dwords of a row piece per lane
+  unsigned fr[8][FD], frn[8][FD];
   unsigned a16[8], a16n[8];
-  auto issue = [&](int kb, u32x2 (&f)[8], unsigned (&a)[8]) {
+  auto issue = [&](int kb, unsigned (&f)[8][FD], unsigned (&a)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int b = kb + 8 * kg + j;
       const bool in = b < b1;
-      f[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_f, (in && fok) ? (unsigned)((long long)b * F * 2 + fcol * 2) : f_bytes, 0, 0);
+      const unsigned vo = (in && fok) ? (unsigned)((long long)b * F * 2 + fcol * 2) : f_bytes;
+      if constexpr (FL == 1) {
+        f[j][0] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_f, vo, 0, 0);
+      } else if constexpr (FL == 2) {
+        f[j][0] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, vo, 0, 0);
+      } else {
+        const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rs_f, vo, 0, 0);
+        f[j][0] = q.x;
+        f[j][FD - 1] = q.y;
+      }
       a[j] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
           rs_dl, (in && n < Cout) ? (unsigned)b * (unsigned)Cout * 2u + 2u * n : dl_bytes, 0, 0);
     }
@@ -1386,32 +1400,37 @@ __device__ __forceinline__ void head_dw_gemm_role(const bf16_t* __restrict__ fea
 #pragma unroll
     for (int d = 0; d < 4; ++d) at[d] = (int)(a16[2 * d] | (a16[2 * d + 1] << 16));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < FL; ++j) {
       const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;   // the odd / even halves of two dwords
       int4v bf;
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        bf[d] = (int)__builtin_amdgcn_perm((j >> 1) ? fr[2 * d + 1].y : fr[2 * d + 1].x, (j >> 1) ? fr[2 * d].y : fr[2 * d].x, sel);
+        bf[d] = FL == 1 ? (int)(fr[2 * d][0] | (fr[2 * d + 1][0] << 16))
+                        : (int)__builtin_amdgcn_perm(fr[2 * d + 1][j >> 1], fr[2 * d][j >> 1], sel);
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, at), __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { fr[j] = frn[j]; a16[j] = a16n[j]; }
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int e = 0; e < FD; ++e) fr[j][e] = frn[j][e];
+      a16[j] = a16n[j];
+    }
   }
-  // acc[j][i] = dW[class 4 kg + i][feature 64 blk + 4 n + j] of this wave's samples
+  // acc[j][i] = dW[class 4 kg + i][feature DWG_FW blk + FL n + j] of this wave's samples
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < FL; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lds[(wv * 16 + j * 4 + i) * 64 + lane] = acc[j][i];
+    for (int i = 0; i < 4; ++i) lds[(wv * (4 * FL) + j * 4 + i) * 64 + lane] = acc[j][i];
   DCTN_STAMP_G(1);
   __syncthreads();
   DCTN_STAMP_G(2);
-  {
+  if (tid < 4 * FL * 64) {
     const int slot = tid >> 6, j = slot >> 2, i = slot & 3;
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < DWG_WAVES; ++w) t += lds[(w * 16 + slot) * 64 + lane];
+    for (int w = 0; w < DWG_WAVES; ++w) t += lds[(w * (4 * FL) + slot) * 64 + lane];
     const int c = 4 * kg + i;
-    const long long f = (long long)blk * 64 + 4 * n + j;
+    const long long f = (long long)blk * DWG_FW + FL * n + j;
     if (c < Cout && f < F) dW[(long long)c * F + f] = (bf16_t)t;
   }
   DCTN_STAMP_G(4);
@@ -1732,8 +1751,8 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
 #undef DCTN_HEAD_LAUNCH
   DCTN_CHECK_LAUNCH();
   if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
-  const int n_core = BN * OP * AT, n_dw = gemm ? (int)(((long long)m.P * OP + 63) / 64) : (int)((nW + 255) / 256);
-  constexpr size_t GEMM_LDS = (size_t)DWG_WAVES * 16 * 64 * sizeof(float);
+  const int n_core = BN * OP * AT, n_dw = gemm ? (int)(((long long)m.P * OP + DWG_FW - 1) / DWG_FW) : (int)((nW + 255) / 256);
+  constexpr size_t GEMM_LDS = (size_t)DWG_WAVES * (DWG_FW / 4) * 64 * sizeof(float);
   static_assert(DWG_WAVES * 64 == 1024, "the gemm role is the whole workgroup of eps_head_reduce_k");
   if (gemm) (void)hipFuncSetAttribute((const void*)eps_head_reduce_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
   hipLaunchKernelGGL(eps_head_reduce_k, dim3(n_core + n_dw + 1), dim3(1024), gemm ? GEMM_LDS : 0, st, (const float*)ws, (S*)dCore,
