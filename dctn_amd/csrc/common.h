@@ -156,6 +156,15 @@ int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores
                     float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);
 // several uniform strings of one layer in one launch each way (DCTN_ERR_UNSUPPORTED: run them one by one)
+// The same for strings of the band family (bonds 9..16): blockIdx.y = string, one tail kernel for all strings.
+size_t convsbs_many_band_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                       int C, int B, int H, int W, int q, int dtype);
+int convsbs_many_fwd_band(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,
+                          const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                          int q, int dtype, hipStream_t st);
+int convsbs_many_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* const* dYs, void* dX,
+                          float* const* dcores, int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                          const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);
 size_t convsbs_many_reg_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
                                       int C, int B, int H, int W, int q, int dtype);
 int convsbs_many_fwd_reg(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,

@@ -123,7 +123,7 @@ __device__ __forceinline__ void bd_barrier() {   // workgroup barrier that order
 // QT: feature values per core (q^C, 2..4) = 16x16 tiles per product.  CH: 1 = one channel (the products ARE the pixel's
 // values), 2 = two channels of two values (QT = 4; the deeper layers of the reference's classifier).
 template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p) {
+__device__ __forceinline__ void bd_bwd_body(const BdP& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
   constexpr int RK = CH == 2 ? 4 : QT;   // gradient values per core and window in the band's LDS rows
@@ -710,6 +710,16 @@ __global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p)
   BD_STAMP(18);
 }
 
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p) { bd_bwd_body<QT, CH>(p); }
+
+// The strings of one ManyConvSBS layer (dctn/conv_sbs.py:367-370) in one launch: blockIdx.y = string.  String s > 0 writes
+// its share of dX into a buffer of its own; the tail kernel adds the strings' shares (and every string's shared rows).
+constexpr int BD_MANY = 2;
+struct BdPMany { BdP s[BD_MANY]; };
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_many_k(const BdPMany pp) { bd_bwd_body<QT, CH>(pp.s[blockIdx.y]); }
+
 // ------------------------------------------------------------------------------------------------ forward
 // The same chain, forwards only: no accumulators, no states to keep - 8 identical waves per workgroup, each with its own
 // 16-window tiles (flat over all windows of the batch), at most 128 registers so that FOUR waves share a SIMD and cover
@@ -727,7 +737,7 @@ struct BdFwdP {
 };
 
 template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP p) {
+__device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
   constexpr int CPT = BD_NPK * QT * 256;
@@ -902,17 +912,23 @@ __global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP
   }
 }
 
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP p) { bd_fwd_body<QT, CH>(p); }
+
+struct BdFwdPMany { BdFwdP s[BD_MANY]; };
+template <int QT, int CH>
+__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_many_k(const BdFwdPMany pp) { bd_fwd_body<QT, CH>(pp.s[blockIdx.y]); }
+
 // dCore_c[e] = sum over the workgroups' records in a fixed order; the pixel rows two bands share = the sum of their two
 // partial sums.  64 elements per workgroup, 4 record subsets, LDS join (as convsbs_dcore_reduce_k).
-__global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
+__device__ __forceinline__ void bd_tail_records(const BdTailP& p, int blk) {
   __shared__ float red[4][64];
-  const int nblk_core = p.records ? (p.rec_len + 63) / 64 : 0;
-  if ((int)blockIdx.x < nblk_core) {
+  {
     // 64 consecutive POSITIONS of the records per workgroup (coalesced: a record is the join area as it stands - middle
     // cores as accumulator tiles [slot][qq][register = r' & 3][lane = l + 16 (r' >> 2)], then the first and the last core
     // [16][4]); the sum goes to the element of the cores' layouts that position stands for.  (Element-major reads
     // gathered one 4-byte word per 64-byte line: 51 MB of traffic for 6.4 MB of records.)
-    const int pos = (int)blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int pos = blk * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (pos < p.rec_len) {
       int r = sub;
@@ -950,6 +966,13 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
       if (c >= 0 && c < p.n && p.dcore[c] != nullptr && qq < p.qc && l < p.bl[c] && r < p.br[c] && o < p.o[c])
         p.dcore[c][((o * p.bl[c] + l) * p.br[c] + r) * p.qc + qq] = v;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
+  const int nblk_core = p.records ? (p.rec_len + 63) / 64 : 0;
+  if ((int)blockIdx.x < nblk_core) {
+    bd_tail_records(p, (int)blockIdx.x);
     return;
   }
   // shared rows: element = (image, boundary, row, column, channel, value)
@@ -968,6 +991,46 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_k(const BdTailP p) {
   const float* s0 = p.side + ((size_t)bi * 2 * p.max_h + yb) * rowlen + r2;
   const float v = s0[0] + s0[(size_t)p.max_h * rowlen];
   p.dX[((((size_t)ch * p.B + img) * p.H + y) * p.W + xc) * p.q + d] = v;
+}
+
+// Several strings: the records of every string, then ONE pass over all of dX - an element is the sum over the strings of
+// the string's own value (its dX buffer) or, on a pixel row two bands share, of the two partial sums of its side buffer.
+// (One thread per element and all strings: string 0's buffer IS dX, nobody else touches the element.)  The strings share
+// the band geometry (checked by the host).
+struct BdTailMany { BdTailP s[BD_MANY]; int ns; };
+__global__ __launch_bounds__(256) void convsbs_band_tail_many_k(const BdTailMany pp) {
+  const BdTailP& p0 = pp.s[0];
+  const int nblk_core = p0.records ? (p0.rec_len + 63) / 64 : 0;
+  if ((int)blockIdx.x < nblk_core * pp.ns) {
+    const int sidx = (int)blockIdx.x / nblk_core;
+    bd_tail_records(pp.s[sidx], (int)blockIdx.x - sidx * nblk_core);
+    return;
+  }
+  if (!p0.dX) return;
+  const long long e = ((long long)blockIdx.x - (long long)nblk_core * pp.ns) * 256 + threadIdx.x;
+  const long long total = (long long)p0.C * p0.B * p0.H * p0.W * p0.q;
+  if (e >= total) return;
+  const int d = (int)(e % p0.q);
+  long long rest = e / p0.q;
+  const int xc = (int)(rest % p0.W); rest /= p0.W;
+  const int y = (int)(rest % p0.H); rest /= p0.H;
+  const int img = (int)(rest % p0.B);
+  const int ch = (int)(rest / p0.B);
+  const int kq = y / p0.band_rows, yb = y - kq * p0.band_rows;
+  const bool shared = kq >= 1 && kq <= p0.nb - 1 && yb < p0.max_h;
+  const int rowlen = p0.W * p0.Cq;
+  float v = 0.f;
+  for (int sidx = 0; sidx < pp.ns; ++sidx) {
+    const BdTailP& p = pp.s[sidx];
+    if (shared) {
+      const long long bi = (long long)img * (p.nb - 1) + (kq - 1);
+      const float* s0 = p.side + ((size_t)bi * 2 * p.max_h + yb) * rowlen + (xc * p.Cq + ch * p.q + d);
+      v += s0[0] + s0[(size_t)p.max_h * rowlen];
+    } else {
+      v += p.dX[e];
+    }
+  }
+  p0.dX[e] = v;
 }
 
 // family check + the launch plan; DCTN_ERR_UNSUPPORTED outside the family
@@ -1171,5 +1234,140 @@ int convsbs_fwd_band(const void* x, const int64_t xs[5], const void* const* core
 #undef BD_FLAUNCH
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("convsbs_fwd_band_f32");
+  return DCTN_OK;
+}
+
+// ---------------------------------------------------------------------------------- several strings per launch
+namespace {
+// the plans of the strings of one layer; DCTN_ERR_UNSUPPORTED unless every string is in the family with the same tile
+// shape and band geometry (the tail kernel's one pass over dX relies on it)
+int bd_plan_many(BdPlan (&pl)[BD_MANY], int ns, const int64_t xs[5], const void* const* cores, int n, const int* out_sizes,
+                 const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W, int q, int dtype) {
+  if (ns != BD_MANY) return DCTN_ERR_UNSUPPORTED;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    const int rc = bd_plan(pl[s2], xs, cores ? cores + s2 * n : nullptr, n, out_sizes + s2 * n, bond_sizes + s2 * n, pos_h + s2 * n,
+                           pos_w + s2 * n, C, B, H, W, q, dtype);
+    if (rc != DCTN_OK) return rc;
+    if (s2 > 0) {
+      const BdP &a = pl[0].p, &b = pl[s2].p;
+      if (pl[s2].QT != pl[0].QT || pl[s2].CH != pl[0].CH || pl[s2].lds_bytes != pl[0].lds_bytes || pl[s2].nwg != pl[0].nwg ||
+          a.nb != b.nb || a.band_rows != b.band_rows || a.max_h != b.max_h || a.Ho != b.Ho || a.Wo != b.Wo)
+        return DCTN_ERR_UNSUPPORTED;
+    }
+  }
+  return DCTN_OK;
+}
+}  // namespace
+
+size_t convsbs_many_band_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
+                                       int C, int B, int H, int W, int q, int dtype) {
+  BdPlan pl[BD_MANY];
+  if (bd_plan_many(pl, ns, nullptr, nullptr, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype) != DCTN_OK) return 0;
+  size_t tot = 256;
+  for (int s2 = 0; s2 < ns; ++s2) tot += bd_align256(pl[s2].records_bytes) + bd_align256(pl[s2].side_bytes);
+  tot += (size_t)(ns - 1) * bd_align256((size_t)C * B * H * W * q * sizeof(float));   // the other strings' shares of dX
+  return tot;
+}
+
+int convsbs_many_fwd_band(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,
+                          const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
+                          int q, int dtype, hipStream_t st) {
+  BdPlan pl[BD_MANY];
+  const int rc = bd_plan_many(pl, ns, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  if (rc != DCTN_OK) return rc;
+  BdFwdPMany pp;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    if (!outs[s2]) return DCTN_ERR_NULL;
+    const BdP& b = pl[s2].p;
+    BdFwdP& p = pp.s[s2];
+    p.x = (const float*)x; p.out = (float*)outs[s2];
+    for (int c = 0; c < BD_NC; ++c) {
+      p.core[c] = b.core[c]; p.o[c] = b.o[c]; p.bl[c] = b.bl[c]; p.br[c] = b.br[c]; p.ph[c] = b.ph[c]; p.pw[c] = b.pw[c]; p.nin[c] = b.nin[c];
+    }
+    for (int i = 0; i < 5; ++i) p.xs[i] = b.xs[i];
+    p.n = n; p.C = C; p.q = q; p.qc = b.qc; p.B = B; p.H = H; p.W = W; p.Ho = b.Ho; p.Wo = b.Wo; p.Otot = b.Otot;
+    p.Wn = (long long)B * b.Ho * b.Wo;
+    p.ntiles = (p.Wn + 15) / 16;
+  }
+  const int lds_bytes = (BD_NPK * pl[0].QT * 256 + 128 + 8 * 2 * BD_NC * 16 * 4) * 4;
+  long long blocks = (pp.s[0].ntiles + 7) / 8;
+  const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;
+  if (blocks > 256 * per_cu / ns) blocks = 256 * per_cu / ns;   // the strings' persistent waves are resident together
+#define BD_FLAUNCH(QTV, CHV)                                                                                         \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_many_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              lds_bytes);                                                                            \
+    hipLaunchKernelGGL((convsbs_fwd_band_many_k<QTV, CHV>), dim3((unsigned)blocks, (unsigned)ns), dim3(BD_THREADS), lds_bytes, st, pp); \
+  } while (0)
+  if (pl[0].CH == 2) BD_FLAUNCH(4, 2);
+  else if (pl[0].QT == 2) BD_FLAUNCH(2, 1);
+  else if (pl[0].QT == 3) BD_FLAUNCH(3, 1);
+  else BD_FLAUNCH(4, 1);
+#undef BD_FLAUNCH
+  DCTN_CHECK_LAUNCH();
+  dctn_set_last_kernel("convsbs_many_fwd_band_f32");
+  return DCTN_OK;
+}
+
+int convsbs_many_bwd_band(const void* x, const int64_t xs[5], const void* const* cores, const void* const* dYs, void* dX,
+                          float* const* dcores, int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
+                          const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes) {
+  BdPlan pl[BD_MANY];
+  const int rc = bd_plan_many(pl, ns, xs, cores, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  if (rc != DCTN_OK) return rc;
+  if (!dX && !dcores) return DCTN_OK;
+  const size_t need = convsbs_many_band_bwd_workspace(ns, n, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
+  if (!ws || ws_bytes < need || ((uintptr_t)ws % 16)) return DCTN_ERR_WORKSPACE;
+  BdPMany pp;
+  BdTailMany tt;
+  tt.ns = ns;
+  unsigned char* cur = (unsigned char*)ws;
+  for (int s2 = 0; s2 < ns; ++s2) {
+    if (!dYs[s2]) return DCTN_ERR_NULL;
+    BdP& p = pl[s2].p;
+    p.x = (const float*)x;
+    p.dY = (const float*)dYs[s2];
+    p.records = dcores ? (float*)cur : nullptr;
+    cur += bd_align256(pl[s2].records_bytes);
+    p.side = (float*)cur;
+    cur += bd_align256(pl[s2].side_bytes);
+    if (!dX) p.dX = nullptr;
+    else if (s2 == 0) p.dX = (float*)dX;
+    else {
+      p.dX = (float*)cur;
+      cur += bd_align256((size_t)C * B * H * W * q * sizeof(float));
+    }
+    p.stamps = nullptr;
+    pp.s[s2] = p;
+    BdTailP& t = tt.s[s2];
+    t.n = n; t.nrec = pl[s2].nwg; t.total = p.core_off[n]; t.qc = p.qc; t.rec_len = pl[s2].rec_len;
+    for (int c = 0; c <= BD_NC; ++c) t.core_off[c] = p.core_off[c];
+    for (int c = 0; c < BD_NC; ++c) { t.bl[c] = p.bl[c]; t.br[c] = p.br[c]; t.o[c] = p.o[c]; }
+    t.c2 = p.c2;
+    for (int c = 0; c < BD_NC; ++c) t.dcore[c] = (dcores && c < n) ? dcores[s2 * n + c] : nullptr;
+    t.records = p.records; t.side = p.side; t.dX = p.dX;
+    t.B = B; t.H = H; t.W = W; t.C = C; t.q = q; t.Cq = C * q; t.nb = p.nb; t.band_rows = p.band_rows; t.max_h = p.max_h;
+    t.nshared = 0;
+  }
+#define BD_LAUNCH(QTV, CHV)                                                                                          \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_many_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              pl[0].lds_bytes);                                                                      \
+    hipLaunchKernelGGL((convsbs_bwd_band_many_k<QTV, CHV>), dim3((unsigned)pl[0].nwg, (unsigned)ns), dim3(BD_THREADS), pl[0].lds_bytes, \
+                       st, pp);                                                                                      \
+  } while (0)
+  if (pl[0].CH == 2) BD_LAUNCH(4, 2);
+  else if (pl[0].QT == 2) BD_LAUNCH(2, 1);
+  else if (pl[0].QT == 3) BD_LAUNCH(3, 1);
+  else BD_LAUNCH(4, 1);
+#undef BD_LAUNCH
+  DCTN_CHECK_LAUNCH();
+  const long long rec_blocks = dcores ? (long long)ns * ((pl[0].rec_len + 63) / 64) : 0;
+  const long long dx_blocks = dX ? ((long long)C * B * H * W * q + 255) / 256 : 0;
+  if (rec_blocks + dx_blocks > 0) {
+    hipLaunchKernelGGL(convsbs_band_tail_many_k, dim3((unsigned)(rec_blocks + dx_blocks)), dim3(256), 0, st, tt);
+    DCTN_CHECK_LAUNCH();
+  }
+  dctn_set_last_kernel("convsbs_many_bwd_band_f32");
   return DCTN_OK;
 }

@@ -631,8 +631,11 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
 size_t dctn_convsbs_many_workspace_bytes(int n_strings, int n_cores, const int* out_sizes, const int* bond_sizes, int C, int B,
                                          int H, int W, int q, const int* pos_h, const int* pos_w, int dtype) {
   if (!out_sizes || !bond_sizes || !pos_h || !pos_w) return 0;
-  return convsbs_many_reg_bwd_workspace(n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
-                                        dtype & DCTN_DTYPE_MASK);
+  const size_t a = convsbs_many_reg_bwd_workspace(n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                                                  dtype & DCTN_DTYPE_MASK);
+  if (a > 0) return a;
+  return convsbs_many_band_bwd_workspace(n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                                         dtype & DCTN_DTYPE_MASK);
 }
 
 int dctn_convsbs_many_fwd(const void* x, const int64_t x_strides[5], const void* const* cores, void* const* outs,
@@ -643,8 +646,11 @@ int dctn_convsbs_many_fwd(const void* x, const int64_t x_strides[5], const void*
   if (dtype & ~DCTN_DTYPE_MASK) return DCTN_ERR_UNSUPPORTED;
   for (int i = 0; i < n_strings * n_cores; ++i)
     if (!cores[i]) return DCTN_ERR_NULL;
-  return convsbs_many_fwd_reg(x, x_strides, cores, outs, n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
-                              dtype, (hipStream_t)stream);
+  const int rc = convsbs_many_fwd_reg(x, x_strides, cores, outs, n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,
+                                      W, q, dtype, (hipStream_t)stream);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  return convsbs_many_fwd_band(x, x_strides, cores, outs, n_strings, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
+                               dtype, (hipStream_t)stream);
 }
 
 int dctn_convsbs_many_bwd(const void* x, const int64_t x_strides[5], const void* const* cores, const void* const* dYs, void* dX,
@@ -657,8 +663,11 @@ int dctn_convsbs_many_bwd(const void* x, const int64_t x_strides[5], const void*
   if (!dX && !dCores) return DCTN_OK;
   for (int i = 0; i < n_strings * n_cores; ++i)
     if (!cores[i] || (dCores && !dCores[i])) return DCTN_ERR_NULL;
-  return convsbs_many_bwd_reg(x, x_strides, cores, dYs, dX, (float* const*)dCores, n_strings, n_cores, out_sizes, bond_sizes,
-                              pos_h, pos_w, C, B, H, W, q, dtype, (hipStream_t)stream, workspace, workspace_bytes);
+  const int rc = convsbs_many_bwd_reg(x, x_strides, cores, dYs, dX, (float* const*)dCores, n_strings, n_cores, out_sizes, bond_sizes,
+                                      pos_h, pos_w, C, B, H, W, q, dtype, (hipStream_t)stream, workspace, workspace_bytes);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  return convsbs_many_bwd_band(x, x_strides, cores, dYs, dX, (float* const*)dCores, n_strings, n_cores, out_sizes, bond_sizes,
+                               pos_h, pos_w, C, B, H, W, q, dtype, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 }  // extern "C"

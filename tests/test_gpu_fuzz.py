@@ -725,6 +725,11 @@ SNAKE9B = ((0, 0), (1, 0), (2, 0), (2, 1), (1, 1), (0, 1), (0, 2), (1, 2), (2, 2
     (2, 2, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), (1, 1, 1, 1, 2, 1, 1, 1, 1), 130, 10, 10),   # its second layer, bond 2, several bands
     (3, 1, 3, (2, 1, 1, 1, 1, 1, 1, 1, 1), (1, 1, 1, 1, 1, 1, 1, 1, 2), 3, 9, 30),      # bond 3, q = 3, different two-valued cores
     (4, 1, 4, (1,) * 9, (1,) * 9, 2, 8, 8),                                              # one output each
+    # bonds 9..16: the band family, blockIdx.y = string (the bond-16 two-string layer of mnist.py:224-242)
+    (16, 1, 3, (1, 1, 1, 1, 2, 1, 1, 1, 1), (1, 1, 1, 1, 2, 1, 1, 1, 1), 5, 12, 11),
+    (16, 2, 2, (1, 1, 1, 1, 2, 1, 1, 1, 1), (1, 1, 2, 1, 1, 1, 1, 1, 1), 130, 10, 10),   # two channels, many images: several bands
+    (12, 1, 2, (1,) * 9, (1,) * 9, 3, 9, 30),
+    (16, 1, 4, (1,) * 9, (1,) * 9, 2, 8, 8),
 ])
 def test_many_convsbs_strings_in_one_launch(bond, C, q, outs_a, outs_b, B, H, W):
     """`ManyConvSBS.forward` (dctn/conv_sbs.py:367-370) for a layer of two nine-core strings over the same 3 x 3 window:
@@ -739,11 +744,12 @@ def test_many_convsbs_strings_in_one_launch(bond, C, q, outs_a, outs_b, B, H, W)
     many = ManyConvSBS(C, q, bond, False, specs, (init, init)).to(DEV)
     x0 = torch.randn(C, B, H, W, q)
     x = x0.to(DEV).requires_grad_(True)
+    fam = "band" if bond > 8 else "reg"
     ya, yb = many(x)
-    assert dctn_amd.last_kernel() == "convsbs_many_fwd_reg_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_many_fwd_{fam}_f32"
     dya, dyb = torch.randn_like(ya), torch.randn_like(yb)
     ((ya * dya).sum() + (yb * dyb).sum()).backward()
-    assert dctn_amd.last_kernel() == "convsbs_many_bwd_reg_f32"
+    assert dctn_amd.last_kernel() == f"convsbs_many_bwd_{fam}_f32"
     dx_sum = torch.zeros_like(x0, dtype=torch.float64)
     for string, pos, y, dy in ((many.strings[0], SNAKE9, ya, dya), (many.strings[1], SNAKE9B, yb, dyb)):
         cores64 = [c.detach().cpu().double() for c in string.cores]

@@ -595,7 +595,7 @@ def test_eps_f32_bigcore_saved_gemm_result(C, B, H, W, Q, K, O):
 
 
 @pytest.mark.parametrize("which", ["eps_bigcore_f32", "eps_generic_q3", "convsbs_generic_bond3", "convsbs_ring_many_bond4",
-                                   "convsbs_saved_states_bond8"])
+                                   "convsbs_saved_states_bond8", "many_convsbs_band_bond16"])
 def test_graph_replays_start_their_accumulators_from_zero(which):
     """Kernels that accumulate into a zero-filled buffer (atomics, slices) must zero it with a kernel of their own: a
     `hipMemsetAsync` recorded into a torch HIP graph filled with garbage from the second replay on
@@ -611,6 +611,21 @@ def test_graph_replays_start_their_accumulators_from_zero(which):
         x = torch.randn(C, B, H, W, Q, device=DEV, requires_grad=True)
         params = [(torch.randn(*(Q,) * N, O, device=DEV) * Q ** (-N / 4)).requires_grad_(True)]
         run = lambda: eps(params[0], x)
+    elif which == "many_convsbs_band_bond16":
+        # the bond-16 two-string layer of the reference's classifier (mnist.py:224-242): one forward launch, the backward
+        # kernel + its tail for both strings (dX summed over the strings by the tail)
+        from dctn_amd.conv_sbs import ManyConvSBS
+        snake_a = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
+        snake_b = ((0, 0), (1, 0), (2, 0), (2, 1), (1, 1), (0, 1), (0, 2), (1, 2), (2, 2))
+        outs = (1, 1, 1, 1, 2, 1, 1, 1, 1)
+        specs = tuple(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(sn, outs)) for sn in (snake_a, snake_b))
+        init = DumbNormalInitialization((4 * 16) ** -0.5 * 1.2)
+        many = ManyConvSBS(2, 2, 16, False, specs, (init, init)).to(DEV)
+        x = torch.randn(2, 3, 7, 8, 2, device=DEV, requires_grad=True)
+        params = list(many.parameters())
+        run = lambda: torch.cat(many(x), dim=-1)
+        run()
+        assert dctn_amd.last_kernel() == "convsbs_many_fwd_band_f32"
     else:
         snake = ((0, 0), (0, 1), (0, 2), (1, 2), (1, 1), (1, 0), (2, 0), (2, 1), (2, 2))
         if which == "convsbs_generic_bond3":
