@@ -89,6 +89,7 @@ SIGNATURES = {
     "dctn_ar_export": (c_int, [c_void, c_void]),
     "dctn_ar_connect": (c_int, [c_void, c_void]),
     "dctn_ar_allreduce": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void]),
+    "dctn_ar_allreduce_algo": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_int, c_void]),
     "dctn_ar_status": (c_int, [c_void]),
     "dctn_ar_destroy": (c_int, [c_void]),
 }

@@ -12,7 +12,14 @@
 //   * staging is double-buffered by the parity of the step, so no second barrier is needed: a rank overwrites
 //     staging[s & 1] at step s + 2, which its peers allow by publishing step s + 1 - after their step-s reads;
 //   * the step counter lives in device memory (the launch is replayable from a HIP graph: no argument changes);
-//   * a wait that does not complete within ~2 s sets an error word instead of hanging the queue (dctn_ar_status).
+//   * a wait that does not complete within ~2 s sets an error word instead of hanging the queue (dctn_ar_status);
+//   * TWO-SHOT form for large buckets (cfg3a: 7.5 MB): reading every peer's whole buffer moves (P - 1) N bytes into every
+//     rank; instead rank r reduces only chunk r (N / P elements, read from every rank's staging: (P - 1) N / P bytes),
+//     leaves the scaled result in its `result` area and publishes a second flag; every rank then copies chunk j from rank
+//     j's result area (another (P - 1) N / P bytes).  Same sums in the same (rank) order, each formed once: bitwise the
+//     one-shot values, identical on all ranks.  `result` is double-buffered like the staging.  Chosen by
+//     dctn_ar_allreduce for world >= 4 and >= 512 KiB (a guess - this build has never run across xGMI);
+//     dctn_ar_allreduce_algo forces either form (the two-rank tests run both).
 #include "common.h"
 
 #include <string.h>
@@ -41,14 +48,48 @@ struct ArP {
 };
 
 // block layout
-__host__ __device__ inline size_t ar_flags_bytes() { return (size_t)AR_MAX_WORLD * AR_FLAG_STRIDE * sizeof(int); }
-__host__ __device__ inline size_t ar_counters_off(size_t max_bytes) { return ar_flags_bytes() + 2 * max_bytes; }
-// counters: [0] step, [1] error word, [2] workgroups done copying, [3] workgroups finished
+// block layout: [flag lines: inputs staged | flag lines: chunk reduced] [staging 0] [staging 1] [result 0] [result 1] [counters]
+__host__ __device__ inline size_t ar_flags_bytes() { return (size_t)2 * AR_MAX_WORLD * AR_FLAG_STRIDE * sizeof(int); }
+__host__ __device__ inline size_t ar_result_off(size_t max_bytes) { return ar_flags_bytes() + 2 * max_bytes; }
+__host__ __device__ inline size_t ar_counters_off(size_t max_bytes) { return ar_flags_bytes() + 4 * max_bytes; }
+// counters: [0] step, [1] error word, [2] workgroups done copying, [3] workgroups finished, [4] workgroups done reducing
 
 template <typename T> struct ArAcc { typedef float type; };
 template <> struct ArAcc<double> { typedef double type; };
 
-template <typename T>
+// every rank's flag in line set `which` (0: inputs staged, 1: chunk reduced) of this rank's block reaches step + 1
+__device__ __forceinline__ void ar_wait(volatile int* my_flags, int which, int world, int step, int* counters) {
+  const int tid = threadIdx.x;
+  if (tid < world) {
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(const_cast<int*>(&my_flags[(which * AR_MAX_WORLD + tid) * AR_FLAG_STRIDE]), __ATOMIC_ACQUIRE,
+                             __HIP_MEMORY_SCOPE_SYSTEM) < step + 1) {
+      if (wall_clock64() - t0 > 200000000LL) { ok = false; break; }   // ~2 s of the 100 MHz clock
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) __hip_atomic_store(&counters[1], 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+}
+
+// the LAST workgroup to bump counters[which_counter] publishes step + 1 in line set `which` of every rank's block
+__device__ __forceinline__ void ar_publish(const ArP& p, int which, int which_counter, int step, int* counters, int* s_last) {
+  const int tid = threadIdx.x;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(&counters[which_counter], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = done == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (*s_last && tid < p.world) {
+    int* f = reinterpret_cast<int*>(p.peer[tid]) + (which * AR_MAX_WORLD + p.rank) * AR_FLAG_STRIDE;
+    __hip_atomic_store(f, step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <typename T, bool TWO>
 __global__ __launch_bounds__(AR_THREADS) void dctn_ar_k(T* __restrict__ buf, ArP p) {
   unsigned char* mine = p.peer[p.rank];
   int* counters = reinterpret_cast<int*>(mine + ar_counters_off(p.max_bytes));
@@ -63,37 +104,47 @@ __global__ __launch_bounds__(AR_THREADS) void dctn_ar_k(T* __restrict__ buf, ArP
   // ---- 1. this rank's values -> its staging buffer (uncached memory: the stores go to memory)
   T* stage = reinterpret_cast<T*>(mine + ar_flags_bytes() + (size_t)slot * p.max_bytes);
   for (long long i = lo + tid; i < hi; i += AR_THREADS) stage[i] = buf[i];
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) {
-    const int done = __hip_atomic_fetch_add(&counters[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = done == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (s_last && tid < p.world) {   // every workgroup has copied: publish step + 1 in every rank's flag line of this rank
-    int* f = reinterpret_cast<int*>(p.peer[tid]) + p.rank * AR_FLAG_STRIDE;
-    __hip_atomic_store(f, step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // ---- 2. wait for every rank's step + 1 (bounded: ~2 s of the 100 MHz clock)
-  if (tid < p.world) {
-    const long long t0 = wall_clock64();
-    bool ok = true;
-    while (__hip_atomic_load(const_cast<int*>(&my_flags[tid * AR_FLAG_STRIDE]), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step + 1) {
-      if (wall_clock64() - t0 > 200000000LL) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (!ok) __hip_atomic_store(&counters[1], 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  // ---- 3. the sum in rank order, scaled, over the rank's own values
+  ar_publish(p, 0, 2, step, counters, &s_last);   // every workgroup has copied: step + 1 in every rank's line of this rank
+  // ---- 2. wait for every rank's step + 1 (bounded)
+  ar_wait(my_flags, 0, p.world, step, counters);
   typedef typename ArAcc<T>::type A;
-  for (long long i = lo + tid; i < hi; i += AR_THREADS) {
-    A acc = 0;
-    for (int r = 0; r < p.world; ++r) {
-      const T* src = reinterpret_cast<const T*>(p.peer[r] + ar_flags_bytes() + (size_t)slot * p.max_bytes);
-      acc += (A)__builtin_nontemporal_load(&src[i]);
+  if (!TWO) {
+    // ---- 3. the sum in rank order, scaled, over the rank's own values
+    for (long long i = lo + tid; i < hi; i += AR_THREADS) {
+      A acc = 0;
+      for (int r = 0; r < p.world; ++r) {
+        const T* src = reinterpret_cast<const T*>(p.peer[r] + ar_flags_bytes() + (size_t)slot * p.max_bytes);
+        acc += (A)__builtin_nontemporal_load(&src[i]);
+      }
+      buf[i] = (T)(acc * (A)p.scale);
     }
-    buf[i] = (T)(acc * (A)p.scale);
+  } else {
+    // ---- 3a. this rank's chunk: the sum in rank order, scaled, into its result area (and its own values)
+    const long long cs = (p.n + p.world - 1) / p.world;
+    const long long c0 = (long long)p.rank * cs, c1 = c0 + cs < p.n ? c0 + cs : p.n;
+    const long long cper = (cs + gridDim.x - 1) / gridDim.x;
+    const long long clo = c0 + (long long)blockIdx.x * cper, chi = clo + cper < c1 ? clo + cper : c1;
+    T* res = reinterpret_cast<T*>(mine + ar_result_off(p.max_bytes) + (size_t)slot * p.max_bytes);
+    for (long long i = clo + tid; i < chi; i += AR_THREADS) {
+      A acc = 0;
+      for (int r = 0; r < p.world; ++r) {
+        const T* src = reinterpret_cast<const T*>(p.peer[r] + ar_flags_bytes() + (size_t)slot * p.max_bytes);
+        acc += (A)__builtin_nontemporal_load(&src[i]);
+      }
+      const T v = (T)(acc * (A)p.scale);
+      res[i] = v;
+      buf[i] = v;
+    }
+    ar_publish(p, 1, 4, step, counters, &s_last);
+    ar_wait(my_flags, 1, p.world, step, counters);
+    // ---- 3b. every other rank's chunk from that rank's result area
+    for (int j = 0; j < p.world; ++j) {
+      if (j == p.rank) continue;
+      const long long j0 = (long long)j * cs, j1 = j0 + cs < p.n ? j0 + cs : p.n;
+      const long long jlo = j0 + (long long)blockIdx.x * cper, jhi = jlo + cper < j1 ? jlo + cper : j1;
+      const T* src = reinterpret_cast<const T*>(p.peer[j] + ar_result_off(p.max_bytes) + (size_t)slot * p.max_bytes);
+      for (long long i = jlo + tid; i < jhi; i += AR_THREADS) buf[i] = __builtin_nontemporal_load(&src[i]);
+    }
   }
   // ---- 4. the last workgroup to finish advances the step
   __syncthreads();
@@ -102,6 +153,7 @@ __global__ __launch_bounds__(AR_THREADS) void dctn_ar_k(T* __restrict__ buf, ArP
     if (fin == (int)gridDim.x - 1) {
       __hip_atomic_store(&counters[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&counters[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&counters[4], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&counters[0], step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -162,8 +214,9 @@ int dctn_ar_connect(void* state, const void* handles) {
   return DCTN_OK;
 }
 
-int dctn_ar_allreduce(void* state, void* buf, int64_t n, int dtype, int average, void* stream) {
+int dctn_ar_allreduce_algo(void* state, void* buf, int64_t n, int dtype, int average, int algorithm, void* stream) {
   if (!state || !buf) return DCTN_ERR_NULL;
+  if (algorithm < 0 || algorithm > 2) return DCTN_ERR_UNSUPPORTED;
   ArState* st = (ArState*)state;
   if (n < 0 || (size_t)n * dtype_size(dtype) > st->max_bytes) return DCTN_ERR_BAD_SHAPE;
   if (dtype != DCTN_F32 && dtype != DCTN_F64 && dtype != DCTN_BF16) return DCTN_ERR_BAD_DTYPE;
@@ -178,14 +231,25 @@ int dctn_ar_allreduce(void* state, void* buf, int64_t n, int dtype, int average,
   if (blocks < 1) blocks = 1;
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   hipStream_t s = (hipStream_t)stream;
+  const bool two = algorithm == 2 || (algorithm == 0 && st->world >= 4 && (size_t)n * dtype_size(dtype) >= (512u << 10));
+#define AR_LAUNCH(TT)                                                                                                  \
+  do {                                                                                                                 \
+    if (two) hipLaunchKernelGGL((dctn_ar_k<TT, true>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);    \
+    else hipLaunchKernelGGL((dctn_ar_k<TT, false>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);       \
+  } while (0)
   switch (dtype) {
-    case DCTN_F32: hipLaunchKernelGGL(dctn_ar_k<float>, dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (float*)buf, p); break;
-    case DCTN_F64: hipLaunchKernelGGL(dctn_ar_k<double>, dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (double*)buf, p); break;
-    default: hipLaunchKernelGGL(dctn_ar_k<bf16_t>, dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (bf16_t*)buf, p); break;
+    case DCTN_F32: AR_LAUNCH(float); break;
+    case DCTN_F64: AR_LAUNCH(double); break;
+    default: AR_LAUNCH(bf16_t); break;
   }
+#undef AR_LAUNCH
   DCTN_CHECK_LAUNCH();
-  dctn_set_last_kernel("allreduce_direct");
+  dctn_set_last_kernel(two ? "allreduce_direct_two_shot" : "allreduce_direct");
   return DCTN_OK;
+}
+
+int dctn_ar_allreduce(void* state, void* buf, int64_t n, int dtype, int average, void* stream) {
+  return dctn_ar_allreduce_algo(state, buf, n, dtype, average, 0, stream);
 }
 
 // 0: every wait so far completed; r + 1: a wait for rank r timed out (synchronises the device)

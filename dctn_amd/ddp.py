@@ -249,9 +249,13 @@ class DirectAllReducer:
     exchanged through the process group with `all_gather_object`; two ranks on one GPU work too).  `__call__(buf)` enqueues
     one kernel on the current stream, in place, capturable into a HIP graph; every rank gets bitwise the same mean (or sum).
     `status()` synchronises and returns 0, or r + 1 when a wait for rank r timed out (~2 s) - that step's values are then
-    invalid and the caller should fall back to the RCCL path."""
+    invalid and the caller should fall back to the RCCL path.  `form`: "auto" (two-shot - every rank reduces one chunk, then
+    the chunks are copied from their owners - for world >= 4 and >= 512 KiB, else one-shot), "one_shot", "two_shot";
+    both forms give bitwise the same values."""
 
-    def __init__(self, max_numel: int, dtype: torch.dtype, device: torch.device, average: bool = True):
+    FORMS = {"auto": 0, "one_shot": 1, "two_shot": 2}
+
+    def __init__(self, max_numel: int, dtype: torch.dtype, device: torch.device, average: bool = True, form: str = "auto"):
         import ctypes
 
         from . import _lib as L
@@ -259,6 +263,7 @@ class DirectAllReducer:
         assert dist.is_initialized(), "DirectAllReducer needs a process group to exchange its IPC handles"
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.average, self.device, self.dtype = average, device, dtype
+        self.form = self.FORMS[form]
         self._L = L
         lib = L.lib()
         nbytes = int(max_numel) * torch.empty((), dtype=dtype).element_size()
@@ -279,8 +284,8 @@ class DirectAllReducer:
     def __call__(self, buf: Tensor) -> None:
         assert buf.is_cuda and buf.is_contiguous() and buf.dtype == self.dtype and buf.numel() <= self.max_numel
         L = self._L
-        L.check(L.lib().dctn_ar_allreduce(self._state, buf.data_ptr(), buf.numel(), L.dtype_code(buf), int(self.average),
-                                           L.stream_ptr(buf.device)), "direct all-reduce")
+        L.check(L.lib().dctn_ar_allreduce_algo(self._state, buf.data_ptr(), buf.numel(), L.dtype_code(buf), int(self.average),
+                                                self.form, L.stream_ptr(buf.device)), "direct all-reduce")
 
     def status(self) -> int:
         return int(self._L.lib().dctn_ar_status(self._state))

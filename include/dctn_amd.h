@@ -389,12 +389,17 @@ int dctn_fiber_gram(const void* A, const void* B, void* out, void* workspace, si
  *   create(world <= 16, rank, max_bytes)  -> opaque state;  export -> dctn_ar_handle_bytes() bytes for the peers;
  *   connect(handles of ALL ranks, rank-major);  allreduce(buf, n elements, dtype, average);
  *   status: 0 = every wait completed, r + 1 = a wait for rank r timed out (the results of that step are invalid).
+ * Two-shot form for large buckets (version 402): rank r reduces chunk r only (reads (P - 1) N / P bytes), leaves it in
+ * its result area and publishes a second flag; every rank copies the other chunks from their owners ((P - 1) N / P
+ * more) instead of reading (P - 1) N bytes - bitwise the one-shot values.  dctn_ar_allreduce picks it for world >= 4
+ * and >= 512 KiB; dctn_ar_allreduce_algo(..., algorithm: 0 = that rule, 1 = one-shot, 2 = two-shot) forces a form.
  * ------------------------------------------------------------------------------------------ */
 size_t dctn_ar_handle_bytes(void);
 int dctn_ar_create(int world, int rank, size_t max_bytes, void** state_out);
 int dctn_ar_export(void* state, void* handle_out);
 int dctn_ar_connect(void* state, const void* handles);
 int dctn_ar_allreduce(void* state, void* buf, int64_t n, int dtype, int average, void* stream);
+int dctn_ar_allreduce_algo(void* state, void* buf, int64_t n, int dtype, int average, int algorithm, void* stream);
 int dctn_ar_status(void* state);
 int dctn_ar_destroy(void* state);
 

@@ -297,8 +297,9 @@ def _direct_worker(rank, world, port, q):
     ddp.init_from_env("gloo")
     out = {"rank": rank}
     try:
-        for dtype, n in ((torch.float32, 29098), (torch.bfloat16, 29098), (torch.float64, 1000), (torch.float32, 1_900_000)):
-            red = ddp.DirectAllReducer(n, dtype, dev, average=True)
+        for dtype, n in ((torch.float32, 29098), (torch.bfloat16, 29099), (torch.float64, 1000), (torch.float32, 1_900_000)):
+            red = ddp.DirectAllReducer(n, dtype, dev, average=True, form="one_shot")
+            red2 = ddp.DirectAllReducer(n, dtype, dev, average=True, form="two_shot")   # chunk per rank, then the owners' chunks
             g = torch.Generator().manual_seed(100 + rank)
             worst = 0.0
             for step in range(5):   # (five steps: both staging buffers, the step counter, flag lines reused)
@@ -308,7 +309,12 @@ def _direct_worker(rank, world, port, q):
                 want = (sum(b.double() for b in both) / world)
                 buf = mine.to(dev)
                 red(buf)
+                buf2 = mine.to(dev)
+                red2(buf2)
                 torch.cuda.synchronize(dev)
+                import dctn_amd
+                assert dctn_amd.last_kernel() == "allreduce_direct_two_shot"
+                assert torch.equal(buf, buf2), "the two-shot form gives bitwise the one-shot values"
                 tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float64: 1e-14}[dtype]
                 worst = max(worst, float((buf.cpu().double() - want).abs().max() / want.abs().max()) / tol)
                 # every rank holds bitwise the same result (same numbers added in the same order)
@@ -318,6 +324,8 @@ def _direct_worker(rank, world, port, q):
                 assert all(torch.equal(allb[0], b) for b in allb)
             out[f"{dtype}_{n}"] = worst
             out[f"status_{dtype}_{n}"] = red.status()
+            out[f"status2_{dtype}_{n}"] = red2.status()
+            red2.close()
             # replayed from a HIP graph: the step counter lives in device memory
             if n == 29098 and dtype == torch.float32:
                 static = torch.zeros(n, device=dev)
@@ -363,7 +371,8 @@ def test_direct_allreduce_two_ranks_on_one_gpu():
     """`dctn_ar_*` / `ddp.DirectAllReducer`: every rank's uncached block is mapped by its peer through an IPC handle; one
     kernel per step and rank copies, publishes its step number, waits for the peer's, and sums both staging buffers in
     rank order - here with two ranks sharing the one GPU of the test box (float32 / bfloat16 / float64, a 58 KB and a
-    7.6 MB message, five steps each, a HIP-graph replay, and through `FlatGradAllReducer(algorithm="direct")`)."""
+    7.6 MB message, five steps each, a HIP-graph replay, and through `FlatGradAllReducer(algorithm="direct")`).  Every
+    message also goes through the TWO-SHOT form (a chunk per rank, then the owners' chunks): bitwise the same values."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
