@@ -79,8 +79,10 @@ class _LinearHeadFunction(torch.autograd.Function):
     def backward(ctx, d_out: Tensor):
         """`dctn_linear_head_bwd`: dFeat and the dWeight slices in one launch, a second one sums the slices (fixed
         order) and emits dBias.  `eps_plus_linear.HEAD_BWD = "blas"` selects three library GEMM / reduction launches
-        instead (bf16 at batch 1024: 21.6 us against 25.8; float32 / odd feature counts: the library was the only path
-        until round 3)."""
+        instead.  Device time per call, replayed from a HIP graph (tools/time_head_bwd.py, round 4, 10 classes):
+        bf16 B = 1024, F = 2704: 20.2 us here against 19.9 through the library; bf16 B = 128, F = 5000: 13.5 against 17.7;
+        float32 B = 128, F = 5000 (the cfg3 heads): 9.8 against 16.3; float32 B = 1024, F = 2704 (no BASELINE config): 32.6
+        against 20.0 - the scalar streaming kernel loses there, and "blas" remains the switch for it."""
         f, w = ctx.saved_tensors
         need_f, need_w, need_b = ctx.needs_input_grad
         return _head_backward(f, w, d_out.contiguous(), need_f, need_w, need_b)
