@@ -51,7 +51,7 @@ int dctn_zero_async(void* ptr, size_t bytes, hipStream_t st) {
 
 extern "C" {
 
-int dctn_version(void) { return 402; }   // round 4: dctn_ar_* (direct all-reduce); ConvSBS band family (also several strings per launch), many-valued register sweep
+int dctn_version(void) { return 403; }   // round 4: dctn_ar_* (direct all-reduce); ConvSBS band family (also several strings per launch), many-valued register sweep
 
 const char* dctn_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 

@@ -128,7 +128,7 @@ int convsbs_bwd_mfma(const void* x, const int64_t xs[5], const void* const* core
                      const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B, int H, int W,
                      int q, int dtype, hipStream_t st, float* partials = nullptr, size_t partial_bytes = 0,
                      const float* saved_states = nullptr);
-// Band-owning backward for bonds 9..16 (two roles per SIMD, nothing kept by the forward) - convsbs_band.hip.  Strings it
+// Band-owning backward for bonds 5..16 (two roles per SIMD, nothing kept by the forward) - convsbs_band.hip.  Strings it
 // covers keep no forward states (convsbs_saved_states_bytes returns 0 for them); `ws` holds the per-workgroup dCore
 // records and the partial sums of the pixel rows two bands share (convsbs_band_bwd_workspace; 0 = outside the family).
 bool convsbs_band_covers(int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w, int C, int B,
@@ -156,7 +156,7 @@ int convsbs_bwd_reg(const void* x, const int64_t xs[5], const void* const* cores
                     float* const* dcores, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h,
                     const int* pos_w, int C, int B, int H, int W, int q, int dtype, hipStream_t st, void* ws, size_t ws_bytes);
 // several uniform strings of one layer in one launch each way (DCTN_ERR_UNSUPPORTED: run them one by one)
-// The same for strings of the band family (bonds 9..16): blockIdx.y = string, one tail kernel for all strings.
+// The same for strings of the band family (bonds 5..16): blockIdx.y = string, one tail kernel for all strings.
 size_t convsbs_many_band_bwd_workspace(int ns, int n, const int* out_sizes, const int* bond_sizes, const int* pos_h, const int* pos_w,
                                        int C, int B, int H, int W, int q, int dtype);
 int convsbs_many_fwd_band(const void* x, const int64_t xs[5], const void* const* cores, void* const* outs, int ns, int n,

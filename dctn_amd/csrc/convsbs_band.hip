@@ -33,6 +33,7 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float bd_f4;
+typedef __attribute__((ext_vector_type(2))) float bd_f2;
 typedef __attribute__((ext_vector_type(2))) int bd_i2;
 
 // diagnostic build only (make EXTRA=-DDCTN_STAMPS, tools/stamp_band.py): wave 0 (chain) and wave 4 (gradient) of every
@@ -116,13 +117,28 @@ __device__ __forceinline__ void bd_wave_lds_sync() {   // LDS written by some la
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// bond index <-> (matrix row, k group, k step) of the packs for NS state values per lane (see bd_bwd_body)
+template <int NS> __device__ __forceinline__ int bd_row(int r) { return NS == 4 ? r : 4 * (r >> 1) + (r & 1); }
+template <int NS> __device__ __forceinline__ int bd_kg(int l) { return NS == 4 ? l >> 2 : l >> 1; }
+template <int NS> __device__ __forceinline__ int bd_ks(int l) { return NS == 4 ? l & 3 : l & 1; }
+// NS consecutive floats at a (NS * 4)-byte aligned LDS address
+template <int NS> __device__ __forceinline__ void bd_store_state(float* dst, const float (&v)[NS]) {
+  if constexpr (NS == 4) *reinterpret_cast<bd_f4*>(dst) = bd_f4{v[0], v[1], v[2], v[3]};
+  else *reinterpret_cast<bd_f2*>(dst) = bd_f2{v[0], v[1]};
+}
+
 __device__ __forceinline__ void bd_barrier() {   // workgroup barrier that orders LDS only: vector-memory loads stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // QT: feature values per core (q^C, 2..4) = 16x16 tiles per product.  CH: 1 = one channel (the products ARE the pixel's
 // values), 2 = two channels of two values (QT = 4; the deeper layers of the reference's classifier).
-template <int QT, int CH>
+// NS: state values per lane and core.  The state layout is l = NS g + s (lane group g, register s); 4 covers bonds up
+// to 16 with four k-steps per product, 2 covers bonds up to 8 with TWO (the packs put core row r' = 2 g + s at matrix
+// row 4 g + s, so the accumulator's registers 0, 1 of lane group g are the new state): half the chain's matrix
+// instructions and half its epilogues; the hand-over tiles, the gradient waves and the records keep their layouts
+// (natural order [window][bond index]; entries 8..15 stay zero).
+template <int QT, int CH, int NS>
 __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
@@ -135,6 +151,9 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
   const int r0 = kb * p.band_rows, r1 = r0 + p.band_rows < p.Ho ? r0 + p.band_rows : p.Ho;
   const int nwin = (r1 - r0) * p.Wo;
   BD_STAMP(0);
+  if constexpr (NS != 4) {   // the chain waves write entries 0 .. 4 NS - 1 of a hand-over row: the rest stays zero
+    for (int e = tid; e < 4 * 4 * BD_TILE; e += BD_THREADS) lds[GVO + e] = 0.f;
+  }
 
   // ---- the packs.  Both are permutations of the middle cores' 6-8 K elements: every thread takes elements of the cores'
   // own (contiguous) layout - coalesced loads, all in flight before the first LDS store - and scatters each to its place
@@ -172,8 +191,8 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
             const int l = t1 - o * bl;
             const int pk = o == 0 ? c - 1 : BD_NPK - 1;
             const float val = j < 3 ? va[c - 1][j < 3 ? j : 0] : vb[c - 1];
-            lds[PACKF + ((pk * QT + qq) * 64 + r + 16 * (l >> 2)) * 4 + (l & 3)] = val;   // A[row r'][k: l = 4 g + s]
-            lds[PACKA + ((pk * QT + qq) * 64 + l + 16 * (r >> 2)) * 4 + (r & 3)] = val;   // A[row l][k: r' = 4 g + s]
+            lds[PACKF + ((pk * QT + qq) * 64 + bd_row<NS>(r) + 16 * bd_kg<NS>(l)) * 4 + bd_ks<NS>(l)] = val;   // A[row r'][k: l = NS g + s]
+            lds[PACKA + ((pk * QT + qq) * 64 + bd_row<NS>(l) + 16 * bd_kg<NS>(r)) * 4 + bd_ks<NS>(r)] = val;   // A[row l][k: r' = NS g + s]
           }
         }
       }
@@ -238,7 +257,7 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
 
     // U_qq = A_qq x vin (K = l or r'): the whole A operand of a pack is QT b128 reads, all in flight before the first MFMA
     // waits for a part of it; k-step outermost so that the QT accumulators form independent chains
-    auto product = [&](int off, int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
+    auto product = [&](int off, int pk, const float (&vin)[NS], bd_f4 (&D)[QT]) {
       bd_f4 a[QT];
 #pragma unroll
       for (int qq = 0; qq < QT; ++qq) {
@@ -247,22 +266,22 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
     };
-    auto fwd_epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[4]) {   // v'[r'] = sum_qq f[qq] U_qq[r']
+    auto fwd_epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[NS]) {   // v'[r'] = sum_qq f[qq] U_qq[r']
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < NS; ++r) {
         float a = f[0] * D[0][r] + f[1] * D[1][r];
         if (QT > 2) a += f[2] * D[2 % QT][r];
         if (QT > 3) a += f[3] * D[3 % QT][r];
         out[r] = a;
       }
     };
-    auto bwd_epi = [&](const bd_f4 (&Wt)[QT], const bd_f4& f, const float (&vin)[4], float (&dv)[4], float (&df)[QT]) {
+    auto bwd_epi = [&](const bd_f4 (&Wt)[QT], const bd_f4& f, const float (&vin)[NS], float (&dv)[NS], float (&df)[QT]) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {   // dv[l] = sum_qq f[qq] W_qq[l];  df[qq] += sum_l v[l] W_qq[l]
+      for (int r = 0; r < NS; ++r) {   // dv[l] = sum_qq f[qq] W_qq[l];  df[qq] += sum_l v[l] W_qq[l]
         float a = f[0] * Wt[0][r] + f[1] * Wt[1][r];
         if (QT > 2) a += f[2] * Wt[2 % QT][r];
         if (QT > 3) a += f[3] * Wt[3 % QT][r];
@@ -272,62 +291,64 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
       }
     };
     // G and v of the tile for the gradient wave (rows = windows, buffer gs & 1); meet(): the hand-over's barrier
-    auto store_tiles = [&](const float (&Gs)[4], const float (&vin)[4]) {
+    auto store_tiles = [&](const float (&Gs)[NS], const float (&vin)[NS]) {
       float* gt = gvb + (gs & 1) * 2 * BD_TILE;
-      *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};              // G[w][r' = 4 g ..]
-      *reinterpret_cast<bd_f4*>(gt + BD_TILE + wl * BD_TS + 4 * g) = bd_f4{vin[0], vin[1], vin[2], vin[3]};  // v[w][l = 4 g ..]
+      bd_store_state<NS>(gt + wl * BD_TS + NS * g, Gs);              // G[w][r' = NS g ..]
+      bd_store_state<NS>(gt + BD_TILE + wl * BD_TS + NS * g, vin);   // v[w][l = NS g ..]
     };
     auto meet = [&]() {
       bd_barrier();
       ++gs;
     };
-    auto handover_g = [&](const float (&Gs)[4]) {   // the first / last core's gradient needs no second operand
+    auto handover_g = [&](const float (&Gs)[NS]) {   // the first / last core's gradient needs no second operand
       float* gt = gvb + (gs & 1) * 2 * BD_TILE;
-      *reinterpret_cast<bd_f4*>(gt + wl * BD_TS + 4 * g) = bd_f4{Gs[0], Gs[1], Gs[2], Gs[3]};
+      bd_store_state<NS>(gt + wl * BD_TS + NS * g, Gs);
       meet();
     };
-    auto first_core = [&](const float* fs, float (&w0)[4]) {   // v[r'] = sum_qq core0[r'][qq] f[qq]
+    auto first_core = [&](const float* fs, float (&w0)[NS]) {   // v[r'] = sum_qq core0[r'][qq] f[qq]
       const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         float a = 0.f;
 #pragma unroll
-        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (4 * g + s) * 4 + qq] * f[qq];   // (4-byte reads: 16 lanes read one entry)
+        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (NS * g + s) * 4 + qq] * f[qq];   // (4-byte reads: 16 lanes read one entry)
         w0[s] = a;
       }
     };
     // forward through middle core c: (w0, w1) -> (w0, w1)
-    auto fwd_core = [&](int c, const float* fs, float (&w0)[4], float (&w1)[4]) {
+    auto fwd_core = [&](int c, const float* fs, float (&w0)[NS], float (&w1)[NS]) {
       const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
-      float n0[4], n1[4] = {0.f, 0.f, 0.f, 0.f};
+      float n0[NS], n1[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) n1[s] = 0.f;
       bd_f4 D[QT];
       product(PACKF, c - 1, w0, D);
       fwd_epi(D, f, n0);
       if (p.o[c] > 1 || p.nin[c] > 1) {
         const bool second_out = p.o[c] > 1;   // (o = 1 from state 0) or (o = 0 from state 1): wave-uniform
-        float vin[4];
+        float vin[NS];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) vin[s] = second_out ? w0[s] : w1[s];
+        for (int s = 0; s < NS; ++s) vin[s] = second_out ? w0[s] : w1[s];
         product(PACKF, second_out ? BD_NPK - 1 : c - 1, vin, D);
         fwd_epi(D, f, n1);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
+      for (int r = 0; r < NS; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
     };
 
-    float Sin0[BD_NC][4], Sin1[BD_NC][4];   // input states of the middle cores of the tile on its way back (slot c)
-    float v0[4], v1[4];                     // input states of its last core
+    float Sin0[BD_NC][NS], Sin1[BD_NC][NS];   // input states of the middle cores of the tile on its way back (slot c)
+    float v0[NS], v1[NS];                     // input states of its last core
     // ---- barrier (P): the gradient wave has staged the first tile's features
     bd_barrier();
     auto forward_sweep = [&](const float* fs) {
       first_core(fs, v0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v1[s] = 0.f;
+      for (int s = 0; s < NS; ++s) v1[s] = 0.f;
 #pragma unroll
       for (int c = 1; c < BD_NC - 1; ++c) {
         if (c + 1 < p.n) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) { Sin0[c][s] = v0[s]; Sin1[c][s] = v1[s]; }
+          for (int s = 0; s < NS; ++s) { Sin0[c][s] = v0[s]; Sin1[c][s] = v1[s]; }
           fwd_core(c, fs, v0, v1);
         }
       }
@@ -368,18 +389,18 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
       };
 
       // ---------------------------------------------------------------- way back
-      float G0[4], G1[4];
+      float G0[NS], G1[NS];
       {   // last core: out[a] = sum_l v_a[l] tl[l],  tl[l] = sum_qq coreL[l][qq] f[qq]
         const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + ((p.n - 1) * 16 + wl) * 4);
-        float df[QT], u[4];
+        float df[QT], u[NS];
 #pragma unroll
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
           float cp[QT], tl = 0.f;
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) {
-            cp[qq] = lds[LAST + (4 * g + s) * 4 + qq];
+            cp[qq] = lds[LAST + (NS * g + s) * 4 + qq];
             tl += cp[qq] * f[qq];
           }
           G0[s] = dy0 * tl;
@@ -400,7 +421,9 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
       for (int c = BD_NC - 2; c >= 1; --c) {
         if (c + 1 < p.n) {
           const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
-          float d0[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, df[QT];
+          float d0[NS], d1[NS], df[QT];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) d1[s] = 0.f;
 #pragma unroll
           for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
           bd_f4 Wt[QT];
@@ -414,15 +437,15 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
           if (it == 1 && c == 3) BD_STAMP(22);
           if (p.o[c] > 1 || p.nin[c] > 1) {   // a second pair: (o = 1, state 0) or (o = 0, state 1)
             const bool b_out = p.o[c] > 1;
-            float vin2[4], dt[4];
+            float vin2[NS], dt[NS];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) vin2[s] = b_out ? Sin0[c][s] : Sin1[c][s];
+            for (int s = 0; s < NS; ++s) vin2[s] = b_out ? Sin0[c][s] : Sin1[c][s];
             store_tiles(G1, vin2);
             product(PACKA, b_out ? BD_NPK - 1 : c - 1, G1, Wt);
             meet();
             bwd_epi(Wt, f, vin2, dt, df);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < NS; ++r) {
               d0[r] += b_out ? dt[r] : 0.f;
               d1[r] = b_out ? 0.f : dt[r];
             }
@@ -430,7 +453,7 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
           put_row(c, df);
           if (it == 1 && c == 3) BD_STAMP(23);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) { G0[s] = d0[s]; G1[s] = d1[s]; }
+          for (int s = 0; s < NS; ++s) { G0[s] = d0[s]; G1[s] = d1[s]; }
           if (it == 1) BD_STAMP(5 + (BD_NC - 1 - c));   // 6 (core 7) .. 12 (core 1)
         }
       }
@@ -439,9 +462,9 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
 #pragma unroll
         for (int qq = 0; qq < QT; ++qq) df[qq] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
-          for (int qq = 0; qq < QT; ++qq) df[qq] += G0[s] * lds[FIRST + (4 * g + s) * 4 + qq];
+          for (int qq = 0; qq < QT; ++qq) df[qq] += G0[s] * lds[FIRST + (NS * g + s) * 4 + qq];
         }
         put_row(0, df);
         handover_g(G0);   // dCore0[r'][qq] = sum_w G0[r', w] f[qq, w]
@@ -710,15 +733,15 @@ __device__ __forceinline__ void bd_bwd_body(const BdP& p) {
   BD_STAMP(18);
 }
 
-template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p) { bd_bwd_body<QT, CH>(p); }
+template <int QT, int CH, int NS>
+__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_k(const BdP p) { bd_bwd_body<QT, CH, NS>(p); }
 
 // The strings of one ManyConvSBS layer (dctn/conv_sbs.py:367-370) in one launch: blockIdx.y = string.  String s > 0 writes
 // its share of dX into a buffer of its own; the tail kernel adds the strings' shares (and every string's shared rows).
 constexpr int BD_MANY = 2;
 struct BdPMany { BdP s[BD_MANY]; };
-template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_many_k(const BdPMany pp) { bd_bwd_body<QT, CH>(pp.s[blockIdx.y]); }
+template <int QT, int CH, int NS>
+__global__ __launch_bounds__(BD_THREADS, 2) void convsbs_bwd_band_many_k(const BdPMany pp) { bd_bwd_body<QT, CH, NS>(pp.s[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ forward
 // The same chain, forwards only: no accumulators, no states to keep - 8 identical waves per workgroup, each with its own
@@ -736,7 +759,7 @@ struct BdFwdP {
   long long Wn, ntiles;
 };
 
-template <int QT, int CH>
+template <int QT, int CH, int NS>
 __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wl = lane & 15, g = lane >> 4;
@@ -773,7 +796,7 @@ __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
             const int o = (int)(((float)t1 + 0.5f) * ibl);
             const int l = t1 - o * bl;
             const int pk = o == 0 ? c - 1 : BD_NPK - 1;
-            lds[PACKF + ((pk * QT + qq) * 64 + r + 16 * (l >> 2)) * 4 + (l & 3)] = va[c - 1][j];
+            lds[PACKF + ((pk * QT + qq) * 64 + bd_row<NS>(r) + 16 * bd_kg<NS>(l)) * 4 + bd_ks<NS>(l)] = va[c - 1][j];
           }
         }
       }
@@ -827,7 +850,7 @@ __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
       }
     }
   };
-  auto product = [&](int pk, const float (&vin)[4], bd_f4 (&D)[QT]) {
+  auto product = [&](int pk, const float (&vin)[NS], bd_f4 (&D)[QT]) {
     bd_f4 a[QT];
 #pragma unroll
     for (int qq = 0; qq < QT; ++qq) {
@@ -836,13 +859,13 @@ __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int qq = 0; qq < QT; ++qq) D[qq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[qq][s], vin[s], D[qq], 0, 0, 0);
   };
-  auto epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[4]) {
+  auto epi = [&](const bd_f4 (&D)[QT], const bd_f4& f, float (&out)[NS]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NS; ++r) {
       float a = f[0] * D[0][r] + f[1] * D[1][r];
       if (QT > 2) a += f[2] * D[2 % QT][r];
       if (QT > 3) a += f[3] * D[3 % QT][r];
@@ -859,45 +882,48 @@ __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
     commit(tile, fs);
     if (tile + nwaves < p.ntiles) issue_loads(tile + nwaves);
     bd_wave_lds_sync();
-    float w0[4], w1[4] = {0.f, 0.f, 0.f, 0.f};
+    float w0[NS], w1[NS];
     {
       const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (0 * 16 + wl) * 4);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         float a = 0.f;
 #pragma unroll
-        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (4 * g + s) * 4 + qq] * f[qq];
+        for (int qq = 0; qq < QT; ++qq) a += lds[FIRST + (NS * g + s) * 4 + qq] * f[qq];
         w0[s] = a;
+        w1[s] = 0.f;
       }
     }
 #pragma unroll
     for (int c = 1; c < BD_NC - 1; ++c) {
       if (c + 1 < p.n) {
         const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + (c * 16 + wl) * 4);
-        float n0[4], n1[4] = {0.f, 0.f, 0.f, 0.f};
+        float n0[NS], n1[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) n1[s] = 0.f;
         bd_f4 D[QT];
         product(c - 1, w0, D);
         epi(D, f, n0);
         if (p.o[c] > 1 || p.nin[c] > 1) {
           const bool second_out = p.o[c] > 1;
-          float vin[4];
+          float vin[NS];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) vin[s] = second_out ? w0[s] : w1[s];
+          for (int s = 0; s < NS; ++s) vin[s] = second_out ? w0[s] : w1[s];
           product(second_out ? BD_NPK - 1 : c - 1, vin, D);
           epi(D, f, n1);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
+        for (int r = 0; r < NS; ++r) { w0[r] = n0[r]; w1[r] = n1[r]; }
       }
     }
     {   // last core: out[a] = sum_l v_a[l] sum_qq coreL[l][qq] f[qq]
       const bd_f4 f = *reinterpret_cast<const bd_f4*>(fs + ((p.n - 1) * 16 + wl) * 4);
       float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         float tl = 0.f;
 #pragma unroll
-        for (int qq = 0; qq < QT; ++qq) tl += lds[LAST + (4 * g + s) * 4 + qq] * f[qq];
+        for (int qq = 0; qq < QT; ++qq) tl += lds[LAST + (NS * g + s) * 4 + qq] * f[qq];
         r0 += w0[s] * tl;
         r1 += w1[s] * tl;
       }
@@ -912,12 +938,12 @@ __device__ __forceinline__ void bd_fwd_body(const BdFwdP& p) {
   }
 }
 
-template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP p) { bd_fwd_body<QT, CH>(p); }
+template <int QT, int CH, int NS>
+__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_k(const BdFwdP p) { bd_fwd_body<QT, CH, NS>(p); }
 
 struct BdFwdPMany { BdFwdP s[BD_MANY]; };
-template <int QT, int CH>
-__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_many_k(const BdFwdPMany pp) { bd_fwd_body<QT, CH>(pp.s[blockIdx.y]); }
+template <int QT, int CH, int NS>
+__global__ __launch_bounds__(BD_THREADS, 4) void convsbs_fwd_band_many_k(const BdFwdPMany pp) { bd_fwd_body<QT, CH, NS>(pp.s[blockIdx.y]); }
 
 // dCore_c[e] = sum over the workgroups' records in a fixed order; the pixel rows two bands share = the sum of their two
 // partial sums.  64 elements per workgroup, 4 record subsets, LDS join (as convsbs_dcore_reduce_k).
@@ -1036,7 +1062,7 @@ __global__ __launch_bounds__(256) void convsbs_band_tail_many_k(const BdTailMany
 // family check + the launch plan; DCTN_ERR_UNSUPPORTED outside the family
 struct BdPlan {
   BdP p;
-  int lds_bytes, nwg, QT, CH, rec_len;
+  int lds_bytes, nwg, QT, CH, NS, rec_len;
   size_t records_bytes, side_bytes;
 };
 
@@ -1048,7 +1074,8 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
     if (bond_sizes[c] < 1) return DCTN_ERR_UNSUPPORTED;
     Ra = bond_sizes[c] > Ra ? bond_sizes[c] : Ra;
   }
-  if (Ra <= 8 || Ra > 16) return DCTN_ERR_UNSUPPORTED;   // (smaller bonds: a quarter-full tile; convsbs_reg / convsbs_mfma take them)
+  if (Ra <= 4 || Ra > 16) return DCTN_ERR_UNSUPPORTED;   // (bonds <= 4: convsbs_reg takes them, lane = window)
+  pl.NS = Ra <= 8 ? 2 : 4;
   int qc = 1;
   for (int c = 0; c < C; ++c) qc *= q;
   if (!((C == 1 && q >= 2 && q <= 4) || (C == 2 && q == 2))) return DCTN_ERR_UNSUPPORTED;
@@ -1171,16 +1198,23 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
 #ifdef DCTN_STAMPS
   if (ws_bytes >= need + (size_t)pl.nwg * 2 * 32 * sizeof(long long)) p.stamps = (long long*)((unsigned char*)ws + need);
 #endif
-#define BD_LAUNCH(QTV, CHV)                                                                                     \
+#define BD_LAUNCH(QTV, CHV, NSV)                                                                                     \
   do {                                                                                                          \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               pl.lds_bytes);                                                                    \
-    hipLaunchKernelGGL((convsbs_bwd_band_k<QTV, CHV>), dim3((unsigned)pl.nwg), dim3(BD_THREADS), pl.lds_bytes, st, p); \
+    hipLaunchKernelGGL((convsbs_bwd_band_k<QTV, CHV, NSV>), dim3((unsigned)pl.nwg), dim3(BD_THREADS), pl.lds_bytes, st, p); \
   } while (0)
-  if (pl.CH == 2) BD_LAUNCH(4, 2);
-  else if (pl.QT == 2) BD_LAUNCH(2, 1);
-  else if (pl.QT == 3) BD_LAUNCH(3, 1);
-  else BD_LAUNCH(4, 1);
+  if (pl.NS == 2) {
+    if (pl.CH == 2) BD_LAUNCH(4, 2, 2);
+    else if (pl.QT == 2) BD_LAUNCH(2, 1, 2);
+    else if (pl.QT == 3) BD_LAUNCH(3, 1, 2);
+    else BD_LAUNCH(4, 1, 2);
+  } else {
+    if (pl.CH == 2) BD_LAUNCH(4, 2, 4);
+    else if (pl.QT == 2) BD_LAUNCH(2, 1, 4);
+    else if (pl.QT == 3) BD_LAUNCH(3, 1, 4);
+    else BD_LAUNCH(4, 1, 4);
+  }
 #undef BD_LAUNCH
   DCTN_CHECK_LAUNCH();
   BdTailP t;
@@ -1221,16 +1255,23 @@ int convsbs_fwd_band(const void* x, const int64_t xs[5], const void* const* core
   long long blocks = (p.ntiles + 7) / 8;
   const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;   // 128 registers: two workgroups (four waves per SIMD) per CU
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-#define BD_FLAUNCH(QTV, CHV)                                                                                    \
+#define BD_FLAUNCH(QTV, CHV, NSV)                                                                                    \
   do {                                                                                                          \
-    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               lds_bytes);                                                                       \
-    hipLaunchKernelGGL((convsbs_fwd_band_k<QTV, CHV>), dim3((unsigned)blocks), dim3(BD_THREADS), lds_bytes, st, p); \
+    hipLaunchKernelGGL((convsbs_fwd_band_k<QTV, CHV, NSV>), dim3((unsigned)blocks), dim3(BD_THREADS), lds_bytes, st, p); \
   } while (0)
-  if (pl.CH == 2) BD_FLAUNCH(4, 2);
-  else if (pl.QT == 2) BD_FLAUNCH(2, 1);
-  else if (pl.QT == 3) BD_FLAUNCH(3, 1);
-  else BD_FLAUNCH(4, 1);
+  if (pl.NS == 2) {
+    if (pl.CH == 2) BD_FLAUNCH(4, 2, 2);
+    else if (pl.QT == 2) BD_FLAUNCH(2, 1, 2);
+    else if (pl.QT == 3) BD_FLAUNCH(3, 1, 2);
+    else BD_FLAUNCH(4, 1, 2);
+  } else {
+    if (pl.CH == 2) BD_FLAUNCH(4, 2, 4);
+    else if (pl.QT == 2) BD_FLAUNCH(2, 1, 4);
+    else if (pl.QT == 3) BD_FLAUNCH(3, 1, 4);
+    else BD_FLAUNCH(4, 1, 4);
+  }
 #undef BD_FLAUNCH
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("convsbs_fwd_band_f32");
@@ -1250,7 +1291,7 @@ int bd_plan_many(BdPlan (&pl)[BD_MANY], int ns, const int64_t xs[5], const void*
     if (rc != DCTN_OK) return rc;
     if (s2 > 0) {
       const BdP &a = pl[0].p, &b = pl[s2].p;
-      if (pl[s2].QT != pl[0].QT || pl[s2].CH != pl[0].CH || pl[s2].lds_bytes != pl[0].lds_bytes || pl[s2].nwg != pl[0].nwg ||
+      if (pl[s2].QT != pl[0].QT || pl[s2].CH != pl[0].CH || pl[s2].NS != pl[0].NS || pl[s2].lds_bytes != pl[0].lds_bytes || pl[s2].nwg != pl[0].nwg ||
           a.nb != b.nb || a.band_rows != b.band_rows || a.max_h != b.max_h || a.Ho != b.Ho || a.Wo != b.Wo)
         return DCTN_ERR_UNSUPPORTED;
     }
@@ -1293,16 +1334,23 @@ int convsbs_many_fwd_band(const void* x, const int64_t xs[5], const void* const*
   long long blocks = (pp.s[0].ntiles + 7) / 8;
   const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;
   if (blocks > 256 * per_cu / ns) blocks = 256 * per_cu / ns;   // the strings' persistent waves are resident together
-#define BD_FLAUNCH(QTV, CHV)                                                                                         \
+#define BD_FLAUNCH(QTV, CHV, NSV)                                                                                         \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_many_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               lds_bytes);                                                                            \
-    hipLaunchKernelGGL((convsbs_fwd_band_many_k<QTV, CHV>), dim3((unsigned)blocks, (unsigned)ns), dim3(BD_THREADS), lds_bytes, st, pp); \
+    hipLaunchKernelGGL((convsbs_fwd_band_many_k<QTV, CHV, NSV>), dim3((unsigned)blocks, (unsigned)ns), dim3(BD_THREADS), lds_bytes, st, pp); \
   } while (0)
-  if (pl[0].CH == 2) BD_FLAUNCH(4, 2);
-  else if (pl[0].QT == 2) BD_FLAUNCH(2, 1);
-  else if (pl[0].QT == 3) BD_FLAUNCH(3, 1);
-  else BD_FLAUNCH(4, 1);
+  if (pl[0].NS == 2) {
+    if (pl[0].CH == 2) BD_FLAUNCH(4, 2, 2);
+    else if (pl[0].QT == 2) BD_FLAUNCH(2, 1, 2);
+    else if (pl[0].QT == 3) BD_FLAUNCH(3, 1, 2);
+    else BD_FLAUNCH(4, 1, 2);
+  } else {
+    if (pl[0].CH == 2) BD_FLAUNCH(4, 2, 4);
+    else if (pl[0].QT == 2) BD_FLAUNCH(2, 1, 4);
+    else if (pl[0].QT == 3) BD_FLAUNCH(3, 1, 4);
+    else BD_FLAUNCH(4, 1, 4);
+  }
 #undef BD_FLAUNCH
   DCTN_CHECK_LAUNCH();
   dctn_set_last_kernel("convsbs_many_fwd_band_f32");
@@ -1349,17 +1397,24 @@ int convsbs_many_bwd_band(const void* x, const int64_t xs[5], const void* const*
     t.B = B; t.H = H; t.W = W; t.C = C; t.q = q; t.Cq = C * q; t.nb = p.nb; t.band_rows = p.band_rows; t.max_h = p.max_h;
     t.nshared = 0;
   }
-#define BD_LAUNCH(QTV, CHV)                                                                                          \
+#define BD_LAUNCH(QTV, CHV, NSV)                                                                                          \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_many_k<QTV, CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               pl[0].lds_bytes);                                                                      \
-    hipLaunchKernelGGL((convsbs_bwd_band_many_k<QTV, CHV>), dim3((unsigned)pl[0].nwg, (unsigned)ns), dim3(BD_THREADS), pl[0].lds_bytes, \
+    hipLaunchKernelGGL((convsbs_bwd_band_many_k<QTV, CHV, NSV>), dim3((unsigned)pl[0].nwg, (unsigned)ns), dim3(BD_THREADS), pl[0].lds_bytes, \
                        st, pp);                                                                                      \
   } while (0)
-  if (pl[0].CH == 2) BD_LAUNCH(4, 2);
-  else if (pl[0].QT == 2) BD_LAUNCH(2, 1);
-  else if (pl[0].QT == 3) BD_LAUNCH(3, 1);
-  else BD_LAUNCH(4, 1);
+  if (pl[0].NS == 2) {
+    if (pl[0].CH == 2) BD_LAUNCH(4, 2, 2);
+    else if (pl[0].QT == 2) BD_LAUNCH(2, 1, 2);
+    else if (pl[0].QT == 3) BD_LAUNCH(3, 1, 2);
+    else BD_LAUNCH(4, 1, 2);
+  } else {
+    if (pl[0].CH == 2) BD_LAUNCH(4, 2, 4);
+    else if (pl[0].QT == 2) BD_LAUNCH(2, 1, 4);
+    else if (pl[0].QT == 3) BD_LAUNCH(3, 1, 4);
+    else BD_LAUNCH(4, 1, 4);
+  }
 #undef BD_LAUNCH
   DCTN_CHECK_LAUNCH();
   const long long rec_blocks = dcores ? (long long)ns * ((pl[0].rec_len + 63) / 64) : 0;

@@ -501,6 +501,12 @@ int bwd_launch(const void* x, const void* dY, void* dX, void* const* dCores, voi
 
 }  // namespace
 
+static int sbs_largest_bond(int n, const int* bond_sizes) {
+  int m = 0;
+  for (int c = 0; c < n; ++c) m = bond_sizes[c] > m ? bond_sizes[c] : m;
+  return m;
+}
+
 extern "C" {
 
 size_t dctn_convsbs_workspace_bytes(int n_cores, const int* out_sizes, const int* bond_sizes,
@@ -549,9 +555,12 @@ int dctn_convsbs_fwd(const void* x, const int64_t x_strides[5], const void* cons
     rc = convsbs_fwd_reg(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
-  // bonds 9..16: the band family's forward (nothing kept: its backward recomputes the chain in registers)
-  rc = convsbs_fwd_band(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
-  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  // bonds 5..16: the band family's forward (nothing kept: its backward recomputes the chain in registers); under
+  // DCTN_SBS_MATRIX_CORE_SWEEP bonds up to 8 stay on the matrix-core sweep below (the tests hold both against the oracle)
+  if (!((dtype_flags & DCTN_SBS_MATRIX_CORE_SWEEP) && sbs_largest_bond(n_cores, bond_sizes) <= 8)) {
+    rc = convsbs_fwd_band(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype, st);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
   const size_t sb = convsbs_saved_states_bytes(n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q, dtype);
   float* save = (sb > 0 && workspace && workspace_bytes >= sb) ? (float*)workspace : nullptr;
   rc = convsbs_fwd_mfma(x, x_strides, cores, out, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H, W, q,
@@ -609,7 +618,8 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
                          W, q, dtype, st, workspace, workspace_bytes);
     if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   }
-  if (dtype == DCTN_F32) {   // bonds 9..16: the band-owning backward (recomputes the chain; no saved states, no helper launches)
+  if (dtype == DCTN_F32 && !((dtype_flags & DCTN_SBS_MATRIX_CORE_SWEEP) && sbs_largest_bond(n_cores, bond_sizes) <= 8)) {
+    // bonds 5..16: the band-owning backward (recomputes the chain; no saved states, no helper launches)
     for (int c = 0; dCores && c < n_cores; ++c)
       if (!dCores[c]) return DCTN_ERR_NULL;
     rc = convsbs_bwd_band(x, x_strides, cores, dY, dX, (float* const*)dCores, n_cores, out_sizes, bond_sizes, pos_h, pos_w, C, B, H,

@@ -234,7 +234,7 @@ int dctn_convsbs_bwd_saved(const void* x, const int64_t x_strides[5], const void
  * string contracts the same input) for layers whose strings are all nine-core strings of one bond <= 4 over the same
  * window positions (the reference's layers: two snakes through one 3 x 3 window, mnist.py:189-252): ONE forward launch,
  * ONE backward launch (+ the small reduction), dX written once, already summed over the strings.  Since version 401
- * also layers of TWO strings of the band family (largest bond 9..16, same band geometry: the bond-16 layer of
+ * also layers of TWO strings of the band family (largest bond 5..16, same band geometry: the bond-16 layer of
  * mnist.py:224-242): one forward launch, one backward launch + one tail kernel that sums the strings' shares of dX.
  *   cores / dCores : n_strings * n_cores pointers, string-major;  out_sizes, bond_sizes, pos_h, pos_w likewise
  *   outs / dYs     : one (B, H', W', prod(out_sizes of the string)) tensor per string

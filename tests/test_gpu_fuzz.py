@@ -476,11 +476,12 @@ def sbs_reg_family_takes(pos, bonds, outs, C, q):
 
 def sbs_band_family_takes(pos, bonds, outs, C, q):
     """Strings whose BACKWARD runs on the band-owning kernels (convsbs_band.hip): float32 open chains of at most 9 cores,
-    largest bond 9..16, at most one two-valued core - a middle one -, q^C <= 4."""
+    largest bond 5..16 (two state values per lane up to 8, four above), at most one two-valued core - a middle one -,
+    q^C <= 4."""
     prod = 1
     for o in outs:
         prod *= o
-    return (3 <= len(pos) <= 9 and bonds[0] == 1 and 8 < max(bonds[1:]) <= 16 and all(o in (1, 2) for o in outs) and prod <= 2
+    return (3 <= len(pos) <= 9 and bonds[0] == 1 and 4 < max(bonds[1:]) <= 16 and all(o in (1, 2) for o in outs) and prod <= 2
             and outs[0] == 1 and outs[-1] == 1 and ((C == 1 and 2 <= q <= 4) or (C == 2 and q == 2)))
 
 
@@ -491,16 +492,17 @@ def test_convsbs_mfma_family_random(case, family):
     """family: small-bond strings run on the register-resident sweep by default; `matrix_core_sweep()` sends them to the
     matrix-core sweep, so both families meet the oracle on the same strings."""
     reg = sbs_reg_family_takes(*case)
+    small_band = sbs_band_family_takes(*case) and max(case[1]) <= 8
     if family == "matrix_cores":
-        if not reg:
+        if not (reg or small_band):
             pytest.skip("the default already is the matrix-core sweep")
         with matrix_core_sweep():
-            _convsbs_family_case(case, "mfma")
+            _convsbs_family_case(case, "mfma", matrix_cores=True)
     else:
         _convsbs_family_case(case, "reg" if reg else "mfma")
 
 
-def _convsbs_family_case(case, fam):
+def _convsbs_family_case(case, fam, matrix_cores=False):
     pos, bonds, outs, C, q = case
     torch.manual_seed(len(pos) * 10 + bonds[1])
     spec = SBSSpecString(tuple(SBSSpecCore(Pos2D(h, w), o) for (h, w), o in zip(pos, outs)), bonds, C, q)
@@ -508,8 +510,8 @@ def _convsbs_family_case(case, fam):
     B, H, W = 3, spec.max_height_pos + 6, spec.max_width_pos + 7      # 126 windows: three full groups and a ragged one
     x = torch.randn(C, B, H, W, q, device=DEV, requires_grad=True)
     y = m(x)
-    if sbs_band_family_takes(*case):
-        fam = "band"   # bonds 9..16: forward and backward of convsbs_band.hip
+    if sbs_band_family_takes(*case) and not (matrix_cores and max(bonds) <= 8):
+        fam = "band"   # bonds 5..16: forward and backward of convsbs_band.hip
     assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, list(pos), x.detach().cpu().double())
@@ -744,7 +746,7 @@ def test_many_convsbs_strings_in_one_launch(bond, C, q, outs_a, outs_b, B, H, W)
     many = ManyConvSBS(C, q, bond, False, specs, (init, init)).to(DEV)
     x0 = torch.randn(C, B, H, W, q)
     x = x0.to(DEV).requires_grad_(True)
-    fam = "band" if bond > 8 else "reg"
+    fam = "band" if bond > 4 else "reg"
     ya, yb = many(x)
     assert dctn_amd.last_kernel() == f"convsbs_many_fwd_{fam}_f32"
     dya, dyb = torch.randn_like(ya), torch.randn_like(yb)

@@ -296,8 +296,8 @@ def test_convsbs_vs_oracle_mnist_snake(r, q, C, B, HW):
     m = many.strings[0].to(DEV)
     x = torch.randn(C, B, HW, HW, q, device=DEV, requires_grad=True)
     (y,) = many(x)
-    # bond <= 4: lane-per-window register sweep; 5..8: the matrix-core sweep; 9..16: the band family (convsbs_band.hip)
-    fam = "reg" if r <= 4 else "mfma" if r <= 8 else "band"
+    # bond <= 4: lane-per-window register sweep; 5..16: the band family (convsbs_band.hip; two state values per lane up to 8)
+    fam = "reg" if r <= 4 else "band"
     assert dctn_amd.last_kernel() == f"convsbs_fwd_{fam}_f32"
     cores64 = [c.detach().cpu().double() for c in m.cores]
     want = R.convsbs_forward(cores64, snake, x.detach().cpu().double())
@@ -317,7 +317,7 @@ def test_convsbs_forward_reports_whether_it_wrote_the_saved_states():
     uninitialised and must never reach `dctn_convsbs_bwd_saved` - checked with a poisoned allocator and the oracle."""
     lib = _lib.lib()
     seen = set()
-    for rows, cols, r, q in ((3, 3, 8, 2), (5, 5, 16, 2), (4, 6, 16, 2)):
+    for rows, cols, r, q in ((2, 5, 8, 2), (5, 5, 16, 2), (4, 6, 16, 2)):   # (ten cores and more: outside the band family)
         pos = [(h, w if h % 2 == 0 else cols - 1 - w) for h in range(rows) for w in range(cols)]   # boustrophedon snake
         n = len(pos)
         torch.manual_seed(n)
@@ -356,7 +356,7 @@ def test_convsbs_forward_reports_whether_it_wrote_the_saved_states():
         assert close(x.grad, gr[0], torch.float32)
         for c, gc in zip(m.cores, gr[1:]):
             assert close(c.grad, gc, torch.float32)
-    assert _lib.SAVED in seen   # (whether a string is declined depends on the LDS plan; the bond-8 snake always saves)
+    assert _lib.SAVED in seen   # (whether a string is declined depends on the LDS plan; the ten-core bond-8 snake always saves)
 
 
 # ------------------------------------------------------------------ logmatmulexp
