@@ -36,6 +36,28 @@ __global__ __launch_bounds__(256) void k(const v4f* __restrict__ mats, v4f* __re
   }
 }
 
+// the fold's BACKWARD pattern: per window L matrices + dOut read, L matrices written (19 KiB per window at L = 9)
+template <int NT>
+__global__ __launch_bounds__(256) void kb(const v4f* __restrict__ mats, const v4f* __restrict__ dout, v4f* __restrict__ dm, long long Wn, int L) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+  for (long long w = wave; w < Wn; w += nw) {
+    v4f q[9];
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      const v4f* src = mats + (w * L + l) * 64 + lane;
+      if (NT) q[l] = __builtin_nontemporal_load(src); else q[l] = *src;
+    }
+    v4f g;
+    if (NT) g = __builtin_nontemporal_load(dout + w * 64 + lane); else g = dout[w * 64 + lane];
+#pragma unroll
+    for (int l = 8; l >= 0; --l) {
+      g += q[l];
+      if (NT) __builtin_nontemporal_store(g, dm + (w * L + l) * 64 + lane); else dm[(w * L + l) * 64 + lane] = g;
+    }
+  }
+}
+
 int main() {
   const long long Wn = 692224; const int L = 9;
   v4f *mats, *out;
@@ -59,5 +81,24 @@ int main() {
       printf("%s%s %2d waves/CU: %.3f ms  %.2f TB/s\n", (variant & 1) ? "nontemporal " : "plain       ", (variant & 2) ? "contiguous range per wave" : "grid stride              ",
              4 * wpc, best, Wn * (L + 1) * 1024.0 / best * 1e-9);
     }
+  {
+    v4f* dm;
+    if (hipMalloc(&dm, Wn * L * 1024) != hipSuccess) return 1;
+    for (int nt = 0; nt < 2; ++nt)
+      for (int wpc = 3; wpc <= 8; ++wpc) {
+        if (wpc == 5 || wpc == 7) continue;
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          (void)hipEventRecord(e0);
+          if (nt) hipLaunchKernelGGL(kb<1>, dim3(256 * wpc), dim3(256), 0, 0, mats, out, dm, Wn, L);
+          else hipLaunchKernelGGL(kb<0>, dim3(256 * wpc), dim3(256), 0, 0, mats, out, dm, Wn, L);
+          (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+          float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+          best = ms < best ? ms : best;
+        }
+        printf("backward pattern %s %2d waves/CU: %.3f ms  %.2f TB/s\n", nt ? "nontemporal" : "plain      ", 4 * wpc, best,
+               Wn * (2 * L + 1) * 1024.0 / best * 1e-9);
+      }
+  }
   return 0;
 }
