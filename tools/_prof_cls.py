@@ -4,7 +4,7 @@ from tests.sbs_classifier import ConvSBSClassifier
 dev = torch.device('cuda:0')
 bond = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 torch.manual_seed(0)
-m = ConvSBSClassifier(bond=bond).to(dev)
+m = ConvSBSClassifier(bond=bond, reference_form=True).to(dev)   # the reference's own model (mnist.py:255-283)
 x = torch.rand(1, 128, 28, 28, 2, device=dev)
 m.calibrate(x)
 y = torch.randint(0, 10, (128,), device=dev)
