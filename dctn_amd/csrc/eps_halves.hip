@@ -679,10 +679,14 @@ __device__ __forceinline__ T hv_xsum(T v) {
 // the six cross-lane levels exchange one value with the lane across one bit; the 2 nd results are wave sums.
 // One wave per window; everything in registers; cfg1 (two 8-factor halves, float64): 2 x 60 us (the table form: 2 x 88;
 // without its loads or without its stores the kernel takes 56-59 us: f64 vector arithmetic and address work, not memory).
+// element offsets of the half's factors relative to the window's top-left pixel, formed on the host: formed in the
+// kernel (two divisions per factor, everything wave-uniform) they were ~600 scalar instructions per window and wave -
+// a wave takes one window
+struct DxQ2Off { long long off[8]; };
 template <int ND, typename T, typename S>
 __global__ __launch_bounds__(256) void halves_dx_half_q2_k(const S* __restrict__ x, const T* __restrict__ dP,
                                                         T* __restrict__ gxw, HalfP h, int second, long long w0,
-                                                        long long nw, DxSavedZ sz) {
+                                                        long long nw, DxSavedZ sz, DxQ2Off fo) {
   constexpr int NI = ND - 6, VPL = 1 << NI, E = 1 << ND;
   const EpsP& p = h.p;
   const int lane = threadIdx.x & 63;
@@ -694,11 +698,10 @@ __global__ __launch_bounds__(256) void halves_dx_half_q2_k(const S* __restrict__
     const long long b = w / hw;
     const int rem = (int)(w - b * hw), ho = rem / p.Wo, wo = rem - ho * p.Wo;
     T xv[ND][2];
+    const S* win = x + b * p.s[1] + (long long)ho * p.s[2] + (long long)wo * p.s[3];
 #pragma unroll
     for (int f = 0; f < ND; ++f) {
-      const int n = base + f;
-      const int pos = n / p.C, ch = n - pos * p.C, dh = pos / p.K, dw = pos - dh * p.K;
-      const S* px = x + ch * p.s[0] + b * p.s[1] + (long long)(ho + dh) * p.s[2] + (long long)(wo + dw) * p.s[3];
+      const S* px = win + fo.off[f];
       xv[f][0] = (T)px[0];
       xv[f][1] = (T)px[p.s[4]];
     }
@@ -862,9 +865,15 @@ int launch_dx_half(const S* x, const T* dP, T* gxw, const HalfP& h, int second, 
   const int ndh = second ? h.n1 : h.n0;
   if (h.p.Q == 2 && ndh >= 6 && ndh <= 8) {   // binary halves of 6..8 factors: the register butterfly
     const dim3 g(blocks_for(nw, 4)), b(256);
-    if (ndh == 8) hipLaunchKernelGGL((halves_dx_half_q2_k<8, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
-    else if (ndh == 7) hipLaunchKernelGGL((halves_dx_half_q2_k<7, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
-    else hipLaunchKernelGGL((halves_dx_half_q2_k<6, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz);
+    DxQ2Off fo;
+    for (int f = 0; f < 8; ++f) {
+      const int n = (second ? h.n0 : 0) + (f < ndh ? f : 0);
+      const int pos = n / h.p.C, ch = n - pos * h.p.C, dh = pos / h.p.K, dw = pos - dh * h.p.K;
+      fo.off[f] = (long long)ch * h.p.s[0] + (long long)dh * h.p.s[2] + (long long)dw * h.p.s[3];
+    }
+    if (ndh == 8) hipLaunchKernelGGL((halves_dx_half_q2_k<8, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz, fo);
+    else if (ndh == 7) hipLaunchKernelGGL((halves_dx_half_q2_k<7, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz, fo);
+    else hipLaunchKernelGGL((halves_dx_half_q2_k<6, T, S>), g, b, 0, st, x, dP, gxw, h, second, w0, nw, sz, fo);
     DCTN_CHECK_LAUNCH();
     return DCTN_OK;
   }
