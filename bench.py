@@ -574,7 +574,11 @@ def extra_cfg1(dev, iters):
     roof = roofline_entry("mfma", "halves_gemm_k<double> (3 GEMMs: Z in the forward - kept -, dCore and dP0 in the backward)", "dctn_eps_bwd", sb, 2 * gemm, by_b, dt,
                           traffic_key="cfg1:halves_gemm_k", traffic_scope="longest halves_gemm_k instantiation (one of the four GEMMs of the call)", fwd_call_us=sf * 1e6, fwd_tflops=gemm / sf / 1e12,
                           step_tflops=3 * gemm / t_fb / 1e12, step_frac=3 * gemm / t_fb / 1e12 / MFMA_PEAK_TFLOPS["float64"],
-                          family=fam)
+                          family=fam,
+                          # measured, not a peak to price against: v_mfma_f64_16x16x4_f64 alone (4 accumulators, 4 waves per
+                          # SIMD, nothing else in the loop) reaches 47.7 of the nominal 78.6 TFLOP/s on MI355X
+                          instruction_ceiling_tflops=47.7, instruction_ceiling_source="tools/probes/mfma_f64_rate.hip",
+                          frac_of_instruction_ceiling=2 * gemm / sb / 1e12 / 47.7)
     # CPU: the oracle's 4-step path in float64 on a bounded sample (8 of the 64 samples)
     cores_n = usable_cores()
     torch.set_num_threads(cores_n)
