@@ -280,12 +280,16 @@ class DirectAllReducer:
             L.check(lib.dctn_ar_connect(state, packed), "direct all-reduce: connect")
         dist.barrier()   # every rank has mapped every block before the first kernel publishes into one
         self.max_numel = int(max_numel)
+        self.max_bytes = nbytes
 
-    def __call__(self, buf: Tensor) -> None:
-        assert buf.is_cuda and buf.is_contiguous() and buf.dtype == self.dtype and buf.numel() <= self.max_numel
+    def __call__(self, buf: Tensor, form: str = None) -> None:
+        """In place.  Any of float32 / float64 / bfloat16 that fits the block (`max_numel` elements of the constructor's
+        dtype); `form` overrides the constructor's for this call.  All ranks must make the same calls in the same order."""
+        assert buf.is_cuda and buf.is_contiguous() and buf.numel() * buf.element_size() <= self.max_bytes
         L = self._L
         L.check(L.lib().dctn_ar_allreduce_algo(self._state, buf.data_ptr(), buf.numel(), L.dtype_code(buf), int(self.average),
-                                                self.form, L.stream_ptr(buf.device)), "direct all-reduce")
+                                                self.form if form is None else self.FORMS[form], L.stream_ptr(buf.device)),
+                "direct all-reduce")
 
     def status(self) -> int:
         return int(self._L.lib().dctn_ar_status(self._state))
