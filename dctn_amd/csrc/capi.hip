@@ -51,7 +51,7 @@ int dctn_zero_async(void* ptr, size_t bytes, hipStream_t st) {
 
 extern "C" {
 
-int dctn_version(void) { return 403; }   // round 4: dctn_ar_* (direct all-reduce); ConvSBS band family (also several strings per launch), many-valued register sweep
+int dctn_version(void) { return 500; }   // round 5: register-resident exact-f32 EPS family (eps_q2f32.hip), fused head both ways in float32
 
 const char* dctn_last_kernel(void) { return g_last_kernel.load(std::memory_order_relaxed); }
 
@@ -92,6 +92,7 @@ int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, 
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return -1;
   if (p.opts & DCTN_OPT_GENERIC_KERNELS) return DCTN_EPS_FAMILY_GENERIC;
   if (eps_mfma_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG;
+  if (eps_q2f32_covers(p, dtype, precision)) return DCTN_EPS_FAMILY_Q2REG_F32;
   if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return DCTN_EPS_FAMILY_BIGCORE_F32;
   if (eps_halves_wanted(p, dtype)) return DCTN_EPS_FAMILY_HALVES;
   return DCTN_EPS_FAMILY_GENERIC;
@@ -111,6 +112,8 @@ static int eps_fwd_impl(const void* x, const int64_t x_strides[5], const void* c
   hipStream_t st = (hipStream_t)stream;
   if (p.opts & DCTN_OPT_GENERIC_KERNELS) return eps_fwd_generic(x, core, out, p, dtype, st);
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
+  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  rc = eps_fwd_q2f32(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
   if (!f32_prefers_halves(p, dtype)) {
     const size_t zb = saved ? eps_bigcore_saved_bytes(p, dtype, precision) : 0;
@@ -145,7 +148,7 @@ size_t dctn_eps_saved_bytes(int C, int B, int H, int W, int Q, int K, int O, int
   const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
-  if ((p.opts & DCTN_OPT_GENERIC_KERNELS) || eps_mfma_covers(p, dtype, precision)) return 0;
+  if ((p.opts & DCTN_OPT_GENERIC_KERNELS) || eps_mfma_covers(p, dtype, precision) || eps_q2f32_covers(p, dtype, precision)) return 0;
   if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return eps_bigcore_saved_bytes(p, dtype, precision);
   return eps_halves_saved_bytes(p, dtype);
 }
@@ -200,7 +203,8 @@ size_t dctn_eps_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, in
   const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
-  const size_t a = align256(eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore));
+  const size_t a = align256(eps_bwd_mfma_workspace(p, dtype, precision, need_dx, need_dcore)) +
+                   align256(need_dcore ? eps_bwd_q2f32_workspace(p, dtype, precision) : 0);
   size_t b = eps_bwd_generic_workspace(p, dtype, need_dx, need_dcore);
   const size_t c = need_dx ? eps_bwd_dfactor_bigcore_workspace(p, dtype, precision) : 0;
   if (c > b) b = c;
@@ -221,7 +225,9 @@ int dctn_eps_head_fwd(const void* x, const int64_t x_strides[5], const void* cor
   const int precision = policy & DCTN_PREC_MASK;
   const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
-  return eps_head_fwd_mfma(x, core, head_weight, head_bias, features, logits, p, Cout, dtype, precision, (hipStream_t)stream);
+  const int rcm = eps_head_fwd_mfma(x, core, head_weight, head_bias, features, logits, p, Cout, dtype, precision, (hipStream_t)stream);
+  if (rcm != DCTN_ERR_UNSUPPORTED) return rcm;
+  return eps_head_fwd_q2f32(x, core, head_weight, head_bias, features, logits, p, Cout, dtype, precision, (hipStream_t)stream);
 }
 
 size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout, int dtype,
@@ -230,7 +236,8 @@ size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int 
   const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
-  return eps_head_bwd_mfma_workspace(p, Cout, dtype, precision) + 256;
+  const size_t a = eps_head_bwd_mfma_workspace(p, Cout, dtype, precision), b = eps_head_bwd_q2f32_workspace(p, Cout, dtype, precision);
+  return (a > b ? a : b) + 256;
 }
 
 int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features, const void* dLogits,
@@ -244,8 +251,11 @@ int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* fea
   const int precision = policy & DCTN_PREC_MASK;
   const int rc = eps_fill_params(p, x_strides, C, B, H, W, Q, K, O, policy);
   if (rc != DCTN_OK) return rc;
-  return eps_head_bwd_mfma(x, features, dLogits, head_weight, dCore, dWeight, dBias, workspace, workspace_bytes, p,
-                           Cout, dtype, precision, (hipStream_t)stream);
+  const int rcm = eps_head_bwd_mfma(x, features, dLogits, head_weight, dCore, dWeight, dBias, workspace, workspace_bytes, p,
+                                    Cout, dtype, precision, (hipStream_t)stream);
+  if (rcm != DCTN_ERR_UNSUPPORTED) return rcm;
+  return eps_head_bwd_q2f32(x, features, dLogits, head_weight, dCore, dWeight, dBias, workspace, workspace_bytes, p, Cout,
+                            dtype, precision, (hipStream_t)stream);
 }
 
 static int eps_bwd_impl(const void* x, const int64_t x_strides[5], const void* core, const void* dY, const void* saved,
@@ -272,8 +282,18 @@ static int eps_bwd_impl(const void* x, const int64_t x_strides[5], const void* c
       return rc;
     }
   }
+  size_t wq = 0;
+  if (dCore && wa == 0 && (wq = align256(eps_bwd_q2f32_workspace(p, dtype, precision))) > 0) {
+    if (!ws || workspace_bytes < wq) return DCTN_ERR_WORKSPACE;
+    rc = eps_bwd_q2f32(x, dY, dCore, ws, wq, p, dtype, precision, st);
+    if (rc == DCTN_OK) {
+      dCore = nullptr;
+    } else if (rc != DCTN_ERR_UNSUPPORTED) {
+      return rc;
+    }
+  }
   if (!dX && !dCore) return DCTN_OK;
-  const size_t off = wa <= workspace_bytes ? wa : workspace_bytes;
+  const size_t off = (wa + wq) <= workspace_bytes ? (wa + wq) : workspace_bytes;
   // float64, and float32 shapes the bigcore family does not take: both gradients on the two-halves GEMM path
   if (dtype == DCTN_F64 || !eps_bigcore_covers(p, dtype, precision) || f32_prefers_halves(p, dtype)) {
     rc = eps_bwd_halves(x, core, dY, dX, dCore, ws ? ws + off : nullptr, workspace_bytes - off, p, dtype, st, saved,

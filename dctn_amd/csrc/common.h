@@ -82,6 +82,19 @@ int eps_bwd_dx_bigcore(const void* x, const void* core, const void* dY, void* dX
                        size_t ws_bytes, const EpsP& p, int dtype, int precision, hipStream_t st,
                        const void* zsaved = nullptr, size_t zsaved_bytes = 0);
 
+// register-resident exact-float32 family for Q = 2, N in {8, 9}, O <= 4 (cfg2 in the reference's own dtype) — eps_q2f32.hip
+bool eps_q2f32_covers(const EpsP& p, int dtype, int precision);
+int eps_fwd_q2f32(const void* x, const void* core, void* out, const EpsP& p, int dtype, int precision, hipStream_t st);
+size_t eps_bwd_q2f32_workspace(const EpsP& p, int dtype, int precision);
+int eps_bwd_q2f32(const void* x, const void* dY, void* dCore, void* ws, size_t ws_bytes, const EpsP& p, int dtype,
+                  int precision, hipStream_t st);
+int eps_head_fwd_q2f32(const void* x, const void* core, const void* head_w, const void* bias, void* feat, void* logits,
+                       const EpsP& p, int Cout, int dtype, int precision, hipStream_t st);
+size_t eps_head_bwd_q2f32_workspace(const EpsP& p, int Cout, int dtype, int precision);
+int eps_head_bwd_q2f32(const void* x, const void* feat, const void* dLogits, const void* head_w, void* dCore, void* dW,
+                       void* dBias, void* ws, size_t ws_bytes, const EpsP& p, int Cout, int dtype, int precision,
+                       hipStream_t st);
+
 // which family the forward of a shape dispatches to (dctn_eps_family)
 bool eps_mfma_covers(const EpsP& p, int dtype, int precision);
 bool eps_bigcore_covers(const EpsP& p, int dtype, int precision);

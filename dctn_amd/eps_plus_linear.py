@@ -117,18 +117,22 @@ class _EpsLinearHeadFunction(torch.autograd.Function):
     the dCore kernel from dLogits and the head weight and accumulates dWeight / dBias in the same pass
     (two kernels instead of three library GEMM / reduction launches + two EPS kernels, and no write +
     read of the (B, H'*W'*O) gradient).  Used when the layer's input needs no gradient (it is
-    the dataset tensor for a single-EPS model) and the shape is in the register-resident MFMA
-    family; anything else takes the two separate nodes."""
+    the dataset tensor for a single-EPS model) and the shape is in one of the two register-resident
+    families (bf16: eps_mfma.hip; float32, the reference's own dtype: eps_q2f32.hip); anything else takes
+    the two separate nodes."""
 
     @staticmethod
     def supported(core: Tensor, x: Tensor, weight: Tensor, bias) -> bool:
         if not (x.is_cuda and bias is not None and not x.requires_grad):
             return False
-        if not (x.dtype == core.dtype == weight.dtype == bias.dtype == torch.bfloat16):
+        if not (x.dtype == core.dtype == weight.dtype == bias.dtype and x.dtype in (torch.bfloat16, torch.float32)):
             return False
         n, o, cout = core.ndim - 1, core.shape[-1], weight.shape[0]
-        return (x.shape[-1] == 2 and n in (8, 9) and o in (2, 4) and cout <= 16 and cout % 2 == 0
-                and weight.shape[1] % 8 == 0 and weight.data_ptr() % 16 == 0 and FUSED_HEAD)
+        if not (x.shape[-1] == 2 and n in (8, 9) and o in (2, 4) and cout <= 16 and weight.data_ptr() % 16 == 0 and FUSED_HEAD):
+            return False
+        if x.dtype == torch.float32:   # the exact-f32 register family (eps_q2f32.hip) under the default policy
+            return (L.precision() & L.PREC_MASK) == L.PREC_EXACT
+        return cout % 2 == 0 and weight.shape[1] % 8 == 0
 
     @staticmethod
     def forward(ctx, core: Tensor, x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:

@@ -97,6 +97,7 @@ const char* dctn_last_kernel(void);
 #define DCTN_EPS_FAMILY_Q2REG 1        /* bf16 MFMA, Q = 2, N in {8, 9} */
 #define DCTN_EPS_FAMILY_BIGCORE_F32 2  /* exact f32 MFMA, LDS-streamed core */
 #define DCTN_EPS_FAMILY_HALVES 3       /* two-halves GEMM path: f64 MFMA, and f32 MFMA for shapes 1 and 2 leave */
+#define DCTN_EPS_FAMILY_Q2REG_F32 4    /* exact f32 MFMA, register-resident core: Q = 2, N in {8, 9}, O <= 4 */
 int dctn_eps_family(int C, int B, int H, int W, int Q, int K, int O, int dtype, int policy);
 size_t dctn_eps_fwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O,
                                     int dtype, int policy);
@@ -178,9 +179,9 @@ int dctn_eps_head_fwd(const void* x, const int64_t x_strides[5], const void* cor
  *   dLogits     : (B, Cout) contiguous;  head_weight : (Cout, H'*W'*O) contiguous
  *   dCore       : same layout as core;  dWeight : like head_weight, or NULL;  dBias : (Cout), or NULL
  *   all three OVERWRITTEN; `workspace` must hold dctn_eps_head_bwd_workspace_bytes().
- * bfloat16 only, the layer's input gets no gradient.  Returns DCTN_ERR_UNSUPPORTED for shapes
- * outside the register-resident MFMA family (the caller then composes dctn_linear_head_bwd or
- * library GEMMs with dctn_eps_bwd; there is no CPU fallback). */
+ * bfloat16 (register-resident bf16 family) and float32 (register-resident exact-f32 family, O in {2, 4}, Cout <= 16);
+ * the layer's input gets no gradient.  Returns DCTN_ERR_UNSUPPORTED for shapes outside those two families (the
+ * caller then composes dctn_linear_head_bwd or library GEMMs with dctn_eps_bwd; there is no CPU fallback). */
 size_t dctn_eps_head_bwd_workspace_bytes(int C, int B, int H, int W, int Q, int K, int O, int Cout,
                                          int dtype, int policy);
 int dctn_eps_head_bwd(const void* x, const int64_t x_strides[5], const void* features,

@@ -844,6 +844,77 @@ def test_eps_plus_linear_fused_head_backward(K, O, size, B):
         assert bf16_close(got_u, ref), name + " (unfused)"
 
 
+@pytest.mark.parametrize("C,K,O,size,B,cout", [(1, 3, 4, 28, 5, 10), (1, 3, 4, 8, 19, 10), (1, 3, 2, 12, 9, 16), (1, 3, 3, 11, 4, 10),
+                                                (2, 2, 4, 9, 5, 6), (2, 2, 2, 7, 3, 1), (1, 3, 4, 40, 3, 10), (1, 3, 4, 28, 70, 10)])
+def test_eps_plus_linear_float32_register_family(C, K, O, size, B, cout):
+    """The headline model in the reference's own arithmetic (float32: new_runner.py:417): layer + flatten + head as one
+    autograd node on the register-resident exact-f32 family (`eps_q2f32.hip`: v_mfma_f32_32x32x2_f32, dY formed in the
+    dCore kernel, dW / dBias by the finishing kernel), against the float64 oracle at the float32 tolerance and
+    against the unfused composition; out sizes that are no power of two (3) take the unfused node on the same family."""
+    import dctn_amd.eps_plus_linear as EPL
+
+    torch.manual_seed(1000 * C + 100 * K + 10 * O + size)
+    core = (torch.randn(*(2,) * (K * K * C), O) * 2.0 ** (-K * K * C / 2 + 1)).to(DEV).requires_grad_(True)
+    side = size - K + 1
+    w = (torch.randn(cout, side * side * O) * 0.05).to(DEV).requires_grad_(True)
+    bias = torch.randn(cout).to(DEV).requires_grad_(True)
+    u = torch.rand(C, B, size, size)
+    x = torch.stack([torch.sin(u * 1.5707963) ** 2, torch.cos(u * 1.5707963) ** 2], dim=-1).to(DEV)
+    g = torch.randn(B, cout)
+
+    def run(fused):
+        EPL.FUSED_HEAD = fused
+        try:
+            for t in (core, w, bias):
+                t.grad = None
+            if EPL._EpsLinearHeadFunction.supported(core, x, w, bias):
+                out = EPL._EpsLinearHeadFunction.apply(core, x, w, bias)
+            else:
+                feat = eps(core, x)
+                out = EPL._LinearHeadFunction.apply(feat.reshape(B, -1), w, bias)
+            out.backward(g.to(DEV))
+            return out.detach().cpu(), [t.grad.detach().cpu() for t in (core, w, bias)], dctn_amd.last_kernel()
+        finally:
+            EPL.FUSED_HEAD = True
+
+    out_f, grads_f, kern_f = run(True)
+    out_u, grads_u, kern_u = run(False)
+    if O in (2, 4):
+        assert kern_f == "eps_head_bwd_q2f32", kern_f
+    assert kern_u != "eps_head_bwd_q2f32"
+    assert _lib.lib().dctn_eps_family(C, B, size, size, 2, K, O, _lib.F32, 0) == 4
+    c64, w64, b64 = (t.detach().cpu().double().requires_grad_(True) for t in (core, w, bias))
+    want = R.eps_plus_linear_forward([c64], w64, b64, x.cpu().double())
+    want.backward(g.double())
+    assert close(out_f, want.detach(), torch.float32) and close(out_u, want.detach(), torch.float32)
+    for name, got_f, got_u, ref in zip(("dCore", "dWeight", "dBias"), grads_f, grads_u, (c64.grad, w64.grad, b64.grad)):
+        assert close(got_f, ref, torch.float32), name
+        assert close(got_u, ref, torch.float32), name + " (unfused)"
+    # a second call reproduces the first bit for bit (fixed-order sums, no float atomics)
+    out_2, grads_2, _ = run(True)
+    assert torch.equal(out_2, out_f) and all(torch.equal(a, b) for a, b in zip(grads_2, grads_f))
+
+
+def test_eps_float32_register_family_strided_input_and_input_gradient():
+    """The same family behind `eps()`: a strided batch slice (dctn/eps.py:136 hands `x.split(batch, dim=1)` pieces) and a
+    permuted input (generic window loads), with the input's gradient taken by the large-core family."""
+    torch.manual_seed(7)
+    core = (torch.randn(*(2,) * 9, 4) * 0.1).to(DEV).requires_grad_(True)
+    big = torch.rand(1, 9, 12, 12, 2).to(DEV)
+    for x in (big[:, 2:7], big.permute(0, 1, 3, 2, 4)[:, 1:4]):
+        x = x.detach().requires_grad_(True)
+        core.grad = None
+        y = eps(core, x)
+        assert dctn_amd.last_kernel() == "eps_fwd_q2f32"
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        c64, x64 = core.detach().cpu().double().requires_grad_(True), x.detach().cpu().double().requires_grad_(True)
+        want = R.eps_4step(c64, x64)
+        want.backward(dy.cpu().double())
+        assert close(y, want.detach(), torch.float32)
+        assert close(core.grad, c64.grad, torch.float32) and close(x.grad, x64.grad, torch.float32)
+
+
 def test_logmatmulexp_fold16_factored_mfma_and_exact_fallback():
     """D = 16 float32 fold: factored exp -> MFMA -> log forward with the exact path taken per step
     when the dynamic range is unsafe (large magnitudes, -inf entries)."""
