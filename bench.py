@@ -52,7 +52,11 @@ WORKLOADS = {
     # --ds-type cifar10_ycbcr --epses-specs '(3,6)' --add-constant-channel): one EPS K=3 on 32x32, Q0 = 3 colour values + 1
     "cfg4_eps36": (((3, 6),), 32, 4, torch.float32),
 }
-EXTRA_CONFIGS = ("cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
+EXTRA_CONFIGS = ("cfg2_f32", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
+# the side configurations whose three scalars (_ms, _frac, _cpu_wps) lead `config` (the driver's record keeps the first
+# ~900 characters of it): every BASELINE / SURVEY 8(d) configuration; cfg3a_bf16 (no BASELINE config) stays in `configs`
+# and `side_summary` only
+CONFIG_SCALARS = ("cfg2_f32", "cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
 # --workload also takes the two BASELINE configs that are not EPS models (configs[3] "ConvSBS ... DDP over 8xMI355X",
 # configs[4] "logmatmulexp ... 8xMI355X"): the same sharding, timing protocol and JSON line as the EPS workloads
 SIDE_WORKLOADS = ("cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg5")
@@ -338,6 +342,11 @@ def eps_call_timers(core, x, need_dx, dev, head=None):
         dl = (torch.randn((B, cout), device=dev) * 0.1).to(x.dtype)
         dw, db = torch.empty_like(w_head), torch.empty_like(b_head)
         wsh = L.workspace(lib.dctn_eps_head_bwd_workspace_bytes(C, B, H, W, Q, K, O, cout, code, pol), dev).clone()
+        logits = torch.empty((B, cout), dtype=x.dtype, device=dev)
+
+        def head_fwd():   # layer + flatten + head as ONE kernel; ERR_UNSUPPORTED where the model composes two calls
+            return lib.dctn_eps_head_fwd(x.data_ptr(), L.strides5(x), core.data_ptr(), w_head.data_ptr(), b_head.data_ptr(),
+                                         feat.data_ptr(), logits.data_ptr(), C, B, H, W, Q, K, O, cout, code, pol, L.stream_ptr(dev))
 
         def bwd(policy=pol):
             L.check(lib.dctn_eps_head_bwd(x.data_ptr(), L.strides5(x), feat.data_ptr(), dl.data_ptr(), w_head.data_ptr(),
@@ -354,16 +363,19 @@ def eps_call_timers(core, x, need_dx, dev, head=None):
                 L.check(lib.dctn_eps_bwd(x.data_ptr(), L.strides5(x), core.data_ptr(), dy.data_ptr(), *tail), "bwd")
     wn = B * Ho * Ho
     gemm = 2 * (Q ** N) * O   # flops per window of the core GEMM (fwd 2*Q^N*O; + the same per gradient)
-    return {"fwd": fwd, "bwd": bwd, "fused": fused, "windows": wn, "gemm_flops": gemm, "K": K, "O": O, "N": N,
+    return {"fwd": fwd, "bwd": bwd, "fused": fused, "head_fwd": head_fwd if fused else None, "windows": wn, "gemm_flops": gemm, "K": K, "O": O, "N": N,
             "bytes_x": x.numel() * x.element_size(), "bytes_y": wn * O * x.element_size(),
             "bytes_core": core.numel() * core.element_size(), "saved_bytes": nsaved, "keep": (out, dy, dcore, dx, wsf, wsb, saved)}
 
 
-def headline_roofline(model, x, specs, steps):
-    """The dominant KERNEL of the headline step, timed alone: the kernels of the register-resident family
-    (cfg2) as a chain of 20 dependent launches replayed from a HIP graph (each launch drains before the next starts,
-    as inside the real step; the backward's small reduce kernel is left out with DCTN_OPT_MAIN_KERNEL_ONLY - an
-    explicit per-call flag of the C-ABI), which is the per-launch duration rocprofv3 reports."""
+def headline_roofline(model, x, specs, steps, ms_per_step=None):
+    """The dominant KERNEL of the step that is timed.  For the register-resident families (cfg2: bf16 `eps_mfma.hip`,
+    float32 `eps_q2f32.hip`) the step is three kernels - layer + head forward (`dctn_eps_head_fwd`), the dCore kernel
+    and the finishing kernel of `dctn_eps_head_bwd` - each timed here as a chain of 20 dependent launches replayed from
+    a HIP graph (each launch drains before the next starts, as inside the real step: the per-launch duration rocprofv3
+    reports).  The dCore kernel alone is the backward call with DCTN_OPT_MAIN_KERNEL_ONLY (an explicit per-call flag
+    of the C-ABI); the finishing kernel is the call's chain minus that (one kernel boundary included).  `step_frac` =
+    the step's algorithmic flops / `ms_per_step` / peak."""
     from dctn_amd import _lib as L
     from dctn_amd.eps import _bf16_through_f32
 
@@ -388,38 +400,55 @@ def headline_roofline(model, x, specs, steps):
 
     t["fwd"]()
     fwd_family = L.last_kernel()
-    q2 = "q2reg" in fwd_family
-    calls = {"eps_fwd": device_time(t["fwd"], dev, n, graph=False), "eps_bwd_dcore": device_time(t["bwd"], dev, n, graph=False)}
-    if q2:
-        main_only = L.precision() | L.OPT_MAIN_KERNEL_ONLY
-        kernels = {"eps_fwd_q2reg_k": chain(t["fwd"]), "eps_bwd_dcore_q2reg_k": chain(lambda: t["bwd"](main_only))}
-    else:
-        kernels = {}
+    t["bwd"]()
+    bwd_family = L.last_kernel()
+    reg_family = t["fused"] and ("q2reg" in bwd_family or "q2f32" in bwd_family)
+    one_kernel_fwd = reg_family and t["head_fwd"]() == 0
     # this path is compute bound (MFMA for the core GEMM, VALU for the Khatri-Rao halves);
-    # algorithmic flops per window: forward 2*Q^N*O (GEMM) + the two halves and the final dot; dCore the
-    # same GEMM size transposed (+ forming dY when the head is fused: 2*Cout*O; dWeight = dLogits^T x features is formed
-    # by the call's second kernel since round 4 and is not counted for this one)
+    # algorithmic flops per window: forward 2*Q^N*O (GEMM) + the two halves and the final dot (+ the head: 2*Cout*O);
+    # dCore kernel the same GEMM size transposed + forming dY (2*Cout*O); dW = dLogits^T x features (2*Cout*O) belongs
+    # to the finishing kernel
     half = 2 * (Q ** ((N + 1) // 2) + Q ** (N // 2)) + 2 * Q ** (N // 2) * O
-    flops = {"eps_fwd": wn * (t["gemm_flops"] + half),
-             "eps_bwd_dcore": wn * (t["gemm_flops"] + half + (2 * cout * O if t["fused"] else 0))}
-    alg = {"eps_fwd": t["bytes_x"] + t["bytes_y"] + t["bytes_core"],
-           # fused: the kernel reads x, dLogits and the head weight and produces dCore; the features are read and
-           # dWeight / dBias written by the call's second kernel since round 4 (not this kernel's bytes any more)
-           "eps_bwd_dcore": (t["bytes_x"] + t["bytes_core"] + (B * cout + w_head.numel()) * esz) if t["fused"]
-                            else t["bytes_x"] + t["bytes_y"] + t["bytes_core"]}
-    if q2:
-        dom = max(("eps_fwd", "eps_bwd_dcore"), key=lambda k: kernels[{"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[k]])
-        kname = {"eps_fwd": "eps_fwd_q2reg_k", "eps_bwd_dcore": "eps_bwd_dcore_q2reg_k"}[dom]
-        sec = kernels[kname]
+    head_fl = 2 * cout * O if t["fused"] else 0
+    flops = {"fwd": wn * (t["gemm_flops"] + half + head_fl), "dcore": wn * (t["gemm_flops"] + half + head_fl), "finish": wn * head_fl}
+    head_bytes = (B * cout + w_head.numel()) * esz
+    alg = {"fwd": t["bytes_x"] + t["bytes_y"] + t["bytes_core"] + (head_bytes if t["fused"] else 0),
+           # fused: the dCore kernel reads x, dLogits and the head weight and produces dCore; the features are read and
+           # dWeight / dBias written by the finishing kernel
+           "dcore": (t["bytes_x"] + t["bytes_core"] + head_bytes) if t["fused"] else t["bytes_x"] + t["bytes_y"] + t["bytes_core"],
+           "finish": t["bytes_y"] + head_bytes + t["bytes_core"]}
+    step_flops = flops["fwd"] + flops["dcore"] + flops["finish"]
+    peak = MFMA_PEAK_TFLOPS[str(x.dtype).replace("torch.", "")]
+    extra = {"fused_head": bool(t["fused"]), "step_algorithmic_flops": int(step_flops), "flops_per_window_step": step_flops / wn}
+    if ms_per_step:
+        extra["step_tflops"] = step_flops / (ms_per_step * 1e-3) / 1e12
+        extra["step_frac"] = extra["step_tflops"] / peak
+    if reg_family:
+        bf16 = "q2reg" in bwd_family
+        names = {"fwd": ("eps_fwd_head_q2reg_k" if bf16 else "eps_fwd_q2f32_k<head>") if one_kernel_fwd else fwd_family,
+                 "dcore": "eps_bwd_dcore_q2reg_k" if bf16 else "eps_bwd_q2f32_k",
+                 "finish": "eps_head_reduce_k" if bf16 else "eps_q2f32_finish_k"}
+        main_only = L.precision() | L.OPT_MAIN_KERNEL_ONLY
+        sec = {"fwd": chain(t["head_fwd"] if one_kernel_fwd else t["fwd"]), "dcore": chain(lambda: t["bwd"](main_only))}
+        call_bwd = chain(t["bwd"])
+        sec["finish"] = max(call_bwd - sec["dcore"], 0.0)
+        dom = max(sec, key=lambda k: sec[k])
+        kname = names[dom]
+        extra.update(kernels_us={names[k]: v * 1e6 for k, v in sec.items()},
+                     kernels_frac={names[k]: (flops[k] / v / 1e12 / peak if v > 0 else None) for k, v in sec.items() if k != "finish"},
+                     calls_us={"dctn_eps_head_fwd" if one_kernel_fwd else "dctn_eps_fwd": sec["fwd"] * 1e6, "dctn_eps_head_bwd": call_bwd * 1e6},
+                     finish_kernel_note="call chain minus dCore-kernel chain (one kernel boundary included)")
+        call = {"fwd": "dctn_eps_head_fwd" if one_kernel_fwd else "dctn_eps_fwd", "dcore": "dctn_eps_head_bwd", "finish": "dctn_eps_head_bwd"}[dom]
+        seconds = sec[dom]
     else:
+        calls = {"fwd": device_time(t["fwd"], dev, n, graph=False), "dcore": device_time(t["bwd"], dev, n, graph=False)}
         dom = max(calls, key=lambda k: calls[k])
-        kname, sec = L.last_kernel() if dom == "eps_bwd_dcore" else fwd_family, calls[dom]
-    return roofline_entry(
-        "mfma", kname, "dctn_eps_fwd" if dom == "eps_fwd" else ("dctn_eps_head_bwd" if t["fused"] else "dctn_eps_bwd"),
-        sec, flops[dom], alg[dom], x.dtype, traffic_key=f"{kname}:B{B}",
-        flops_per_window=flops[dom] / wn, bytes_per_window=alg[dom] / wn, hbm_frac=alg[dom] / sec / 1e9 / HBM_PEAK_GBS,
-        fused_head=bool(t["fused"]), calls_us={k: v * 1e6 for k, v in calls.items()},
-        kernels_us={k: v * 1e6 for k, v in kernels.items()})
+        kname, seconds = (bwd_family if dom == "dcore" else fwd_family), calls[dom]
+        call = "dctn_eps_fwd" if dom == "fwd" else ("dctn_eps_head_bwd" if t["fused"] else "dctn_eps_bwd")
+        extra.update(calls_us={k: v * 1e6 for k, v in calls.items()})
+    return roofline_entry("mfma", kname, call, seconds, flops[dom], alg[dom], x.dtype, traffic_key=f"{kname}:B{B}",
+                          flops_per_window=flops[dom] / wn, bytes_per_window=alg[dom] / wn,
+                          hbm_frac=alg[dom] / seconds / 1e9 / HBM_PEAK_GBS, **extra)
 
 
 def convsbs_call_timers(string, x, dy, dev):
@@ -536,6 +565,45 @@ def extra_eps_model(name, dev, iters):
             "value": windows / t_fb, "unit": "windows/s", "layers": layers, "roofline": roof,
             "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, torch.float32 if dtype == torch.bfloat16 else dtype,
                                                    batch=8, target_seconds=4.0)}
+
+
+def extra_cfg2_f32(dev, batch=1024, gsteps=20):
+    """cfg2 in the reference's OWN arithmetic (new_runner.py:417 runs float32 and nothing else): the headline model,
+    float32 tensors, B = 1024, the headline's protocol (fwd + bwd(out_grad) replayed from a HIP graph of 20 steps) and
+    the headline's roofline object (the step's three kernels timed as chains of dependent launches)."""
+    from dctn_amd.eps_plus_linear import EPSesPlusLinear, UnitTheoreticalOutputStd
+
+    specs, image_size, q0, dtype = WORKLOADS["cfg2_f32"]
+    torch.manual_seed(0)
+    model = EPSesPlusLinear(specs, UnitTheoreticalOutputStd(), 1.0, dev, dtype, image_size=image_size, Q_0=q0)
+    params = list(model.parameters())
+    x = synthetic_input(batch, image_size, q0, dtype, dev, seed=1)
+    out_grad = torch.randn(batch, 10, device=dev).to(dtype)
+
+    def fwd():
+        with torch.no_grad():
+            model(x)
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        model(x).backward(out_grad)
+
+    def several(fn):
+        def body():
+            for _ in range(gsteps):
+                fn()
+        return body
+
+    t_fb = device_time(several(fwd_bwd), dev, 10, blocks=5) / gsteps
+    t_f = device_time(several(fwd), dev, 10) / gsteps
+    windows = windows_per_sample(specs, image_size) * batch
+    roof = headline_roofline(model, x, specs, 100, ms_per_step=t_fb * 1e3)
+    return {"workload": f"cfg2_f32: EPSesPlusLinear({specs}) float32 (the reference's dtype) on MNIST-shaped 28x28 Q0=2, fwd + bwd(out_grad), "
+                        f"batch {batch}, HIP graph of {gsteps} steps",
+            "dtype": "f32", "windows_per_step": windows, "ms_per_step": t_fb * 1e3, "fwd_ms": t_f * 1e3,
+            "value": windows / t_fb, "unit": "windows/s", "roofline": roof,
+            "cpu_baseline": cpu_baseline_eps_model(specs, image_size, q0, torch.float32, batch=64, target_seconds=4.0)}
 
 
 def extra_cfg1(dev, iters):
@@ -737,25 +805,46 @@ def extra_cfg5(dev, iters):
                                        f"{Wc} of {Wn} windows, {it} fwd+bwd iterations, {dtc*1e3:.1f} ms/iteration"}}
 
 
+def _sig(v, digits=4):
+    """`v` rounded to `digits` significant digits (short in the JSON line, exact enough for a record)."""
+    return float(f"{v:.{digits}g}")
+
+
 def side_scalars(name, e):
-    """One side configuration's entry flattened into scalar `config` keys."""
+    """One side configuration as THREE scalar `config` keys (a driver that keeps the contract's keys keeps scalars only,
+    and only the first ~900 characters of `config`): side_<cfg>_ms = ms per fwd+bwd step, _frac = the dominant call's
+    fraction of its roofline, _cpu_wps = the CPU oracle's windows/s.  Everything else is in `configs` / `side_summary`."""
     if "value" not in e:
-        return {f"side_{name}_error": str(e.get("error", "failed"))[:120]}
-    roof = e.get("roofline", {})
-    out = {f"side_{name}_ms": round(e["ms_per_step"], 5), f"side_{name}_wps": round(e["value"]),
-           f"side_{name}_frac": round(roof.get("frac", 0.0), 4), f"side_{name}_bound": roof.get("bound")}
-    if roof.get("step_frac") is not None:
-        out[f"side_{name}_step_frac"] = round(roof["step_frac"], 4)
-    if roof.get("fwd_frac") is not None:
-        out[f"side_{name}_fwd_frac"] = round(roof["fwd_frac"], 4)
-    if roof.get("traffic") is not None and roof.get("algorithmic_bytes"):
-        out[f"side_{name}_traffic_x"] = round(roof["traffic"] / roof["algorithmic_bytes"], 2)
+        return {f"side_{name}_error": str(e.get("error", "failed"))[:60]}
+    out = {f"side_{name}_ms": _sig(e["ms_per_step"]), f"side_{name}_frac": round(e.get("roofline", {}).get("frac", 0.0), 3)}
     if "cpu_baseline" in e:
-        out[f"side_{name}_cpu_wps"] = round(e["cpu_baseline"]["value"])
+        out[f"side_{name}_cpu_wps"] = int(_sig(e["cpu_baseline"]["value"], 3))
     return out
 
 
+def compact_config(base, names, entries):
+    """`config` of the line: the workload keys, then three scalars per configuration of CONFIG_SCALARS."""
+    cfg = dict(base)
+    for name, e in zip(names, entries):
+        if name in CONFIG_SCALARS:
+            cfg.update(side_scalars(name, e))
+    return cfg
+
+
+def side_summary_row(e):
+    """[ms per step, windows/s, frac, bound, step_frac, traffic / algorithmic bytes, cpu windows/s] of one side configuration."""
+    if "value" not in e:
+        return {"error": str(e.get("error", "failed"))[:120]}
+    roof = e.get("roofline", {})
+    tx = (round(roof["traffic"] / roof["algorithmic_bytes"], 2) if roof.get("traffic") is not None and roof.get("algorithmic_bytes") else None)
+    return [_sig(e["ms_per_step"], 5), round(e["value"]), round(roof.get("frac", 0.0), 4), roof.get("bound"),
+            round(roof["step_frac"], 4) if roof.get("step_frac") is not None else None, tx,
+            round(e["cpu_baseline"]["value"]) if "cpu_baseline" in e else None]
+
+
 def run_extra(name, dev):
+    if name == "cfg2_f32":
+        return extra_cfg2_f32(dev)
     if name == "cfg1":
         return extra_cfg1(dev, 20)
     if name in ("cfg3a", "cfg3b", "cfg3a_bf16", "cfg3b_bf16", "cfg4_eps36"):
@@ -1135,6 +1224,8 @@ def main():
             del g1
 
     windows_step = windows_rank * world
+    short = (f"{args.workload} EPS{list(specs)}+linear {DTYPE_NAME[dtype]} B{batch}/GPU".replace(", ", ",")
+             if eps_model else what.split(",")[0][:60])   # (the full description: run.workload)
     line = {
         "metric": "EPS-contraction windows/sec (fwd+bwd)",
         "value": windows_step * args.steps / elapsed,
@@ -1148,16 +1239,23 @@ def main():
         "vs_baseline": None,
         "dtype": DTYPE_NAME[dtype],
         "data": "synthetic",
-        "config": {
+        # `config` stays SHORT (< 850 characters, asserted by tests/test_bench_host.py): the workload, then - at N = 1 -
+        # three scalars per side configuration.  How the run went is in `run`, prose in `notes`.
+        "config": {"workload": short, "parallelism": f"dp{world}"},
+        "run": {
             "workload": what,
-            "windows_per_step": windows_step,
             "per_gpu_batch": batch,
-            "parallelism": f"dp{world}",
+            "windows_per_step": windows_step,
             "hip_graph": graph is not None,
             "steps_per_graph_launch": gsteps,
             "us_per_step_at_one_step_per_graph_launch": one_step_us,
-            "timing": f"median of {BLOCKS} blocks of {args.steps} steps (each block: barrier + synchronize on both sides, max over ranks)",
             "blocks_ms": [b * 1e3 for b in block_s],
+            "last_kernel": kernel_used,
+        },
+        "notes": {"timing": f"median of {BLOCKS} blocks of {args.steps} steps (each block: barrier + synchronize on both sides, max over ranks)"},
+    }
+    if reducer is not None or world > 1:
+        line["run"].update({
             "allreduce_in_graph": reduce_in_graph,
             "allreduce_capture_probe": probe_ok,
             "allreduce": args.allreduce if reducer is not None else None,
@@ -1167,21 +1265,19 @@ def main():
             "allreduce_bytes": allreduce_bytes,
             "step_without_allreduce_us": step_without_allreduce_us,
             "rccl_env": rccl_env,
-            "last_kernel": kernel_used,
             "grad_allreduce": ("none: the workload has no parameters (windows sharded, no data-path collective)" if not params else None) if reducer is None else (
                 "in place on the backward's flat gradient buffer (1 launch)" if getattr(reducer, "_flat_key", None)
                 else "gather -> all_reduce -> scatter (3 launches)"),
-        },
-    }
+        })
     if rank == 0:
         if eps_model:
             log(f"headline: {line['ms_per_step']*1e3:.1f} us/step; timing its kernels")
-            line["roofline"] = headline_roofline(model, x, specs, args.steps)
+            line["roofline"] = headline_roofline(model, x, specs, args.steps, ms_per_step=line["ms_per_step"])
             if world == 1 and not args.no_cpu_baseline:
                 log("cpu baseline of the headline workload")
                 line["cpu_baseline"] = cpu_baseline_eps_model(specs, image_size, q0)
-                line["config"]["cpu_baseline_note"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
-                                                       f"{DTYPE_NAME[dtype]} at batch {batch}")
+                line["notes"]["cpu_baseline"] = ("cpu_baseline runs the float32 oracle at batch 128 on the host cores; the GPU step is "
+                                                 f"{DTYPE_NAME[dtype]} at batch {batch}")
         else:
             # ConvSBS / logmatmulexp as the timed workload: roofline and CPU baseline of the same configuration, measured
             # at its BASELINE size in a child process on this rank's GPU (the timed region is over)
@@ -1193,7 +1289,7 @@ def main():
                 line["roofline"] = entry["roofline"]
             if "cpu_baseline" in entry:
                 line["cpu_baseline"] = entry["cpu_baseline"]
-            line["config"]["single_gpu_entry"] = {k: entry.get(k) for k in ("ms_per_step", "value", "windows_per_step", "error") if k in entry}
+            line["run"]["single_gpu_entry"] = {k: entry.get(k) for k in ("ms_per_step", "value", "windows_per_step", "error") if k in entry}
         if world == 1 and args.configs != "none" and eps_model:
             names = EXTRA_CONFIGS if args.configs == "all" else tuple(n for n in args.configs.split(",") if n)
             entries = []
@@ -1205,14 +1301,14 @@ def main():
                 entries.append(run_extra_in_child(name, args.no_cpu_baseline))
                 entries[-1]["bench_seconds"] = round(time.perf_counter() - t0, 1)
             line["configs"] = entries
-            # the same numbers as SCALAR keys of `config` (a driver that keeps the contract's keys keeps scalars only:
-            # round 3's dict-valued `config.side` was dropped): side_<cfg>_ms = ms per fwd+bwd step, _wps = windows/s,
-            # _frac = fraction of the stated roofline reached by the dominant call, _bound = which roofline,
-            # _step_frac = the same for the whole step where defined, _cpu_wps = the CPU oracle's windows/s
-            for name, e in zip(names, entries):
-                line["config"].update(side_scalars(name, e))
-            line["config"]["side_legend"] = ("side_<cfg>_ms: ms per fwd+bwd step; _wps: windows/s; _frac: dominant call's fraction of its "
-                                             "roofline (_bound: hbm | mfma); _step_frac: whole step; _cpu_wps: CPU oracle windows/s")
+            # three scalars per BASELINE / SURVEY 8(d) configuration right behind the workload (what a record that keeps
+            # ~900 characters of `config` still holds), and ALL of them once more as the line's LAST key, so that the
+            # tail of stdout carries every configuration too
+            line["config"] = compact_config(line["config"], names, entries)
+            line["notes"]["side"] = ("config.side_<cfg>_ms: ms per fwd+bwd step; _frac: dominant call's fraction of its roofline; _cpu_wps: CPU "
+                                     "oracle windows/s.  side_summary.<cfg> = [ms per step, windows/s, frac, bound, step_frac, "
+                                     "counter traffic / algorithmic bytes, cpu windows/s]")
+            line["side_summary"] = {name: side_summary_row(e) for name, e in zip(names, entries)}
         print(json.dumps(line), flush=True)
     barrier()
     if dist.is_initialized():

@@ -1,6 +1,6 @@
-// ConvSBS backward for LARGE bonds (8 < largest bond <= 16) on the f32 matrix cores, one launch + one tail:
+// ConvSBS forward and backward for bonds 5..16 (largest bond of the string) on the f32 matrix cores, one launch + one tail:
 // float32 open chains of at most nine cores (the snakes of mnist.py:189-223), at most two output values, both on one
-// middle core, q^C <= 4 - BASELINE cfg4 at r = 16.
+// middle core, q^C <= 4 - BASELINE cfg4 at r = 16 and r = 8 (bonds <= 8: two state values per lane, template NS = 2).
 //
 // Replaces torch autograd through dctn/conv_sbs.py:258-304 for these strings, and the round-2 backward of
 // convsbs_mfma.hip (convsbs_bwd_mfma16_k: forward states through HBM - 81 MB written by the forward and read back -,

@@ -23,18 +23,36 @@ def bench():
 def test_side_configs_become_scalar_config_keys(bench):
     e = {"ms_per_step": 6.9712345, "value": 2.1e7, "roofline": {"frac": 0.66123, "bound": "mfma", "step_frac": 0.65,
                                                                  "traffic": 84, "algorithmic_bytes": 12},
-         "cpu_baseline": {"value": 31000.4}}
+         "cpu_baseline": {"value": 31040.4}}
     flat = bench.side_scalars("cfg3a", e)
-    assert flat == {"side_cfg3a_ms": 6.97123, "side_cfg3a_wps": 21000000, "side_cfg3a_frac": 0.6612, "side_cfg3a_bound": "mfma",
-                    "side_cfg3a_step_frac": 0.65, "side_cfg3a_traffic_x": 7.0, "side_cfg3a_cpu_wps": 31000}
+    assert flat == {"side_cfg3a_ms": 6.971, "side_cfg3a_frac": 0.661, "side_cfg3a_cpu_wps": 31000}
     assert all(isinstance(v, (int, float, str)) for v in flat.values())      # scalars only: dicts and lists are dropped
     assert bench.side_scalars("cfg5", {"workload": "cfg5", "error": "timed out after 420 s"}) == {"side_cfg5_error": "timed out after 420 s"}
-    # every configuration SURVEY 8(d) fixes is in the default side set (cfg4 r = 8 and the EPS (3,6) colour model included)
-    assert set(bench.EXTRA_CONFIGS) >= {"cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5"}
+    assert bench.side_summary_row(e) == [6.9712, 21000000, 0.6612, "mfma", 0.65, 7.0, 31040]
+    # every configuration SURVEY 8(d) fixes is in the default side set (cfg4 r = 8, the EPS (3,6) colour model and the
+    # headline model in the reference's own dtype included), and its scalars are among those that lead `config`
+    want = {"cfg2_f32", "cfg1", "cfg3a", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5"}
+    assert set(bench.EXTRA_CONFIGS) >= want and set(bench.CONFIG_SCALARS) == want
     specs, image_size, q0, _ = bench.WORKLOADS["cfg4_eps36"]
     assert (specs, image_size, q0) == (((3, 6),), 32, 4) and bench.windows_per_sample(specs, image_size) * 128 == 115200
+    assert bench.WORKLOADS["cfg2_f32"][0] == bench.WORKLOADS["cfg2"][0] and bench.WORKLOADS["cfg2_f32"][3] == __import__("torch").float32
     x = bench.synthetic_input(2, 32, 4, __import__("torch").float32, "cpu", 0)
     assert x.shape == (1, 2, 32, 32, 4) and bool((x[..., 3] == 1).all())   # the constant channel (dataset_loading.py:349-364)
+
+
+def test_config_of_the_line_stays_within_what_the_driver_keeps(bench):
+    """The driver's record kept ~900 characters of `config` (round 4: everything behind side_cfg1_frac was cut): the
+    workload and three scalars for EVERY side configuration must fit 850 characters, prose lives elsewhere."""
+    entries = [{"ms_per_step": 123.45678 / (i + 1), "value": 6.9e8 / (i + 1), "roofline": {"frac": 0.6543 / (i + 1), "bound": "mfma"},
+                "cpu_baseline": {"value": 8412345.6 / (i + 1)}} for i in range(len(bench.EXTRA_CONFIGS))]
+    base = {"workload": "cfg2 EPS[(3,4)]+linear bf16 B1024/GPU", "parallelism": "dp1"}
+    cfg = bench.compact_config(base, bench.EXTRA_CONFIGS, entries)
+    assert list(cfg)[:2] == ["workload", "parallelism"]
+    for name in bench.CONFIG_SCALARS:
+        assert {f"side_{name}_ms", f"side_{name}_frac", f"side_{name}_cpu_wps"} <= set(cfg)
+    assert "side_cfg3a_bf16_ms" not in cfg
+    assert len(json.dumps(cfg)) < 850, len(json.dumps(cfg))
+    assert all(not isinstance(v, (dict, list)) and v is not None for v in cfg.values())
 
 
 def test_gpus_n_without_world_size_starts_its_own_ranks(bench, monkeypatch, capsys):

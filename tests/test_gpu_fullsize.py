@@ -124,6 +124,63 @@ def test_cfg2_full_batch_1024_bf16():
         assert float((a - c).abs().max()) < 2e-2 * scale, name + ": whole batch vs sum of slices"
 
 
+def test_cfg2_full_batch_1024_f32():
+    """BASELINE configs[1] in the reference's own arithmetic (float32, new_runner.py:417): EPSesPlusLinear(((3,4),)),
+    x (1,1024,28,28,2) float32 on the register-resident exact-f32 family (eps_q2f32.hip) - bench config cfg2_f32."""
+    torch.manual_seed(2)
+    model = EPSesPlusLinear(((3, 4),), UnitTheoreticalOutputStd(), 1.0, DEV, torch.float32)
+    with torch.no_grad():
+        model.linear.weight.mul_(8.0)
+    x = mnist_like(1024, 28, torch.float32, 1)
+    core = model.epses[0].detach()
+    feat = eps(core, x)
+    assert feat.shape == (1024, 26, 26, 4) and dctn_amd.last_kernel() == "eps_fwd_q2f32"
+    # batch independence, bit for bit (slices start at odd offsets: other workgroups, other waves)
+    for lo, hi in ((0, 1), (3, 260), (517, 1024)):
+        assert torch.equal(eps(core, x[:, lo:hi]), feat[lo:hi])
+    assert torch.equal(eps(core * 4, x), feat * 4)   # exact homogeneity
+    idx = [0, 1, 511, 512, 777, 1023]
+    want = R.eps_4step(core.cpu().double(), x[:, idx].cpu().double())
+    assert rel_err(feat[idx], want) < 2e-5
+    g = (torch.randn(1024, 10, generator=torch.Generator().manual_seed(3)) * 0.1).to(DEV)
+
+    def grads(xs, gs, fused):
+        import dctn_amd.eps_plus_linear as EPL
+        EPL.FUSED_HEAD = fused
+        try:
+            for prm in model.parameters():
+                prm.grad = None
+            out = model(xs)
+            kfw = dctn_amd.last_kernel()
+            out.backward(gs)
+            return out.detach(), [prm.grad.detach().cpu() for prm in model.parameters()], (kfw, dctn_amd.last_kernel())
+        finally:
+            EPL.FUSED_HEAD = True
+
+    out_f, gf, kf = grads(x, g, True)
+    out_u, gu, ku = grads(x, g, False)
+    assert kf == ("eps_head_fwd_q2f32", "eps_head_bwd_q2f32") and ku[1] != kf[1]
+    # the one-kernel forward stores the same features and sums the head's products in another order
+    assert torch.equal(model(x), out_f)
+    assert float((out_f - out_u).abs().max()) <= 2e-5 * float(out_u.abs().max())
+    w64, b64 = model.linear.weight.detach().cpu().double(), model.linear.bias.detach().cpu().double()
+    want_logits = R.eps_plus_linear_forward([core.cpu().double()], w64, b64, x[:, idx].cpu().double())
+    assert rel_err(out_f[idx], want_logits) < 2e-5
+    parts = [grads(x[:, lo:hi], g[lo:hi], True)[1] for lo, hi in ((0, 300), (300, 301), (301, 1024))]
+    for name, a, b, c in zip(("dCore", "dWeight", "dBias"), gf, gu, [sum(p[i] for p in parts) for i in range(3)]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) < 2e-4 * scale, name + ": fused vs unfused"      # the float32 tolerance (rtol 2e-4)
+        assert float((a - c).abs().max()) < 2e-4 * scale, name + ": whole batch vs sum of slices"
+    # oracle on the gradients of a slice of the batch (the same tensors)
+    lo, hi = 300, 316
+    c64 = core.cpu().double().requires_grad_(True)
+    w64g, b64g = w64.clone().requires_grad_(True), b64.clone().requires_grad_(True)
+    R.eps_plus_linear_forward([c64], w64g, b64g, x[:, lo:hi].cpu().double()).backward(g[lo:hi].cpu().double())
+    got = grads(x[:, lo:hi], g[lo:hi], True)[1]
+    for name, a, ref in zip(("dCore", "dWeight", "dBias"), got, (c64.grad, w64g.grad, b64g.grad)):
+        assert rel_err(a, ref) < 2e-5, name
+
+
 def test_cfg3a_full_batch_128_f32():
     """BASELINE cfg3 (reference-canonical spec): EPSesPlusLinear(((4,4),(3,6))), f32, B = 128."""
     torch.manual_seed(3)

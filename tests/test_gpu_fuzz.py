@@ -677,7 +677,7 @@ BAND_CASES = [
     len(c[0]), max(c[1]), "".join(map(str, c[2])), c[3], c[4], c[5], c[6], c[7], "" if c[8] else "_nodx", "" if c[9] else "_nodcore",
     "_strided" if c[10] else ""))
 def test_convsbs_band_family_shapes(case):
-    """Bonds 9..16, backward by band-owning workgroups with two roles per SIMD (chain waves and gradient waves): bands of
+    """Bonds 5..16, backward by band-owning workgroups with two roles per SIMD (chain waves and gradient waves): bands of
     one image and the pixel rows they share, ragged tiles, chain waves without a tile, every position of the two-valued
     core, unequal bonds (zero-padded packs), both channel modes, every q - against the oracle, and bit-reproducible."""
     pos, bonds, outs, C, q, B, H, W, x_grad, core_grad, strided = case

@@ -282,6 +282,38 @@ def test_module_surfaces():
     assert alias.eps is eps
 
 
+def test_runner_import_lines_resolve_against_the_alias_package():
+    """new_runner.py:14-59 imports these names from the package's modules on the path (the runner's other imports -
+    dataset_loading, tb_logging, libcrap, ignite - are out of scope); dctn/utils.py:20-31,50-51."""
+    from dctn.utils import (  # noqa: F401  (new_runner.py:51-59, the line as the runner has it)
+        implies,
+        xor,
+        exactly_one_true,
+        ZeroCenteredNormalInitialization,
+        ZeroCenteredUniformInitialization,
+        FromFileInitialization,
+        OneTensorInitialization,
+    )
+    from dctn.utils import raise_exception, transform_dataset, id_assert_shape_matches  # noqa: F401
+    from dctn.eps_plus_linear import (  # noqa: F401  (new_runner.py:25-31)
+        EPSesPlusLinear,
+        UnitEmpiricalOutputStd,
+        UnitTheoreticalOutputStd,
+        ManuallyChosenInitialization,
+    )
+    from dctn.evaluation import score  # noqa: F401
+    from dctn.training import train, every_n_iters_intervals  # noqa: F401
+
+    assert implies(False, False) and implies(False, True) and implies(True, True) and not implies(True, False)
+    assert xor() is False and xor(True) is True and xor(True, True) is False and xor(True, False, False) is True
+    assert xor(True, True, True) is True   # parity, as the reference's reduce
+    assert exactly_one_true(False, True, False) and not exactly_one_true(True, True) and not exactly_one_true()
+    with pytest.raises(AssertionError):
+        exactly_one_true(1, 0)   # dctn/utils.py:29: genuine bools only
+    with pytest.raises(KeyError):
+        raise_exception(KeyError("x"))
+
+
 def test_eps_plus_linear_ctor_state_dict_and_manual_init():  # cf. reference tests/test_eps_plus_linear.py:13-36
     from dctn_amd.eps_plus_linear import EPSesPlusLinear, ManuallyChosenInitialization, UnitTheoreticalOutputStd
     from dctn_amd.utils import ZeroCenteredNormalInitialization, ZeroCenteredUniformInitialization
