@@ -113,8 +113,14 @@ static int eps_fwd_impl(const void* x, const int64_t x_strides[5], const void* c
   if (p.opts & DCTN_OPT_GENERIC_KERNELS) return eps_fwd_generic(x, core, out, p, dtype, st);
   rc = eps_fwd_mfma(x, core, out, p, dtype, precision, st);
   if (rc != DCTN_ERR_UNSUPPORTED) return rc;
-  rc = eps_fwd_q2f32(x, core, out, p, dtype, precision, st);
-  if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  // the register-resident exact-f32 family keeps nothing for a backward: a training forward whose input needs a gradient
+  // (the caller brought a buffer for the GEMM result) stays on the large-core family, whose backward reads that buffer
+  const bool wants_saved = saved && saved_bytes > 0 && saved_bytes >= eps_bigcore_saved_bytes(p, dtype, precision) &&
+                           eps_bigcore_saved_bytes(p, dtype, precision) > 0 && !f32_prefers_halves(p, dtype);
+  if (!wants_saved) {
+    rc = eps_fwd_q2f32(x, core, out, p, dtype, precision, st);
+    if (rc != DCTN_ERR_UNSUPPORTED) return rc;
+  }
   if (!f32_prefers_halves(p, dtype)) {
     const size_t zb = saved ? eps_bigcore_saved_bytes(p, dtype, precision) : 0;
     const bool keep = zb > 0 && saved_bytes >= zb;
@@ -148,7 +154,7 @@ size_t dctn_eps_saved_bytes(int C, int B, int H, int W, int Q, int K, int O, int
   const int precision = policy & DCTN_PREC_MASK;
   const int64_t dummy[5] = {0, 0, 0, 0, 1};
   if (!dtype_ok(dtype) || eps_fill_params(p, dummy, C, B, H, W, Q, K, O, policy) != DCTN_OK) return 0;
-  if ((p.opts & DCTN_OPT_GENERIC_KERNELS) || eps_mfma_covers(p, dtype, precision) || eps_q2f32_covers(p, dtype, precision)) return 0;
+  if ((p.opts & DCTN_OPT_GENERIC_KERNELS) || eps_mfma_covers(p, dtype, precision)) return 0;
   if (eps_bigcore_covers(p, dtype, precision) && !f32_prefers_halves(p, dtype)) return eps_bigcore_saved_bytes(p, dtype, precision);
   return eps_halves_saved_bytes(p, dtype);
 }
@@ -283,7 +289,7 @@ static int eps_bwd_impl(const void* x, const int64_t x_strides[5], const void* c
     }
   }
   size_t wq = 0;
-  if (dCore && wa == 0 && (wq = align256(eps_bwd_q2f32_workspace(p, dtype, precision))) > 0) {
+  if (dCore && wa == 0 && !saved && (wq = align256(eps_bwd_q2f32_workspace(p, dtype, precision))) > 0) {
     if (!ws || workspace_bytes < wq) return DCTN_ERR_WORKSPACE;
     rc = eps_bwd_q2f32(x, dY, dCore, ws, wq, p, dtype, precision, st);
     if (rc == DCTN_OK) {

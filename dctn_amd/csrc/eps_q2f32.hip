@@ -56,7 +56,7 @@ struct Q2fP {
   unsigned s1b, s2b, s3b;        // byte strides of x (batch, row, column)
   unsigned x_bytes;              // extent of x in bytes (< 2^31: buffer range check, 32-bit offsets)
   unsigned o_bytes, o_s1b;       // extent of out / dY in bytes (< 2^31), bytes per sample
-  Q2FastDiv div_wo;
+  Q2FastDiv div_wo, div_npg;
   int ovec;                      // out / dY rows: O == OP and aligned -> one 16- / 8-byte access per window
   int Cout;                      // fused head: classes
   unsigned hw_rowb, hw_bytes;    //   bytes per row of the head weight (P * O * 4) and in total
@@ -150,6 +150,21 @@ __device__ __forceinline__ void build_p0_pairs(const float (*xv)[2], f32x2 (&pp)
     for (int jj = 0; jj < 4; ++jj) pp[4 * i + jj] = q2_bmul2(u[i], vp[jj]);
 }
 
+#ifdef DCTN_STAMPS
+// diagnostic build only (tools/stamp_q2f32.py): per wave 16 slots of s_memtime (shader clock) + the wave's HW_ID
+__device__ unsigned long long qf_stamps[2048 * 16];
+#define QF_STAMP(SLOT)                                                                                          \
+  do {                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                 \
+    if ((threadIdx.x & 63) == 0 && (SLOT) < 16 && blockIdx.x * QF_WAVES + (threadIdx.x >> 6) < 2048)            \
+      qf_stamps[(blockIdx.x * QF_WAVES + (threadIdx.x >> 6)) * 16 + (SLOT)] = t_;                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  } while (0)
+#else
+#define QF_STAMP(SLOT) do { } while (0)
+#endif
+
 // position of a lane in the sample: byte offsets of its window in x and of its row in out / dY
 struct LanePos {
   unsigned voff_x, voff_o;
@@ -192,6 +207,8 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
   constexpr int CG = (HEADC + 3) / 4;   // class groups of the head product
   static_assert(MT >= 1 && OP >= 2 && OP <= 4, "tile shape");
   extern __shared__ __attribute__((aligned(16))) float fsm[];   // head: FWD_GS feature rows, then the partial logit tiles
+  __shared__ unsigned step_ctr_mem;
+  unsigned* step_ctr = &step_ctr_mem;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = (int)blockIdx.x * p.spc;
@@ -220,28 +237,46 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
     }
   }
 
+  QF_STAMP(0);
+#ifdef DCTN_STAMPS
+  if (lane == 0 && blockIdx.x * QF_WAVES + wv < 2048) qf_stamps[(blockIdx.x * QF_WAVES + wv) * 16 + 15] = __builtin_amdgcn_s_getreg(63492);
+  int stamp_i = 1;
+#endif
   const int gs = HEADC > 0 ? FWD_GS : nb;   // no head: one group
   for (int g0 = 0; g0 < nb; g0 += gs) {
     const int ng = g0 + gs <= nb ? gs : nb - g0;
-    // (sample, position group) steps of the group dealt round-robin over the waves: step i = wv, wv + 8, ...
-    int s = 0, pg = wv;
-    while (pg >= p.npg) { pg -= p.npg; ++s; }
+    // The group's (sample, position group) steps, i = s * npg + pg, are PULLED from a counter in LDS: the two waves of
+    // a SIMD do not advance alike (the older one wins the issue arbitration: with a fixed 6 / 5 split it sat at the
+    // group's barrier for 10 000 of 67 000 cycles while its partner finished alone - tools/stamp_q2f32.py), so each
+    // takes a new step when it is done with one.  Tickets are drawn two steps ahead: the step whose window loads are in
+    // flight is already chosen when the current one starts.
+    const int nsteps = ng * p.npg;
+    if (tid == 0) *step_ctr = 2 * QF_WAVES;   // steps 0 .. 15 are dealt: wave w starts with w and w + 8
+    __syncthreads();
+    auto draw = [&]() {
+      unsigned v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    int cur = wv, nxt = wv + QF_WAVES;
+    int s = (int)q2_fdiv((unsigned)cur, p.div_npg), pg = cur - s * p.npg;
     RawWinF<N, WIN> raw;
     LanePos lp = lane_pos(p, pg, lane);
-    if (s < ng) issue_win<N, WIN>(rs_x, lp.voff_x, (unsigned)(b0 + g0 + s) * p.s1b, p, raw);
-    while (s < ng) {
+    issue_win<N, WIN>(rs_x, cur < nsteps ? lp.voff_x : p.x_bytes, (unsigned)(b0 + g0 + (cur < nsteps ? s : 0)) * p.s1b, p, raw);
+    while (cur < nsteps) {
       float xv[N][2];
       unpack_win<N, WIN>(raw, xv);
       const unsigned voff_o = lp.voff_o, soff_o = (unsigned)(b0 + g0 + s) * p.o_s1b;
       const bool valid = lp.valid;
       float* frow = fsm + s * LP + (pg * 64 + lane) * OP;
-      {  // the wave's next step: its window loads go out before this step's arithmetic
-        pg += QF_WAVES;
-        while (pg >= p.npg) { pg -= p.npg; ++s; }
-        if (s < ng) {
-          lp = lane_pos(p, pg, lane);
-          issue_win<N, WIN>(rs_x, lp.voff_x, (unsigned)(b0 + g0 + s) * p.s1b, p, raw);
-        }
+      {  // the wave's next step: its window loads go out before this step's arithmetic (past the last step every lane
+         // is out of range and reads zeros: no control flow around the loads); and the ticket of the step after it
+        cur = nxt;
+        s = (int)q2_fdiv((unsigned)cur, p.div_npg);
+        pg = cur - s * p.npg;
+        lp = lane_pos(p, pg, lane);
+        issue_win<N, WIN>(rs_x, cur < nsteps ? lp.voff_x : p.x_bytes, (unsigned)(b0 + g0 + (cur < nsteps ? s : 0)) * p.s1b, p, raw);
+        nxt = draw();
         __builtin_amdgcn_sched_barrier(0);
       }
       f32x2 pp[KS];
@@ -251,7 +286,7 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
       for (int j = 0; j < KS; ++j) {
         op0[j] = pp[j][0];
         op1[j] = pp[j][1];
-        q2_swap_halves(op0[j], op1[j]);
+        q2_swap_halves_inplace(op0[j], op1[j]);
       }
       // P1 over the last n1 factors: b bit u <-> factor N-1-u; bit 0 (factor N-1) is the lane half of the accumulator
       // row.  m0 / m1: multipliers this lane applies in tile 0 / tile 1.
@@ -273,7 +308,7 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
           const f32x2 mm = q2_bmul2(ph[bh], f32x2{xv[N - 1][0], xv[N - 1][1]});
           m0[bh] = mm[0];
           m1[bh] = mm[1];
-          q2_swap_halves(m0[bh], m1[bh]);
+          q2_swap_halves_inplace(m0[bh], m1[bh]);
         }
       }
       float res0[OP], res1[OP];
@@ -289,12 +324,17 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cf[t][ks], nt ? op1[ks] : op0[ks], acc, 0, 0, 0);
+          // registers v, v + 1 (v even) are the outputs o, o + 1 of one b: one packed fused multiply-add per pair (the
+          // f32 matrix instructions and the vector ALU share a pipe - tools/stamp_q2f32.py: a wave's time is the SUM of
+          // its matrix and vector instruction times - so what counts is the number of vector instructions)
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int code = (t << 4) | v;
+          for (int v = 0; v < 16; v += 2) {
+            const int code = (t << 4) | v, o = code & (OP - 1);
             const float mm = nt ? m1[code >> LOGO] : m0[code >> LOGO];
-            float& dst = nt ? res1[code & (OP - 1)] : res0[code & (OP - 1)];
-            dst = __builtin_fmaf(acc[v], mm, dst);
+            float* dst = nt ? res1 : res0;
+            const f32x2 rr = __builtin_elementwise_fma(f32x2{mm, mm}, f32x2{acc[v], acc[v + 1]}, f32x2{dst[o], dst[o + 1]});
+            dst[o] = rr[0];
+            dst[o + 1] = rr[1];
           }
         }
       }
@@ -303,7 +343,7 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
 #pragma unroll
       for (int o = 0; o < OP; ++o) {
         float a0 = res0[o], a1 = res1[o];
-        q2_swap_halves(a0, a1);
+        q2_swap_halves_inplace(a0, a1);
         res[o] = a0 + a1;
       }
       if (p.ovec) {   // (lanes without a position: out of range, nothing stored)
@@ -323,6 +363,10 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
           else *reinterpret_cast<f32x2*>(frow) = f32x2{res[0], res[1]};
         }
       }
+#ifdef DCTN_STAMPS
+      QF_STAMP(stamp_i);
+      if (stamp_i < 9) ++stamp_i;
+#endif
     }
     if constexpr (HEADC > 0) {
       // ---- the group's head product.  Weight fragments first (nothing of the group is needed for them).
@@ -340,7 +384,9 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
           wf[i][cg] = __builtin_amdgcn_raw_buffer_load_b128(rs_hw, vo, 0, 0);
         }
       }
+      QF_STAMP(10);
       __syncthreads();   // every wave's feature rows of the group are in the tile
+      QF_STAMP(11);
       f32x4 hd[CG];
 #pragma unroll
       for (int cg = 0; cg < CG; ++cg) hd[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -378,6 +424,7 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_fwd_q2f32_k(const float* __
         const int c = 4 * cg + v;
         if (w == 0 && cg < CG && c < p.Cout && sl < ng) logits[(long long)(b0 + g0 + sl) * p.Cout + c] = t + bias[c];
       }
+      QF_STAMP(12);
       // (the next group's steps write the tile only after every thread has passed the barrier above, and its partial
       //  tiles are written behind its own first barrier: the sums just read are safe)
     }
@@ -402,10 +449,13 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_bwd_q2f32_k(const float* __
   float* T = dsm + wv * (TROWS * QF_PITCH);
 
   // workgroup = (chunk block cb, position group pg), pg fastest; its 8 waves = the 8 sample chunks of cb
+  // the batch is split evenly: chunk block cb owns samples [cb B / ncb, (cb + 1) B / ncb), its waves take n / 8 of them
+  // each and the first n % 8 waves one more
   const int cb = (int)blockIdx.x / p.npg, pg = (int)blockIdx.x - cb * p.npg;
-  const int chunk = cb * QF_WAVES + wv;
-  const int sb0 = chunk * p.spc < p.B ? chunk * p.spc : p.B;
-  const int sb1 = sb0 + p.spc < p.B ? sb0 + p.spc : p.B;
+  const int c0 = (int)((long long)cb * p.B / p.ncb), c1 = (int)((long long)(cb + 1) * p.B / p.ncb);
+  const int per = (c1 - c0) / QF_WAVES, rem = (c1 - c0) - per * QF_WAVES;
+  const int sb0 = c0 + wv * per + (wv < rem ? wv : rem);
+  const int sb1 = sb0 + per + (wv < rem ? 1 : 0);
   const LanePos lp = lane_pos(p, pg, lane);
   const __amdgpu_buffer_rsrc_t rs_x = q2_make_rsrc(x, p.x_bytes);
 
@@ -482,11 +532,10 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_bwd_q2f32_k(const float* __
         dyl[3] = __uint_as_float(rawdy.w);
       }
     }
-    {  // prefetch the next sample of this wave
-      if (b + 1 < sb1) {
-        issue_win<N, WIN>(rs_x, lp.voff_x, (unsigned)(b + 1) * p.s1b, p, raw);
-        issue_dy(b + 1);
-      }
+    {  // prefetch the next sample of this wave (the last step re-reads its own: no control flow around the loads)
+      const int bn = b + 1 < sb1 ? b + 1 : b;
+      issue_win<N, WIN>(rs_x, lp.voff_x, (unsigned)bn * p.s1b, p, raw);
+      issue_dy(bn);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (HEADC > 0) {   // dLogits of the sample: wave-uniform (scalar loads)
@@ -495,7 +544,9 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_bwd_q2f32_k(const float* __
       for (int o = 0; o < OP; ++o) dyl[o] = 0.f;
 #pragma unroll
       for (int c = 0; c < HEADC; ++c) {
-        const float d = c < p.Cout ? dl[c < p.Cout ? c : 0] : 0.f;
+        // HEADC == 10 is instantiated for Cout == 10 exactly (the row loads as s_load_dwordx8 + x2, no control flow);
+        // the padded bound 16 reads a clamped index and selects
+        const float d = HEADC == 10 ? dl[c] : (c < p.Cout ? dl[c < p.Cout ? c : p.Cout - 1] : 0.f);
 #pragma unroll
         for (int o = 0; o < OP; ++o) dyl[o] = __builtin_fmaf(d, hwf[c][o], dyl[o]);
       }
@@ -531,7 +582,14 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_bwd_q2f32_k(const float* __
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const f32x4 pq = *reinterpret_cast<const f32x4*>(rd_p1[t] + 4 * j);
-        const f32x4 z = pq * dq;
+        // Z = P1 (x) dY for 4 k-steps as two packed multiplies (written as text: the compiler scalarises a general
+        // pair x pair product; the 2 wait states between a vector write and the matrix instruction reading it are part
+        // of the text, the hazard recogniser does not see into it)
+        f32x2 z01, z23;
+        asm volatile("v_pk_mul_f32 %0, %2, %4\n\tv_pk_mul_f32 %1, %3, %5\n\ts_nop 1"
+                     : "=&v"(z01), "=&v"(z23)
+                     : "v"(f32x2{pq[0], pq[1]}), "v"(f32x2{pq[2], pq[3]}), "v"(f32x2{dq[0], dq[1]}), "v"(f32x2{dq[2], dq[3]}));
+        const float z[4] = {z01[0], z01[1], z23[0], z23[1]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[e], bq[e], acc[t], 0, 0, 0);
       }
@@ -622,7 +680,7 @@ __device__ __forceinline__ void head_dw_role_f32(const float* __restrict__ feat,
 // Workgroups [0, n_core): dCore[a][b][o] = sum_blocks partial[blk][m = b*OP + o][a] for 32 consecutive (m, a)
 // entries (thread (k32, c) streams every 32nd block's 128-byte segment: one round of independent loads for up to 256
 // blocks); the next n_dw: the head-weight gradient slices; the last one: dBias.
-constexpr int FIN_FL = 2;
+template <int FIN_FL>
 __global__ __launch_bounds__(64 * FIN_WAVES) void eps_q2f32_finish_k(const float* __restrict__ partial, float* __restrict__ dCore,
                                                                      int nblk, int A, int BN, int O, int OP, int n_core,
                                                                      const float* __restrict__ feat, const float* __restrict__ dL,
@@ -733,6 +791,7 @@ void fill_qp(Q2fP& m, const EpsP& p) {
   m.o_s1b = (unsigned)((long long)m.P * p.O * 4);
   m.o_bytes = (unsigned)(p.Wn * p.O * 4);
   m.div_wo = q2_make_fastdiv((unsigned)p.Wo);
+  m.div_npg = q2_make_fastdiv((unsigned)m.npg);
   m.ovec = 0;
   m.Cout = 0; m.hw_rowb = 0; m.hw_bytes = 0;
   m.opts = p.opts;
@@ -799,11 +858,10 @@ int fwd_head_launch_t(const void* x, const void* core, const void* hw, const voi
 int plan_bwd(Q2fP& m) {
   if (m.npg > QF_NUM_CU) return 0;
   long long ncb = QF_NUM_CU / m.npg;
-  const long long need = (m.B + QF_WAVES - 1) / QF_WAVES;
+  const long long need = (m.B + QF_WAVES - 1) / QF_WAVES;   // at least one sample per wave where the batch allows
   if (ncb > need) ncb = need;
-  m.spc = (int)((m.B + ncb * QF_WAVES - 1) / (ncb * QF_WAVES));
-  const int nchunks = (m.B + m.spc - 1) / m.spc;
-  m.ncb = (nchunks + QF_WAVES - 1) / QF_WAVES;
+  m.ncb = (int)ncb;
+  m.spc = 0;
   return m.ncb * m.npg;
 }
 
@@ -829,7 +887,7 @@ int bwd_launch_t(const void* x, const void* dY, const void* hw, const void* feat
   m.ovec = (!head && row_vec_ok(m, OP, dY)) ? 1 : 0;
   const dim3 g((unsigned)grid), b(64 * QF_WAVES);
   if (head) {
-    if (m.Cout <= 10) {
+    if (m.Cout == 10) {
       if (win != 0) QF_BWD_LAUNCH(WROWS, 10); else QF_BWD_LAUNCH(0, 10);
     } else {
       if (win != 0) QF_BWD_LAUNCH(WROWS, 16); else QF_BWD_LAUNCH(0, 16);
@@ -841,8 +899,10 @@ int bwd_launch_t(const void* x, const void* dY, const void* hw, const void* feat
   if (m.opts & DCTN_OPT_MAIN_KERNEL_ONLY) return DCTN_PARTIAL;   // measurement option: partial sums only, gradients NOT written
   const int n_core = MT * 32;
   const long long F = (long long)m.P * OP;
-  const int n_dw = (head && dW) ? (int)((F + 16 * FIN_FL - 1) / (16 * FIN_FL)) : 0;
-  hipLaunchKernelGGL(eps_q2f32_finish_k, dim3(n_core + n_dw + (head && dBias ? 1 : 0)), dim3(64 * FIN_WAVES), 0, st,
+  // head-weight gradient: 16-feature slices (64-byte pieces of the feature rows: 5.3 us for the finishing kernel at
+  // B = 1024 against 6.7 with 32-feature slices - a sector is the least a piece costs, and 169 workgroups instead of 85)
+  const int n_dw = (head && dW) ? (int)((F + 15) / 16) : 0;
+  hipLaunchKernelGGL(eps_q2f32_finish_k<1>, dim3(n_core + n_dw + (head && dBias ? 1 : 0)), dim3(64 * FIN_WAVES), 0, st,
                      (const float*)ws, (float*)dCore, grid, A, BN, m.O, OP, n_core, (const float*)feat, (const float*)dY,
                      (float*)dW, (float*)dBias, m.B, m.Cout, F, n_dw);
   DCTN_CHECK_LAUNCH();
@@ -853,6 +913,12 @@ int bwd_launch_t(const void* x, const void* dY, const void* hw, const void* feat
 #undef QF_BWD_LAUNCH
 
 }  // namespace
+
+#ifdef DCTN_STAMPS
+extern "C" int dctn_debug_read_qf_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qf_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 bool eps_q2f32_covers(const EpsP& p, int dtype, int precision) { return family_ok(p, dtype, precision); }
 

@@ -17,6 +17,14 @@ __device__ __forceinline__ void q2_swap_halves(float& a, float& b) {
   b = __int_as_float(r[1]);
 }
 
+// the same exchange on the two registers as they stand (the builtin form makes the compiler copy one operand to a
+// fresh register first when both come out of one packed instruction: a v_mov per swap).  The compiler's hazard
+// recogniser does not see into inline assembly, so the wait states it would put around the instruction (2 between a
+// vector write of an operand and the swap; 2 before a matrix instruction reads the result) are part of the text.
+__device__ __forceinline__ void q2_swap_halves_inplace(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
 // LDS hand-over inside one wave (writes of all lanes visible to the reads of all lanes)
 __device__ __forceinline__ void q2_wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

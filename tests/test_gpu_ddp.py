@@ -277,12 +277,14 @@ def test_bench_gpus_2_starts_itself_without_world_size(algorithm):
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout[-1000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["config"]["windows_per_step"] == 2 * 64 * 676
-    assert line["config"]["allreduce_bytes"] and line["value"] > 0 and line["config"]["allreduce"] == algorithm
+    run = line["run"]   # how the run went (`config` holds the workload and the side configurations' scalars only)
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and run["windows_per_step"] == 2 * 64 * 676
+    assert line["config"]["parallelism"] == "dp2" and "B64/GPU" in line["config"]["workload"]
+    assert run["allreduce_bytes"] and line["value"] > 0 and run["allreduce"] == algorithm
     # both algorithms are timed on the step's message whichever one the step uses (`--backend gloo` stands in for RCCL here)
-    assert line["config"]["allreduce_us_direct"] > 0 and line["config"]["allreduce_us_rccl"] > 0
+    assert run["allreduce_us_direct"] > 0 and run["allreduce_us_rccl"] > 0
     if algorithm == "direct":
-        assert line["config"]["allreduce_in_graph"] is True   # a plain kernel launch: captured without a probe
+        assert run["allreduce_in_graph"] is True   # a plain kernel launch: captured without a probe
 
 
 # ------------------------------------------------------------------ the direct (one-shot) all-reduce
