@@ -824,6 +824,227 @@ __global__ __launch_bounds__(64 * HEAD_FWD_MAXPG) void eps_fwd_head_q2reg_k(cons
   DCTN_STAMP(p, 4);
 }
 
+// ---- the same forward, second structure (round 5): steps PULLED from a counter, head as a tail phase.
+// The structure above ties a wave to one position group (its head-weight fragments live in registers), so a workgroup is
+// 11 waves on 4 SIMDs (3 + 3 + 3 + 2) and, the kernel being bound by vector-instruction issue, the SIMDs with three
+// waves set its length: wave 0 of a workgroup was done at 5.1 us, the kernel at 9.4.  Here a workgroup is 16 waves
+// (4 per SIMD, <= 128 registers) that draw (sample, position group) steps from an LDS counter, two steps ahead of the
+// one they compute - whichever wave is done takes the next step, the SIMDs end together.  Every step leaves its
+// bf16 features in an LDS tile [sample][feature]; when the group's steps are done the workgroup forms
+// logits[s][c] = bias[c] + sum_k W[c][k] * feat[s][k] on v_mfma_f32_16x16x32_bf16 (rows = classes, columns = the 4
+// samples, k-steps of 32 features dealt over the waves; the weight fragments - 16-byte loads straight from memory in
+// operand order - are requested BEFORE the barrier that closes the group, they depend on nothing), the waves' partial
+// tiles meet in LDS and are summed in wave order.  Same arithmetic as above: bf16 products, float32 sums.
+constexpr int HEADT_WAVES = 16;
+constexpr int HEADT_GS = 4;          // samples per group = columns of the head product in use
+constexpr int HEADT_MAXKS = 6;       // 32-feature steps per wave of the head product: at most 16 * 6 * 32 = 3072 features
+constexpr int headt_pitch(int F) { return (F + 31) / 32 * 32 + 8; }   // shorts per sample row of the tile (+16 bytes: the samples' banks differ)
+
+template <int N0, int N1, int OP, int ROWS>
+__global__ __launch_bounds__(64 * HEADT_WAVES) void eps_fwd_head_q2reg_t_k(const bf16_t* __restrict__ x,
+                                                                           const bf16_t* __restrict__ core,
+                                                                           const bf16_t* __restrict__ hw,
+                                                                           const bf16_t* __restrict__ bias,
+                                                                           bf16_t* __restrict__ out,
+                                                                           bf16_t* __restrict__ logits, MfmaP p) {
+  typedef bf16_t S;
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  constexpr int N = N0 + N1, A = 1 << N0, BN = 1 << N1, KS = A / 16, MT = BN * OP / 32;
+  constexpr int LOGO = ilog2(OP);
+  constexpr int TOT = A * BN * OP;
+  static_assert(OP % 2 == 0 && TOT % 4 == 0, "outputs are handled as bf16 pairs");
+  __shared__ __attribute__((aligned(16))) bf16_t cs[TOT];
+  __shared__ float hsum[HEADT_WAVES][HEADT_GS][16];
+  __shared__ unsigned step_ctr;
+  extern __shared__ __attribute__((aligned(16))) short ftile[];   // [HEADT_GS][LP]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = (int)blockIdx.x * p.spc, b1 = b0 + p.spc < p.B ? b0 + p.spc : p.B;
+  const int F = p.P * OP, LP = headt_pitch(F);
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x, p.x_bytes), rs_o = make_rsrc(out, p.o_bytes);
+  // core -> LDS in fragment order (as eps_fwd_q2reg_k): 4 elements per thread and batch, the loads of a batch in flight together
+  for (int e0 = 0; e0 < TOT; e0 += 4 * 64 * HEADT_WAVES) {
+    S tmp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ec = e0 + tid + i * 64 * HEADT_WAVES, e = ec < TOT ? ec : TOT - 1, o = e % OP, ab = e / OP;
+      tmp[i] = core[(long long)ab * p.O + (o < p.O ? o : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = e0 + tid + i * 64 * HEADT_WAVES, o = e % OP, ab = e / OP, bb = ab % BN, aa = ab / BN;
+      const int code = ((bb >> 1) << LOGO) | o;
+      const int row = (((code >> 2) & 3) << 3) | ((bb & 1) << 2) | (code & 3);
+      const int dst = ((((code >> 4) * KS + (aa >> 4)) * 64 + ((aa >> 3) & 1) * 32 + row) << 3) | (aa & 7);
+      if (e < TOT) cs[dst] = o < p.O ? tmp[i] : (bf16_t)0.f;
+    }
+  }
+  // the tile's features past F meet zero weights: they must be finite
+  for (int e = tid; e < HEADT_GS * (LP - F); e += 64 * HEADT_WAVES) ftile[(e / (LP - F)) * LP + F + e % (LP - F)] = 0;
+  __syncthreads();
+  bf16x8 cf[MT][KS];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      cf[t][s] = *reinterpret_cast<const bf16x8*>(&cs[((t * KS + s) * 64 + lane) * 8]);
+
+  auto lane_at = [&](int pg, bool live, unsigned& voff_x, unsigned& voff_o, int& pos) {
+    pos = pg * 64 + lane;
+    const bool valid = live && pos < p.P;
+    const unsigned pu = (unsigned)(pos < p.P ? pos : p.P - 1);
+    const unsigned ho = fdiv(pu, p.div_wo), wo = pu - ho * (unsigned)p.Wo;
+    voff_x = valid ? ho * p.s2b + wo * p.s3b : p.x_bytes;
+    voff_o = valid ? pu * (unsigned)(OP * 2) : p.o_bytes;
+  };
+  auto draw = [&]() {
+    unsigned v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(&step_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (int)__builtin_amdgcn_readfirstlane(v);
+  };
+
+  for (int g0 = b0; g0 < b1; g0 += HEADT_GS) {
+    const int ng = g0 + HEADT_GS < b1 ? HEADT_GS : b1 - g0;
+    const int nsteps = ng * p.npg;
+    if (tid == 0) step_ctr = 2 * HEADT_WAVES;   // steps 0 .. 31 are dealt: wave w starts with w and w + 16
+    __syncthreads();
+    int cur = wv, nxt = wv + HEADT_WAVES;
+    int s = cur / p.npg, pg = cur - s * p.npg, pos;
+    unsigned voff_x, voff_o;
+    lane_at(pg, cur < nsteps, voff_x, voff_o, pos);
+    RawWindow<S, N, true, ROWS> raw;
+    issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)(g0 + (cur < nsteps ? s : 0)) * p.s1b, p, raw);
+    while (cur < nsteps) {
+      float xv[N][2];
+      unpack_window<S, N, true, ROWS>(raw, xv);
+      const unsigned vo = voff_o, so = (unsigned)(g0 + s) * p.o_s1b;
+      short* trow = ftile + s * LP + (pos < p.P ? pos : 0) * OP;
+      const bool tvalid = pos < p.P;
+      {  // the wave's next step: its window goes out before this step's arithmetic (past the last step every lane is out
+         // of range: zeros, no control flow around the loads); and the ticket of the step after it
+        cur = nxt;
+        s = cur / p.npg;
+        pg = cur - s * p.npg;
+        lane_at(pg, cur < nsteps, voff_x, voff_o, pos);
+        issue_window<S, N, true, ROWS>(rs_x, voff_x, (unsigned)(g0 + (cur < nsteps ? s : 0)) * p.s1b, p, raw);
+        nxt = draw();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 pf0[KS], pf1[KS];
+      build_p0<N0>(xv, pf0, pf1);
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) swap_halves(pf0[s2], pf1[s2]);
+      float m0[BN / 2], m1[BN / 2];
+      {
+        float ph[BN / 2];
+        ph[0] = xv[N - 2][0];
+        ph[1] = xv[N - 2][1];
+#pragma unroll
+        for (int u = 2; u < N1; ++u)
+#pragma unroll
+          for (int bh = (1 << (u - 1)) - 1; bh >= 0; --bh) {
+            const f32x2 pr = bmul2(ph[bh], f32x2{xv[N - 1 - u][0], xv[N - 1 - u][1]});
+            ph[bh] = pr[0];
+            ph[bh | (1 << (u - 1))] = pr[1];
+          }
+#pragma unroll
+        for (int bh = 0; bh < BN / 2; ++bh) {
+          const f32x2 mm = bmul2(ph[bh], f32x2{xv[N - 1][0], xv[N - 1][1]});
+          m0[bh] = mm[0];
+          m1[bh] = mm[1];
+          swap_halves(m0[bh], m1[bh]);
+        }
+      }
+      float res0[OP], res1[OP];
+#pragma unroll
+      for (int o = 0; o < OP; ++o) { res0[o] = 0.f; res1[o] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+          f32x16 acc;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+          for (int s2 = 0; s2 < KS; ++s2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[t][s2], set ? pf1[s2] : pf0[s2], acc, 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const int code = (t << 4) | ((v >> 2) << 2) | (v & 3);
+            const float mm = set ? m1[code >> LOGO] : m0[code >> LOGO];
+            float* dst = set ? res1 : res0;
+            const int o = code & (OP - 1);
+            const f32x2 r = __builtin_elementwise_fma(f32x2{mm, mm}, f32x2{acc[v], acc[v + 1]}, f32x2{dst[o], dst[o + 1]});
+            dst[o] = r[0];
+            dst[o + 1] = r[1];
+          }
+        }
+      }
+      unsigned pk[OP / 2];
+#pragma unroll
+      for (int i = 0; i < OP / 2; ++i) {
+        float a0 = res0[2 * i], a1 = res1[2 * i], c0 = res0[2 * i + 1], c1 = res1[2 * i + 1];
+        swap_halves(a0, a1);
+        swap_halves(c0, c1);
+        pk[i] = pack_bf16(a0 + a1, c0 + c1);
+      }
+      if constexpr (OP == 2) {
+        __builtin_amdgcn_raw_buffer_store_b32(pk[0], rs_o, vo, so, 0);
+        if (tvalid) *reinterpret_cast<unsigned*>(trow) = pk[0];
+      } else if constexpr (OP == 4) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[0], pk[1]}, rs_o, vo, so, 0);
+        if (tvalid) *reinterpret_cast<u32x2*>(trow) = u32x2{pk[0], pk[1]};
+      } else {
+#pragma unroll
+        for (int i = 0; i < OP / 8; ++i) {
+          const u32x4 q = u32x4{pk[4 * i], pk[4 * i + 1], pk[4 * i + 2], pk[4 * i + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(q, rs_o, vo, so + 16u * i, 0);
+          if (tvalid) *reinterpret_cast<u32x4*>(trow + 8 * i) = q;
+        }
+      }
+    }
+    // ---- the group's head product: weight fragments first (they depend on nothing of the group)
+    const int nks = (F + 31) / 32;
+    const int c = lane & 15, kg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_hw = make_rsrc(hw, p.hw_bytes);
+    u32x4 wf[HEADT_MAXKS];
+#pragma unroll
+    for (int i = 0; i < HEADT_MAXKS; ++i) {
+      const int ks = wv + HEADT_WAVES * i, k = 32 * ks + 8 * kg;
+      const unsigned vo2 = (ks < nks && c < p.Cout && k + 7 < F) ? (unsigned)c * p.hw_rowb + (unsigned)k * 2u : p.hw_bytes;
+      wf[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_hw, vo2, 0, 0);
+    }
+    __syncthreads();   // every wave's feature rows of the group are in the tile
+    f32x4v hd = {0.f, 0.f, 0.f, 0.f};
+    const short* brd = ftile + (c < HEADT_GS ? c : HEADT_GS - 1) * LP + 8 * kg;
+#pragma unroll
+    for (int i = 0; i < HEADT_MAXKS; ++i) {
+      const int ks = wv + HEADT_WAVES * i;
+      if (ks < nks) {   // wave-uniform
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(brd + 32 * ks);
+        hd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), fb, hd, 0, 0, 0);
+      }
+    }
+    // D: column = lane % 16 (sample of the group), rows 4 (lane / 16) + v (classes)
+    if (c < HEADT_GS) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) hsum[wv][c][4 * kg + v] = hd[v];
+    }
+    __syncthreads();
+    if (tid < HEADT_GS * 16) {
+      const int sl = tid >> 4, cc = tid & 15;
+      if (sl < ng && cc < p.Cout) {
+        float t = (float)bias[cc];
+#pragma unroll
+        for (int w = 0; w < HEADT_WAVES; ++w) t += hsum[w][sl][cc];
+        logits[(long long)(g0 + sl) * p.Cout + cc] = (bf16_t)t;
+      }
+    }
+    // (the next group's steps write the tile only behind the barrier at its start; its partial tiles behind its own
+    //  first barrier after that: the sums just read are safe)
+  }
+}
+
 // ------------------------------------------------------------------------------ backward: dCore
 // feature index m of Z: code = m = (mt << 5) | (s << 4) | (h << 3) | j;  o = m & (OP-1), b = m >> LOGO
 constexpr int BWD_WAVES = 8;  // waves per workgroup of the dCore kernel (one LDS reduction per block)
@@ -1775,8 +1996,20 @@ int fwd_head_launch_t(const void* x, const void* core, const void* hw, const voi
   int nwg = m.B < NUM_CU ? m.B : NUM_CU;
   m.spc = (m.B + nwg - 1) / nwg;
   nwg = (m.B + m.spc - 1) / m.spc;
-  const dim3 g((unsigned)nwg), b((unsigned)(64 * m.npg));
   constexpr int RW = (N0 + N1) == 9 ? 3 : 4;
+  const long long F = (long long)m.P * OP;
+  if (!(m.opts & DCTN_OPT_SMALL_CHUNKS) && F % 8 == 0 && F <= (long long)HEADT_WAVES * HEADT_MAXKS * 32) {
+    // steps pulled from a counter by 16 waves, head as a tail phase (DCTN_OPT_SMALL_CHUNKS keeps the round-4 structure:
+    // a wave per position group, for same-box comparisons)
+    const size_t dyn = (size_t)HEADT_GS * headt_pitch((int)F) * sizeof(short);
+    (void)hipFuncSetAttribute((const void*)eps_fwd_head_q2reg_t_k<N0, N1, OP, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL((eps_fwd_head_q2reg_t_k<N0, N1, OP, RW>), dim3((unsigned)nwg), dim3(64 * HEADT_WAVES), dyn, st, (const S*)x,
+                       (const S*)core, (const S*)hw, (const S*)bias, (S*)out, (S*)logits, m);
+    DCTN_CHECK_LAUNCH();
+    dctn_set_last_kernel("eps_head_fwd_mfma_q2reg");
+    return DCTN_OK;
+  }
+  const dim3 g((unsigned)nwg), b((unsigned)(64 * m.npg));
   hipLaunchKernelGGL((eps_fwd_head_q2reg_k<N0, N1, OP, RW>), g, b, 0, st, (const S*)x, (const S*)core, (const S*)hw,
                      (const S*)bias, (S*)out, (S*)logits, m);
   DCTN_CHECK_LAUNCH();
