@@ -928,6 +928,9 @@ def main():
                     help="gradient all-reduce of the step: rccl (default: torch.distributed all_reduce = RCCL ring / tree) or direct "
                          "(dctn_ar_*: one kernel per step and rank reading every peer's buffer over its own xGMI link, "
                          "always inside the step's HIP graph); the line carries allreduce_us of both")
+    ap.add_argument("--time-other-allreduce", type=int, default=1,
+                    help="at N > 1 also time the step's message through the algorithm the step does NOT use (0: skip - the "
+                         "direct algorithm maps IPC blocks of every peer, which an RCCL-only run may not want)")
     ap.add_argument("--configs", default="all",
                     help="the other BASELINE configs measured into `configs` at N = 1: all (default), none, or a comma list of "
                          + ", ".join(EXTRA_CONFIGS))
@@ -1187,17 +1190,21 @@ def main():
             if direct:
                 other = ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce, algorithm="rccl")
                 other_us = device_time(lambda: other._reduce(buf), dev, 100, graph=False) * 1e6
-            elif world > 1 and msg.is_cuda:
+            elif world > 1 and msg.is_cuda and args.time_other_allreduce:
+                # (DirectAllReducer's constructor is rank-symmetric: it raises on every rank or on none, so the ranks
+                #  cannot part ways between its collectives and the MAX all-reduce below)
                 dr = ddp.DirectAllReducer(msg.numel(), msg.dtype, dev, average=True)
 
                 def ten_direct():
                     for _ in range(10):
                         dr(buf)
                 other_us = device_time(ten_direct, dev, 20) / 10 * 1e6
-                if dr.status() != 0:
+                if not ddp.all_ranks_agree(dr.status() == 0, dev):
                     other_us = None
         except Exception as e:   # noqa: BLE001
             log(f"timing the other all-reduce algorithm failed ({type(e).__name__}: {e})")
+        if direct and not ddp.all_ranks_agree(reducer._direct.status() == 0, dev):
+            raise SystemExit("the step's direct all-reduce timed out waiting for a peer: the timed steps are invalid")
         if world > 1:   # the slowest rank's figures
             t = torch.tensor([allreduce_us, step_without_allreduce_us, other_us if other_us is not None else -1.0],
                              dtype=torch.float64, device=dev)

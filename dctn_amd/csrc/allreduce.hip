@@ -44,7 +44,7 @@ struct ArP {
   int world, rank;
   size_t max_bytes;
   long long n;        // elements
-  float scale;
+  double scale;   // 1 / world (or 1) in double: float64 buffers get the mean to their own precision for any world size
 };
 
 // block layout
@@ -89,8 +89,92 @@ __device__ __forceinline__ void ar_publish(const ArP& p, int which, int which_co
   }
 }
 
-template <typename T, bool TWO>
+// 16 bytes of T per lane and access (the rates the HBM and xGMI paths are quoted at are for 16 B per lane; one element
+// per lane - 2 B for bf16 - left most of the path idle).  VEC = false: element accesses (a buffer that is not 16-byte
+// aligned: a view into a larger gradient buffer at an odd offset).
+template <typename T> struct ArVec { static constexpr int VE = 16 / (int)sizeof(T); };
+template <typename T>
+__device__ __forceinline__ void ar_ld16(const T* src, T (&v)[ArVec<T>::VE], bool nt) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  const u4 q = nt ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src)) : *reinterpret_cast<const u4*>(src);
+  __builtin_memcpy(v, &q, 16);
+}
+template <typename T>
+__device__ __forceinline__ void ar_st16(T* dst, const T (&v)[ArVec<T>::VE]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  u4 q;
+  __builtin_memcpy(&q, v, 16);
+  *reinterpret_cast<u4*>(dst) = q;
+}
+
+// out[i] = in[i] for i in [lo, hi): 16-byte pieces where VEC (lo a multiple of VE), elements for the rest
+template <typename T, bool VEC>
+__device__ __forceinline__ void ar_copy(T* __restrict__ out, const T* __restrict__ in, long long lo, long long hi, bool nt) {
+  constexpr int VE = ArVec<T>::VE;
+  const int tid = threadIdx.x;
+  long long i = lo;
+  if (VEC) {
+    const long long nv = (hi - lo) / VE;
+    for (long long v = tid; v < nv; v += AR_THREADS) {
+      T t[VE];
+      ar_ld16(in + lo + v * VE, t, nt);
+      ar_st16(out + lo + v * VE, t);
+    }
+    i = lo + nv * VE;
+  }
+  for (long long e = i + tid; e < hi; e += AR_THREADS) out[e] = nt ? __builtin_nontemporal_load(&in[e]) : in[e];
+}
+
+// out0[i] (and out1[i]) = scale * sum over ranks r, in rank order, of staging_r[i] for i in [lo, hi)
+template <typename T, bool VEC>
+__device__ __forceinline__ void ar_sum(const ArP& p, size_t stage_off, T* __restrict__ out0, T* __restrict__ out1, long long lo,
+                                       long long hi) {
+  typedef typename ArAcc<T>::type A;
+  constexpr int VE = ArVec<T>::VE;
+  const int tid = threadIdx.x;
+  const A scale = (A)p.scale;
+  long long i = lo;
+  if (VEC) {
+    const long long nv = (hi - lo) / VE;
+    for (long long v = tid; v < nv; v += AR_THREADS) {
+      A acc[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] = 0;
+      for (int r = 0; r < p.world; ++r) {
+        T t[VE];
+        ar_ld16(reinterpret_cast<const T*>(p.peer[r] + stage_off) + lo + v * VE, t, true);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += (A)t[e];
+      }
+      T o[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] = (T)(acc[e] * scale);
+      ar_st16(out0 + lo + v * VE, o);
+      if (out1) ar_st16(out1 + lo + v * VE, o);
+    }
+    i = lo + nv * VE;
+  }
+  for (long long e = i + tid; e < hi; e += AR_THREADS) {
+    A acc = 0;
+    for (int r = 0; r < p.world; ++r) acc += (A)__builtin_nontemporal_load(&reinterpret_cast<const T*>(p.peer[r] + stage_off)[e]);
+    const T o = (T)(acc * scale);
+    out0[e] = o;
+    if (out1) out1[e] = o;
+  }
+}
+
+// [lo, hi) of workgroup `blk` of `nblk` over [0, n), the cut points multiples of `unit` elements
+__device__ __forceinline__ void ar_range(long long n, int unit, int blk, int nblk, long long& lo, long long& hi) {
+  const long long units = (n + unit - 1) / unit, per = (units + nblk - 1) / nblk;
+  lo = (long long)blk * per * unit;
+  hi = lo + per * unit;
+  if (lo > n) lo = n;
+  if (hi > n) hi = n;
+}
+
+template <typename T, bool TWO, bool VEC>
 __global__ __launch_bounds__(AR_THREADS) void dctn_ar_k(T* __restrict__ buf, ArP p) {
+  constexpr int VE = ArVec<T>::VE;
   unsigned char* mine = p.peer[p.rank];
   int* counters = reinterpret_cast<int*>(mine + ar_counters_off(p.max_bytes));
   volatile int* my_flags = reinterpret_cast<volatile int*>(mine);
@@ -99,51 +183,40 @@ __global__ __launch_bounds__(AR_THREADS) void dctn_ar_k(T* __restrict__ buf, ArP
   if (tid == 0) s_step = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int step = s_step, slot = step & 1;
-  const long long per = (p.n + gridDim.x - 1) / gridDim.x;
-  const long long lo = (long long)blockIdx.x * per, hi = lo + per < p.n ? lo + per : p.n;
+  long long lo, hi;
+  ar_range(p.n, VE, (int)blockIdx.x, (int)gridDim.x, lo, hi);
   // ---- 1. this rank's values -> its staging buffer (uncached memory: the stores go to memory)
-  T* stage = reinterpret_cast<T*>(mine + ar_flags_bytes() + (size_t)slot * p.max_bytes);
-  for (long long i = lo + tid; i < hi; i += AR_THREADS) stage[i] = buf[i];
+  const size_t stage_off = ar_flags_bytes() + (size_t)slot * p.max_bytes;
+  ar_copy<T, VEC>(reinterpret_cast<T*>(mine + stage_off), buf, lo, hi, false);
   ar_publish(p, 0, 2, step, counters, &s_last);   // every workgroup has copied: step + 1 in every rank's line of this rank
   // ---- 2. wait for every rank's step + 1 (bounded)
   ar_wait(my_flags, 0, p.world, step, counters);
-  typedef typename ArAcc<T>::type A;
   if (!TWO) {
     // ---- 3. the sum in rank order, scaled, over the rank's own values
-    for (long long i = lo + tid; i < hi; i += AR_THREADS) {
-      A acc = 0;
-      for (int r = 0; r < p.world; ++r) {
-        const T* src = reinterpret_cast<const T*>(p.peer[r] + ar_flags_bytes() + (size_t)slot * p.max_bytes);
-        acc += (A)__builtin_nontemporal_load(&src[i]);
-      }
-      buf[i] = (T)(acc * (A)p.scale);
-    }
+    ar_sum<T, VEC>(p, stage_off, buf, (T*)nullptr, lo, hi);
   } else {
-    // ---- 3a. this rank's chunk: the sum in rank order, scaled, into its result area (and its own values)
-    const long long cs = (p.n + p.world - 1) / p.world;
-    const long long c0 = (long long)p.rank * cs, c1 = c0 + cs < p.n ? c0 + cs : p.n;
-    const long long cper = (cs + gridDim.x - 1) / gridDim.x;
-    const long long clo = c0 + (long long)blockIdx.x * cper, chi = clo + cper < c1 ? clo + cper : c1;
-    T* res = reinterpret_cast<T*>(mine + ar_result_off(p.max_bytes) + (size_t)slot * p.max_bytes);
-    for (long long i = clo + tid; i < chi; i += AR_THREADS) {
-      A acc = 0;
-      for (int r = 0; r < p.world; ++r) {
-        const T* src = reinterpret_cast<const T*>(p.peer[r] + ar_flags_bytes() + (size_t)slot * p.max_bytes);
-        acc += (A)__builtin_nontemporal_load(&src[i]);
-      }
-      const T v = (T)(acc * (A)p.scale);
-      res[i] = v;
-      buf[i] = v;
-    }
+    // ---- 3a. this rank's chunk (chunks are cut at multiples of VE elements): the sum in rank order, scaled, into its
+    //          result area (and its own values)
+    const long long cs = ((p.n + p.world - 1) / p.world + VE - 1) / VE * VE;
+    const size_t res_off = ar_result_off(p.max_bytes) + (size_t)slot * p.max_bytes;
+    auto chunk_part = [&](int j, long long& a, long long& b) {   // this workgroup's part of rank j's chunk
+      const long long j0 = (long long)j * cs < p.n ? (long long)j * cs : p.n, j1 = j0 + cs < p.n ? j0 + cs : p.n;
+      long long l, h;
+      ar_range(j1 - j0, VE, (int)blockIdx.x, (int)gridDim.x, l, h);
+      a = j0 + l;
+      b = j0 + h;
+    };
+    long long clo, chi;
+    chunk_part(p.rank, clo, chi);
+    ar_sum<T, VEC>(p, stage_off, reinterpret_cast<T*>(mine + res_off), buf, clo, chi);
     ar_publish(p, 1, 4, step, counters, &s_last);
     ar_wait(my_flags, 1, p.world, step, counters);
     // ---- 3b. every other rank's chunk from that rank's result area
     for (int j = 0; j < p.world; ++j) {
       if (j == p.rank) continue;
-      const long long j0 = (long long)j * cs, j1 = j0 + cs < p.n ? j0 + cs : p.n;
-      const long long jlo = j0 + (long long)blockIdx.x * cper, jhi = jlo + cper < j1 ? jlo + cper : j1;
-      const T* src = reinterpret_cast<const T*>(p.peer[j] + ar_result_off(p.max_bytes) + (size_t)slot * p.max_bytes);
-      for (long long i = jlo + tid; i < jhi; i += AR_THREADS) buf[i] = __builtin_nontemporal_load(&src[i]);
+      long long jlo, jhi;
+      chunk_part(j, jlo, jhi);
+      ar_copy<T, VEC>(buf, reinterpret_cast<const T*>(p.peer[j] + res_off), jlo, jhi, true);
     }
   }
   // ---- 4. the last workgroup to finish advances the step
@@ -226,16 +299,21 @@ int dctn_ar_allreduce_algo(void* state, void* buf, int64_t n, int dtype, int ave
   ArP p;
   for (int r = 0; r < AR_MAX_WORLD; ++r) p.peer[r] = st->peer[r];
   p.world = st->world; p.rank = st->rank; p.max_bytes = st->max_bytes; p.n = n;
-  p.scale = average ? 1.0f / (float)st->world : 1.0f;
+  p.scale = average ? 1.0 / (double)st->world : 1.0;
   long long blocks = ((long long)n * (long long)dtype_size(dtype) + 16383) / 16384;
   if (blocks < 1) blocks = 1;
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   hipStream_t s = (hipStream_t)stream;
   const bool two = algorithm == 2 || (algorithm == 0 && st->world >= 4 && (size_t)n * dtype_size(dtype) >= (512u << 10));
-#define AR_LAUNCH(TT)                                                                                                  \
-  do {                                                                                                                 \
-    if (two) hipLaunchKernelGGL((dctn_ar_k<TT, true>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);    \
-    else hipLaunchKernelGGL((dctn_ar_k<TT, false>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);       \
+  // 16-byte accesses need a 16-byte aligned buffer (the staging / result areas are: the block and max_bytes are 256-byte
+  // aligned); a view at an odd offset takes the element form
+  const bool vec = ((uintptr_t)buf % 16) == 0;
+#define AR_LAUNCH(TT)                                                                                                        \
+  do {                                                                                                                       \
+    if (two && vec) hipLaunchKernelGGL((dctn_ar_k<TT, true, true>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);   \
+    else if (two) hipLaunchKernelGGL((dctn_ar_k<TT, true, false>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);    \
+    else if (vec) hipLaunchKernelGGL((dctn_ar_k<TT, false, true>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);    \
+    else hipLaunchKernelGGL((dctn_ar_k<TT, false, false>), dim3((unsigned)blocks), dim3(AR_THREADS), 0, s, (TT*)buf, p);            \
   } while (0)
   switch (dtype) {
     case DCTN_F32: AR_LAUNCH(float); break;

@@ -56,7 +56,24 @@ constexpr int BD_TS = 20;         // floats per row of a hand-over tile [window]
                                   // gradient wave's transposed b32 reads (rows 4 apart: 80 floats = 16 banks) are conflict-free
 constexpr int BD_TILE = 16 * BD_TS;      // one hand-over tile (G or v)
 constexpr int BD_FS = (BD_NC + 1) * 16 * 4;   // feature products of a 16-window tile: [core][window][4]; row 9: the windows' dY
-constexpr int BD_LDS_BUDGET = 160 * 1024;      // the whole LDS of a CU: one workgroup per CU
+constexpr int BD_LDS_BUDGET = 160 * 1024;      // gfx950: the whole LDS of a CU (one workgroup per CU); the run-time value: bd_dev()
+
+// LDS per CU and CU count of the current device, asked once (the family is written for gfx950: 160 KiB, 256 CUs; on a
+// device with less LDS the plans below then decline - DCTN_ERR_UNSUPPORTED, the caller takes the matrix-core sweep -
+// instead of reporting `covers` and failing at the launch)
+struct BdDev { int lds, cus; };
+static BdDev bd_dev() {
+  static const BdDev d = [] {
+    BdDev r{BD_LDS_BUDGET, 256};
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && v >= 64 * 1024) r.lds = v;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) r.cus = v;
+    }
+    return r;
+  }();
+  return d;
+}
 constexpr int BD_THREADS = 512;
 constexpr int BD_NFS = 3;         // feature buffers per chain wave: the tile on its way back, the next one, the one the gradient
                                   // wave may still be reading right behind the last barrier of the previous tile
@@ -1131,14 +1148,14 @@ int bd_plan(BdPlan& pl, const int64_t xs[5], const void* const* cores, int n, co
   const int RK = pl.CH == 2 ? 4 : pl.QT;
   const int min_rows = max_h > 1 ? max_h : 1;
   // bands per image: enough workgroups for the chip, every band at least max_h rows, the band's gradient rows in LDS
-  int nb = (256 + B - 1) / B;
+  int nb = (bd_dev().cus + B - 1) / B;
   if (nb < 1) nb = 1;
   if (nb > p.Ho / min_rows) nb = p.Ho / min_rows;
   if (nb < 1) return DCTN_ERR_UNSUPPORTED;
   for (;;) {
     const int rows = (p.Ho + nb - 1) / nb;
     const long long rows_floats = (long long)rows * p.Wo * n * RK;
-    if ((long long)(off + rows_floats) * 4 <= BD_LDS_BUDGET) {
+    if ((long long)(off + rows_floats) * 4 <= bd_dev().lds) {
       p.band_rows = rows;
       break;
     }
@@ -1200,8 +1217,9 @@ int convsbs_bwd_band(const void* x, const int64_t xs[5], const void* const* core
 #endif
 #define BD_LAUNCH(QTV, CHV, NSV)                                                                                     \
   do {                                                                                                          \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              pl.lds_bytes);                                                                    \
+    if (hipFuncSetAttribute((const void*)convsbs_bwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              pl.lds_bytes) != hipSuccess)                                                                    \
+      return DCTN_ERR_UNSUPPORTED;   /* less LDS than the plan assumed */                                        \
     hipLaunchKernelGGL((convsbs_bwd_band_k<QTV, CHV, NSV>), dim3((unsigned)pl.nwg), dim3(BD_THREADS), pl.lds_bytes, st, p); \
   } while (0)
   if (pl.NS == 2) {
@@ -1254,11 +1272,12 @@ int convsbs_fwd_band(const void* x, const int64_t xs[5], const void* const* core
   const int lds_bytes = (BD_NPK * pl.QT * 256 + 128 + 8 * 2 * BD_NC * 16 * 4) * 4;   // pack + tables + 8 waves x 2 feature buffers
   long long blocks = (p.ntiles + 7) / 8;
   const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;   // 128 registers: two workgroups (four waves per SIMD) per CU
-  if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+  if (blocks > (long long)bd_dev().cus * per_cu) blocks = (long long)bd_dev().cus * per_cu;
 #define BD_FLAUNCH(QTV, CHV, NSV)                                                                                    \
   do {                                                                                                          \
-    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              lds_bytes);                                                                       \
+    if (hipFuncSetAttribute((const void*)convsbs_fwd_band_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              lds_bytes) != hipSuccess)                                                                       \
+      return DCTN_ERR_UNSUPPORTED;   /* less LDS than the plan assumed */                                        \
     hipLaunchKernelGGL((convsbs_fwd_band_k<QTV, CHV, NSV>), dim3((unsigned)blocks), dim3(BD_THREADS), lds_bytes, st, p); \
   } while (0)
   if (pl.NS == 2) {
@@ -1333,11 +1352,12 @@ int convsbs_many_fwd_band(const void* x, const int64_t xs[5], const void* const*
   const int lds_bytes = (BD_NPK * pl[0].QT * 256 + 128 + 8 * 2 * BD_NC * 16 * 4) * 4;
   long long blocks = (pp.s[0].ntiles + 7) / 8;
   const long long per_cu = (160 * 1024) / lds_bytes >= 2 ? 2 : 1;
-  if (blocks > 256 * per_cu / ns) blocks = 256 * per_cu / ns;   // the strings' persistent waves are resident together
+  if (blocks > (long long)bd_dev().cus * per_cu / ns) blocks = (long long)bd_dev().cus * per_cu / ns;   // the strings' persistent waves are resident together
 #define BD_FLAUNCH(QTV, CHV, NSV)                                                                                         \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)convsbs_fwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              lds_bytes);                                                                            \
+    if (hipFuncSetAttribute((const void*)convsbs_fwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              lds_bytes) != hipSuccess)                                                                            \
+      return DCTN_ERR_UNSUPPORTED;   /* less LDS than the plan assumed */                                        \
     hipLaunchKernelGGL((convsbs_fwd_band_many_k<QTV, CHV, NSV>), dim3((unsigned)blocks, (unsigned)ns), dim3(BD_THREADS), lds_bytes, st, pp); \
   } while (0)
   if (pl[0].NS == 2) {
@@ -1399,8 +1419,9 @@ int convsbs_many_bwd_band(const void* x, const int64_t xs[5], const void* const*
   }
 #define BD_LAUNCH(QTV, CHV, NSV)                                                                                          \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)convsbs_bwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              pl[0].lds_bytes);                                                                      \
+    if (hipFuncSetAttribute((const void*)convsbs_bwd_band_many_k<QTV, CHV, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              pl[0].lds_bytes) != hipSuccess)                                                                      \
+      return DCTN_ERR_UNSUPPORTED;   /* less LDS than the plan assumed */                                        \
     hipLaunchKernelGGL((convsbs_bwd_band_many_k<QTV, CHV, NSV>), dim3((unsigned)pl[0].nwg, (unsigned)ns), dim3(BD_THREADS), pl[0].lds_bytes, \
                        st, pp);                                                                                      \
   } while (0)

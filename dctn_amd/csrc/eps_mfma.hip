@@ -1954,7 +1954,13 @@ int bwd_head_launch_t(const void* x, const void* dL, const void* hw, const void*
   const long long nW = (long long)m.Cout * m.P * OP;   // dwpart: [ncb][Cout][P*O]
   // the condition under which the kernel below takes its HEADMM path and leaves dW to eps_head_reduce_k's gemm role
   constexpr int MT = BN * OP / 32;
-  const bool gemm = A == 32 && MT <= 2 && OP == 4 && m.vec_ok && (long long)m.B * m.P * OP * 2 < (1LL << 31);
+  // `headmm` is exactly the kernel's compile-time HEADMM condition for the instantiations launched below (XVEC = m.vec_ok,
+  // OVEC = true, bf16); such a kernel forms no dW, so the finishing kernel MUST take its gemm role, which addresses the
+  // features through a 32-bit buffer descriptor: a batch beyond that range is declined here (family_ok already bounds
+  // B * P * O * 2 below 2^31, so the two conditions cannot disagree - stated once, for both)
+  const bool headmm = A == 32 && MT <= 2 && OP == 4 && m.vec_ok;
+  if (headmm && (long long)m.B * m.P * OP * 2 >= (1LL << 31)) return DCTN_ERR_UNSUPPORTED;
+  const bool gemm = headmm;
 
   const dim3 g(grid), b(64 * BWD_WAVES);
   constexpr int NN = N0 + N1;

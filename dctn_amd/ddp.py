@@ -147,12 +147,21 @@ class FlatGradAllReducer:
     """
 
     def __init__(self, params: Iterable[Tensor], average: bool = True, skip_single_rank: bool = True,
-                 algorithm: str = "rccl"):
+                 algorithm: str = "rccl", check_every: int = 1):
         """algorithm: "rccl" (default: `dist.all_reduce`) or "direct" (`DirectAllReducer`: one kernel per step reading the
-        peers' buffers over all xGMI links at once; ranks of one node, device tensors)."""
+        peers' buffers over all xGMI links at once; ranks of one node, device tensors).
+
+        check_every (direct only): the direct kernel bounds its wait for a late peer (~2 s) and then sets an error word
+        instead of hanging the queue - the step's values are then WRONG.  Every `check_every`-th call (default: every
+        call) `check()` reads that word, agrees on it across the ranks and raises `RuntimeError` on all of them, so a
+        rank skew above the bound (a checkpoint on rank 0, a stalled data loader) stops the run instead of letting the
+        replicas diverge.  The check synchronises the device; 0 disables it (the caller then calls `check()` itself:
+        after every replay when the call sits inside a HIP graph, where this method does not run)."""
         self.params: List[Tensor] = [p for p in params if p.requires_grad]
         self.average = average
         self.algorithm = algorithm
+        self.check_every = int(check_every)
+        self._calls = 0
         self._direct: Optional["DirectAllReducer"] = None
         self.skip_single_rank = skip_single_rank   # False: issue the collective even for one rank (rehearsal)
         self._seen_grads: List[Optional[Tensor]] = []
@@ -180,6 +189,9 @@ class FlatGradAllReducer:
         the dtype refuses it (raised synchronously at enqueue), fall back to SUM + divide for good."""
         if self._direct is not None and buf.is_cuda and buf.dtype == self._direct.dtype and buf.numel() <= self._direct.max_numel:
             self._direct(buf)
+            self._calls += 1
+            if self.check_every > 0 and self._calls % self.check_every == 0 and not torch.cuda.is_current_stream_capturing():
+                self.check()
             return
         if self.use_avg:
             try:
@@ -190,6 +202,19 @@ class FlatGradAllReducer:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         if self.average:
             buf.div_(self.world)
+
+    def check(self) -> None:
+        """Direct algorithm only: raises `RuntimeError` on EVERY rank when a wait of any rank's all-reduce kernel timed
+        out since the block was created (the gradients of that step are invalid).  Synchronises the device and runs one
+        small collective; a no-op for the RCCL path (RCCL waits)."""
+        if self._direct is None:
+            return
+        code = self._direct.status()
+        if not all_ranks_agree(code == 0, self.bucket.device):
+            raise RuntimeError(
+                "direct all-reduce: a rank did not arrive within the kernel's wait bound"
+                + (f" (this rank gave up waiting for rank {code - 1})" if code > 0 else " (seen by another rank)")
+                + "; the gradients of that step are invalid - restart from the last checkpoint, or use algorithm='rccl'")
 
     def _contiguous_flat(self, grads) -> Optional[Tensor]:
         """One 1-D tensor aliasing all gradients when they already sit back to back, in parameter
@@ -268,16 +293,30 @@ class DirectAllReducer:
         lib = L.lib()
         nbytes = int(max_numel) * torch.empty((), dtype=dtype).element_size()
         state = ctypes.c_void_p()
+        self._state = None
+        # Rank-symmetric on failure: a rank whose create / export / connect fails still takes part in every collective
+        # of this constructor (it contributes an empty handle), the ranks agree on the outcome after each phase, and
+        # ALL of them raise together - a failing rank never leaves its peers blocked in all_gather_object / barrier.
         with torch.cuda.device(device):
-            L.check(lib.dctn_ar_create(self.world, self.rank, nbytes, ctypes.byref(state)), "direct all-reduce: create")
-            self._state = state
             hb = int(lib.dctn_ar_handle_bytes())
             mine = ctypes.create_string_buffer(hb)
-            L.check(lib.dctn_ar_export(state, mine), "direct all-reduce: export")
+            rc = lib.dctn_ar_create(self.world, self.rank, nbytes, ctypes.byref(state))
+            if rc == 0:
+                self._state = state
+                rc = lib.dctn_ar_export(state, mine)
             handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(mine.raw))
-            packed = ctypes.create_string_buffer(b"".join(handles), hb * self.world)
-            L.check(lib.dctn_ar_connect(state, packed), "direct all-reduce: connect")
+            dist.all_gather_object(handles, (rc, bytes(mine.raw)))
+            failed = [r for r, (code, _) in enumerate(handles) if code != 0]
+            if failed:
+                self.close()
+                raise RuntimeError(f"direct all-reduce: create / export failed on rank(s) {failed} "
+                                   f"({L.lib().dctn_strerror(handles[failed[0]][0]).decode()})")
+            packed = ctypes.create_string_buffer(b"".join(h for _, h in handles), hb * self.world)
+            rc = lib.dctn_ar_connect(state, packed)
+            if not all_ranks_agree(rc == 0, device if dist.get_backend() == "nccl" else None):
+                self.close()
+                raise RuntimeError("direct all-reduce: mapping the peers' blocks failed on at least one rank"
+                                   + (f" (this rank: {L.lib().dctn_strerror(rc).decode()})" if rc != 0 else ""))
         dist.barrier()   # every rank has mapped every block before the first kernel publishes into one
         self.max_numel = int(max_numel)
         self.max_bytes = nbytes

@@ -403,3 +403,137 @@ def test_direct_allreduce_two_ranks_on_one_gpu():
         assert "two_shot_mismatch" not in o, o["two_shot_mismatch"]   # bitwise the one-shot values
         assert all(v <= 1.0 for k, v in o.items() if k.startswith("torch.")), o
         assert o["graph"] is True and o["flat"] is True, o
+
+
+def _direct_worker_many(rank, world, port, q):
+    """More than two ranks on the one GPU: the DEFAULT rule (`form="auto"`), element counts that neither the world size nor
+    the 16-byte vectors divide, a buffer at an odd element offset (element accesses instead of 16-byte ones)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("gloo")
+    out = {"rank": rank}
+    try:
+        import dctn_amd
+
+        red = ddp.DirectAllReducer(400_000, torch.float32, dev, average=True)   # form="auto": the default rule
+        cases = ((torch.float32, 150_003, 0), (torch.bfloat16, 300_005, 0), (torch.float64, 70_001, 0), (torch.float32, 1_001, 0),
+                 (torch.float32, 150_003, 1), (torch.bfloat16, 300_005, 3))
+        for dtype, n, off in cases:
+            tol = {torch.float32: 1e-6, torch.bfloat16: 8e-3, torch.float64: 2e-15}[dtype]
+            big = n * torch.empty((), dtype=dtype).element_size() >= (512 << 10)
+            want_kernel = "allreduce_direct_two_shot" if (world >= 4 and big) else "allreduce_direct"
+            g = torch.Generator().manual_seed(1000 + rank)
+            for step in range(3):
+                mine = torch.randn(n, generator=g).to(dtype)
+                every = [torch.empty(n, dtype=dtype) for _ in range(world)]
+                dist.all_gather(every, mine)
+                want = sum(b.double() for b in every) / world
+                res = {}
+                for form in (None, "one_shot"):     # the default rule first, then the one-shot form on the same inputs
+                    hold = torch.zeros(n + off, dtype=dtype, device=dev)
+                    buf = hold[off:]                  # off > 0: not 16-byte aligned
+                    buf.copy_(mine)
+                    red(buf, form=form)
+                    torch.cuda.synchronize(dev)
+                    if form is None and dctn_amd.last_kernel() != want_kernel:
+                        out.setdefault("wrong_form", []).append((str(dtype), n, dctn_amd.last_kernel()))
+                    res[form] = buf.cpu()
+                key = f"{dtype}_{n}_{off}"
+                out[key] = max(out.get(key, 0.0), float((res[None].double() - want).abs().max() / want.abs().max()) / tol)
+                if not torch.equal(res[None], res["one_shot"]):
+                    out.setdefault("default_vs_one_shot", []).append((str(dtype), n, off, step))
+                mineb = res[None].view(torch.uint8)
+                allb = [torch.empty_like(mineb) for _ in range(world)]
+                dist.all_gather(allb, mineb)
+                if not all(torch.equal(allb[0], b) for b in allb):
+                    out.setdefault("ranks_differ", []).append((str(dtype), n, off, step))
+        out["status"] = red.status()
+        red.close()
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 3])
+def test_direct_allreduce_default_rule_more_ranks_on_one_gpu(world):
+    """Four ranks time-sharing the one GPU take the DEFAULT rule into the two-shot form (world >= 4 and >= 512 KiB) with
+    element counts that 4 does not divide (150 003 float32, 300 005 bfloat16, 70 001 float64): chunk remainders, the
+    16-byte main part and its element tail, flag lines of more than two ranks - bitwise the one-shot values, identical on
+    every rank, the float64 mean to float64 precision (three ranks: 1 / 3 is no power of two)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker_many, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for o in outs:
+        assert "error" not in o, o
+        assert o["status"] == 0, f"a wait timed out: {o}"
+        assert "wrong_form" not in o, o["wrong_form"]
+        assert "default_vs_one_shot" not in o, o["default_vs_one_shot"]
+        assert "ranks_differ" not in o, o["ranks_differ"]
+        assert all(v <= 1.0 for k, v in o.items() if k.startswith("torch.")), o
+
+
+def _late_rank_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+
+    import torch.distributed as dist
+
+    from dctn_amd import ddp
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ddp.init_from_env("gloo")
+    out = {"rank": rank, "raised": None}
+    try:
+        params = [torch.nn.Parameter(torch.randn(300, device=dev))]
+        params[0].grad = torch.full_like(params[0], float(rank + 1))
+        fr = ddp.FlatGradAllReducer(params, average=True, algorithm="direct")   # check_every = 1: the default
+        fr()                                   # in step: fine
+        torch.cuda.synchronize(dev)
+        out["first"] = bool((params[0].grad == (world + 1) / 2).all())
+        dist.barrier()
+        if rank == 1:
+            time.sleep(3.5)                    # above the kernel's ~2 s wait bound: rank 0 gives up on this step
+        try:
+            fr()
+            out["raised"] = False
+        except RuntimeError as e:
+            out["raised"] = str(e)
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_allreduce_late_rank_raises_on_every_rank():
+    """The direct kernel bounds its wait (~2 s) and then sums whatever is there: `FlatGradAllReducer(algorithm="direct")`
+    reads the error word after the call (default `check_every=1`), agrees on it across the ranks and raises on ALL of
+    them - the late rank included, whose own kernel saw nothing wrong."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=300) for _ in procs), key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+    for o in outs:
+        assert "error" not in o, o
+        assert o["first"] is True
+        assert isinstance(o["raised"], str) and "did not arrive" in o["raised"], o
+    assert "gave up waiting for rank 1" in outs[0]["raised"] and "seen by another rank" in outs[1]["raised"]
