@@ -575,24 +575,44 @@ __global__ __launch_bounds__(64 * QF_WAVES) void eps_bwd_q2f32_k(const float* __
 #pragma unroll
     for (int o = 0; o < OP; ++o) T[(A + BN + o) * QF_PITCH + lane] = dyl[o];
     q2_wave_lds_sync();
+    // 8 groups of 4 k-steps; the reads of group j + 1 are issued BEFORE the 8 matrix instructions of group j (issued
+    // behind them they came back ~100 cycles after the pipe had drained: a bubble per group)
+    f32x4 bq = *reinterpret_cast<const f32x4*>(rd_p0), dq = *reinterpret_cast<const f32x4*>(rd_dy), pq[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) pq[t] = *reinterpret_cast<const f32x4*>(rd_p1[t]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(rd_p0 + 4 * j);
-      const f32x4 dq = *reinterpret_cast<const f32x4*>(rd_dy + 4 * j);
+      f32x4 bqn = bq, dqn = dq, pqn[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) pqn[t] = pq[t];
+      if (j + 1 < 8) {
+        bqn = *reinterpret_cast<const f32x4*>(rd_p0 + 4 * (j + 1));
+        dqn = *reinterpret_cast<const f32x4*>(rd_dy + 4 * (j + 1));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) pqn[t] = *reinterpret_cast<const f32x4*>(rd_p1[t] + 4 * (j + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // Z = P1 (x) dY for 4 k-steps as two packed multiplies per tile (written as text: the compiler scalarises a
+      // general pair x pair product; the 2 wait states between a vector write and the matrix instruction reading it are
+      // part of the text, the hazard recogniser does not see into it)
+      float z[MT][4];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const f32x4 pq = *reinterpret_cast<const f32x4*>(rd_p1[t] + 4 * j);
-        // Z = P1 (x) dY for 4 k-steps as two packed multiplies (written as text: the compiler scalarises a general
-        // pair x pair product; the 2 wait states between a vector write and the matrix instruction reading it are part
-        // of the text, the hazard recogniser does not see into it)
         f32x2 z01, z23;
         asm volatile("v_pk_mul_f32 %0, %2, %4\n\tv_pk_mul_f32 %1, %3, %5\n\ts_nop 1"
                      : "=&v"(z01), "=&v"(z23)
-                     : "v"(f32x2{pq[0], pq[1]}), "v"(f32x2{pq[2], pq[3]}), "v"(f32x2{dq[0], dq[1]}), "v"(f32x2{dq[2], dq[3]}));
-        const float z[4] = {z01[0], z01[1], z23[0], z23[1]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[e], bq[e], acc[t], 0, 0, 0);
+                     : "v"(f32x2{pq[t][0], pq[t][1]}), "v"(f32x2{pq[t][2], pq[t][3]}), "v"(f32x2{dq[0], dq[1]}), "v"(f32x2{dq[2], dq[3]}));
+        z[t][0] = z01[0]; z[t][1] = z01[1]; z[t][2] = z23[0]; z[t][3] = z23[1];
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[t][e], bq[e], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bq = bqn;
+      dq = dqn;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) pq[t] = pqn[t];
     }
   }
 
