@@ -219,7 +219,7 @@ def device_time(fn, dev, iters, graph=True, blocks=3):
 
 
 _TRAFFIC = None
-TRAFFIC_FILE = "r04_pmc_traffic.json"   # the current round's passes only (tools/profile_round.sh + condense_round.py)
+TRAFFIC_FILE = "r05_pmc_traffic.json"   # the current round's passes only (tools/profile_round.sh + condense_round.py)
 
 
 def library_sha256():
@@ -425,7 +425,7 @@ def headline_roofline(model, x, specs, steps, ms_per_step=None):
         extra["step_frac"] = extra["step_tflops"] / peak
     if reg_family:
         bf16 = "q2reg" in bwd_family
-        names = {"fwd": ("eps_fwd_head_q2reg_k" if bf16 else "eps_fwd_q2f32_k<head>") if one_kernel_fwd else fwd_family,
+        names = {"fwd": ("eps_fwd_head_q2reg_t_k" if bf16 else "eps_fwd_q2f32_k") if one_kernel_fwd else fwd_family,
                  "dcore": "eps_bwd_dcore_q2reg_k" if bf16 else "eps_bwd_q2f32_k",
                  "finish": "eps_head_reduce_k" if bf16 else "eps_q2f32_finish_k"}
         main_only = L.precision() | L.OPT_MAIN_KERNEL_ONLY

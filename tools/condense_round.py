@@ -18,8 +18,10 @@ import json
 import os
 import sys
 
-CONFIGS = ("headline", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
-HEADLINE_KEYS = ("eps_fwd_head_q2reg_k", "eps_fwd_q2reg_k", "eps_bwd_dcore_q2reg_k", "eps_head_reduce_k", "eps_bwd_dcore_reduce_k",
+CONFIGS = ("headline", "cfg2_f32", "cfg1", "cfg3a", "cfg3a_bf16", "cfg3b", "cfg4_r4", "cfg4_r8", "cfg4_r16", "cfg4_eps36", "cfg5")
+# the float32 register family's kernels (cfg2_f32): their traffic gets flat keys like the headline's
+F32_KEYS = ("eps_fwd_q2f32_k", "eps_bwd_q2f32_k", "eps_q2f32_finish_k")
+HEADLINE_KEYS = ("eps_fwd_head_q2reg_t_k", "eps_fwd_head_q2reg_k", "eps_fwd_q2reg_k", "eps_bwd_dcore_q2reg_k", "eps_head_reduce_k", "eps_bwd_dcore_reduce_k",
                  "head_fwd_k")
 
 
@@ -50,7 +52,7 @@ def ours(name):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
     src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
     dst = sys.argv[3] if len(sys.argv) > 3 else "profiles"
     traffic, lines = {"_note": "HBM-side bytes per launch: (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE is "
@@ -88,6 +90,11 @@ def main():
         entries.sort(key=lambda e: -(e["avg_us"] or 0) * e["launches"])
         if entries:
             traffic[cfg] = entries
+        if cfg == "cfg2_f32":
+            for e in entries:
+                for key in F32_KEYS:
+                    if key in e["kernel"]:
+                        traffic.setdefault(f"{key}:B1024", e["traffic_bytes"])
         if cfg == "headline":
             for e in entries:
                 for key in HEADLINE_KEYS:
