@@ -928,9 +928,10 @@ def main():
                     help="gradient all-reduce of the step: rccl (default: torch.distributed all_reduce = RCCL ring / tree) or direct "
                          "(dctn_ar_*: one kernel per step and rank reading every peer's buffer over its own xGMI link, "
                          "always inside the step's HIP graph); the line carries allreduce_us of both")
-    ap.add_argument("--time-other-allreduce", type=int, default=1,
-                    help="at N > 1 also time the step's message through the algorithm the step does NOT use (0: skip - the "
-                         "direct algorithm maps IPC blocks of every peer, which an RCCL-only run may not want)")
+    ap.add_argument("--time-other-allreduce", type=int, default=0,
+                    help="1: at N > 1 also time the step's message through the algorithm the step does NOT use.  Off by default: "
+                         "a default `--allreduce rccl` run then never creates the direct all-reduce's IPC-mapped blocks (that "
+                         "path has not run across xGMI from this build; a default multi-GPU benchmark must not depend on it)")
     ap.add_argument("--configs", default="all",
                     help="the other BASELINE configs measured into `configs` at N = 1: all (default), none, or a comma list of "
                          + ", ".join(EXTRA_CONFIGS))
@@ -1187,7 +1188,7 @@ def main():
         # the same message through the OTHER algorithm (eager launches; the direct one replayed from a graph too)
         other_us = None
         try:
-            if direct:
+            if direct and args.time_other_allreduce:
                 other = ddp.FlatGradAllReducer(params, skip_single_rank=not force_reduce, algorithm="rccl")
                 other_us = device_time(lambda: other._reduce(buf), dev, 100, graph=False) * 1e6
             elif world > 1 and msg.is_cuda and args.time_other_allreduce:

@@ -271,7 +271,8 @@ def test_bench_gpus_2_starts_itself_without_world_size(algorithm):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["DCTN_BENCH_ONE_DEVICE"] = "1"
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4",
-                          "--warmup", "2", "--batch", "64", "--configs", "none", "--no-cpu-baseline", "--allreduce", algorithm],
+                          "--warmup", "2", "--batch", "64", "--configs", "none", "--no-cpu-baseline", "--allreduce", algorithm,
+                          "--time-other-allreduce", "1"],
                          cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]

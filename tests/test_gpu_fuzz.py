@@ -308,6 +308,54 @@ def test_eps_head_fused_backward_random(C, K, size, B, O, Cout):
     check(bd.grad, b64.grad, torch.bfloat16, "dBias")
 
 
+# (C, K, H, W, B, O, Cout, strided): the register-resident exact-float32 family (eps_q2f32.hip) across its shape family -
+# rectangular images, position groups with idle lanes, fewer steps than waves, more than four samples per workgroup (several
+# groups: B > 4 * 256 on a small image), every out size 1..4 (3: zero-padded core rows, element stores; 1: half-empty tiles),
+# class counts 1..16, both window modes plus the generic one (strided input), images too large for the one-kernel forward
+Q2F32_CASES = [(1, 3, 10, 10, 1, 4, 10, False), (1, 3, 5, 17, 7, 2, 4, False), (2, 2, 9, 6, 13, 4, 16, False), (1, 3, 12, 12, 70, 4, 1, False),
+               (1, 3, 7, 9, 1100, 4, 10, False), (2, 2, 13, 5, 33, 2, 10, True), (1, 3, 30, 11, 19, 3, 6, False), (1, 3, 28, 28, 9, 1, 16, False),
+               (1, 3, 9, 9, 5, 4, 7, True), (1, 3, 40, 40, 3, 4, 10, False), (2, 2, 4, 4, 3, 3, 5, False), (1, 3, 3, 3, 2, 4, 10, False)]
+
+
+@pytest.mark.parametrize("C,K,H,W,B,O,Cout,strided", Q2F32_CASES)
+def test_eps_float32_register_family_random(C, K, H, W, B, O, Cout, strided):
+    from dctn_amd import _lib
+    from dctn_amd.eps_plus_linear import _EpsLinearHeadFunction, _LinearHeadFunction
+
+    torch.manual_seed(C * 1000 + K * 100 + H * 7 + W + B + O + Cout)
+    N = K * K * C
+    F = (H - K + 1) * (W - K + 1) * O
+    core = torch.randn(*(2,) * N, O) * 2.0 ** (-N / 2) * 4
+    u = torch.rand(C, B, H, W)
+    x = torch.stack([torch.sin(u * 1.5707963) ** 2, torch.cos(u * 1.5707963) ** 2], dim=-1)
+    if strided:   # (C, B, W, H, 2) permuted back: same values, pixel rows no longer contiguous -> one 4-byte load per feature
+        x = x.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    w = torch.randn(Cout, F) * F ** -0.5 * 4
+    bias = torch.randn(Cout) * 0.1
+    g = torch.randn(B, Cout)
+    cd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (core, w, bias))
+    xd = x.to(DEV) if not strided else x.permute(0, 1, 3, 2, 4).to(DEV).permute(0, 1, 3, 2, 4)
+    assert _lib.lib().dctn_eps_family(C, B, H, W, 2, K, O, _lib.F32, 0) == 4
+    fused = _EpsLinearHeadFunction.supported(cd, xd, wd, bd)
+    assert fused == (O in (2, 4))
+    if fused:
+        out = _EpsLinearHeadFunction.apply(cd, xd, wd, bd)
+    else:
+        feat = eps(cd, xd)
+        assert dctn_amd.last_kernel() == "eps_fwd_q2f32"
+        out = _LinearHeadFunction.apply(feat.reshape(B, -1), wd, bd)
+    out.backward(g.to(DEV))
+    if fused:
+        assert dctn_amd.last_kernel() == "eps_head_bwd_q2f32"
+    c64, w64, b64 = (t.double().requires_grad_(True) for t in (core, w, bias))
+    want = R.eps_plus_linear_forward([c64], w64, b64, x.double())
+    check(out, want.detach(), torch.float32, "logits")
+    want.backward(g.double())
+    check(cd.grad, c64.grad, torch.float32, "dCore")
+    check(wd.grad, w64.grad, torch.float32, "dWeight")
+    check(bd.grad, b64.grad, torch.float32, "dBias")
+
+
 # (C, B, H, W, Q, K, O): large-core exact-f32 MFMA family with out sizes that are NOT powers of two
 # (rows in memory order, o outermost in the transposed GEMMs' k, exact dCore columns), row halves of
 # 16 .. 256 entries, one and two input channels
