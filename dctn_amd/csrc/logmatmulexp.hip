@@ -10,6 +10,7 @@
 // small_experiments/logmatmulexp_benchmark/benchmark.py:30 for one window per workgroup with
 // every prefix kept in LDS (BASELINE config 5).
 #include "common.h"
+#include "q2_common.h"
 
 #include <math.h>
 
@@ -239,6 +240,18 @@ __device__ __forceinline__ float wave16_max(float v) {
   return vmax(__int_as_float(r[0]), __int_as_float(r[1]));
 }
 
+// max over the 16 lanes of a row (lanes (0..15, g)), in every lane: four rotate steps
+// (one v_max_f32_dpp per step; the builtin form is v_mov 0 + v_mov_dpp + v_max.  A DPP operand needs two wait states behind
+// the vector instruction that wrote it, and the compiler does not look into the text.)
+__device__ __forceinline__ float row16_max(float v) {
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(v));
+  return v;
+}
+
 constexpr int LME_PST = 20;                 // padded row stride of a 16x16 tile in LDS
 constexpr int LME_TILE = 16 * LME_PST;      // floats per tile
 
@@ -260,7 +273,7 @@ __device__ __forceinline__ void lds_transpose16(float* scr, int c, int g, const 
 }
 
 __device__ __forceinline__ bool lme_step_ok(const f32x4_t& S) {
-  return (S[0] >= LME_SMIN) && (S[1] >= LME_SMIN) && (S[2] >= LME_SMIN) && (S[3] >= LME_SMIN);
+  return (S[0] >= LME_SMIN) & (S[1] >= LME_SMIN) & (S[2] >= LME_SMIN) & (S[3] >= LME_SMIN);
 }
 
 // The running prefix is carried in SCALED form, not in the log domain: P[t][r] = a_t + log2 E[t][r] with max_r E[t][r] = 1
@@ -296,6 +309,33 @@ __device__ __forceinline__ f32x4_t lme_step16s(const float (&E)[4], const float 
   for (int s = 0; s < 4; ++s)
     S = __builtin_amdgcn_mfma_f32_16x16x4f32(ex2(__builtin_fmaf(mcol[s], LME_LOG2E, nb)), E[s], S, 0, 0, 0);
   return S;
+}
+
+// The same product with ONE shift for the whole matrix (nb = -max M log2e, the same number in every lane): EM is formed
+// once, in the ROW layout the matrix was loaded in (row c, columns 4g..4g+3 - the layout the way back multiplies with), and
+// taken through the per-wave LDS tile into the k-major operand layout - where the column shifts needed the exponentials of
+// both layouts (8 v_exp_f32 per lane and step) and 2^(b_i - b_0) factors behind the product.  Columns whose largest entry
+// lies 2^-126 below the matrix maximum flush to zero; their S is 0 and the step is rejected like any other the
+// factorisation cannot represent.
+__device__ __forceinline__ float lme_matrix_shift(const float (&mrow)[4]) {
+  return row16_max(wave16_max(max4(mrow))) * -LME_LOG2E;
+}
+__device__ __forceinline__ f32x4_t lme_step16g(float* scr, int c, int g, const float (&E)[4], const float (&emrow)[4]) {
+  float emcol[4];
+  lds_transpose16(scr, c, g, make_float4(emrow[0], emrow[1], emrow[2], emrow[3]), emcol);
+  f32x4_t S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_16x16x4f32(emcol[s], E[s], S, 0, 0, 0);
+  return S;
+}
+// E' = S / max_i S and the row's new shift: a' = a + b + log2 max_i S  (da = log2 rmax - nb)
+__device__ __forceinline__ bool lme_rescale_g(const f32x4_t& S, float (&En)[4], float& rinv) {
+  const float T[4] = {S[0], S[1], S[2], S[3]};
+  const float rmax = wave16_max(max4(T));
+  rinv = __builtin_amdgcn_rcpf(rmax);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) En[reg] = T[reg] * rinv;
+  return rmax < LME_BIG;
 }
 
 // E' and the row's new shift (base-2 domain) from S; returns false (in any lane of the row) when 2^(b_i - b_0) overflowed
@@ -481,54 +521,194 @@ __global__ __launch_bounds__(256) void lme_fold16_fwd_mfma_k(const float* __rest
   }
 }
 
-// Factored backward of the same fold (D = 16, float32), one wave per window.  Pass 1 reads every
-// matrix once (all loads in flight together), recomputes the scaled prefixes E_1..E_{L-1} exactly as the
-// forward kernel does and keeps, per step, E, the product S and EM = 2^(M - b_i) (in the place of the matrix)
-// in registers (LMAX is the compile-time bound on L); pass 2 walks back with, per step (EP = E_{l-1}, EM, S of step l):
+// Factored backward of the same fold (D = 16, float32), one wave per window.  Pass 1 recomputes the scaled prefixes
+// E_1..E_{L-2} and keeps, per step, E, the row factor 1 / max_i S and EM = 2^(M - b) (in the place of the matrix) in
+// registers; pass 2 walks back with, per step (EP = E_{l-1}, EM, S of step l):
 //   H = G / S              dP = EP .* (H x EM^T)          dM = EM .* (EP^T x H)
-// (the shifts 2^(a_t), 2^(b_i) cancel between the numerator and S), i.e. two 16x16x16 products on
-// v_mfma_f32_16x16x4_f32 plus 4 v_rcp_f32 per lane - every exp of the step was taken in pass 1.  dP^T comes out of
-// the matrix core in the state layout (lane (t, g) holds columns 4g..4g+3 of row t) so it feeds the next step directly;
-// the operands of dM need t on the k index, so EP and H take one trip through a per-wave LDS scratch tile.  A window with a
-// step the factorisation cannot represent is flagged and left to the exact kernel.
+// (the shifts 2^(a_t), 2^b cancel between the numerator and S), i.e. two 16x16x16 products on v_mfma_f32_16x16x4_f32 plus
+// 4 v_rcp_f32 per lane - every exp of the step was taken in pass 1.  S itself is not kept: S_l = E_l / Rinv_l (E_l is S
+// scaled to a row maximum of 1), so H = G * Rinv * rcp(E); only the last step, which is not rescaled, keeps its S.
+// dP^T comes out of the matrix core in the state layout (lane (t, g) holds columns 4g..4g+3 of row t) so it feeds the
+// next step directly; the operands of dM need t on the k index, so EP and H take one trip through a per-wave LDS tile.
+//
+// b is ONE shift per matrix here (the forward kernel keeps one per column): EM is formed once, in the row layout the
+// way back multiplies with, and transposed through LDS for the recomputed product - 4 v_exp_f32 per lane and step
+// where the column shifts took 8 + 1 and a ds_bpermute per value.  A step whose matrix has columns 2^-100 below its
+// maximum is rejected here (S = 0) even where the forward accepted it: the window is flagged and left to the exact
+// recomputing kernel, which rewrites its gradients behind this launch - it still walks back here on whatever its steps
+// produced, because a second way round the loop, taken or not, costs every window its wait counts (below).
+//
+// What the memory side is built to (round 5; each item measured on cfg5, 692 224 windows, 2.87 -> 2.50 ms):
+//  * the chain length is a TEMPLATE parameter: with `if (l < L)` around unrolled steps the compiler merged the counter
+//    state of the skipped path at every join and each step of the way back waited for the load it had just issued
+//    (`s_waitcnt vmcnt(1)`: a memory round trip per step).  Any other edge into the loop top does the same (a `continue`
+//    for flagged windows; the prologue, which is therefore drained by hand).
+//  * loads and stores share ONE in-order counter on this part (vmcnt): a wait for a load also waits for every store issued
+//    before it.  The window's dM tiles therefore wait in LDS (the lane reads back what it wrote) and go out in one burst
+//    BEHIND the last load of the next window's matrices: every wait of the next window then covers only stores that are a
+//    whole window old.  (With the stores in the steps the first steps of a window stood behind the acknowledgement of
+//    stores a few hundred cycles old.)
+//  * window bases are scalars (the wave index through readfirstlane) in raw buffer descriptors: one vector register of
+//    addresses for the whole kernel, ~25 registers and a third of the vector instructions fewer than with 64-bit pointers
+//    per access - 124 registers at L = 9, four waves per SIMD without a spill (a spill is a scratch access: it shares vmcnt
+//    and turned every wait into vmcnt(0)).
 constexpr int LME_BWD_WAVES = 4;
 
-template <int LMAX, bool NT>
-__device__ __forceinline__ void lme_fold16_bwd_body(
+template <int L, bool NT>
+__global__ __launch_bounds__(64 * LME_BWD_WAVES) __attribute__((amdgpu_waves_per_eu(L <= 9 ? 4 : (L <= 12 ? 3 : 2)))) void lme_fold16_bwd_mfma_k(
     const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
-    int* __restrict__ flags, long long Wn, int L) {
+    int* __restrict__ flags, long long Wn) {
+  constexpr int LO = L <= 15 ? 2 : 3;   // tiles LO .. L - 1 are staged in LDS (64 KiB per workgroup), the last ones formed stay in registers
+  constexpr int NST = L > LO ? L - LO : 1;
   __shared__ __align__(16) float scratch[LME_BWD_WAVES][2][LME_TILE];
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  __shared__ __align__(16) float stage[LME_BWD_WAVES][NST][256];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // a scalar: so are the window bases
   float* scrE = scratch[wv][0];
   float* scrH = scratch[wv][1];
+  float* stg = &stage[wv][0][0] + 4 * lane - LO * 256;
   const int st_off = c * LME_PST + 4 * g;       // state layout: row c, columns 4g..4g+3
-  const int gl_off = c * 16 + 4 * g;
   const long long wave = (long long)blockIdx.x * LME_BWD_WAVES + wv;
   const long long nwaves = (long long)gridDim.x * LME_BWD_WAVES;
   if (wave >= Wn) return;
   // Slot l: matrix l of the current window (natural log) until pass 1 has turned it into EM_l, EM_l until pass 2 has used
   // it, then matrix l of the wave's NEXT window at once - the loads of a window are spread over the previous window's
-  // way back instead of standing, all nine, in front of its first step (the kernel was short of bytes in flight: a wave
-  // had loads outstanding for a fifth of its time).  Matrix 1, whose slot frees last and is needed first, waits in N1.
-  float Mr[LMAX][4], N1[4] = {0.f, 0.f, 0.f, 0.f};
-  auto load4 = [&](float (&dst)[4], const float* src) {
-    const float4 q = lme_ld4<NT>(src);
-    dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
-  };
+  // way back instead of standing in front of its first step.  Matrix 1, whose slot frees last and is needed first, waits in N1.
+  float Mr[L][4], N1[4] = {0.f, 0.f, 0.f, 0.f}, G[4];
+  typedef __attribute__((ext_vector_type(4))) unsigned lme_u4;
+  constexpr int AUX = NT ? 2 : 0;   // nt
+  const unsigned voff = (unsigned)(c * 16 + 4 * g) * 4u;
+  constexpr unsigned wbytes = (unsigned)L * 1024u;
+  auto load4 = [&](float (&dst)[4], __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+    const lme_u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
+    // (through scalars: __builtin_bit_cast on a vector ELEMENT reads element 0 for every index with this compiler)
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l) load4(Mr[l], mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
+    for (int e = 0; e < 4; ++e) {
+      const unsigned bits = q[e];
+      dst[e] = __uint_as_float(bits);
+    }
+  };
+  auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned soff, const float4& q) {
+    const lme_u4 v = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, AUX);
+  };
+  {
+    const __amdgpu_buffer_rsrc_t r0 = q2_make_rsrc(mats + wave * (long long)L * 256, wbytes);
+#pragma unroll
+    for (int l = 0; l < L; ++l) load4(Mr[l], r0, (unsigned)l * 1024u);
+    load4(G, q2_make_rsrc(dOut + wave * 256, 1024u), 0u);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loop top joins the back edge with an empty counter state
   for (long long w = wave; w < Wn; w += nwaves) {
-    const float* nbase = mats + (w + nwaves < Wn ? w + nwaves : w) * (long long)L * 256 + gl_off;   // (the last window re-reads itself)
-    float G[4];
-    load4(G, dOut + w * 256 + gl_off);   // needed after pass 1: its round trip hides behind it
+    const long long wn = w + nwaves < Wn ? w + nwaves : w;   // (the last window re-reads itself)
+    const __amdgpu_buffer_rsrc_t rn = q2_make_rsrc(mats + wn * (long long)L * 256, wbytes);    // the next window's matrices
+    const __amdgpu_buffer_rsrc_t rd = q2_make_rsrc(dMats + w * (long long)L * 256, wbytes);   // this window's gradients
     // ---------------- pass 1
-    float Es[LMAX][4];     // E_l in the state layout
-    float Ss[LMAX][4];     // S of step l
+    float Es[L][4];        // E_l in the state layout
+    float Rinv[L];         // 1 / max_i S of step l
+    float Slast[4];        // S of the last step
     {
       float a0;
       lme_to_scaled(Mr[0], Es[0], a0);
-      load4(Mr[0], nbase);
+      load4(Mr[0], rn, 0u);
     }
+    bool ok = true;
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+      const float nb = lme_matrix_shift(Mr[l]);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Mr[l][reg] = ex2(__builtin_fmaf(Mr[l][reg], LME_LOG2E, nb));   // EM[r = c][i = 4g + reg]
+      const f32x4_t S = lme_step16g(scrE, c, g, Es[l - 1], Mr[l]);
+      ok = ok & lme_step_ok(S);
+      if (l + 1 < L) {
+        ok = lme_rescale_g(S, Es[l], Rinv[l]) & ok;
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Slast[reg] = S[reg];
+      }
+    }
+    const bool all_ok = __all(ok);
+    if (lane == 0) flags[w] = all_ok ? 0 : 1;
+    // ---------------- pass 2: walk back
+    if (L > 1) load4(N1, rn, 1024u);
+    float4 dmr[LO];
+#pragma unroll
+    for (int l = L - 1; l >= 1; --l) {
+      const float* EM = Mr[l];
+      const float* EP = Es[l - 1];
+      float H[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        H[s] = l + 1 < L ? G[s] * Rinv[l] * __builtin_amdgcn_rcpf(Es[l][s]) : G[s] * __builtin_amdgcn_rcpf(Slast[s]);   // G / S
+      wave_lds_sync();   // the previous step's reads of the scratch tiles are done
+      *reinterpret_cast<float4*>(scrE + st_off) = make_float4(EP[0], EP[1], EP[2], EP[3]);
+      *reinterpret_cast<float4*>(scrH + st_off) = make_float4(H[0], H[1], H[2], H[3]);
+      f32x4_t T1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) T1 = __builtin_amdgcn_mfma_f32_16x16x4f32(EM[s], H[s], T1, 0, 0, 0);
+      wave_lds_sync();
+      float EPc[4], Hc[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        EPc[s] = scrE[(4 * g + s) * LME_PST + c];                    // EP[t = 4g+s][r = c]
+        Hc[s] = scrH[(4 * g + s) * LME_PST + c];                     // H[t = 4g+s][i = c]
+      }
+      f32x4_t T2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) T2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hc[s], EPc[s], T2, 0, 0, 0);
+      const float4 dm = make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]);
+      if (l >= LO) *reinterpret_cast<float4*>(stg + l * 256) = dm;
+      else dmr[l] = dm;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) G[s] = T1[s] * EP[s];
+      if (l >= 2) load4(Mr[l], rn, (unsigned)l * 1024u);
+    }
+    const float4 g0 = make_float4(G[0], G[1], G[2], G[3]);
+    load4(G, q2_make_rsrc(dOut + wn * 256, 1024u), 0u);   // the next window's, needed behind its pass 1
+    asm volatile("" ::: "memory");                          // every load of the next window is issued: now the burst
+#pragma unroll
+    for (int l = L - 1; l >= LO; --l) store4(rd, (unsigned)l * 1024u, *reinterpret_cast<const float4*>(stg + l * 256));
+#pragma unroll
+    for (int l = LO - 1; l >= 1; --l)
+      if (l < L) store4(rd, (unsigned)l * 1024u, dmr[l]);
+    store4(rd, 0u, g0);
+    if (L > 1) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Mr[L > 1 ? 1 : 0][s] = N1[s];
+    }
+  }
+}
+
+// Second tier of the factored backward: the windows the kernel above flagged, with one shift per COLUMN of every matrix
+// (the forward kernel's factorisation: it represents matrices whose columns lie hundreds of nats apart, which one shift per
+// matrix flushes).  One wave per flagged window, nothing pipelined - a handful of windows in a batch at most; a window it
+// can represent has its flag cleared, the others are left to the exact recomputing kernel, whose float32 log-domain
+// prefixes carry the error of torch's own float32 logsumexp (1e-4 relative at magnitudes of a few hundred).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void lme_fold16_bwd_cols_k(
+    const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
+    int* __restrict__ flags, long long Wn, int L) {
+  constexpr int LMAX = 16;
+  __shared__ __align__(16) float scratch[4][2][LME_TILE];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  float* scrE = scratch[wv][0];
+  float* scrH = scratch[wv][1];
+  const int st_off = c * LME_PST + 4 * g;
+  const int gl_off = c * 16 + 4 * g;
+  const long long nwaves = (long long)gridDim.x * 4;
+  for (long long w = (long long)blockIdx.x * 4 + wv; w < Wn; w += nwaves) {
+    if (flags[w] == 0) continue;   // (wave-uniform)
+    const float* base = mats + w * (long long)L * 256 + gl_off;
+    float Mr[LMAX][4], Es[LMAX][4], Ss[LMAX][4], G[4];
+    auto load4 = [&](float (&dst)[4], const float* src) {
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
+    };
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l)
+      if (l < L) load4(Mr[l], base + (long long)l * 256);
+    load4(G, dOut + w * 256 + gl_off);
+    float a0;
+    lme_to_scaled(Mr[0], Es[0], a0);
     bool ok = true;
 #pragma unroll
     for (int l = 1; l < LMAX; ++l) {
@@ -536,25 +716,16 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
         float mcol[4], nb, da;
         lds_transpose16(scrE, c, g, make_float4(Mr[l][0], Mr[l][1], Mr[l][2], Mr[l][3]), mcol);
         const f32x4_t S = lme_step16s(Es[l - 1], mcol, nb);
-        ok = ok && lme_step_ok(S);
+        ok = ok & lme_step_ok(S);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           Ss[l][reg] = S[reg];
           Mr[l][reg] = ex2(__builtin_fmaf(Mr[l][reg], LME_LOG2E, __shfl(nb, 4 * g + reg, 64)));   // EM[r = c][i = 4g + reg]
         }
-        if (l + 1 < L) ok = lme_rescale(S, nb, g, Es[l], da) && ok;
+        if (l + 1 < L) ok = lme_rescale(S, nb, g, Es[l], da) & ok;
       }
     }
-    const bool all_ok = __all(ok);
-    if (lane == 0) flags[w] = all_ok ? 0 : 1;
-    if (!all_ok) {   // left to the exact kernel: only the slots move on
-#pragma unroll
-      for (int l = 1; l < LMAX; ++l)
-        if (l < L) load4(Mr[l], nbase + (long long)l * 256);
-      continue;
-    }
-    // ---------------- pass 2: walk back
-    if (L > 1) load4(N1, nbase + 256);
+    if (!__all(ok)) continue;   // stays flagged
 #pragma unroll
     for (int l = LMAX - 1; l >= 1; --l) {
       if (l < L) {
@@ -563,7 +734,7 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
         float H[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) H[s] = G[s] * __builtin_amdgcn_rcpf(Ss[l][s]);
-        wave_lds_sync();   // the previous step's reads of the scratch tiles are done
+        wave_lds_sync();
         *reinterpret_cast<float4*>(scrE + st_off) = make_float4(EP[0], EP[1], EP[2], EP[3]);
         *reinterpret_cast<float4*>(scrH + st_off) = make_float4(H[0], H[1], H[2], H[3]);
         f32x4_t T1 = {0.f, 0.f, 0.f, 0.f};
@@ -573,26 +744,24 @@ __device__ __forceinline__ void lme_fold16_bwd_body(
         float EPc[4], Hc[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          EPc[s] = scrE[(4 * g + s) * LME_PST + c];                    // EP[t = 4g+s][r = c]
-          Hc[s] = scrH[(4 * g + s) * LME_PST + c];                     // H[t = 4g+s][i = c]
+          EPc[s] = scrE[(4 * g + s) * LME_PST + c];
+          Hc[s] = scrH[(4 * g + s) * LME_PST + c];
         }
         f32x4_t T2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) T2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hc[s], EPc[s], T2, 0, 0, 0);
-        lme_st4<NT>(dMats + (w * L + l) * 256 + gl_off, make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]));
+        *reinterpret_cast<float4*>(dMats + (w * L + l) * 256 + gl_off) =
+            make_float4(T2[0] * EM[0], T2[1] * EM[1], T2[2] * EM[2], T2[3] * EM[3]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) G[s] = T1[s] * EP[s];
-        if (l >= 2) load4(Mr[l], nbase + (long long)l * 256);
       }
     }
-    lme_st4<NT>(dMats + (w * L) * 256 + gl_off, make_float4(G[0], G[1], G[2], G[3]));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) Mr[1 < LMAX ? 1 : 0][s] = N1[s];
+    *reinterpret_cast<float4*>(dMats + (w * L) * 256 + gl_off) = make_float4(G[0], G[1], G[2], G[3]);
+    if (lane == 0) flags[w] = 0;
   }
 }
 
-// workgroups of `threads` that are resident at once on the whole device (cached per kernel by callers
-// being static functions is not needed: the query is a cheap host-side table lookup)
+// workgroups of `threads` that are resident at once on the whole device
 long long resident_blocks(const void* fn, int threads) {
   int per_cu = 0, dev = 0, cus = 256;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -600,25 +769,22 @@ long long resident_blocks(const void* fn, int threads) {
   return (long long)per_cu * cus;
 }
 
-template <int LMAX, bool NT>
-__global__ __launch_bounds__(64 * LME_BWD_WAVES) __attribute__((amdgpu_waves_per_eu(LMAX <= 9 ? 3 : 1))) void lme_fold16_bwd_mfma_k(
-    const float* __restrict__ mats, const float* __restrict__ dOut, float* __restrict__ dMats,
-    int* __restrict__ flags, long long Wn, int L) {
-  lme_fold16_bwd_body<LMAX, NT>(mats, dOut, dMats, flags, Wn, L);
-}
-
-// (Round 3: the same body held to 128 registers with amdgpu_waves_per_eu(4, 4) - four waves per SIMD instead of three,
-// 14 spilled registers - measured SLOWER at L = 9: 3.93 against 3.37 ms for 692 224 windows.  The kernel's three pipes
-// are together ~100 % busy (vector 46 %, matrix 29 %, LDS 24 %: profiles/r02_sq_cfg5.json); the spill traffic costs
-// more than the fourth wave's overlap gains.)
-template <int LMAX, bool NT>
-void fold16_bwd_launch(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, int L,
-                       hipStream_t st) {
+template <int L, bool NT>
+void fold16_bwd_launch_t(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, hipStream_t st) {
   long long blocks = (Wn + LME_BWD_WAVES - 1) / LME_BWD_WAVES;
-  const long long cap = resident_blocks((const void*)lme_fold16_bwd_mfma_k<LMAX, NT>, 64 * LME_BWD_WAVES);
+  const long long cap = resident_blocks((const void*)lme_fold16_bwd_mfma_k<L, NT>, 64 * LME_BWD_WAVES);
   if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
-  hipLaunchKernelGGL((lme_fold16_bwd_mfma_k<LMAX, NT>), dim3((unsigned)blocks), dim3(64 * LME_BWD_WAVES), 0, st,
-                     mats, dOut, dMats, flags, Wn, L);
+  hipLaunchKernelGGL((lme_fold16_bwd_mfma_k<L, NT>), dim3((unsigned)blocks), dim3(64 * LME_BWD_WAVES), 0, st, mats, dOut, dMats, flags, Wn);
+}
+template <bool NT>
+void fold16_bwd_launch(const float* mats, const float* dOut, float* dMats, int* flags, long long Wn, int L, hipStream_t st) {
+  switch (L) {
+#define LME_BWD_CASE(LL) case LL: return fold16_bwd_launch_t<LL, NT>(mats, dOut, dMats, flags, Wn, st);
+    LME_BWD_CASE(2) LME_BWD_CASE(3) LME_BWD_CASE(4) LME_BWD_CASE(5) LME_BWD_CASE(6) LME_BWD_CASE(7) LME_BWD_CASE(8) LME_BWD_CASE(9)
+    LME_BWD_CASE(10) LME_BWD_CASE(11) LME_BWD_CASE(12) LME_BWD_CASE(13) LME_BWD_CASE(14) LME_BWD_CASE(15) LME_BWD_CASE(16)
+#undef LME_BWD_CASE
+    default: break;   // (the caller sends 2 <= L <= 16)
+  }
 }
 
 // the fold's matrices do not fit the last-level cache (256 MiB): stream them (lme_ld4<true>)
@@ -803,7 +969,7 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats, 
   if (Wn < 1 || L < 1 || D < 1) return DCTN_ERR_BAD_SHAPE;
   if (D > 32) return DCTN_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DCTN_F32 && D == 16 && L <= 16 && workspace &&
+  if (dtype == DCTN_F32 && D == 16 && L >= 2 && L <= 16 && workspace &&
       workspace_bytes >= 256 + (size_t)Wn * sizeof(int) && ((uintptr_t)mats % 16 == 0) &&
       ((uintptr_t)dOut % 16 == 0) && ((uintptr_t)dMats % 16 == 0) && ((uintptr_t)workspace % 4 == 0) &&
       (size_t)(L + 2) * 16 * 17 * sizeof(float) <= DCTN_LDS_BUDGET) {
@@ -812,10 +978,14 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats, 
     const float* dy = (const float*)dOut;
     float* dm = (float*)dMats;
     const bool nt = lme_streams(Wn, L);
-    if (L <= 5) nt ? fold16_bwd_launch<5, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<5, false>(m, dy, dm, flags, Wn, L, st);
-    else if (L <= 9) nt ? fold16_bwd_launch<9, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<9, false>(m, dy, dm, flags, Wn, L, st);
-    else nt ? fold16_bwd_launch<16, true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<16, false>(m, dy, dm, flags, Wn, L, st);
+    nt ? fold16_bwd_launch<true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<false>(m, dy, dm, flags, Wn, L, st);
     DCTN_CHECK_LAUNCH();
+    {   // second tier (column shifts) over the flagged windows; what it cannot represent either stays flagged
+      long long blocks = (Wn + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(lme_fold16_bwd_cols_k, dim3((unsigned)blocks), dim3(256), 0, st, m, dy, dm, flags, (long long)Wn, L);
+      DCTN_CHECK_LAUNCH();
+    }
     const int rc = fold_bwd_launch<float, float>(mats, dOut, dMats, Wn, L, D, st, flags);  // flagged windows only
     if (rc != DCTN_OK) return rc;
     dctn_set_last_kernel("logmatmulexp_fold_bwd_mfma16");
