@@ -785,7 +785,7 @@ def extra_cfg5(dev, iters):
     t_b = max(t_fb - t_f, 1e-9)
     fl = Wn * (Ln - 1) * 2 * D ** 3
     roof = roofline_entry("hbm", "lme_fold16_bwd_mfma_k" if "mfma16" in fam_b else fam_b, "dctn_logmatmulexp_fold_bwd", t_b, 2 * fl, by_b,
-                          torch.float32, traffic_key="cfg5:lme_fold16_bwd_mfma_k", fwd_kernel="lme_fold16_fwd_slots_k" if "mfma16" in fam_f else fam_f,
+                          torch.float32, traffic_key="cfg5:lme_fold16_bwd_mfma_k", fwd_kernel="lme_fold16_fwd_k" if "mfma16" in fam_f else fam_f,
                           fwd_us=t_f * 1e6, fwd_gbs=by_f / t_f / 1e9, fwd_frac=by_f / t_f / 1e9 / HBM_PEAK_GBS,
                           step_gbs=(by_f + by_b) / t_fb / 1e9, step_frac=(by_f + by_b) / t_fb / 1e9 / HBM_PEAK_GBS,
                           bytes_per_window={"fwd": by_f // Wn, "bwd": by_b // Wn}, formulation="factored (exp -> MFMA), prefix carried in scaled form; a window with a rejected step restarts in the log domain")

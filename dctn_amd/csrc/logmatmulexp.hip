@@ -436,46 +436,93 @@ __device__ __forceinline__ bool lme_fwd_step(float* scr, int c, int g, const flo
   return true;
 }
 
-// L <= LMAX: slot l holds matrix l of the wave's current window until step l has used it and is refilled at once with
-// matrix l of the wave's NEXT window - the steps are unrolled, so every slot is a fixed set of registers (a rotating
-// queue of four cost 12 v_mov per step) and up to LMAX KiB per wave are in flight across the window boundary.
-template <int LMAX, bool NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 9 ? 4 : 1))) void lme_fold16_fwd_slots_k(const float* __restrict__ mats, float* __restrict__ out,
-                                                              long long Wn, int L) {
+// Slot l holds matrix l of the wave's current window until step l has used it and is refilled at once with matrix l of the
+// wave's NEXT window - the steps are unrolled, so every slot is a fixed set of registers (a rotating queue of four cost 12
+// v_mov per step) and up to L KiB per wave are in flight across the window boundary.
+//
+// 2 <= L <= 16, the chain length a template parameter (round 5; what the backward kernel below taught): no step is
+// conditional, window bases are scalars in buffer descriptors (one vector register of addresses), and a window whose
+// steps the factorisation cannot represent is only NOTED in the loop (one bit per iteration in a per-wave LDS mask) and
+// redone in the log domain behind it - a second way round the loop with memory operations in it joins the loop top with
+// another counter state and costs every window its wait counts.
+constexpr int LME_FWD_ITMAX = 4096;   // iterations a wave can note (the host grows the grid beyond that)
+
+template <int L, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L <= 9 ? 4 : (L <= 12 ? 3 : 2)))) void lme_fold16_fwd_k(
+    const float* __restrict__ mats, float* __restrict__ out, long long Wn) {
   __shared__ __align__(16) float scratch[4][LME_TILE];
+  __shared__ unsigned rej[4][LME_FWD_ITMAX / 32];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  float* scr = scratch[threadIdx.x >> 6];
-  const int gl_off = c * 16 + 4 * g;
-  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* scr = scratch[wv];
+  const long long wave = (long long)blockIdx.x * 4 + wv;
   const long long nwaves = (long long)gridDim.x * 4;
   if (wave >= Wn) return;
-  float4 Mq[LMAX];
+  for (int i = lane; i < LME_FWD_ITMAX / 32; i += 64) rej[wv][i] = 0u;
+  typedef __attribute__((ext_vector_type(4))) unsigned lme_u4;
+  constexpr int AUX = NT ? 2 : 0;   // nt
+  const unsigned voff = (unsigned)(c * 16 + 4 * g) * 4u;
+  constexpr unsigned wbytes = (unsigned)L * 1024u;
+  auto load4 = [&](float (&dst)[4], __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+    const lme_u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
 #pragma unroll
-  for (int l = 0; l < LMAX; ++l)
-    Mq[l] = lme_ld4<NT>(mats + (wave * (long long)L + (l < L ? l : L - 1)) * 256 + gl_off);
-  for (long long w = wave; w < Wn; w += nwaves) {
-    const float* nbase = mats + (w + nwaves < Wn ? w + nwaves : w) * (long long)L * 256 + gl_off;   // (the last window re-reads itself)
-    const float4 v4 = Mq[0];
-    Mq[0] = lme_ld4<NT>(nbase);
-    if (L == 1) {   // nothing to fold
-      lme_st4<NT>(out + w * 256 + gl_off, v4);
-      continue;
+    for (int e = 0; e < 4; ++e) {
+      const unsigned bits = q[e];   // (through a scalar: see the backward kernel)
+      dst[e] = __uint_as_float(bits);
     }
+  };
+  float Mq[L][4];
+  {
+    const __amdgpu_buffer_rsrc_t r0 = q2_make_rsrc(mats + wave * (long long)L * 256, wbytes);
+#pragma unroll
+    for (int l = 0; l < L; ++l) load4(Mq[l], r0, (unsigned)l * 1024u);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loop top joins the back edge with an empty counter state
+  int it = 0;
+  for (long long w = wave; w < Wn; w += nwaves, ++it) {
+    const long long wn = w + nwaves < Wn ? w + nwaves : w;   // (the last window re-reads itself)
+    const __amdgpu_buffer_rsrc_t rn = q2_make_rsrc(mats + wn * (long long)L * 256, wbytes);
     float E[4], a;
-    {
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-      lme_to_scaled(v, E, a);
-    }
-    bool good = true;
+    lme_to_scaled(Mq[0], E, a);
+    load4(Mq[0], rn, 0u);
+    bool ok = true;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int l = 1; l < LMAX; ++l) {
-      if (l < L) {
-        const float4 qm = Mq[l];
-        Mq[l] = lme_ld4<NT>(nbase + (long long)l * 256);
-        if (good) good = lme_fwd_step<NT>(scr, c, g, qm, E, a, l == L - 1, out + w * 256 + gl_off);
+    for (int l = 1; l < L; ++l) {
+      float mcol[4], nb;
+      lds_transpose16(scr, c, g, make_float4(Mq[l][0], Mq[l][1], Mq[l][2], Mq[l][3]), mcol);   // mcol[s] = M_l[4g + s][c]
+      load4(Mq[l], rn, (unsigned)l * 1024u);
+      const f32x4_t S = lme_step16s(E, mcol, nb);
+      ok = ok & lme_step_ok(S);
+      if (l + 1 < L) {
+        float En[4], da;
+        ok = lme_rescale(S, nb, g, En, da) & ok;
+        a += da;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) E[reg] = En[reg];
+      } else {
+        // S[reg] = sum for (i = 4g + reg, t = c); b_i lives in the lanes whose c equals i
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) r[reg] = (lg2(S[reg]) + a - __shfl(nb, 4 * g + reg, 64)) * LME_LN2;
       }
     }
-    if (!good) lme_exact_window(mats + w * (long long)L * 256, out + w * 256, L, c, g);
+    {
+      const lme_u4 v = {__float_as_uint(r[0]), __float_as_uint(r[1]), __float_as_uint(r[2]), __float_as_uint(r[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, q2_make_rsrc(out + w * 256, 1024u), voff, 0u, AUX);
+    }
+    if (!__all(ok) && lane == 0) rej[wv][it >> 5] |= 1u << (it & 31);
+  }
+  // the noted windows, in the log domain from their first matrix (the scaled prefix has flushed what lies far below a row
+  // maximum, and in such a step that may be what matters)
+  wave_lds_sync();
+  for (int wd = 0; wd * 32 < it; ++wd) {
+    unsigned m = rej[wv][wd];   // (wave-uniform)
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1;
+      const long long w = wave + (long long)(wd * 32 + b) * nwaves;
+      lme_exact_window(mats + w * (long long)L * 256, out + w * 256, L, c, g);
+    }
   }
 }
 
@@ -941,15 +988,29 @@ int dctn_logmatmulexp_fold_fwd(const void* mats, void* out, int64_t Wn, int L, i
     const bool nt = lme_streams(Wn, L);
     long long blocks = (Wn + 3) / 4;
     const dim3 b(256);
-    auto slots = [&](auto kern) {
+    if (L == 1) {   // nothing to fold
+      if (hipMemcpyAsync(out, mats, (size_t)Wn * 1024, hipMemcpyDeviceToDevice, st) != hipSuccess) return DCTN_ERR_LAUNCH;
+      dctn_set_last_kernel("logmatmulexp_fold_fwd_mfma16");
+      return DCTN_OK;
+    }
+    auto exact = [&](auto kern) {
       const long long cap = resident_blocks((const void*)kern, 256);
-      if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round
-      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+      if (blocks > cap) blocks = cap;   // persistent waves: exactly one resident round ...
+      const long long need = (Wn + 4ll * LME_FWD_ITMAX - 1) / (4ll * LME_FWD_ITMAX);   // ... unless a wave would run out of note bits
+      if (blocks < need) blocks = need;
+      hipLaunchKernelGGL(kern, dim3((unsigned)blocks), b, 0, st, (const float*)mats, (float*)out, (long long)Wn);
     };
-    if (L <= 5) nt ? slots(lme_fold16_fwd_slots_k<5, true>) : slots(lme_fold16_fwd_slots_k<5, false>);
-    else if (L <= 9) nt ? slots(lme_fold16_fwd_slots_k<9, true>) : slots(lme_fold16_fwd_slots_k<9, false>);
-    else if (L <= 16) nt ? slots(lme_fold16_fwd_slots_k<16, true>) : slots(lme_fold16_fwd_slots_k<16, false>);
-    else slots(lme_fold16_fwd_mfma_k);
+    switch (L) {
+#define LME_FWD_CASE(LL) case LL: nt ? exact(lme_fold16_fwd_k<LL, true>) : exact(lme_fold16_fwd_k<LL, false>); break;
+      LME_FWD_CASE(2) LME_FWD_CASE(3) LME_FWD_CASE(4) LME_FWD_CASE(5) LME_FWD_CASE(6) LME_FWD_CASE(7) LME_FWD_CASE(8) LME_FWD_CASE(9)
+      LME_FWD_CASE(10) LME_FWD_CASE(11) LME_FWD_CASE(12) LME_FWD_CASE(13) LME_FWD_CASE(14) LME_FWD_CASE(15) LME_FWD_CASE(16)
+#undef LME_FWD_CASE
+      default: {
+        const long long cap = resident_blocks((const void*)lme_fold16_fwd_mfma_k, 256);
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(lme_fold16_fwd_mfma_k, dim3((unsigned)blocks), b, 0, st, (const float*)mats, (float*)out, (long long)Wn, L);
+      }
+    }
     DCTN_CHECK_LAUNCH();
     dctn_set_last_kernel("logmatmulexp_fold_fwd_mfma16");
     return DCTN_OK;

@@ -387,15 +387,19 @@ def _eps_bigcore_exact_out_size(C, B, H, W, Q, K, O, fsuf):
     check(xd.grad, dx, torch.float32, "dX")
 
 
-@pytest.mark.parametrize("Wn,L", [(7, 3), (33, 5), (20, 6), (9, 10), (5, 16), (4, 17), (257, 9)])
+@pytest.mark.parametrize("Wn,L", [(7, 3), (33, 5), (20, 6), (9, 10), (5, 16), (4, 17), (257, 9), (9001, 2), (4700, 4), (11, 13)])
 def test_logmatmulexp_fold16_all_chain_lengths(Wn, L):
-    """D = 16 float32 fold: every template bound of the factored backward (L <= 5, <= 9, <= 16), the
-    exact recomputing kernel beyond 16, and windows flagged for the exact path in the middle of a batch."""
+    """D = 16 float32 fold: chain lengths on both sides of every occupancy step of the per-length kernels (2..16), the
+    exact recomputing kernel beyond 16, windows noted / flagged for the exact path in the middle of a batch and in a later
+    turn of a persistent wave's loop."""
     torch.manual_seed(Wn * 31 + L)
     m = torch.randn(Wn, L, 16, 16) * 1.5
     if Wn > 4:
         m[2] *= 40.0                                  # range far beyond what the factorisation accepts
         m[Wn - 1, L // 2, 3, :] = -float("inf")       # a -inf row in one factor
+    if Wn > 4096:                                     # more windows than resident waves: windows noted in a LATER turn of a wave's loop
+        m[4096 + 5] *= 40.0
+        m[Wn - 3, 0, :, 2] += 300.0                   # a column the one-shift-per-matrix backward flushes: its second tier takes it
     md = m.to(DEV).requires_grad_(True)
     y = logmatmulexp_fold(md)
     want = R.logmatmulexp_fold_batched(m.double())

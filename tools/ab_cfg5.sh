@@ -6,8 +6,11 @@ for l in sys.stdin:
     if l.startswith('{') or l.startswith('['):
         d=json.loads(l); e=d[0] if isinstance(d,list) else d
         e = e.get('configs',[e])[0] if isinstance(e,dict) and 'configs' in e else e
-        print('$1', e.get('ms_per_step'), e.get('roofline',{}).get('launch_us'))
+        r=e.get('roofline',{})
+        print('$1', e.get('ms_per_step'), r.get('launch_us'), r.get('fwd_us'))
 "; }
-timeout -k 10 300 python -m pytest tests -q -m gpu -k "logmatmulexp or lme or fold" 2>&1 | tail -2
-run DEFAULT
-run DEFAULT
+cp dctn_amd/libdctn_amd.so /tmp/base.so
+run BASE
+for v in A B C D E; do cp tools/lme_variants/lib_$v.so dctn_amd/libdctn_amd.so; run $v; done
+cp /tmp/base.so dctn_amd/libdctn_amd.so
+run BASE
