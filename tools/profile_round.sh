@@ -39,7 +39,7 @@ echo "[profile] SQ busy counters, cfg2 kernels at B = 1024"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/headline_sq1 -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_sq1.err || echo "sq1 failed"
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_COEXEC_CYCLES --kernel-trace -d $OUT/headline_sq2 -o p --output-format csv -- python3 bench.py --configs none --no-cpu-baseline --steps 40 --warmup 20 --graph 0 > /dev/null 2> $OUT/headline_sq2.err || echo "sq2 failed"
 fi
-SQCFGS=${SQCFGS:-"cfg2_f32 cfg4_r4 cfg4_r16 cfg3a"}
+SQCFGS=${SQCFGS:-"cfg2_f32 cfg4_r4 cfg4_r16 cfg3a cfg5"}
 for cfg in $SQCFGS; do
   echo "[profile] SQ counters, $cfg"
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${cfg}_sq1 -o p --output-format csv -- python3 bench.py --skip-headline --configs $cfg --no-cpu-baseline > /dev/null 2> $OUT/${cfg}_sq1.err || echo "$cfg sq1 failed"
