@@ -249,35 +249,39 @@ bool head_ok(long long B, int F, int Cout, int dtype) {
 // Tensile GEMM launches in the backward).  Same three streaming passes as above in scalar form: S = storage type,
 // A = accumulator (float; double for float64).  The work is tiny (B x F x Cout <= a few MFLOP) and bound by launch
 // latency and one pass over `feat`; no matrix cores needed.
-constexpr int HG_SPB = 4;   // samples per workgroup, forward
+constexpr int HG_SPB = 4;   // samples per workgroup, forward (large batches; one per workgroup below 1024 samples)
 
-template <typename S, typename A>
+// (round 5: batches below 1024 samples put one sample into a workgroup - four left 32 workgroups on 256 CUs at B = 128 -
+// and the feature loop is unrolled by four: its 11 loads per turn were one memory round trip per turn, 46 us for cfg3a's
+// 128 x 3174 features.)
+template <typename S, typename A, int SPB>
 __global__ __launch_bounds__(256) void head_fwd_gen_k(const S* __restrict__ feat, const S* __restrict__ W,
                                                       const S* __restrict__ bias, S* __restrict__ out, long long B, int F,
                                                       int Cout) {
-  __shared__ A red[4][HG_SPB * HEAD_MAXC];
+  __shared__ A red[4][SPB * HEAD_MAXC];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long long b0 = (long long)blockIdx.x * HG_SPB;
-  A acc[HG_SPB][HEAD_MAXC];
+  const long long b0 = (long long)blockIdx.x * SPB;
+  A acc[SPB][HEAD_MAXC];
 #pragma unroll
-  for (int s2 = 0; s2 < HG_SPB; ++s2)
+  for (int s2 = 0; s2 < SPB; ++s2)
 #pragma unroll
     for (int c = 0; c < HEAD_MAXC; ++c) acc[s2][c] = A(0);
+#pragma unroll 4
   for (int f = tid; f < F; f += 256) {
-    A xv[HG_SPB];
+    A xv[SPB];
 #pragma unroll
-    for (int s2 = 0; s2 < HG_SPB; ++s2) xv[s2] = b0 + s2 < B ? (A)feat[(b0 + s2) * (long long)F + f] : A(0);
+    for (int s2 = 0; s2 < SPB; ++s2) xv[s2] = b0 + s2 < B ? (A)feat[(b0 + s2) * (long long)F + f] : A(0);
 #pragma unroll
     for (int c = 0; c < HEAD_MAXC; ++c) {
       if (c < Cout) {
         const A w = (A)W[(long long)c * F + f];
 #pragma unroll
-        for (int s2 = 0; s2 < HG_SPB; ++s2) acc[s2][c] += xv[s2] * w;
+        for (int s2 = 0; s2 < SPB; ++s2) acc[s2][c] += xv[s2] * w;
       }
     }
   }
 #pragma unroll
-  for (int s2 = 0; s2 < HG_SPB; ++s2)
+  for (int s2 = 0; s2 < SPB; ++s2)
 #pragma unroll
     for (int c = 0; c < HEAD_MAXC; ++c) {
       if (c < Cout) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void head_fwd_gen_k(const S* __restrict__ feat
       }
     }
   __syncthreads();
-  if (tid < HG_SPB * HEAD_MAXC) {
+  if (tid < SPB * HEAD_MAXC) {
     const int s2 = tid / HEAD_MAXC, c = tid % HEAD_MAXC;
     if (b0 + s2 < B && c < Cout)
       out[(b0 + s2) * Cout + c] = (S)(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + (A)bias[c]);
@@ -395,8 +399,12 @@ bool head_gen_ok(long long B, int F, int Cout, int dtype) {
 
 template <typename S, typename A>
 int head_fwd_gen(const void* feat, const void* weight, const void* bias, void* out, long long B, int F, int Cout, hipStream_t st) {
-  hipLaunchKernelGGL((head_fwd_gen_k<S, A>), dim3((unsigned)((B + HG_SPB - 1) / HG_SPB)), dim3(256), 0, st, (const S*)feat,
-                     (const S*)weight, (const S*)bias, (S*)out, B, F, Cout);
+  if (B >= 1024)
+    hipLaunchKernelGGL((head_fwd_gen_k<S, A, HG_SPB>), dim3((unsigned)((B + HG_SPB - 1) / HG_SPB)), dim3(256), 0, st, (const S*)feat,
+                       (const S*)weight, (const S*)bias, (S*)out, B, F, Cout);
+  else
+    hipLaunchKernelGGL((head_fwd_gen_k<S, A, 1>), dim3((unsigned)B), dim3(256), 0, st, (const S*)feat, (const S*)weight,
+                       (const S*)bias, (S*)out, B, F, Cout);
   DCTN_CHECK_LAUNCH();
   return DCTN_OK;
 }

@@ -146,8 +146,7 @@ __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__
   A* g = cur + D * DP;                  // [D][D+1]     gradient wrt the current prefix
   const int tid = threadIdx.x;
   const int t = tid / D, i = tid - t * D;
-  for (long long w = blockIdx.x; w < Wn; w += gridDim.x) {
-    if (only_flagged && only_flagged[w] == 0) continue;  // uniform over the workgroup
+  auto window = [&](long long w) {
     const S* base = mats + w * (long long)L * DD;
     __syncthreads();
     A v = (A)base[tid];
@@ -187,6 +186,24 @@ __global__ void lme_fold_bwd_k(const S* __restrict__ mats, const S* __restrict__
     }
     __syncthreads();
     dMats[(w * L) * (long long)DD + tid] = (S)g[t * DP + i];
+  };
+  if (!only_flagged) {
+    for (long long w = blockIdx.x; w < Wn; w += gridDim.x) window(w);
+    return;
+  }
+  // flagged windows only: the workgroup reads blockDim.x flags at a time (one coalesced load; a flag per turn of a
+  // per-window loop was a dependent memory round trip per window: 72 us for 692 224 clean windows) and walks those set
+  __shared__ int nlist;
+  __shared__ int list[1024];
+  const int nthr = blockDim.x;
+  for (long long base0 = (long long)blockIdx.x * nthr; base0 < Wn; base0 += (long long)gridDim.x * nthr) {
+    __syncthreads();
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    if (base0 + tid < Wn && only_flagged[base0 + tid] != 0) list[atomicAdd(&nlist, 1)] = tid;   // (order is irrelevant: windows are independent)
+    __syncthreads();
+    const int n = nlist;
+    for (int k = 0; k < n; ++k) window(base0 + list[k]);
   }
 }
 
@@ -742,8 +759,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void l
   const int st_off = c * LME_PST + 4 * g;
   const int gl_off = c * 16 + 4 * g;
   const long long nwaves = (long long)gridDim.x * 4;
-  for (long long w = (long long)blockIdx.x * 4 + wv; w < Wn; w += nwaves) {
-    if (flags[w] == 0) continue;   // (wave-uniform)
+  // a wave reads 64 flags at a time (a flag per turn was a dependent round trip per window: 118 us for 692 224 clean windows)
+  for (long long w0 = ((long long)blockIdx.x * 4 + wv) * 64; w0 < Wn; w0 += nwaves * 64) {
+   unsigned long long todo = __ballot(w0 + lane < Wn && flags[w0 + lane] != 0);
+   while (todo) {
+    const long long w = w0 + __builtin_ctzll(todo);
+    todo &= todo - 1;
     const float* base = mats + w * (long long)L * 256 + gl_off;
     float Mr[LMAX][4], Es[LMAX][4], Ss[LMAX][4], G[4];
     auto load4 = [&](float (&dst)[4], const float* src) {
@@ -805,6 +826,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void l
     }
     *reinterpret_cast<float4*>(dMats + (w * L) * 256 + gl_off) = make_float4(G[0], G[1], G[2], G[3]);
     if (lane == 0) flags[w] = 0;
+   }
   }
 }
 
@@ -895,7 +917,11 @@ int fold_bwd_launch(const void* mats, const void* dOut, void* dMats, long long W
   if (lds > DCTN_LDS_BUDGET) return DCTN_ERR_UNSUPPORTED;
   (void)hipFuncSetAttribute((const void*)lme_fold_bwd_k<S, A>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const unsigned grid = (unsigned)(Wn < 256 * 32 ? Wn : 256 * 32);
+  unsigned grid = (unsigned)(Wn < 256 * 32 ? Wn : 256 * 32);
+  if (only_flagged) {   // one turn of D * D flags per workgroup
+    const long long g = (Wn + (long long)D * D - 1) / ((long long)D * D);
+    grid = (unsigned)(g < 256 * 32 ? g : 256 * 32);
+  }
   hipLaunchKernelGGL((lme_fold_bwd_k<S, A>), dim3(grid), dim3(D * D), lds, st, (const S*)mats,
                      (const S*)dOut, (S*)dMats, Wn, L, D, only_flagged);
   DCTN_CHECK_LAUNCH();
@@ -1042,8 +1068,8 @@ int dctn_logmatmulexp_fold_bwd(const void* mats, const void* dOut, void* dMats, 
     nt ? fold16_bwd_launch<true>(m, dy, dm, flags, Wn, L, st) : fold16_bwd_launch<false>(m, dy, dm, flags, Wn, L, st);
     DCTN_CHECK_LAUNCH();
     {   // second tier (column shifts) over the flagged windows; what it cannot represent either stays flagged
-      long long blocks = (Wn + 3) / 4;
-      if (blocks > 1024) blocks = 1024;
+      long long blocks = (Wn + 255) / 256;   // a wave per 64 flags
+      if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(lme_fold16_bwd_cols_k, dim3((unsigned)blocks), dim3(256), 0, st, m, dy, dm, flags, (long long)Wn, L);
       DCTN_CHECK_LAUNCH();
     }
