@@ -1,6 +1,6 @@
 set -e
-timeout -k 10 600 python -m pytest tests -q -m gpu -k "head or linear or plus_linear or composition" 2>&1 | tail -2
-for c in cfg3b cfg4_eps36 cfg3a; do
+timeout -k 10 900 python -m pytest tests -q -m gpu -k "bigcore or eps_golden or eps_vs_oracle or cfg3 or fullsize" 2>&1 | tail -2
+for c in cfg3b cfg3a; do
 python bench.py --skip-headline --configs $c --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
