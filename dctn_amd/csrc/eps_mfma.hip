@@ -1678,9 +1678,10 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
     for (int k0 = 0; k0 < nblk; k0 += 256) {   // nblk <= 256: one trip
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < 8; ++i) {   // clamped index + select: a predicated load is a branch and a wait on the spot (four round trips for eight loads)
         const int k = k0 + k32 + 32 * i;
-        v[i] = k < nblk ? partial[k * stride + e] : 0.f;
+        const float ld = partial[(k < nblk ? k : nblk - 1) * stride + e];
+        v[i] = k < nblk ? ld : 0.f;
       }
       acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
@@ -1711,7 +1712,8 @@ __global__ __launch_bounds__(1024) void eps_head_reduce_k(const float* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = sub + 4 * i;
-      v[i] = (k < ncb && e < nW) ? dwpart[(long long)k * nW + e] : 0.f;
+      const float ld = dwpart[(long long)(k < ncb ? k : ncb - 1) * nW + (e < nW ? e : nW - 1)];   // (no branch between the loads)
+      v[i] = (k < ncb && e < nW) ? ld : 0.f;
     }
     float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     for (int k = 32 + sub; k < ncb; k += 4) t += e < nW ? dwpart[(long long)k * nW + e] : 0.f;

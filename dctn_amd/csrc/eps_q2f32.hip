@@ -719,7 +719,8 @@ __global__ __launch_bounds__(64 * FIN_WAVES) void eps_q2f32_finish_k(const float
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = k0 + k32 + 32 * i;
-        v[i] = k < nblk ? partial[k * stride + e] : 0.f;
+        const float ld = partial[(k < nblk ? k : nblk - 1) * stride + e];   // (clamped index + select: no branch between the loads)
+        v[i] = k < nblk ? ld : 0.f;
       }
       acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }

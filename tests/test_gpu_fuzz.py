@@ -387,7 +387,8 @@ def _eps_bigcore_exact_out_size(C, B, H, W, Q, K, O, fsuf):
     check(xd.grad, dx, torch.float32, "dX")
 
 
-@pytest.mark.parametrize("Wn,L", [(7, 3), (33, 5), (20, 6), (9, 10), (5, 16), (4, 17), (257, 9), (9001, 2), (4700, 4), (11, 13)])
+@pytest.mark.parametrize("Wn,L", [(7, 3), (33, 5), (20, 6), (9, 10), (5, 16), (4, 17), (257, 9), (9001, 2), (4700, 4), (11, 13), (6, 7), (6, 8), (5, 11),
+                                  (9, 12), (5, 14), (7, 15)])
 def test_logmatmulexp_fold16_all_chain_lengths(Wn, L):
     """D = 16 float32 fold: chain lengths on both sides of every occupancy step of the per-length kernels (2..16), the
     exact recomputing kernel beyond 16, windows noted / flagged for the exact path in the middle of a batch and in a later

@@ -1,13 +1,11 @@
 set -e
-timeout -k 10 900 python -m pytest tests -q -m gpu -k "bigcore or eps_golden or eps_vs_oracle or cfg3 or fullsize" 2>&1 | tail -2
-for c in cfg3b cfg3a; do
-python bench.py --skip-headline --configs $c --no-cpu-baseline 2>/dev/null | python -c "
+timeout -k 10 900 python -m pytest tests -q -m gpu -k "plus_linear or head or q2 or register_family or eps_golden" 2>&1 | tail -2
+python bench.py --configs cfg2_f32 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()
-    if l.startswith('{') or l.startswith('['):
-        d=json.loads(l); e=d[0] if isinstance(d,list) else d
-        e = e.get('configs',[e])[0] if isinstance(e,dict) and 'configs' in e else e
-        print('$c', e.get('ms_per_step'))
+    if l.startswith('{'):
+        d=json.loads(l)
+        print('headline', d['ms_per_step']*1e3, d['roofline']['kernels_us'], d['run'].get('us_per_step_at_one_step_per_graph_launch'))
+        print('f32', d['side_summary'])
 "
-done
