@@ -468,8 +468,11 @@ __global__ __launch_bounds__(256) void convsbs_bwd_mfma_k(const float* __restric
       // input state of core c
 #pragma unroll
       for (int s = 0; s < SR; ++s) {
-        v0[s] = valid ? states[(p.st_off[c] + 2 * s + h) * p.Wn + w] : 0.f;
-        v1[s] = (valid && oacc_in > 1) ? states[(p.st_off[c] + R + 2 * s + h) * p.Wn + w] : 0.f;
+        // (clamped address + select: a predicated load is a branch and a wait on the spot)
+        const float l0 = states[(p.st_off[c] + 2 * s + h) * p.Wn + (valid ? w : 0)];
+        const float l1 = states[(p.st_off[c] + (oacc_in > 1 ? R : 0) + 2 * s + h) * p.Wn + (valid ? w : 0)];
+        v0[s] = valid ? l0 : 0.f;
+        v1[s] = (valid && oacc_in > 1) ? l1 : 0.f;
       }
       load_features(fs, c, lane, f);
       float df[4] = {0.f, 0.f, 0.f, 0.f};
@@ -815,20 +818,28 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
           const float x00 = xsp[0], x01 = xsp[WPG], x10 = xsp[2 * WPG], x11 = xsp[3 * WPG];
           const float gx[4] = {df[0][t] * x10 + df[1][t] * x11, df[2][t] * x10 + df[3][t] * x11,    // channel 0, d = 0, 1
                                df[0][t] * x00 + df[2][t] * x01, df[1][t] * x00 + df[3][t] * x01};   // channel 1, e = 0, 1
+          // (slices after the first add to what is there: the four old values in ONE round of loads - `*gp = accum ? *gp + v : v`
+          // per element was a load and a wait on the spot per element, 36+ dependent round trips per group of windows)
+          float* gp0 = gxw + (long long)(c * 4) * p.Wn + wt[t];
+          float old[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.accum) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float* gp = gxw + (long long)(c * 4 + k) * p.Wn + wt[t];
-            *gp = p.accum ? *gp + gx[k] : gx[k];
+            for (int k = 0; k < 4; ++k) old[k] = gp0[(long long)k * p.Wn];
           }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) gp0[(long long)k * p.Wn] = old[k] + gx[k];
           continue;
         }
         if (ONECH == 1 || p.C == 1) {   // one channel: the feature IS the pixel's value index (no integer divisions, no re-reads of x)
+          float* gp0 = gxw + (long long)(c * p.q) * p.Wn + wt[t];
+          float old[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.accum) {
+#pragma unroll
+            for (int qv = 0; qv < 4; ++qv) old[qv] = gp0[(long long)(qv < p.q ? qv : 0) * p.Wn];
+          }
 #pragma unroll
           for (int qv = 0; qv < 4; ++qv)
-            if (qv < p.q) {
-              float* gp = gxw + (long long)(c * p.q + qv) * p.Wn + wt[t];
-              *gp = p.accum ? *gp + df[qv][t] : df[qv][t];
-            }
+            if (qv < p.q) gp0[(long long)qv * p.Wn] = old[qv] + df[qv][t];
           continue;
         }
         if constexpr (ONECH == 0)
@@ -889,8 +900,10 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < SN; ++s) {
-          v[0][s][t] = vt_ok[t] ? states[(p.st_off[p.n - 1] + 4 * s + g) * p.Wn + wt[t]] : 0.f;
-          v[1][s][t] = (vt_ok[t] && oacc > 1) ? states[(p.st_off[p.n - 1] + R + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+          const float l0 = states[(p.st_off[p.n - 1] + 4 * s + g) * p.Wn + (vt_ok[t] ? wt[t] : 0)];   // (clamped address + select)
+          const float l1 = states[(p.st_off[p.n - 1] + (oacc > 1 ? R : 0) + 4 * s + g) * p.Wn + (vt_ok[t] ? wt[t] : 0)];
+          v[0][s][t] = vt_ok[t] ? l0 : 0.f;
+          v[1][s][t] = (vt_ok[t] && oacc > 1) ? l1 : 0.f;
         }
     } else {
       load_f(0);
@@ -946,8 +959,12 @@ __global__ __launch_bounds__(256, (R == 4 ? 4 : R == 8 ? 2 : 1)) void convsbs_bw
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int s = 0; s < SN; ++s) {
-          vnext[0][s][t] = vt_ok[t] ? states[(p.st_off[c] + 4 * s + g) * p.Wn + wt[t]] : 0.f;
-          vnext[1][s][t] = (vt_ok[t] && nstates > 1) ? states[(p.st_off[c] + R + 4 * s + g) * p.Wn + wt[t]] : 0.f;
+          // clamped address + select: as predicated loads each of these was a branch with a wait behind it - the prefetch
+          // one core ahead waited for itself
+          const float l0 = states[(p.st_off[c] + 4 * s + g) * p.Wn + (vt_ok[t] ? wt[t] : 0)];
+          const float l1 = states[(p.st_off[c] + (nstates > 1 ? R : 0) + 4 * s + g) * p.Wn + (vt_ok[t] ? wt[t] : 0)];
+          vnext[0][s][t] = vt_ok[t] ? l0 : 0.f;
+          vnext[1][s][t] = (vt_ok[t] && nstates > 1) ? l1 : 0.f;
         }
     };
     if (p.n > 2) {

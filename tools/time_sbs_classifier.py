@@ -6,7 +6,10 @@ import contextlib
 dev = torch.device('cuda:0')
 # both forms of tests/sbs_classifier.py: the reference's own model (mnist.py:255-283: layers + mean, strings rescaled on a
 # batch) and the tests' variant with tanh(scale * output) between the layers (20 more elementwise launches per step)
+ONLY = [int(a) for a in sys.argv[1:]]   # e.g. `python tools/time_sbs_classifier.py 16` (under rocprofv3: one bond's kernels)
 for bond, ref in ((2, True), (4, True), (8, True), (16, True), (2, False), (4, False)):
+    if ONLY and (bond not in ONLY or not ref):
+        continue
     torch.manual_seed(0)
     m = ConvSBSClassifier(bond=bond, reference_form=ref).to(dev)
     x = torch.rand(1, 128, 28, 28, 2, device=dev)
