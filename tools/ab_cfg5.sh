@@ -1,11 +1,14 @@
 set -e
-timeout -k 10 900 python -m pytest tests -q -m gpu -k "band or sbs or convsbs" 2>&1 | tail -2
-python bench.py --skip-headline --configs cfg4_r16,cfg4_r8,cfg4_r4 --no-cpu-baseline 2>/dev/null | python -c "
+run() { python bench.py --skip-headline --configs cfg3b,cfg3a,cfg4_eps36 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()
     if l.startswith('{'):
         d=json.loads(l)
-        for e in d['configs']: print(e['workload'][:12], e['ms_per_step'])
-"
-timeout -k 10 300 python tools/time_sbs_classifier.py 8 16 2>&1 | grep "reference form"
+        print('$1', [(e['workload'][:10], round(e['ms_per_step'],4)) for e in d['configs']])
+"; }
+cp dctn_amd/libdctn_amd.so /tmp/base.so
+run BASE
+cp tools/variants/lib_bc_slp.so dctn_amd/libdctn_amd.so; run BCSLP
+cp /tmp/base.so dctn_amd/libdctn_amd.so; run BASE
+cp tools/variants/lib_bc_slp.so dctn_amd/libdctn_amd.so; run BCSLP
