@@ -991,6 +991,47 @@ __device__ __forceinline__ void sm_prefix_suffix(const float* pack, const SrP& p
   }
 }
 
+// The features of every core of a window, all loads issued before the first use (round 5): core by core through
+// sr_features, the two-channel products made every core's loads a round trip of their own - a branch on the pixel layout
+// around each load, the product right behind it - nine dependent round trips per window in front of the chain.  Cores
+// beyond n re-read the last one; `raw` keeps the pixel values of the two-channel mode (the way back needs them).
+template <int QC, bool TWOCH, int NC>
+__device__ __forceinline__ void sm_features_all(const SrP& p, long long b, int ho, int wo, float (*f)[QC], float (*raw)[4]) {
+  const float* win = p.x + b * p.xs[1] + (long long)ho * p.xs[2] + (long long)wo * p.xs[3];
+  if constexpr (TWOCH) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int cc = c < p.n ? c : p.n - 1;
+      const float* px = win + (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
+      raw[c][0] = px[0];
+      raw[c][1] = px[p.xs[4]];
+      raw[c][2] = px[p.xs[0]];
+      raw[c][3] = px[p.xs[0] + p.xs[4]];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool in = c < p.n;
+      f[c][0] = in ? raw[c][0] * raw[c][2] : 0.f;
+      f[c][1] = in ? raw[c][0] * raw[c][3] : 0.f;
+      f[c][2] = in ? raw[c][1] * raw[c][2] : 0.f;
+      f[c][3] = in ? raw[c][1] * raw[c][3] : 0.f;
+    }
+  } else {
+    float ld[NC][QC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int cc = c < p.n ? c : p.n - 1;
+      const float* px = win + (long long)p.ph[cc] * p.xs[2] + (long long)p.pw[cc] * p.xs[3];
+#pragma unroll
+      for (int qq = 0; qq < QC; ++qq) ld[c][qq] = px[qq * p.xs[4]];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int qq = 0; qq < QC; ++qq) f[c][qq] = c < p.n ? ld[c][qq] : 0.f;
+  }
+}
+
 template <int R, int QC, bool TWOCH>
 __global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regmv_k(SrP p, float* __restrict__ out) {
   constexpr int NC = SR_MAXC, E = R * R * QC;
@@ -1004,13 +1045,10 @@ __global__ __launch_bounds__(SR_FWD_THREADS) void convsbs_fwd_regmv_k(SrP p, flo
     const long long b = w / hw;
     const int rem = (int)(w - b * hw);
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    float f[NC][QC], xr[4];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (c < p.n) sr_features<QC, TWOCH>(p, c, b, ho, wo, f[c], xr);
-      else
-#pragma unroll
-        for (int qq = 0; qq < QC; ++qq) f[c][qq] = 0.f;
+    float f[NC][QC];
+    {
+      float raw[TWOCH ? NC : 1][4];
+      sm_features_all<QC, TWOCH, NC>(p, b, ho, wo, f, raw);
     }
     float vs[NC + 1][R], ss[NC + 1][R];
     sm_prefix_suffix<R, QC, NC>(pack, p, f, vs, ss);
@@ -1073,13 +1111,23 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
     const bool owner = valid && ho >= r0 && p.part != nullptr;   // dCore counts a window in the band of its top-left pixel
     const bool first = base == wave * 64;
 
-    float f[NC][QC], xr[4];
+    float f[NC][QC];
+    {
+      float raw[TWOCH ? NC : 1][4];
+      sm_features_all<QC, TWOCH, NC>(p, img, ho, wo, f, raw);
+      // two channels: the way back turns d/d(products) into d/d(pixel values) and needs the pixel values again - they wait
+      // in the window's own slots of `dfl`, which the way back overwrites with the gradients (re-read from memory core by
+      // core they were nine more round trips per window)
+      if constexpr (TWOCH) {
+        if (valid && p.dX != nullptr) {
+          float* d = dfl + (size_t)i * NCq;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (c < p.n) sr_features<QC, TWOCH>(p, c, img, ho, wo, f[c], xr);
-      else
+          for (int c = 0; c < NC; ++c)
+            if (c < p.n)
 #pragma unroll
-        for (int qq = 0; qq < QC; ++qq) f[c][qq] = 0.f;
+              for (int k = 0; k < 4; ++k) d[c * 4 + k] = raw[c][k];
+        }
+      }
     }
     float vs[NC + 1][R], ss[NC + 1][R];
     sm_prefix_suffix<R, QC, NC>(pack, p, f, vs, ss);
@@ -1102,8 +1150,7 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
       if (!valid || p.dX == nullptr) return;
       float* d = dfl + (size_t)i * NCq + c * Cq;
       if constexpr (TWOCH) {
-        float fc[QC], xv[4];
-        sr_features<QC, TWOCH>(p, c, img, ho, wo, fc, xv);   // (the raw values again: a cache hit, not 36 registers held)
+        const float xv[4] = {d[0], d[1], d[2], d[3]};   // the pixel values left here at the window's start
         d[0] = dF[0] * xv[2] + dF[1] * xv[3];
         d[1] = dF[2] * xv[2] + dF[3] * xv[3];
         d[2] = dF[0] * xv[0] + dF[2] * xv[1];
@@ -1117,9 +1164,11 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
     // ---- the many-valued core, pass A: dCore_m[o] += dY[o] (v x s x f) - O lane sums of E products
     const float* dyp = p.dY + w * p.O;
     if (p.part != nullptr) {
+      float gnext = dyp[0];   // (the next label's dY is in flight while this one's 64 lane sums run: a load per turn was a round trip per label)
 #pragma unroll 1
       for (int o = 0; o < p.O; ++o) {
-        const float g = owner ? dyp[o] : 0.f;
+        const float g = owner ? gnext : 0.f;
+        gnext = dyp[o + 1 < p.O ? o + 1 : o];
         float prod[E];
 #pragma unroll
         for (int l = 0; l < R; ++l)
@@ -1138,9 +1187,11 @@ __global__ __launch_bounds__(SR_BWD_THREADS) void convsbs_bwd_regmv_k(SrP p) {
       float dz[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) dz[e] = 0.f;
+      float gnext = dyp[0];
 #pragma unroll 1
       for (int o = 0; o < p.O; ++o) {
-        const float g = valid ? dyp[o] : 0.f;
+        const float g = valid ? gnext : 0.f;
+        gnext = dyp[o + 1 < p.O ? o + 1 : o];
         const float* pk = pack + (NC + o) * E;
 #pragma unroll
         for (int e = 0; e < E; ++e) dz[e] = fmaf(g, pk[e], dz[e]);

@@ -315,7 +315,10 @@ __global__ __launch_bounds__(256) void head_bwd_gen_k(const S* __restrict__ feat
     }
     A w[HEAD_MAXC];
 #pragma unroll
-    for (int c = 0; c < HEAD_MAXC; ++c) w[c] = (c < Cout && f < F) ? (A)W[(long long)c * F + f] : A(0);
+    for (int c = 0; c < HEAD_MAXC; ++c) {   // clamped indices + select: no branch between the loads
+      const A ld = (A)W[(long long)(c < Cout ? c : Cout - 1) * F + (f < F ? f : F - 1)];
+      w[c] = (c < Cout && f < F) ? ld : A(0);
+    }
     __syncthreads();
     if (f < F) {
 #pragma unroll
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(256) void head_bwd_gen_k(const S* __restrict__ feat
 #pragma unroll
     for (int s2 = 0; s2 < DW_SPS; ++s2) {
       const long long b = b0 + s2 < B ? b0 + s2 : B - 1;
-      raw[s2] = f < F ? (A)feat[b * (long long)F + f] : A(0);
+      const A ld = (A)feat[b * (long long)F + (f < F ? f : F - 1)];
+      raw[s2] = f < F ? ld : A(0);
     }
     __syncthreads();
     A acc[HEAD_MAXC];

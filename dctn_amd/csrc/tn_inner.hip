@@ -42,7 +42,10 @@ __global__ __launch_bounds__(TN_THREADS) void tn_mode_product_k(const S* __restr
     const long long bi = fiber_base(f, q, post), bo = fiber_base(f, q2, post);
     A v[QP];
 #pragma unroll
-    for (int i = 0; i < QP; ++i) v[i] = i < q ? (A)in[bi + i * post] : (A)0;
+    for (int i = 0; i < QP; ++i) {   // clamped index + select: no branch between the loads
+      const A ld = (A)in[bi + (i < q ? i : 0) * post];
+      v[i] = i < q ? ld : (A)0;
+    }
 #pragma unroll
     for (int j = 0; j < QP; ++j) {
       if (j < q2) {
